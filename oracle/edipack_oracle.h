@@ -1,0 +1,141 @@
+/*
+ * edipack_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of the EDIpack Hamiltonian-times-vector hot path.
+ * It exists to CHECK the HIP product path (tests/, __graft_entry__.smoke(),
+ * bench.py's cpu_baseline leg).  Nothing under edipack_amd/ may include, link
+ * or call it.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * /root/reference/src/singlesite unless noted).
+ *
+ * Parity status: PINNED against the reference's own golden fixtures
+ * (test/src/{NORMAL,HYBRID}_{NORMAL,SUPERC,NONSU2}/{evals,dens,docc}.check), see
+ * tests/test_oracle_golden.py.  The Lanczos recurrence (SciFortran
+ * sp_lanc_tridiag, third party, un-vendored, un-pinned "master") is restated
+ * from its published algorithm; it is pinned only end-to-end.
+ */
+#ifndef EDIPACK_ORACLE_H
+#define EDIPACK_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAXORB 5
+#define ORC_MAXBATH 16
+
+/* Model parameters: the module-global state of the reference that the
+ * Hamiltonian builders read (ED_INPUT_VARS / ED_VARS_GLOBAL / dmft_bath). */
+typedef struct {
+  int ed_mode;   /* 0 normal, 1 superc, 2 nonsu2                (ED_INPUT_VARS ED_MODE)   */
+  int bath_type; /* 0 normal, 1 hybrid, 2 replica, 3 general    (ED_INPUT_VARS BATH_TYPE) */
+  int norb, nbath, nspin;
+  int hfmode;
+  double xmu;
+  /* interaction tables after set_umatrix (ED_PARSE_UMATRIX.f90:92-142) */
+  double uloc[ORC_MAXORB];
+  double ust[ORC_MAXORB][ORC_MAXORB];
+  double jh[ORC_MAXORB][ORC_MAXORB];
+  double jx[ORC_MAXORB][ORC_MAXORB];
+  double jp[ORC_MAXORB][ORC_MAXORB];
+  /* impHloc(ispin,jspin,iorb,jorb) and mfHloc, complex */
+  double hloc_re[2][2][ORC_MAXORB][ORC_MAXORB];
+  double hloc_im[2][2][ORC_MAXORB][ORC_MAXORB];
+  double mfh_re[2][2][ORC_MAXORB][ORC_MAXORB];
+  double mfh_im[2][2][ORC_MAXORB][ORC_MAXORB];
+  double anom_re[ORC_MAXORB][ORC_MAXORB]; /* impHloc_anomalous(1,1,:,:) */
+  double anom_im[ORC_MAXORB][ORC_MAXORB];
+  double pair_field[ORC_MAXORB];
+  double spin_field[ORC_MAXORB][3];
+  double exc_field[4];
+  /* dmft_bath%e,v,d,u(ispin,iorb,k); hybrid uses iorb=0 only for e,d */
+  double be[2][ORC_MAXORB][ORC_MAXBATH];
+  double bv[2][ORC_MAXORB][ORC_MAXBATH];
+  double bd[2][ORC_MAXORB][ORC_MAXBATH];
+  double bu[2][ORC_MAXORB][ORC_MAXBATH];
+  /* replica/general: build_Hreplica(lambda) result hbath_tmp(is,js,io,jo,k) */
+  double hb_re[2][2][ORC_MAXORB][ORC_MAXORB][ORC_MAXBATH];
+  double hb_im[2][2][ORC_MAXORB][ORC_MAXORB][ORC_MAXBATH];
+  double vr[ORC_MAXBATH];                 /* replica: item(k)%v            */
+  double vg[2 * ORC_MAXORB][ORC_MAXBATH]; /* general: item(k)%vg(io+Norb*(is-1)) */
+} orc_model;
+
+/* CSR matrix in the reference's row order (insertion order inside a row,
+ * duplicates accumulated into the first occurrence: ED_SPARSE_MATRIX.f90:328-360).
+ * Indices are 0-based here.  val holds nnz doubles (real) or 2*nnz (complex). */
+typedef struct {
+  int64_t nrow, ncol, nnz;
+  int is_complex;
+  int64_t *rowptr;
+  int32_t *col;
+  double *val;
+} orc_csr;
+
+/* normal-mode Kronecker pieces (ED_VARS_GLOBAL.f90:190-195: spH0d, spH0ups(1), spH0dws(1), spH0nd) */
+typedef struct {
+  int ns, nup, ndw;
+  int64_t dimup, dimdw, dim;
+  int32_t *mapup, *mapdw;
+  double *hd; /* spH0d: one entry per row */
+  orc_csr up, dw, nd;
+  int has_nd;
+} orc_hnormal;
+
+int orc_ns(const orc_model *m);
+int64_t orc_binomial(int n1, int n2);
+int orc_bath_stride(const orc_model *m, int iorb, int kp); /* 1-based in, 1-based out */
+
+/* ED_SECTOR.f90:165-373 */
+int orc_build_sector_normal(int ns, int nup, int ndw, int32_t *mapup, int32_t *mapdw);
+int64_t orc_build_sector_superc(int ns, int sz, int32_t *map);  /* map may be NULL: count only */
+int64_t orc_build_sector_nonsu2(int ns, int ntot, int32_t *map);
+
+/* ED_AUX_FUNX.f90:334-384, :463-480 */
+int orc_c(int pos, int32_t in, int32_t *out, double *sgn);
+int orc_cdg(int pos, int32_t in, int32_t *out, double *sgn);
+int64_t orc_binary_search(const int32_t *a, int64_t n, int32_t value); /* 1-based result, 0 = not found */
+
+/* ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:26-267 (+ stored/H_local, H_up, H_dw, H_non_local) */
+orc_hnormal *orc_buildh_normal_main(const orc_model *m, int nup, int ndw);
+void orc_hnormal_free(orc_hnormal *h);
+/* ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:517-650 */
+void orc_spmatvec_normal_main(const orc_hnormal *h, const double *v, double *hv);
+/* dense dump: ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:209-262 (column-major nothing: symmetric, row-major out) */
+void orc_hnormal_dense(const orc_hnormal *h, double *hmat);
+
+/* flat CSR modes: ED_SUPERC/ED_HAMILTONIAN_SUPERC_STORED_HxV.f90:29-293, ED_NONSU2/..._STORED_HxV.f90:29-175 */
+typedef struct {
+  int ns;
+  int64_t dim;
+  int32_t *map;
+  orc_csr h; /* complex */
+} orc_hflat;
+orc_hflat *orc_buildh_superc_main(const orc_model *m, int sz);
+orc_hflat *orc_buildh_nonsu2_main(const orc_model *m, int ntot);
+void orc_hflat_free(orc_hflat *h);
+/* ED_SUPERC/..._STORED_HxV.f90:312-362, ED_NONSU2/..._STORED_HxV.f90:194-209 */
+void orc_spmatvec_flat_z(const orc_hflat *h, const double *v, double *hv);
+void orc_hflat_dense(const orc_hflat *h, double *hmat_re_im);
+
+/* generic CSR y = A x in the reference's loop order (ED_SPARSE_MATRIX.f90:778-793) */
+void orc_csr_matvec_d(const orc_csr *a, const double *x, double *y);
+void orc_csr_matvec_z(const orc_csr *a, const double *x, double *y);
+
+/* SciFortran SF_SP_LINALG sp_lanc_tridiag restated (three-term recurrence);
+ * call sites ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:360-365 etc.  vin is
+ * overwritten (as in the reference).  Returns the number of iterations done. */
+int orc_lanc_tridiag_normal(const orc_hnormal *h, double *vin, int nitermax, double *alanc,
+                            double *blanc, double threshold);
+int orc_lanc_tridiag_flat(const orc_hflat *h, double *vin, int nitermax, double *alanc,
+                          double *blanc, double threshold);
+
+/* accessors for ctypes */
+void orc_hnormal_sizes(const orc_hnormal *h, int64_t out[8]);
+void orc_hflat_sizes(const orc_hflat *h, int64_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,434 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front-end of the CPU oracle (oracle/edipack_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product (edipack_amd/) never does.
+
+Besides loading the C restatement it holds the small host-side pieces that are
+needed to reproduce the reference's own regression fixtures
+(/root/reference/test/src/*/*.check):
+
+* ``init_dmft_bath``   -- ED_BATH/ED_BATH_DMFT.f90:178-307 (deterministic start bath)
+* ``kanamori_tables``  -- ED_PARSE_UMATRIX.f90:136-142 (ed_use_kanamori=T branch)
+* ``ground_state``     -- dense LAPACK spectrum of every sector, as the reference does
+                          for dim <= lanc_dim_threshold (ED_NORMAL/ED_DIAG_NORMAL.f90:226-236)
+
+Parity status: pinned by tests/test_oracle_golden.py against evals/dens/docc.check.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libedipack_oracle.so")
+
+MAXORB = 5
+MAXBATH = 16
+
+ED_MODES = {"normal": 0, "superc": 1, "nonsu2": 2}
+BATH_TYPES = {"normal": 0, "hybrid": 1, "replica": 2, "general": 3}
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (idempotent)."""
+    srcs = [os.path.join(HERE, f) for f in ("edipack_oracle.c", "edipack_oracle_flat.inc", "edipack_oracle.h")]
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", HERE, "-B"])
+    return LIB_PATH
+
+
+_D = C.c_double
+
+
+class OrcModel(C.Structure):
+    _fields_ = [
+        ("ed_mode", C.c_int), ("bath_type", C.c_int),
+        ("norb", C.c_int), ("nbath", C.c_int), ("nspin", C.c_int),
+        ("hfmode", C.c_int),
+        ("xmu", _D),
+        ("uloc", _D * MAXORB),
+        ("ust", (_D * MAXORB) * MAXORB),
+        ("jh", (_D * MAXORB) * MAXORB),
+        ("jx", (_D * MAXORB) * MAXORB),
+        ("jp", (_D * MAXORB) * MAXORB),
+        ("hloc_re", (((_D * MAXORB) * MAXORB) * 2) * 2),
+        ("hloc_im", (((_D * MAXORB) * MAXORB) * 2) * 2),
+        ("mfh_re", (((_D * MAXORB) * MAXORB) * 2) * 2),
+        ("mfh_im", (((_D * MAXORB) * MAXORB) * 2) * 2),
+        ("anom_re", (_D * MAXORB) * MAXORB),
+        ("anom_im", (_D * MAXORB) * MAXORB),
+        ("pair_field", _D * MAXORB),
+        ("spin_field", (_D * 3) * MAXORB),
+        ("exc_field", _D * 4),
+        ("be", ((_D * MAXBATH) * MAXORB) * 2),
+        ("bv", ((_D * MAXBATH) * MAXORB) * 2),
+        ("bd", ((_D * MAXBATH) * MAXORB) * 2),
+        ("bu", ((_D * MAXBATH) * MAXORB) * 2),
+        ("hb_re", ((((_D * MAXBATH) * MAXORB) * MAXORB) * 2) * 2),
+        ("hb_im", ((((_D * MAXBATH) * MAXORB) * MAXORB) * 2) * 2),
+        ("vr", _D * MAXBATH),
+        ("vg", (_D * MAXBATH) * (2 * MAXORB)),
+    ]
+
+
+def _np_view(struct: C.Structure, name: str) -> np.ndarray:
+    """numpy view (no copy) onto an array member of a ctypes struct."""
+    f = getattr(struct, name)
+    return np.ctypeslib.as_array(f)
+
+
+@dataclass
+class Model:
+    """Python-side description of one impurity problem (the reference's input globals)."""
+    ed_mode: str = "normal"
+    bath_type: str = "normal"
+    norb: int = 1
+    nbath: int = 1
+    nspin: int = 1
+    hfmode: bool = True
+    xmu: float = 0.0
+    uloc: tuple = (2.0,)
+    ust: float = 0.0
+    jh: float = 0.0
+    jx: float = 0.0
+    jp: float = 0.0
+    ed_hw_bath: float = 2.0
+    deltasc: float = 0.02
+    # impHloc[ispin, jspin, iorb, jorb] complex
+    hloc: np.ndarray | None = None
+    pair_field: tuple | None = None
+    # bath arrays e,v,d,u [nspin, norb(or 1), nbath]; None -> init_dmft_bath
+    be: np.ndarray | None = None
+    bv: np.ndarray | None = None
+    bd: np.ndarray | None = None
+    bu: np.ndarray | None = None
+
+    @property
+    def ns(self) -> int:
+        # ED_SETUP.f90:118-126
+        return self.nbath + self.norb if self.bath_type == "hybrid" else (self.nbath + 1) * self.norb
+
+
+def init_dmft_bath(m: Model) -> None:
+    """ED_BATH/ED_BATH_DMFT.f90:211-244 -- deterministic initial bath for normal/hybrid."""
+    nb, hw = m.nbath, m.ed_hw_bath
+    nfoo = 1 if m.bath_type == "hybrid" else m.norb
+    e = np.zeros(nb)
+    e[0] = -hw
+    e[nb - 1] = hw
+    nh = nb // 2
+    if nb % 2 == 0 and nb >= 4:
+        de = hw / max(nh - 1, 1)
+        e[nh - 1] = -1.0e-1
+        e[nh] = 1.0e-1
+        for i in range(2, nh):
+            e[i - 1] = -hw + (i - 1) * de
+            e[nb - i] = hw - (i - 1) * de
+    elif nb % 2 != 0 and nb >= 3:
+        de = hw / nh
+        e[nh] = 0.0
+        for i in range(2, nh + 1):
+            e[i - 1] = -hw + (i - 1) * de
+            e[nb - i] = hw - (i - 1) * de
+    m.be = np.broadcast_to(e, (m.nspin, nfoo, nb)).copy()
+    m.bv = np.full((m.nspin, m.norb, nb), max(0.1, 1.0 / np.sqrt(float(nb))))
+    m.bd = np.full((m.nspin, nfoo, nb), m.deltasc) if m.ed_mode == "superc" else None
+    m.bu = m.bv.copy() if m.ed_mode == "nonsu2" else None
+
+
+def to_struct(m: Model) -> OrcModel:
+    s = OrcModel()
+    s.ed_mode = ED_MODES[m.ed_mode]
+    s.bath_type = BATH_TYPES[m.bath_type]
+    s.norb, s.nbath, s.nspin = m.norb, m.nbath, m.nspin
+    s.hfmode = int(m.hfmode)
+    s.xmu = m.xmu
+    no = m.norb
+    assert no <= MAXORB and m.nbath <= MAXBATH
+    _np_view(s, "uloc")[:no] = np.asarray(m.uloc, dtype=float)[:no]
+    # ED_PARSE_UMATRIX.f90:136-142 (ed_use_kanamori): off-diagonal constants
+    off = 1.0 - np.eye(no)
+    _np_view(s, "ust")[:no, :no] = m.ust * off
+    _np_view(s, "jh")[:no, :no] = m.jh * off
+    _np_view(s, "jx")[:no, :no] = m.jx * off
+    _np_view(s, "jp")[:no, :no] = m.jp * off
+    if m.hloc is not None:
+        h = np.asarray(m.hloc, dtype=complex)
+        nsn = h.shape[0]
+        _np_view(s, "hloc_re")[:nsn, :nsn, :no, :no] = h.real
+        _np_view(s, "hloc_im")[:nsn, :nsn, :no, :no] = h.imag
+    if m.pair_field is not None:
+        _np_view(s, "pair_field")[:no] = np.asarray(m.pair_field, dtype=float)
+    if m.be is None:
+        init_dmft_bath(m)
+    for name, arr in (("be", m.be), ("bv", m.bv), ("bd", m.bd), ("bu", m.bu)):
+        if arr is None:
+            continue
+        a = np.asarray(arr, dtype=float)
+        _np_view(s, name)[: a.shape[0], : a.shape[1], : a.shape[2]] = a
+    return s
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(LIB_PATH)
+    vp, i64p, i32p, dp = C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    L.orc_ns.restype = C.c_int
+    L.orc_ns.argtypes = [C.POINTER(OrcModel)]
+    L.orc_binomial.restype = C.c_int64
+    L.orc_binomial.argtypes = [C.c_int, C.c_int]
+    L.orc_build_sector_normal.argtypes = [C.c_int, C.c_int, C.c_int, i32p, i32p]
+    L.orc_build_sector_superc.restype = C.c_int64
+    L.orc_build_sector_superc.argtypes = [C.c_int, C.c_int, i32p]
+    L.orc_build_sector_nonsu2.restype = C.c_int64
+    L.orc_build_sector_nonsu2.argtypes = [C.c_int, C.c_int, i32p]
+    L.orc_buildh_normal_main.restype = vp
+    L.orc_buildh_normal_main.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int]
+    L.orc_hnormal_free.argtypes = [vp]
+    L.orc_hnormal_sizes.argtypes = [vp, i64p]
+    L.orc_spmatvec_normal_main.argtypes = [vp, dp, dp]
+    L.orc_hnormal_dense.argtypes = [vp, dp]
+    L.orc_lanc_tridiag_normal.restype = C.c_int
+    L.orc_lanc_tridiag_normal.argtypes = [vp, dp, C.c_int, dp, dp, C.c_double]
+    L.orc_buildh_superc_main.restype = vp
+    L.orc_buildh_superc_main.argtypes = [C.POINTER(OrcModel), C.c_int]
+    L.orc_buildh_nonsu2_main.restype = vp
+    L.orc_buildh_nonsu2_main.argtypes = [C.POINTER(OrcModel), C.c_int]
+    L.orc_hflat_free.argtypes = [vp]
+    L.orc_hflat_sizes.argtypes = [vp, i64p]
+    L.orc_spmatvec_flat_z.argtypes = [vp, dp, dp]
+    L.orc_hflat_dense.argtypes = [vp, dp]
+    L.orc_lanc_tridiag_flat.restype = C.c_int
+    L.orc_lanc_tridiag_flat.argtypes = [vp, dp, C.c_int, dp, dp, C.c_double]
+    L.orc_csr_matvec_d.argtypes = [vp, dp, dp]
+    L.orc_csr_matvec_z.argtypes = [vp, dp, dp]
+    _lib = L
+    return L
+
+
+def _dp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class _Csr(C.Structure):
+    _fields_ = [("nrow", C.c_int64), ("ncol", C.c_int64), ("nnz", C.c_int64), ("is_complex", C.c_int),
+                ("rowptr", C.POINTER(C.c_int64)), ("col", C.POINTER(C.c_int32)), ("val", C.POINTER(C.c_double))]
+
+
+class _HNormal(C.Structure):
+    _fields_ = [("ns", C.c_int), ("nup", C.c_int), ("ndw", C.c_int),
+                ("dimup", C.c_int64), ("dimdw", C.c_int64), ("dim", C.c_int64),
+                ("mapup", C.POINTER(C.c_int32)), ("mapdw", C.POINTER(C.c_int32)),
+                ("hd", C.POINTER(C.c_double)),
+                ("up", _Csr), ("dw", _Csr), ("nd", _Csr), ("has_nd", C.c_int)]
+
+
+class _HFlat(C.Structure):
+    _fields_ = [("ns", C.c_int), ("dim", C.c_int64), ("map", C.POINTER(C.c_int32)), ("h", _Csr)]
+
+
+def _csr_arrays(c: _Csr):
+    """Copy a C orc_csr into (rowptr int64, col int32, val float64|complex128)."""
+    if c.nrow == 0:
+        return np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float64)
+    rowptr = np.ctypeslib.as_array(c.rowptr, shape=(c.nrow + 1,)).copy()
+    if c.nnz == 0:
+        return rowptr, np.zeros(0, np.int32), np.zeros(0, np.complex128 if c.is_complex else np.float64)
+    col = np.ctypeslib.as_array(c.col, shape=(c.nnz,)).copy()
+    if c.is_complex:
+        v = np.ctypeslib.as_array(c.val, shape=(2 * c.nnz,)).copy().view(np.complex128)
+    else:
+        v = np.ctypeslib.as_array(c.val, shape=(c.nnz,)).copy()
+    return rowptr, col, v
+
+
+class HNormal:
+    """Oracle-built normal-mode sector Hamiltonian (Kronecker pieces)."""
+
+    def __init__(self, model: Model, nup: int, ndw: int):
+        self._L = lib()
+        self.model = model
+        self._s = to_struct(model)
+        self._h = self._L.orc_buildh_normal_main(C.byref(self._s), nup, ndw)
+        if not self._h:
+            raise RuntimeError("oracle: normal build failed")
+        hs = C.cast(self._h, C.POINTER(_HNormal)).contents
+        self.ns, self.nup, self.ndw = hs.ns, nup, ndw
+        self.dimup, self.dimdw, self.dim = hs.dimup, hs.dimdw, hs.dim
+        self.mapup = np.ctypeslib.as_array(hs.mapup, shape=(hs.dimup,)).copy()
+        self.mapdw = np.ctypeslib.as_array(hs.mapdw, shape=(hs.dimdw,)).copy()
+        self.hd = np.ctypeslib.as_array(hs.hd, shape=(hs.dim,)).copy()
+        self.up = _csr_arrays(hs.up)
+        self.dw = _csr_arrays(hs.dw)
+        self.has_nd = bool(hs.has_nd)
+        self.nd = _csr_arrays(hs.nd) if self.has_nd else None
+
+    def matvec(self, v: np.ndarray) -> np.ndarray:
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        hv = np.empty_like(v)
+        self._L.orc_spmatvec_normal_main(self._h, _dp(v), _dp(hv))
+        return hv
+
+    def dense(self) -> np.ndarray:
+        out = np.empty((self.dim, self.dim))
+        self._L.orc_hnormal_dense(self._h, _dp(out))
+        return out
+
+    def lanc_tridiag(self, vin: np.ndarray, nitermax: int, threshold: float = 0.0):
+        v = np.array(vin, dtype=np.float64, copy=True)
+        a = np.zeros(nitermax)
+        b = np.zeros(nitermax)
+        n = self._L.orc_lanc_tridiag_normal(self._h, _dp(v), nitermax, _dp(a), _dp(b), threshold)
+        return a, b, n
+
+    def close(self):
+        if self._h:
+            self._L.orc_hnormal_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HFlat:
+    """Oracle-built flat-CSR sector Hamiltonian (superc: sector=Sz, nonsu2: sector=Ntot)."""
+
+    def __init__(self, model: Model, sector: int):
+        self._L = lib()
+        self.model = model
+        self._s = to_struct(model)
+        if model.ed_mode == "superc":
+            self._h = self._L.orc_buildh_superc_main(C.byref(self._s), sector)
+        elif model.ed_mode == "nonsu2":
+            self._h = self._L.orc_buildh_nonsu2_main(C.byref(self._s), sector)
+        else:
+            raise ValueError(model.ed_mode)
+        if not self._h:
+            raise RuntimeError("oracle: flat build failed / unsupported terms")
+        hs = C.cast(self._h, C.POINTER(_HFlat)).contents
+        self.ns, self.dim = hs.ns, hs.dim
+        self.map = np.ctypeslib.as_array(hs.map, shape=(hs.dim,)).copy() if hs.dim else np.zeros(0, np.int32)
+        self.csr = _csr_arrays(hs.h)
+
+    def matvec(self, v: np.ndarray) -> np.ndarray:
+        v = np.ascontiguousarray(v, dtype=np.complex128)
+        hv = np.empty_like(v)
+        self._L.orc_spmatvec_flat_z(self._h, _dp(v.view(np.float64)), _dp(hv.view(np.float64)))
+        return hv
+
+    def dense(self) -> np.ndarray:
+        out = np.empty((self.dim, self.dim), dtype=np.complex128)
+        self._L.orc_hflat_dense(self._h, _dp(out.view(np.float64)))
+        return out
+
+    def lanc_tridiag(self, vin: np.ndarray, nitermax: int, threshold: float = 0.0):
+        v = np.array(vin, dtype=np.complex128, copy=True)
+        a = np.zeros(nitermax)
+        b = np.zeros(nitermax)
+        n = self._L.orc_lanc_tridiag_flat(self._h, _dp(v.view(np.float64)), nitermax, _dp(a), _dp(b), threshold)
+        return a, b, n
+
+    def close(self):
+        if self._h:
+            self._L.orc_hflat_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------
+# generic CSR products in the reference loop order (checker for the flat kernels)
+# ----------------------------------------------------------------------------
+def csr_matvec(rowptr: np.ndarray, col: np.ndarray, val: np.ndarray, x: np.ndarray) -> np.ndarray:
+    L = lib()
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    cplx = np.iscomplexobj(val) or np.iscomplexobj(x)
+    dt = np.complex128 if cplx else np.float64
+    val = np.ascontiguousarray(val, dtype=dt)
+    x = np.ascontiguousarray(x, dtype=dt)
+    nrow = rowptr.shape[0] - 1
+    y = np.empty(nrow, dtype=dt)
+    c = _Csr(nrow, x.shape[0], col.shape[0], int(cplx),
+             rowptr.ctypes.data_as(C.POINTER(C.c_int64)), col.ctypes.data_as(C.POINTER(C.c_int32)),
+             val.view(np.float64).ctypes.data_as(C.POINTER(C.c_double)))
+    fn = L.orc_csr_matvec_z if cplx else L.orc_csr_matvec_d
+    fn(C.byref(c), _dp(x.view(np.float64)), _dp(y.view(np.float64)))
+    return y
+
+
+# ----------------------------------------------------------------------------
+# reference-fixture level checks
+# ----------------------------------------------------------------------------
+def sectors(m: Model):
+    """Sector labels scanned by diagonalize_impurity (ED_SETUP.f90:137-165)."""
+    ns = m.ns
+    if m.ed_mode == "normal":
+        return [(nu, nd) for nu in range(ns + 1) for nd in range(ns + 1)]
+    if m.ed_mode == "superc":
+        return list(range(-ns, ns + 1))
+    return list(range(0, 2 * ns + 1))
+
+
+def hbuild(m: Model, sector):
+    if m.ed_mode == "normal":
+        return HNormal(m, sector[0], sector[1])
+    return HFlat(m, sector)
+
+
+def ground_state(m: Model, gs_threshold: float = 1e-9):
+    """Lowest energy over all sectors + T=0 impurity observables averaged over the
+    degenerate ground-state manifold (dens, docc): what evals/dens/docc.check pin.
+
+    Spectrum by dense LAPACK as the reference does below lanc_dim_threshold
+    (ED_NORMAL/ED_DIAG_NORMAL.f90:226-236); observables as in
+    ED_NORMAL/ED_OBSERVABLES_NORMAL.f90 (dens=<nup+ndw>, docc=<nup ndw>)."""
+    found = []  # (energy, sector, vector, H object)
+    for sec in sectors(m):
+        h = hbuild(m, sec)
+        if h.dim == 0:
+            continue
+        w, v = np.linalg.eigh(h.dense())
+        found.append((w, v, sec, h))
+    e0 = min(w[0] for w, _, _, _ in found)
+    dens = np.zeros(m.norb)
+    docc = np.zeros(m.norb)
+    ngs = 0
+    ns = m.ns
+    for w, v, sec, h in found:
+        for k in range(len(w)):
+            if w[k] - e0 > gs_threshold:
+                break
+            ngs += 1
+            p = np.abs(v[:, k]) ** 2
+            if m.ed_mode == "normal":
+                iup = np.arange(h.dim) % h.dimup
+                idw = np.arange(h.dim) // h.dimup
+                mu, md = h.mapup[iup], h.mapdw[idw]
+            else:
+                mu, md = h.map & ((1 << ns) - 1), h.map >> ns
+            for io in range(m.norb):
+                nu = (mu >> io) & 1
+                nd = (md >> io) & 1
+                dens[io] += np.sum(p * (nu + nd))
+                docc[io] += np.sum(p * (nu * nd))
+    return e0, dens / ngs, docc / ngs, ngs
