@@ -1,0 +1,131 @@
+"""ctypes binding of the C ABI in include/edigpu.h (libedigpu.so, hipcc-built for gfx950).
+
+This is the Python-side twin of the Fortran ISO_C_BINDING shim (fortran/edigpu_shim.f90):
+plain pointers and sizes in, status code out.  There is no CPU fallback -- if the shared
+library is missing or no HIP device is usable every call raises :class:`EdigpuError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libedigpu.so")
+HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "edigpu.h")
+
+MAXORB = 5
+MAXBATH = 16
+
+
+class EdigpuError(RuntimeError):
+    """Raised when a C-ABI call returns non-zero (the Fortran shim does ``stop msg``)."""
+
+
+class EdigpuModel(C.Structure):
+    """struct edigpu_model (include/edigpu.h)."""
+    _fields_ = [
+        ("ed_mode", C.c_int32), ("bath_type", C.c_int32),
+        ("norb", C.c_int32), ("nbath", C.c_int32), ("nspin", C.c_int32), ("hfmode", C.c_int32),
+        ("xmu", C.c_double),
+        ("uloc", C.c_double * MAXORB),
+        ("ust", C.c_double * (MAXORB * MAXORB)),
+        ("jh", C.c_double * (MAXORB * MAXORB)),
+        ("jx", C.c_double * (MAXORB * MAXORB)),
+        ("jp", C.c_double * (MAXORB * MAXORB)),
+        ("hloc", C.c_double * (2 * 2 * MAXORB * MAXORB * 2)),
+        ("pair_field", C.c_double * MAXORB),
+        ("be", C.c_double * (2 * MAXORB * MAXBATH)),
+        ("bv", C.c_double * (2 * MAXORB * MAXBATH)),
+        ("bd", C.c_double * (2 * MAXORB * MAXBATH)),
+        ("bu", C.c_double * (2 * MAXORB * MAXBATH)),
+    ]
+
+
+_lib = None
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_pi64 = C.POINTER(C.c_int64)
+_pi32 = C.POINTER(C.c_int32)
+_pd = C.POINTER(C.c_double)
+_pint = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); kept in one table so tests can check it against the header
+SIGNATURES = {
+    "edigpu_last_error": (C.c_char_p, []),
+    "edigpu_version": (C.c_int, []),
+    "edigpu_device_count": (C.c_int, [_pint]),
+    "edigpu_init": (C.c_int, [C.c_int]),
+    "edigpu_normal_create": (C.c_int, [C.POINTER(_vp), _i64, _i64, _i64, _i64, _pd, _pi64, _pi32, _pd,
+                                       _pi64, _pi32, _pd, _pi64, _pi32, _pd]),
+    "edigpu_csr_create_d": (C.c_int, [C.POINTER(_vp), _i64, _i64, _i64, _pi64, _pi32, _pd]),
+    "edigpu_csr_create_z": (C.c_int, [C.POINTER(_vp), _i64, _i64, _i64, _pi64, _pi32, _pd]),
+    "edigpu_normal_build": (C.c_int, [C.POINTER(_vp), C.POINTER(EdigpuModel), C.c_int, C.c_int, _i64, _i64]),
+    "edigpu_flat_build": (C.c_int, [C.POINTER(_vp), C.POINTER(EdigpuModel), C.c_int, _i64, _i64]),
+    "edigpu_sector_dim": (C.c_int, [C.POINTER(EdigpuModel), C.c_int, C.c_int, _pi64]),
+    "edigpu_info": (C.c_int, [_vp, _pi64]),
+    "edigpu_algorithmic_bytes": (C.c_int, [_vp, _pd, _pd]),
+    "edigpu_normal_export": (C.c_int, [_vp, _pd, _pi64, _pi32, _pd, _pi64, _pi32, _pd, _pi64, _pi32, _pd]),
+    "edigpu_csr_export": (C.c_int, [_vp, _pi64, _pi32, _pd]),
+    "edigpu_apply_d": (C.c_int, [_vp, _i64, _pd, _pd]),
+    "edigpu_apply_z": (C.c_int, [_vp, _i64, _pd, _pd]),
+    "edigpu_apply_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "edigpu_apply_local_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "edigpu_apply_remote_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "edigpu_lanczos_tridiag": (C.c_int, [_vp, _pd, C.c_int, _pd, _pd, C.c_double, _pint]),
+    "edigpu_lanczos_eigh": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int, _pd, _pd, _pd, _pint]),
+    "edigpu_time_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _pd]),
+    "edigpu_destroy": (C.c_int, [_vp]),
+}
+
+
+def lib() -> C.CDLL:
+    """Load libedigpu.so (built by ``__graft_entry__.build()``); fail loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EdigpuError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    msg = lib().edigpu_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise EdigpuError(f"{what}: {last_error()}" if what else last_error())
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().edigpu_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def init(device: int = 0) -> None:
+    check(lib().edigpu_init(int(device)), "edigpu_init")
+
+
+def pd(a: np.ndarray):
+    return a.ctypes.data_as(_pd)
+
+
+def pi64(a: np.ndarray):
+    return a.ctypes.data_as(_pi64)
+
+
+def pi32(a: np.ndarray):
+    return a.ctypes.data_as(_pi32)

@@ -1,0 +1,845 @@
+// edigpu_capi.hip -- implementation of the C ABI declared in include/edigpu.h.
+//
+// Host-side orchestration only: device memory layout of a sector, uploads, kernel
+// sequencing on the handle's HIP stream, the device-resident Lanczos driver.
+// There is no CPU compute path: without a usable HIP device every entry point fails.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "kernels.hpp"
+
+namespace edigpu {
+
+static thread_local std::string g_err;
+static thread_local int g_device = 0;
+void set_error(const std::string& msg) { g_err = msg; }
+
+template <class T>
+static int dev_upload(T** d, const T* h, size_t n) {
+  *d = nullptr;
+  if (n == 0) return 0;
+  EDIGPU_HIP(hipMalloc((void**)d, n * sizeof(T)));
+  EDIGPU_HIP(hipMemcpy(*d, h, n * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+template <class T>
+static void dev_free(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+static int ensure_device(int* count_out = nullptr) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_error(std::string("edigpu: no usable HIP device (") +
+              (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+              "); this library has no CPU fallback");
+    if (count_out) *count_out = 0;
+    return 1;
+  }
+  if (count_out) *count_out = n;
+  return 0;
+}
+
+// upload a CSR given with int64 row pointers; columns optionally shifted
+static int upload_csr(DevCsr& d, int64_t nrow, const int64_t* rowptr, const int32_t* col,
+                      const double* val, int cplx) {
+  d = DevCsr();
+  d.nrow = nrow;
+  d.nnz = rowptr ? rowptr[nrow] : 0;
+  d.avg_row = nrow > 0 ? (double)d.nnz / (double)nrow : 0.0;
+  if (nrow == 0) return 0;
+  if (d.nnz >= ((int64_t)1 << 31)) {
+    d.wide = 1;
+    if (dev_upload(&d.rowptr64, rowptr, (size_t)nrow + 1)) return 1;
+  } else {
+    std::vector<int32_t> rp((size_t)nrow + 1);
+    for (int64_t i = 0; i <= nrow; i++) rp[i] = (int32_t)rowptr[i];
+    if (dev_upload(&d.rowptr32, rp.data(), rp.size())) return 1;
+  }
+  if (dev_upload(&d.col, col, (size_t)d.nnz)) return 1;
+  if (dev_upload(&d.val, val, (size_t)d.nnz * (cplx ? 2 : 1))) return 1;
+  return 0;
+}
+
+static void free_csr(DevCsr& d) {
+  dev_free(d.rowptr32);
+  dev_free(d.rowptr64);
+  dev_free(d.col);
+  dev_free(d.val);
+}
+
+static int upload_ell(DevEll& e, const HostCsr& a) {
+  e = DevEll();
+  e.nrow = a.nrow;
+  e.pitch = (a.nrow + 63) / 64 * 64;
+  int w = 0;
+  for (int64_t i = 0; i < a.nrow; i++) w = std::max<int>(w, (int)(a.rowptr[i + 1] - a.rowptr[i]));
+  e.width = w;
+  if (w == 0 || a.nrow == 0) return 0;
+  std::vector<int32_t> col((size_t)w * e.pitch);
+  std::vector<double> val((size_t)w * e.pitch, 0.0);
+  for (int k = 0; k < w; k++)
+    for (int64_t i = 0; i < e.pitch; i++) col[(size_t)k * e.pitch + i] = (int32_t)std::min(i, a.nrow - 1);
+  for (int64_t i = 0; i < a.nrow; i++) {
+    int k = 0;
+    for (int64_t p = a.rowptr[i]; p < a.rowptr[i + 1]; p++, k++) {
+      col[(size_t)k * e.pitch + i] = a.col[p];
+      val[(size_t)k * e.pitch + i] = a.val[p];
+    }
+  }
+  if (dev_upload(&e.col, col.data(), col.size())) return 1;
+  if (dev_upload(&e.val, val.data(), val.size())) return 1;
+  return 0;
+}
+
+static std::string check_csr(int64_t nrow, int64_t ncol, const int64_t* rowptr, const int32_t* col,
+                             const char* what) {
+  if (!rowptr) return std::string(what) + ": rowptr is NULL";
+  if (rowptr[0] != 0) return std::string(what) + ": rowptr[0] != 0";
+  for (int64_t i = 0; i < nrow; i++)
+    if (rowptr[i + 1] < rowptr[i]) return std::string(what) + ": rowptr not monotone";
+  const int64_t nnz = rowptr[nrow];
+  if (nnz > 0 && !col) return std::string(what) + ": col is NULL";
+  for (int64_t k = 0; k < nnz; k++)
+    if (col[k] < 0 || col[k] >= ncol) return std::string(what) + ": column index out of range";
+  return "";
+}
+
+static int finish_handle(edigpu_sector* s) {
+  EDIGPU_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  return 0;
+}
+
+static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_t dw_first,
+                        int64_t dw_count, const double* hd, const HostCsr& up, const HostCsr& dw,
+                        const int64_t* nd_rowptr, const int32_t* nd_col, const double* nd_val) {
+  s->kind = 0;
+  s->is_complex = 0;
+  s->device = g_device;
+  s->dim_up = dim_up;
+  s->dim_dw = dim_dw;
+  s->dw_first = dw_first;
+  s->dw_count = dw_count;
+  s->dim = dim_up * dim_dw;
+  s->nloc = dim_up * dw_count;
+  s->row_first = dw_first * dim_up;
+  s->h_up = up;
+  s->h_dw = dw;
+  if (dev_upload(&s->d_hd, hd, (size_t)s->nloc)) return 1;
+  if (upload_ell(s->up_ell, up)) return 1;
+  if (upload_csr(s->dw, dim_dw, dw.rowptr.data(), dw.col.data(), dw.val.data(), 0)) return 1;
+  s->has_nd = nd_rowptr != nullptr && nd_rowptr[s->nloc] > 0;
+  if (s->has_nd && upload_csr(s->nd, s->nloc, nd_rowptr, nd_col, nd_val, 0)) return 1;
+  s->rows_per_block = normal_pick_rows_per_block(dim_up, dw_count);
+  return finish_handle(s);
+}
+
+// split a local-row CSR with global columns into shard-local and non-local blocks
+static int setup_flat(edigpu_sector* s, int64_t nrow_local, int64_t ncol_global, int64_t row_first,
+                      const int64_t* rowptr, const int32_t* col, const double* val, int cplx) {
+  s->kind = 1;
+  s->is_complex = cplx;
+  s->device = g_device;
+  s->dim = ncol_global;
+  s->nloc = nrow_local;
+  s->row_first = row_first;
+  const int w = cplx ? 2 : 1;
+  const int64_t lo = row_first, hi = row_first + nrow_local;
+  std::vector<int64_t> rpl((size_t)nrow_local + 1, 0), rpn((size_t)nrow_local + 1, 0);
+  for (int64_t i = 0; i < nrow_local; i++) {
+    int64_t nl = 0;
+    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; k++)
+      if (col[k] >= lo && col[k] < hi) nl++;
+    rpl[i + 1] = rpl[i] + nl;
+    rpn[i + 1] = rpn[i] + (rowptr[i + 1] - rowptr[i] - nl);
+  }
+  std::vector<int32_t> cl((size_t)rpl[nrow_local]), cn((size_t)rpn[nrow_local]);
+  std::vector<double> vl((size_t)rpl[nrow_local] * w), vn((size_t)rpn[nrow_local] * w);
+  for (int64_t i = 0; i < nrow_local; i++) {
+    int64_t pl = rpl[i], pn = rpn[i];
+    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; k++) {
+      if (col[k] >= lo && col[k] < hi) {
+        cl[pl] = (int32_t)(col[k] - lo);
+        for (int q = 0; q < w; q++) vl[pl * w + q] = val[k * w + q];
+        pl++;
+      } else {
+        cn[pn] = col[k];
+        for (int q = 0; q < w; q++) vn[pn * w + q] = val[k * w + q];
+        pn++;
+      }
+    }
+  }
+  if (upload_csr(s->loc, nrow_local, rpl.data(), cl.data(), vl.data(), cplx)) return 1;
+  if (upload_csr(s->nonloc, nrow_local, rpn.data(), cn.data(), vn.data(), cplx)) return 1;
+  return finish_handle(s);
+}
+
+static int ensure_workspace(edigpu_sector* s) {
+  const int64_t len = s->nloc * (s->is_complex ? 2 : 1);
+  if (s->d_vin && s->ws_len == len) return 0;
+  dev_free(s->d_vin);
+  dev_free(s->d_vout);
+  dev_free(s->d_tmp);
+  dev_free(s->d_partial);
+  dev_free(s->d_scal);
+  const size_t n = (size_t)std::max<int64_t>(len, 1);
+  EDIGPU_HIP(hipMalloc((void**)&s->d_vin, n * sizeof(double)));
+  EDIGPU_HIP(hipMalloc((void**)&s->d_vout, n * sizeof(double)));
+  EDIGPU_HIP(hipMalloc((void**)&s->d_tmp, n * sizeof(double)));
+  EDIGPU_HIP(hipMalloc((void**)&s->d_partial, kRedBlocks * sizeof(double)));
+  s->ws_len = len;
+  return 0;
+}
+
+static int apply_any(edigpu_sector* s, const double* v_local, const double* v_full, double* hv,
+                     int phase, hipStream_t st) {
+  if (s->kind == 0) return launch_normal(s, v_local, v_full, hv, phase, st);
+  // flat: loc block then non-local block
+  if (phase & 1) {
+    if (launch_csr(s->loc, s->is_complex, v_local, hv, 0, st)) return 1;
+  }
+  if (phase & 2) {
+    if (launch_csr(s->nonloc, s->is_complex, v_full, hv, 1, st)) return 1;
+  }
+  return 0;
+}
+
+static int single_shard(const edigpu_sector* s, const char* who) {
+  if (s->nloc != s->dim) {
+    set_error(std::string(who) + ": handle is a shard (local rows != global dim); use the _dev entry points");
+    return 1;
+  }
+  return 0;
+}
+
+// symmetric tridiagonal eigen-decomposition (implicit QL).  d: diagonal (n), e: sub-diagonal
+// e[1..n-1] (e[0] unused).  On return d holds eigenvalues, z (n*n, column-major) eigenvectors.
+static int tql2(int n, std::vector<double>& d, std::vector<double>& e, std::vector<double>& z) {
+  z.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; i++) z[(size_t)i * n + i] = 1.0;
+  for (int i = 1; i < n; i++) e[i - 1] = e[i];
+  if (n > 0) e[n - 1] = 0.0;
+  for (int l = 0; l < n; l++) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; m++) {
+        const double dd = fabs(d[m]) + fabs(d[m + 1]);
+        if (fabs(e[m]) <= 2.3e-16 * dd) break;
+      }
+      if (m != l) {
+        if (iter++ == 200) return 1;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + (g >= 0 ? fabs(r) : -fabs(r)));
+        double sn = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; i--) {
+          double f = sn * e[i], b = c * e[i];
+          e[i + 1] = (r = hypot(f, g));
+          if (r == 0.0) {
+            d[i + 1] -= p;
+            e[m] = 0.0;
+            break;
+          }
+          sn = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * sn + 2.0 * c * b;
+          d[i + 1] = g + (p = sn * r);
+          g = c * r - b;
+          for (int k = 0; k < n; k++) {
+            f = z[(size_t)(i + 1) * n + k];
+            z[(size_t)(i + 1) * n + k] = sn * z[(size_t)i * n + k] + c * f;
+            z[(size_t)i * n + k] = c * z[(size_t)i * n + k] - sn * f;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  return 0;
+}
+
+// enqueue one Lanczos step (iter is 0-based); vin/vout/tmp live in the workspace
+static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
+  const int64_t len = s->ws_len;
+  if (iter > 0 && lz_rotate(s->d_vin, s->d_vout, len, s->d_scal, st)) return 1;
+  if (apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st)) return 1;
+  if (lz_alpha(s->d_vin, s->d_vout, s->d_tmp, len, s->d_partial, s->d_scal, iter, nlanc, st)) return 1;
+  if (lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, iter, nlanc, st)) return 1;
+  return 0;
+}
+
+static int lanczos_prepare(edigpu_sector* s, int nlanc, double threshold, hipStream_t st) {
+  dev_free(s->d_scal);
+  const size_t ns = (size_t)SC_AB + 2 * (size_t)nlanc;
+  EDIGPU_HIP(hipMalloc((void**)&s->d_scal, ns * sizeof(double)));
+  EDIGPU_HIP(hipMemsetAsync(s->d_scal, 0, ns * sizeof(double), st));
+  EDIGPU_HIP(hipMemcpyAsync(s->d_scal + SC_THR, &threshold, sizeof(double), hipMemcpyHostToDevice, st));
+  EDIGPU_HIP(hipMemsetAsync(s->d_vout, 0, (size_t)s->ws_len * sizeof(double), st));
+  return 0;
+}
+
+}  // namespace edigpu
+
+using namespace edigpu;
+
+extern "C" {
+
+const char* edigpu_last_error(void) { return g_err.c_str(); }
+
+int edigpu_version(void) { return 100; }
+
+int edigpu_device_count(int* count) {
+  int n = 0;
+  int rc = ensure_device(&n);
+  if (count) *count = n;
+  return rc;
+}
+
+int edigpu_init(int device) {
+  int n = 0;
+  if (ensure_device(&n)) return 1;
+  if (device < 0 || device >= n) {
+    set_error("edigpu_init: device index out of range");
+    return 1;
+  }
+  EDIGPU_HIP(hipSetDevice(device));
+  g_device = device;
+  return 0;
+}
+
+int edigpu_normal_create(edigpu_handle* h, int64_t dim_up, int64_t dim_dw, int64_t dw_first,
+                         int64_t dw_count, const double* hd, const int64_t* up_rowptr,
+                         const int32_t* up_col, const double* up_val, const int64_t* dw_rowptr,
+                         const int32_t* dw_col, const double* dw_val, const int64_t* nd_rowptr,
+                         const int32_t* nd_col, const double* nd_val) {
+  if (!h) {
+    set_error("edigpu_normal_create: handle pointer is NULL");
+    return 1;
+  }
+  *h = nullptr;
+  if (ensure_device()) return 1;
+  if (dim_up <= 0 || dim_dw <= 0 || dw_first < 0 || dw_count < 0 || dw_first + dw_count > dim_dw) {
+    set_error("edigpu_normal_create: inconsistent dimensions");
+    return 1;
+  }
+  if (dim_up * dim_dw >= ((int64_t)1 << 31)) {
+    set_error("edigpu_normal_create: sector dimension >= 2^31");
+    return 1;
+  }
+  if (!hd && dw_count > 0) {
+    set_error("edigpu_normal_create: hd is NULL");
+    return 1;
+  }
+  std::string e = check_csr(dim_up, dim_up, up_rowptr, up_col, "edigpu_normal_create(up)");
+  if (e.empty()) e = check_csr(dim_dw, dim_dw, dw_rowptr, dw_col, "edigpu_normal_create(dw)");
+  if (e.empty() && nd_rowptr)
+    e = check_csr(dim_up * dw_count, dim_up * dim_dw, nd_rowptr, nd_col, "edigpu_normal_create(nd)");
+  if (!e.empty()) {
+    set_error(e);
+    return 1;
+  }
+  HostCsr up, dw;
+  up.nrow = up.ncol = dim_up;
+  up.rowptr.assign(up_rowptr, up_rowptr + dim_up + 1);
+  up.col.assign(up_col, up_col + up_rowptr[dim_up]);
+  up.val.assign(up_val, up_val + up_rowptr[dim_up]);
+  dw.nrow = dw.ncol = dim_dw;
+  dw.rowptr.assign(dw_rowptr, dw_rowptr + dim_dw + 1);
+  dw.col.assign(dw_col, dw_col + dw_rowptr[dim_dw]);
+  dw.val.assign(dw_val, dw_val + dw_rowptr[dim_dw]);
+  std::unique_ptr<edigpu_sector> s(new edigpu_sector());
+  if (setup_normal(s.get(), dim_up, dim_dw, dw_first, dw_count, hd, up, dw, nd_rowptr, nd_col, nd_val)) {
+    edigpu_destroy(s.release());
+    return 1;
+  }
+  *h = s.release();
+  return 0;
+}
+
+static int csr_create_any(edigpu_handle* h, int64_t nrow_local, int64_t ncol_global,
+                          int64_t row_first, const int64_t* rowptr, const int32_t* col,
+                          const double* val, int cplx) {
+  if (!h) {
+    set_error("edigpu_csr_create: handle pointer is NULL");
+    return 1;
+  }
+  *h = nullptr;
+  if (ensure_device()) return 1;
+  if (nrow_local < 0 || ncol_global <= 0 || row_first < 0 || row_first + nrow_local > ncol_global) {
+    set_error("edigpu_csr_create: inconsistent dimensions");
+    return 1;
+  }
+  if (ncol_global >= ((int64_t)1 << 31)) {
+    set_error("edigpu_csr_create: dimension >= 2^31");
+    return 1;
+  }
+  std::string e = check_csr(nrow_local, ncol_global, rowptr, col, "edigpu_csr_create");
+  if (!e.empty()) {
+    set_error(e);
+    return 1;
+  }
+  std::unique_ptr<edigpu_sector> s(new edigpu_sector());
+  if (setup_flat(s.get(), nrow_local, ncol_global, row_first, rowptr, col, val, cplx)) {
+    edigpu_destroy(s.release());
+    return 1;
+  }
+  *h = s.release();
+  return 0;
+}
+
+int edigpu_csr_create_d(edigpu_handle* h, int64_t nrow_local, int64_t ncol_global,
+                        int64_t row_first, const int64_t* rowptr, const int32_t* col,
+                        const double* val) {
+  return csr_create_any(h, nrow_local, ncol_global, row_first, rowptr, col, val, 0);
+}
+
+int edigpu_csr_create_z(edigpu_handle* h, int64_t nrow_local, int64_t ncol_global,
+                        int64_t row_first, const int64_t* rowptr, const int32_t* col,
+                        const double* val_re_im) {
+  return csr_create_any(h, nrow_local, ncol_global, row_first, rowptr, col, val_re_im, 1);
+}
+
+int edigpu_normal_build(edigpu_handle* h, const edigpu_model* model, int nup, int ndw,
+                        int64_t dw_first, int64_t dw_count) {
+  if (!h || !model) {
+    set_error("edigpu_normal_build: NULL argument");
+    return 1;
+  }
+  *h = nullptr;
+  if (ensure_device()) return 1;
+  HostNormal hn;
+  std::string e = build_normal(*model, nup, ndw, dw_first, dw_count, hn);
+  if (!e.empty()) {
+    set_error(e);
+    return 1;
+  }
+  std::unique_ptr<edigpu_sector> s(new edigpu_sector());
+  if (setup_normal(s.get(), hn.dim_up, hn.dim_dw, hn.dw_first, hn.dw_count, hn.hd.data(), hn.up,
+                   hn.dw, hn.has_nd ? hn.nd.rowptr.data() : nullptr, hn.nd.col.data(),
+                   hn.nd.val.data())) {
+    edigpu_destroy(s.release());
+    return 1;
+  }
+  *h = s.release();
+  return 0;
+}
+
+int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, int64_t row_first,
+                      int64_t row_count) {
+  if (!h || !model) {
+    set_error("edigpu_flat_build: NULL argument");
+    return 1;
+  }
+  *h = nullptr;
+  if (ensure_device()) return 1;
+  HostFlat hf;
+  std::string e = build_flat(*model, sector, row_first, row_count, hf);
+  if (!e.empty()) {
+    set_error(e);
+    return 1;
+  }
+  if (hf.dim == 0) {
+    set_error("edigpu_flat_build: empty sector");
+    return 1;
+  }
+  std::unique_ptr<edigpu_sector> s(new edigpu_sector());
+  if (setup_flat(s.get(), hf.row_count, hf.dim, hf.row_first, hf.h.rowptr.data(), hf.h.col.data(),
+                 hf.h.val.data(), 1)) {
+    edigpu_destroy(s.release());
+    return 1;
+  }
+  *h = s.release();
+  return 0;
+}
+
+int edigpu_sector_dim(const edigpu_model* model, int q1, int q2, int64_t* dim) {
+  if (!model || !dim) {
+    set_error("edigpu_sector_dim: NULL argument");
+    return 1;
+  }
+  std::string e = sector_dim(*model, q1, q2, *dim);
+  if (!e.empty()) {
+    set_error(e);
+    return 1;
+  }
+  return 0;
+}
+
+int edigpu_info(edigpu_handle s, int64_t info[10]) {
+  if (!s || !info) {
+    set_error("edigpu_info: NULL argument");
+    return 1;
+  }
+  info[0] = s->dim;
+  info[1] = s->nloc;
+  info[2] = s->row_first;
+  info[3] = s->is_complex;
+  info[4] = s->kind;
+  info[5] = s->dim_up;
+  info[6] = s->dim_dw;
+  if (s->kind == 0) {
+    info[7] = s->h_up.nnz() + s->h_dw.nnz();
+    info[8] = s->has_nd ? s->nd.nnz : 0;
+  } else {
+    info[7] = s->loc.nnz;
+    info[8] = s->nonloc.nnz;
+  }
+  info[9] = s->device;
+  return 0;
+}
+
+int edigpu_algorithmic_bytes(edigpu_handle s, double* bytes_hv, double* bytes_step) {
+  if (!s) {
+    set_error("edigpu_algorithmic_bytes: NULL handle");
+    return 1;
+  }
+  // reference storage format, every array read once, v read once, Hv written once
+  double b = 0.0;
+  const double sz = s->is_complex ? 16.0 : 8.0;
+  if (s->kind == 0) {
+    const double n = (double)s->nloc;
+    b = 3.0 * sz * n;
+    if (s->has_nd) b += (sz + 4.0) * (double)s->nd.nnz + 4.0 * (n + 1.0);
+    b += (sz + 4.0) * (double)(s->h_up.nnz() + s->h_dw.nnz()) + 4.0 * (double)(s->dim_up + s->dim_dw + 2);
+  } else {
+    const double n = (double)s->nloc;
+    b = (sz + 4.0) * (double)(s->loc.nnz + s->nonloc.nnz) + 4.0 * (n + 1.0) + 2.0 * sz * n;
+  }
+  if (bytes_hv) *bytes_hv = b;
+  if (bytes_step) *bytes_step = b + 3.0 * sz * (double)s->nloc;
+  return 0;
+}
+
+static int download_csr(const DevCsr& d, int64_t* rowptr, int32_t* col, double* val, int w) {
+  if (rowptr) {
+    if (d.nrow == 0) {
+      rowptr[0] = 0;
+    } else if (d.wide) {
+      EDIGPU_HIP(hipMemcpy(rowptr, d.rowptr64, ((size_t)d.nrow + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    } else {
+      std::vector<int32_t> rp((size_t)d.nrow + 1);
+      EDIGPU_HIP(hipMemcpy(rp.data(), d.rowptr32, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i <= d.nrow; i++) rowptr[i] = rp[i];
+    }
+  }
+  if (col && d.nnz) EDIGPU_HIP(hipMemcpy(col, d.col, (size_t)d.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (val && d.nnz) EDIGPU_HIP(hipMemcpy(val, d.val, (size_t)d.nnz * w * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int edigpu_normal_export(edigpu_handle s, double* hd, int64_t* up_rowptr, int32_t* up_col,
+                         double* up_val, int64_t* dw_rowptr, int32_t* dw_col, double* dw_val,
+                         int64_t* nd_rowptr, int32_t* nd_col, double* nd_val) {
+  if (!s || s->kind != 0) {
+    set_error("edigpu_normal_export: not a normal-mode handle");
+    return 1;
+  }
+  EDIGPU_HIP(hipSetDevice(s->device));
+  if (hd && s->nloc) EDIGPU_HIP(hipMemcpy(hd, s->d_hd, (size_t)s->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  auto cp = [](const HostCsr& a, int64_t* rp, int32_t* c, double* v) {
+    if (rp) std::copy(a.rowptr.begin(), a.rowptr.end(), rp);
+    if (c) std::copy(a.col.begin(), a.col.end(), c);
+    if (v) std::copy(a.val.begin(), a.val.end(), v);
+  };
+  cp(s->h_up, up_rowptr, up_col, up_val);
+  cp(s->h_dw, dw_rowptr, dw_col, dw_val);
+  if (s->has_nd) return download_csr(s->nd, nd_rowptr, nd_col, nd_val, 1);
+  if (nd_rowptr)
+    for (int64_t i = 0; i <= s->nloc; i++) nd_rowptr[i] = 0;
+  return 0;
+}
+
+int edigpu_csr_export(edigpu_handle s, int64_t* rowptr, int32_t* col, double* val) {
+  if (!s || s->kind != 1) {
+    set_error("edigpu_csr_export: not a flat-CSR handle");
+    return 1;
+  }
+  EDIGPU_HIP(hipSetDevice(s->device));
+  const int w = s->is_complex ? 2 : 1;
+  const int64_t n = s->nloc;
+  std::vector<int64_t> rl((size_t)n + 1), rn((size_t)n + 1);
+  std::vector<int32_t> cl((size_t)s->loc.nnz), cn((size_t)s->nonloc.nnz);
+  std::vector<double> vl((size_t)s->loc.nnz * w), vn((size_t)s->nonloc.nnz * w);
+  if (download_csr(s->loc, rl.data(), cl.data(), vl.data(), w)) return 1;
+  if (download_csr(s->nonloc, rn.data(), cn.data(), vn.data(), w)) return 1;
+  int64_t p = 0;
+  if (rowptr) rowptr[0] = 0;
+  for (int64_t i = 0; i < n; i++) {
+    for (int64_t k = rl[i]; k < rl[i + 1]; k++, p++) {
+      if (col) col[p] = (int32_t)(cl[k] + s->row_first);
+      if (val)
+        for (int q = 0; q < w; q++) val[p * w + q] = vl[k * w + q];
+    }
+    for (int64_t k = rn[i]; k < rn[i + 1]; k++, p++) {
+      if (col) col[p] = cn[k];
+      if (val)
+        for (int q = 0; q < w; q++) val[p * w + q] = vn[k * w + q];
+    }
+    if (rowptr) rowptr[i + 1] = p;
+  }
+  return 0;
+}
+
+static int apply_host(edigpu_handle s, int64_t nloc, const double* v_host, double* hv_host, int cplx) {
+  if (!s || !v_host || !hv_host) {
+    set_error("edigpu_apply: NULL argument");
+    return 1;
+  }
+  if ((s->is_complex != 0) != (cplx != 0)) {
+    set_error("edigpu_apply: real/complex mismatch between handle and entry point");
+    return 1;
+  }
+  if (nloc != s->nloc) {
+    set_error("edigpu_apply: Nloc does not match the handle's local dimension");
+    return 1;
+  }
+  if (single_shard(s, "edigpu_apply")) return 1;
+  EDIGPU_HIP(hipSetDevice(s->device));
+  if (ensure_workspace(s)) return 1;
+  const size_t bytes = (size_t)s->ws_len * sizeof(double);
+  EDIGPU_HIP(hipMemcpyAsync(s->d_vin, v_host, bytes, hipMemcpyHostToDevice, s->stream));
+  if (apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, s->stream)) return 1;
+  EDIGPU_HIP(hipMemcpyAsync(hv_host, s->d_tmp, bytes, hipMemcpyDeviceToHost, s->stream));
+  EDIGPU_HIP(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+int edigpu_apply_d(edigpu_handle h, int64_t nloc, const double* v_host, double* hv_host) {
+  return apply_host(h, nloc, v_host, hv_host, 0);
+}
+
+int edigpu_apply_z(edigpu_handle h, int64_t nloc, const double* v_host, double* hv_host) {
+  return apply_host(h, nloc, v_host, hv_host, 1);
+}
+
+int edigpu_apply_dev(edigpu_handle s, const void* v_full_dev, void* hv_dev, void* stream) {
+  if (!s || !v_full_dev || !hv_dev) {
+    set_error("edigpu_apply_dev: NULL argument");
+    return 1;
+  }
+  hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  const int w = s->is_complex ? 2 : 1;
+  const double* vf = (const double*)v_full_dev;
+  return apply_any(s, vf + s->row_first * w, vf, (double*)hv_dev, 3, st);
+}
+
+int edigpu_apply_local_dev(edigpu_handle s, const void* v_local_dev, void* hv_dev, void* stream) {
+  if (!s || !v_local_dev || !hv_dev) {
+    set_error("edigpu_apply_local_dev: NULL argument");
+    return 1;
+  }
+  hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  return apply_any(s, (const double*)v_local_dev, nullptr, (double*)hv_dev, 1, st);
+}
+
+int edigpu_apply_remote_dev(edigpu_handle s, const void* v_full_dev, void* hv_dev, void* stream) {
+  if (!s || !v_full_dev || !hv_dev) {
+    set_error("edigpu_apply_remote_dev: NULL argument");
+    return 1;
+  }
+  hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  return apply_any(s, nullptr, (const double*)v_full_dev, (double*)hv_dev, 2, st);
+}
+
+int edigpu_lanczos_tridiag(edigpu_handle s, const double* vin_host, int nlanc, double* alanc,
+                           double* blanc, double threshold, int* niter_done) {
+  if (!s || !vin_host || !alanc || !blanc || nlanc <= 0) {
+    set_error("edigpu_lanczos_tridiag: bad argument");
+    return 1;
+  }
+  if (single_shard(s, "edigpu_lanczos_tridiag")) return 1;
+  EDIGPU_HIP(hipSetDevice(s->device));
+  if (ensure_workspace(s)) return 1;
+  hipStream_t st = s->stream;
+  if (lanczos_prepare(s, nlanc, threshold, st)) return 1;
+  EDIGPU_HIP(hipMemcpyAsync(s->d_vin, vin_host, (size_t)s->ws_len * sizeof(double), hipMemcpyHostToDevice, st));
+  if (lz_norm_begin(s->d_vin, s->ws_len, s->d_partial, s->d_scal, st)) return 1;
+  for (int it = 0; it < nlanc; it++)
+    if (lanczos_step(s, it, nlanc, st)) return 1;
+  std::vector<double> sc((size_t)SC_AB + 2 * (size_t)nlanc);
+  EDIGPU_HIP(hipMemcpyAsync(sc.data(), s->d_scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  EDIGPU_HIP(hipStreamSynchronize(st));
+  for (int k = 0; k < nlanc; k++) {
+    alanc[k] = sc[SC_AB + k];
+    blanc[k] = sc[SC_AB + nlanc + k];
+  }
+  if (niter_done) *niter_done = (int)sc[SC_NDONE];
+  return 0;
+}
+
+int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_every,
+                        const double* v0_host, double* eval, double* evec_host, int* niter_done) {
+  if (!s || !eval || nitermax <= 0) {
+    set_error("edigpu_lanczos_eigh: bad argument");
+    return 1;
+  }
+  if (single_shard(s, "edigpu_lanczos_eigh")) return 1;
+  EDIGPU_HIP(hipSetDevice(s->device));
+  if (ensure_workspace(s)) return 1;
+  if (check_every <= 0) check_every = 10;
+  if ((int64_t)nitermax > s->nloc) nitermax = (int)s->nloc;
+  hipStream_t st = s->stream;
+  const int64_t len = s->ws_len;
+  const size_t vbytes = (size_t)len * sizeof(double);
+  // keep the normalised start vector for the second pass
+  double* d_v0 = nullptr;
+  EDIGPU_HIP(hipMalloc((void**)&d_v0, vbytes));
+  auto fail = [&](void) {
+    (void)hipFree(d_v0);
+    return 1;
+  };
+  if (lanczos_prepare(s, nitermax, 0.0, st)) return fail();
+  if (v0_host) {
+    if (hipMemcpyAsync(s->d_vin, v0_host, vbytes, hipMemcpyHostToDevice, st) != hipSuccess) return fail();
+  } else if (lz_fill_random(s->d_vin, len, 0x5eed1234ull, st)) {
+    return fail();
+  }
+  if (lz_norm_begin(s->d_vin, len, s->d_partial, s->d_scal, st)) return fail();
+  if (hipMemcpyAsync(d_v0, s->d_vin, vbytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail();
+
+  std::vector<double> sc((size_t)SC_AB + 2 * (size_t)nitermax), d, e, z;
+  double e_old = 0.0;
+  int ndone = 0;
+  bool have = false, conv = false;
+  for (int it = 0; it < nitermax && !conv; it++) {
+    if (lanczos_step(s, it, nitermax, st)) return fail();
+    if ((it + 1) % check_every == 0 || it + 1 == nitermax) {
+      if (hipMemcpyAsync(sc.data(), s->d_scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess)
+        return fail();
+      if (hipStreamSynchronize(st) != hipSuccess) return fail();
+      ndone = (int)sc[SC_NDONE];
+      if (ndone == 0) break;
+      d.assign(sc.begin() + SC_AB, sc.begin() + SC_AB + ndone);
+      e.assign(sc.begin() + SC_AB + nitermax, sc.begin() + SC_AB + nitermax + ndone);
+      if (tql2(ndone, d, e, z)) {
+        set_error("edigpu_lanczos_eigh: tridiagonal QL did not converge");
+        return fail();
+      }
+      const double e_new = *std::min_element(d.begin(), d.end());
+      if (have && fabs(e_new - e_old) < tol) conv = true;
+      if (sc[SC_STOP] != 0.0) conv = true;  // invariant subspace reached
+      e_old = e_new;
+      have = true;
+    }
+  }
+  if (ndone == 0) {
+    set_error("edigpu_lanczos_eigh: zero start vector");
+    return fail();
+  }
+  *eval = e_old;
+  if (niter_done) *niter_done = ndone;
+  if (evec_host) {
+    // Ritz vector = sum_k y_k v_k : regenerate the v_k with the same (deterministic) kernels
+    const int kmin = (int)(std::min_element(d.begin(), d.end()) - d.begin());
+    std::vector<double> y(ndone);
+    for (int k = 0; k < ndone; k++) y[k] = z[(size_t)kmin * ndone + k];
+    double* d_acc = nullptr;
+    if (hipMalloc((void**)&d_acc, vbytes) != hipSuccess) {
+      set_error("edigpu_lanczos_eigh: out of device memory");
+      return fail();
+    }
+    (void)hipMemsetAsync(d_acc, 0, vbytes, st);
+    (void)hipMemcpyAsync(s->d_vin, d_v0, vbytes, hipMemcpyDeviceToDevice, st);
+    if (lanczos_prepare(s, ndone, 0.0, st)) {
+      (void)hipFree(d_acc);
+      return fail();
+    }
+    int rc = 0;
+    for (int it = 0; it < ndone && !rc; it++) {
+      if (it > 0) rc |= lz_rotate(s->d_vin, s->d_vout, len, s->d_scal, st);
+      rc |= lz_axpy_coef(d_acc, s->d_vin, len, y[it], s->d_scal, -1, st);
+      if (it + 1 < ndone) {
+        rc |= apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st);
+        rc |= lz_alpha(s->d_vin, s->d_vout, s->d_tmp, len, s->d_partial, s->d_scal, it, ndone, st);
+        rc |= lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, it, ndone, st);
+      }
+    }
+    // normalise
+    if (!rc) rc |= lz_norm_begin(d_acc, len, s->d_partial, s->d_scal, st);
+    if (!rc && hipMemcpyAsync(evec_host, d_acc, vbytes, hipMemcpyDeviceToHost, st) != hipSuccess) rc = 1;
+    if (hipStreamSynchronize(st) != hipSuccess) rc = 1;
+    (void)hipFree(d_acc);
+    if (rc) {
+      if (g_err.empty()) set_error("edigpu_lanczos_eigh: second pass failed");
+      return fail();
+    }
+  }
+  (void)hipFree(d_v0);
+  return 0;
+}
+
+int edigpu_time_apply(edigpu_handle s, int warmup, int steps, int lanczos, double* ms_per_step) {
+  if (!s || steps <= 0 || !ms_per_step) {
+    set_error("edigpu_time_apply: bad argument");
+    return 1;
+  }
+  if (single_shard(s, "edigpu_time_apply")) return 1;
+  EDIGPU_HIP(hipSetDevice(s->device));
+  if (ensure_workspace(s)) return 1;
+  hipStream_t st = s->stream;
+  const int64_t len = s->ws_len;
+  const int total = warmup + steps;
+  if (lanczos_prepare(s, std::max(total, 1), 0.0, st)) return 1;
+  if (lz_fill_random(s->d_vin, len, 12345ull, st)) return 1;
+  if (lz_norm_begin(s->d_vin, len, s->d_partial, s->d_scal, st)) return 1;
+  hipEvent_t e0, e1;
+  EDIGPU_HIP(hipEventCreate(&e0));
+  EDIGPU_HIP(hipEventCreate(&e1));
+  int rc = 0;
+  for (int it = 0; it < total && !rc; it++) {
+    if (it == warmup) rc |= (hipEventRecord(e0, st) != hipSuccess);
+    if (lanczos) {
+      rc |= lanczos_step(s, it, total, st);
+    } else {
+      // fixed source vector -> fixed destination: the plain SpMV measurement
+      rc |= apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st);
+    }
+  }
+  if (!rc) rc |= (hipEventRecord(e1, st) != hipSuccess);
+  if (!rc) rc |= (hipEventSynchronize(e1) != hipSuccess);
+  float ms = 0.f;
+  if (!rc) rc |= (hipEventElapsedTime(&ms, e0, e1) != hipSuccess);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc) {
+    if (g_err.empty()) set_error("edigpu_time_apply: HIP failure");
+    return 1;
+  }
+  *ms_per_step = (double)ms / (double)steps;
+  return 0;
+}
+
+int edigpu_destroy(edigpu_handle s) {
+  if (!s) return 0;
+  (void)hipSetDevice(s->device);
+  if (s->stream) {
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipStreamDestroy(s->stream);
+  }
+  dev_free(s->d_hd);
+  dev_free(s->up_ell.col);
+  dev_free(s->up_ell.val);
+  free_csr(s->dw);
+  free_csr(s->nd);
+  free_csr(s->loc);
+  free_csr(s->nonloc);
+  dev_free(s->d_vin);
+  dev_free(s->d_vout);
+  dev_free(s->d_tmp);
+  dev_free(s->d_partial);
+  dev_free(s->d_scal);
+  delete s;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// edigpu_internal.hpp -- internal types of the gfx950 H*v engine (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/edigpu.h"
+#include "host_build.hpp"
+
+namespace edigpu {
+
+void set_error(const std::string& msg);
+
+#define EDIGPU_HIP(call)                                                                     \
+  do {                                                                                       \
+    hipError_t _e = (call);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      ::edigpu::set_error(std::string(#call) + " failed: " + hipGetErrorString(_e) + " (" +  \
+                          __FILE__ + ":" + std::to_string(__LINE__) + ")");                  \
+      return 1;                                                                              \
+    }                                                                                        \
+  } while (0)
+
+// device CSR with 32-bit or 64-bit row pointers (64-bit only when nnz >= 2^31)
+struct DevCsr {
+  int64_t nrow = 0, nnz = 0;
+  int wide = 0;             // 1: rowptr64 used
+  int32_t* rowptr32 = nullptr;
+  int64_t* rowptr64 = nullptr;
+  int32_t* col = nullptr;
+  double* val = nullptr;    // nnz (real) or 2*nnz (complex)
+  double avg_row = 0.0;
+};
+
+// ELL (column-major [slot][row]) image of a small square factor matrix
+struct DevEll {
+  int64_t nrow = 0, pitch = 0;
+  int width = 0;
+  int32_t* col = nullptr;   // width*pitch, padding: col=row, val=0
+  double* val = nullptr;
+};
+
+}  // namespace edigpu
+
+struct edigpu_sector {
+  int kind = 0;        // 0 normal (Kronecker), 1 flat CSR
+  int is_complex = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t dim = 0, nloc = 0, row_first = 0;
+  // ---- normal ----
+  int64_t dim_up = 0, dim_dw = 0, dw_first = 0, dw_count = 0;
+  double* d_hd = nullptr;
+  edigpu::DevEll up_ell;
+  edigpu::DevCsr dw;          // DimDw rows
+  edigpu::DevCsr nd;          // local rows, global columns
+  int has_nd = 0;
+  edigpu::HostCsr h_up, h_dw; // kept for export (tiny)
+  int rows_per_block = 1;     // TD of the LDS row-block kernel (0: generic kernel)
+  // ---- flat ----
+  edigpu::DevCsr loc, nonloc; // local rows; loc columns are shard-relative, nonloc global
+  // ---- Lanczos workspace (lazily allocated) ----
+  double* d_vin = nullptr;
+  double* d_vout = nullptr;
+  double* d_tmp = nullptr;
+  double* d_partial = nullptr;  // reduction partials
+  double* d_scal = nullptr;     // alpha/beta/flags on device
+  int64_t ws_len = 0;           // in doubles per vector
+};

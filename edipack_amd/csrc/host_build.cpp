@@ -1,0 +1,574 @@
+// host_build.cpp -- see host_build.hpp.  Product code; shares nothing with oracle/.
+#include "host_build.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstring>
+
+namespace edigpu {
+
+using cplx = std::complex<double>;
+
+int model_ns(const edigpu_model& m) {
+  // Ns as in ed_setup_dimensions (ED_SETUP.f90:118-126)
+  return m.bath_type == 1 ? m.nbath + m.norb : (m.nbath + 1) * m.norb;
+}
+
+int64_t binomial(int n, int k) {
+  if (k < 0 || k > n) return 0;
+  k = std::min(k, n - k);
+  __int128 r = 1;
+  for (int i = 1; i <= k; i++) r = r * (n - k + i) / i;
+  return (int64_t)r;
+}
+
+static inline int popc(uint32_t x) { return __builtin_popcount(x); }
+
+void CombBasis::init(int nbits_, int npart_) {
+  nbits = nbits_;
+  npart = npart_;
+  hbits = nbits / 2;
+  const int64_t n = binomial(nbits, npart);
+  states.resize(n);
+  off_hi.assign((size_t)1 << (nbits - hbits), 0);
+  rank_lo.assign((size_t)1 << hbits, 0);
+  if (n == 0) return;
+  // ascending enumeration of fixed-popcount words (next-combination bit trick)
+  uint32_t m = npart == 0 ? 0u : ((1u << npart) - 1u);
+  const uint32_t lomask = (1u << hbits) - 1u;
+  uint32_t last_hi = 0xffffffffu;
+  for (int64_t k = 0; k < n; k++) {
+    states[k] = (int32_t)m;
+    uint32_t hi = m >> hbits, lo = m & lomask;
+    if (hi != last_hi) {
+      off_hi[hi] = (int32_t)k;
+      last_hi = hi;
+    }
+    rank_lo[lo] = (int32_t)(k - off_hi[hi]);
+    if (npart == 0) break;
+    uint32_t c = m & (0u - m), r = m + c;
+    m = (((r ^ m) >> 2) / c) | r;
+  }
+}
+
+namespace {
+
+struct Idx {
+  const edigpu_model& m;
+  explicit Idx(const edigpu_model& mm) : m(mm) {}
+  double uloc(int a) const { return m.uloc[a]; }
+  // the reference always reads the (a<b) entry (stored/H_local.f90:44-58)
+  double ust(int a, int b) const { return m.ust[a * EDIGPU_MAXORB + b]; }
+  double jh(int a, int b) const { return m.jh[a * EDIGPU_MAXORB + b]; }
+  double jx(int a, int b) const { return m.jx[a * EDIGPU_MAXORB + b]; }
+  double jp(int a, int b) const { return m.jp[a * EDIGPU_MAXORB + b]; }
+  cplx hloc(int is, int js, int a, int b) const {
+    const double* p = &m.hloc[((((is * 2) + js) * EDIGPU_MAXORB + a) * EDIGPU_MAXORB + b) * 2];
+    return cplx(p[0], p[1]);
+  }
+  double bath(const double* arr, int is, int a, int k) const {
+    return arr[(is * EDIGPU_MAXORB + a) * EDIGPU_MAXBATH + k];
+  }
+  // 0-based level of bath site k of orbital a (getBathStride, ED_SETUP.f90:605-622)
+  int bath_pos(int a, int k) const {
+    switch (m.bath_type) {
+      case 1: return m.norb + k;
+      case 2:
+      case 3: return a + (k + 1) * m.norb;
+      default: return m.norb + a * m.nbath + k;
+    }
+  }
+  int n_ebath_orb() const { return m.bath_type == 1 ? 1 : m.norb; }
+};
+
+std::string check_model(const edigpu_model& m) {
+  if (m.norb < 1 || m.norb > EDIGPU_MAXORB) return "edigpu: norb out of range";
+  if (m.nbath < 0 || m.nbath > EDIGPU_MAXBATH) return "edigpu: nbath out of range";
+  if (m.nspin < 1 || m.nspin > 2) return "edigpu: nspin must be 1 or 2";
+  if (m.bath_type == 2 || m.bath_type == 3)
+    return "edigpu: replica/general baths are not built by the library yet; hand the matrices "
+           "over with edigpu_normal_create / edigpu_csr_create_z";
+  if (m.bath_type < 0 || m.bath_type > 3) return "edigpu: unknown bath_type";
+  int ns = model_ns(m);
+  if (ns > 30) return "edigpu: Ns > 30 levels per spin not supported";
+  return "";
+}
+
+// one-body data of one spin species: off-diagonal A(p,q) = coeff of c^+_p c_q, diagonal eps(p)
+struct OneBody {
+  int ns;
+  std::vector<double> a;    // ns*ns
+  std::vector<double> eps;  // ns
+};
+
+// spin: 0 = up, 1 = down.  The down species reads the (Nspin,Nspin) blocks.
+OneBody one_body_normal(const edigpu_model& m, int spin) {
+  Idx ix(m);
+  const int ns = model_ns(m), norb = m.norb;
+  const int s = spin == 0 ? 0 : m.nspin - 1;
+  OneBody ob;
+  ob.ns = ns;
+  ob.a.assign((size_t)ns * ns, 0.0);
+  ob.eps.assign(ns, 0.0);
+  for (int a = 0; a < norb; a++) {
+    for (int b = 0; b < norb; b++) {
+      if (a == b) continue;
+      ob.a[a * ns + b] += ix.hloc(s, s, a, b).real();
+    }
+    double e = ix.hloc(s, s, a, a).real() - m.xmu;
+    if (m.hfmode) {
+      e -= 0.5 * ix.uloc(a);
+      for (int b = 0; b < norb; b++) {
+        if (b == a) continue;
+        int lo = std::min(a, b), hi = std::max(a, b);
+        e -= 0.5 * ix.ust(lo, hi) + 0.5 * (ix.ust(lo, hi) - ix.jh(lo, hi));
+      }
+    }
+    ob.eps[a] = e;
+    for (int k = 0; k < m.nbath; k++) {
+      const int p = ix.bath_pos(a, k);
+      const double v = ix.bath(m.bv, s, a, k);
+      ob.a[p * ns + a] += v;
+      ob.a[a * ns + p] += v;
+    }
+  }
+  for (int a = 0; a < ix.n_ebath_orb(); a++)
+    for (int k = 0; k < m.nbath; k++) ob.eps[ix.bath_pos(a, k)] += ix.bath(m.be, s, a, k);
+  return ob;
+}
+
+inline uint32_t between_mask(int p, int q) {
+  const int lo = std::min(p, q), hi = std::max(p, q);
+  return ((1u << hi) - 1u) & ~((1u << (lo + 1)) - 1u);
+}
+
+// rows of the hopping matrix of one species in a fixed-N basis
+void hop_csr(const OneBody& ob, const CombBasis& b, HostCsr& out) {
+  const int ns = ob.ns;
+  const int64_t n = b.size();
+  out.nrow = out.ncol = n;
+  out.is_complex = false;
+  out.rowptr.assign(n + 1, 0);
+  out.col.clear();
+  out.val.clear();
+  // the hops that exist at all
+  struct Hop { int q, p; double t; uint32_t btw; };
+  std::vector<Hop> hops;
+  for (int q = 0; q < ns; q++)
+    for (int p = 0; p < ns; p++)
+      if (p != q && ob.a[q * ns + p] != 0.0) hops.push_back({q, p, ob.a[q * ns + p], between_mask(p, q)});
+  out.col.reserve((size_t)n * 8);
+  out.val.reserve((size_t)n * 8);
+  for (int64_t i = 0; i < n; i++) {
+    const uint32_t mi = (uint32_t)b.states[i];
+    for (const Hop& h : hops) {
+      if (!((mi >> h.q) & 1u) || ((mi >> h.p) & 1u)) continue;
+      const uint32_t mj = mi ^ (1u << h.q) ^ (1u << h.p);
+      const double sg = (popc(mi & h.btw) & 1) ? -1.0 : 1.0;
+      out.col.push_back(b.rank(mj));
+      out.val.push_back(h.t * sg);
+    }
+    out.rowptr[i + 1] = (int64_t)out.col.size();
+  }
+}
+
+}  // namespace
+
+std::string sector_dim(const edigpu_model& m, int q1, int q2, int64_t& dim) {
+  std::string e = check_model(m);
+  if (!e.empty()) return e;
+  const int ns = model_ns(m);
+  switch (m.ed_mode) {
+    case 0: dim = binomial(ns, q1) * binomial(ns, q2); return "";
+    case 1: {  // superc, Sz = q1: sum over nup-ndw = Sz
+      int64_t d = 0;
+      for (int nd = 0; nd <= ns; nd++) d += binomial(ns, nd) * binomial(ns, nd + q1);
+      dim = d;
+      return "";
+    }
+    case 2: dim = binomial(2 * ns, q1); return "";
+    default: return "edigpu: unknown ed_mode";
+  }
+}
+
+std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_first,
+                         int64_t dw_count, HostNormal& out) {
+  std::string e = check_model(m);
+  if (!e.empty()) return e;
+  if (m.ed_mode != 0) return "edigpu_normal_build: model.ed_mode is not normal";
+  Idx ix(m);
+  const int ns = model_ns(m), norb = m.norb;
+  if (nup < 0 || nup > ns || ndw < 0 || ndw > ns) return "edigpu_normal_build: bad sector";
+  out.ns = ns;
+  out.nup = nup;
+  out.ndw = ndw;
+  out.bup.init(ns, nup);
+  out.bdw.init(ns, ndw);
+  out.dim_up = out.bup.size();
+  out.dim_dw = out.bdw.size();
+  if (out.dim_up * out.dim_dw >= ((int64_t)1 << 31))
+    return "edigpu_normal_build: sector dimension >= 2^31 (the reference's integer range)";
+  if (dw_count < 0) {
+    dw_first = 0;
+    dw_count = out.dim_dw;
+  }
+  if (dw_first < 0 || dw_first + dw_count > out.dim_dw) return "edigpu_normal_build: bad shard";
+  out.dw_first = dw_first;
+  out.dw_count = dw_count;
+  const int64_t DimUp = out.dim_up;
+
+  OneBody oup = one_body_normal(m, 0), odw = one_body_normal(m, 1);
+  hop_csr(oup, out.bup, out.up);
+  hop_csr(odw, out.bdw, out.dw);
+
+  // ---- diagonal: Hd(iup,idw) = Eu(iup) + Ed(idw) + X(imp bits up, imp bits dw) ----
+  const uint32_t impmask = (1u << norb) - 1u;
+  auto species_energy = [&](const OneBody& ob, const CombBasis& b, std::vector<double>& en) {
+    en.resize(b.size());
+    for (int64_t i = 0; i < b.size(); i++) {
+      const uint32_t s = (uint32_t)b.states[i];
+      double x = 0.0;
+      for (int p = 0; p < ns; p++)
+        if ((s >> p) & 1u) x += ob.eps[p];
+      for (int a = 0; a < norb; a++)
+        for (int bb = a + 1; bb < norb; bb++)
+          if (((s >> a) & 1u) && ((s >> bb) & 1u)) x += ix.ust(a, bb) - ix.jh(a, bb);
+      en[i] = x;
+    }
+  };
+  std::vector<double> eu, ed;
+  species_energy(oup, out.bup, eu);
+  species_energy(odw, out.bdw, ed);
+  std::vector<double> xt((size_t)1 << (2 * norb));
+  double cst = 0.0;
+  if (m.hfmode) {
+    for (int a = 0; a < norb; a++) cst += 0.25 * ix.uloc(a);
+    for (int a = 0; a < norb; a++)
+      for (int b = a + 1; b < norb; b++) cst += 0.5 * ix.ust(a, b) + 0.5 * (ix.ust(a, b) - ix.jh(a, b));
+  }
+  for (uint32_t iu = 0; iu <= impmask; iu++)
+    for (uint32_t id = 0; id <= impmask; id++) {
+      double x = cst;
+      for (int a = 0; a < norb; a++) {
+        const int nu = (iu >> a) & 1, nd = (id >> a) & 1;
+        x += ix.uloc(a) * nu * nd;
+        for (int b = a + 1; b < norb; b++) {
+          const int nub = (iu >> b) & 1, ndb = (id >> b) & 1;
+          x += ix.ust(a, b) * (nu * ndb + nub * nd);
+        }
+      }
+      xt[(iu << norb) | id] = x;
+    }
+  out.hd.resize((size_t)(dw_count * DimUp));
+  for (int64_t r = 0; r < dw_count; r++) {
+    const int64_t idw = dw_first + r;
+    const uint32_t md = (uint32_t)out.bdw.states[idw];
+    const double edr = ed[idw];
+    const double* xrow_base = xt.data();
+    double* dst = &out.hd[(size_t)(r * DimUp)];
+    for (int64_t iup = 0; iup < DimUp; iup++) {
+      const uint32_t mu = (uint32_t)out.bup.states[iup];
+      dst[iup] = eu[iup] + edr + xrow_base[((mu & impmask) << norb) | (md & impmask)];
+    }
+  }
+
+  // ---- non-local block: spin exchange + pair hopping (only touches impurity bits) ----
+  bool any_jx = false, any_jp = false;
+  for (int a = 0; a < norb; a++)
+    for (int b = 0; b < norb; b++) {
+      if (ix.jx(a, b) != 0.0) any_jx = true;
+      if (ix.jp(a, b) != 0.0) any_jp = true;
+    }
+  out.has_nd = norb > 1 && (any_jx || any_jp);
+  out.nd = HostCsr();
+  if (out.has_nd) {
+    struct Term { uint32_t xu, xd; double val; };
+    std::vector<std::vector<Term>> terms((size_t)1 << (2 * norb));
+    for (uint32_t iu = 0; iu <= impmask; iu++)
+      for (uint32_t id = 0; id <= impmask; id++) {
+        auto& tl = terms[(iu << norb) | id];
+        for (int a = 0; a < norb; a++)
+          for (int b = 0; b < norb; b++) {
+            if (a == b) continue;
+            const uint32_t ba = 1u << a, bb = 1u << b, btw = between_mask(a, b);
+            const double sg = ((popc(iu & btw) + popc(id & btw)) & 1) ? -1.0 : 1.0;
+            // spin exchange: up b->a, down a->b
+            if (any_jx && (iu & bb) && !(iu & ba) && (id & ba) && !(id & bb) && ix.jx(a, b) != 0.0)
+              tl.push_back({ba | bb, ba | bb, ix.jx(a, b) * sg});
+            // pair hopping: up b->a, down b->a
+            if (any_jp && (iu & bb) && !(iu & ba) && (id & bb) && !(id & ba) && ix.jp(a, b) != 0.0)
+              tl.push_back({ba | bb, ba | bb, ix.jp(a, b) * sg});
+          }
+      }
+    HostCsr& nd = out.nd;
+    nd.nrow = dw_count * DimUp;
+    nd.ncol = out.dim_up * out.dim_dw;
+    nd.rowptr.assign(nd.nrow + 1, 0);
+    int64_t nnz = 0;
+    for (int64_t r = 0; r < dw_count; r++) {
+      const uint32_t md = (uint32_t)out.bdw.states[dw_first + r] & impmask;
+      for (int64_t iup = 0; iup < DimUp; iup++) {
+        const uint32_t mu = (uint32_t)out.bup.states[iup] & impmask;
+        nnz += (int64_t)terms[(mu << norb) | md].size();
+        nd.rowptr[r * DimUp + iup + 1] = nnz;
+      }
+    }
+    nd.col.resize(nnz);
+    nd.val.resize(nnz);
+    for (int64_t r = 0; r < dw_count; r++) {
+      const uint32_t sd = (uint32_t)out.bdw.states[dw_first + r];
+      for (int64_t iup = 0; iup < DimUp; iup++) {
+        const uint32_t su = (uint32_t)out.bup.states[iup];
+        const auto& tl = terms[((su & impmask) << norb) | (sd & impmask)];
+        int64_t k = nd.rowptr[r * DimUp + iup];
+        for (const Term& t : tl) {
+          const int64_t jup = out.bup.rank(su ^ t.xu), jdw = out.bdw.rank(sd ^ t.xd);
+          nd.col[k] = (int32_t)(jup + jdw * DimUp);
+          nd.val[k] = t.val;
+          k++;
+        }
+      }
+    }
+  }
+  return "";
+}
+
+// --------------------------------------------------------------------------------------
+// flat row-CSR sectors (superc: fixed Sz = Nup-Ndw; nonsu2: fixed Ntot)
+// --------------------------------------------------------------------------------------
+namespace {
+
+// Basis ordered as build_sector does for these modes (ED_SECTOR.f90:263-281, :351-368):
+// state = iup + idw*2^Ns, idw outer / iup inner, i.e. ascending integer.  Ranking is
+// off_dw[idw] + rk_up[iup] (rk_up = rank among words of equal popcount).
+struct SpinBasis {
+  int ns = 0;
+  std::vector<int32_t> states, off_dw, rk_up;
+  int mode = 1, q = 0;
+  int nup_for(int ndw) const { return mode == 1 ? ndw + q : q - ndw; }
+  void init(int ns_, int mode_, int q_) {
+    ns = ns_;
+    mode = mode_;
+    q = q_;
+    const uint32_t nw = 1u << ns;
+    rk_up.assign(nw, 0);
+    std::vector<int32_t> cnt(ns + 1, 0);
+    for (uint32_t w = 0; w < nw; w++) rk_up[w] = cnt[popc(w)]++;
+    off_dw.assign(nw, 0);
+    int64_t tot = 0;
+    for (uint32_t d = 0; d < nw; d++) {
+      off_dw[d] = (int32_t)tot;
+      tot += binomial(ns, nup_for(popc(d)));
+    }
+    states.resize(tot);
+    for (uint32_t d = 0; d < nw; d++) {
+      const int nu = nup_for(popc(d));
+      if (nu < 0 || nu > ns) continue;
+      int64_t k = off_dw[d];
+      uint32_t u = nu == 0 ? 0u : ((1u << nu) - 1u);
+      const int64_t n = binomial(ns, nu);
+      for (int64_t t = 0; t < n; t++) {
+        states[k++] = (int32_t)(u | (d << ns));
+        if (nu == 0) break;
+        uint32_t c = u & (0u - u), r = u + c;
+        u = (((r ^ u) >> 2) / c) | r;
+      }
+    }
+  }
+  inline int64_t rank(uint32_t s) const {
+    return (int64_t)off_dw[s >> ns] + rk_up[s & ((1u << ns) - 1u)];
+  }
+};
+
+// apply c (create=false) or c^+ (create=true) at level pos; returns false if it annihilates
+inline bool apply_op(uint32_t& s, int pos, bool create, double& sg) {
+  const uint32_t b = 1u << pos;
+  if (create ? (s & b) : !(s & b)) return false;
+  if (popc(s & (b - 1u)) & 1) sg = -sg;
+  s ^= b;
+  return true;
+}
+
+struct OpTerm {           // coef * op[n-1] ... op[1] op[0]  (op[0] acts first)
+  int n;
+  int pos[4];
+  bool create[4];
+  cplx coef;              // value inserted at (row = source state, col = result state)
+};
+
+}  // namespace
+
+std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
+                       HostFlat& out) {
+  std::string e = check_model(m);
+  if (!e.empty()) return e;
+  if (m.ed_mode != 1 && m.ed_mode != 2) return "edigpu_flat_build: model.ed_mode must be superc or nonsu2";
+  if (m.ed_mode == 2 && m.nspin != 2) return "edigpu_flat_build: nonsu2 needs nspin=2";
+  Idx ix(m);
+  const int ns = model_ns(m), norb = m.norb, nbath = m.nbath;
+  if (2 * ns > 30) return "edigpu_flat_build: 2*Ns > 30 bits (the reference's integer range)";
+  const int sd = m.nspin - 1;  // spin index used for the down species
+  SpinBasis sb;
+  sb.init(ns, m.ed_mode, sector);
+  out.ns = ns;
+  out.dim = (int64_t)sb.states.size();
+  if (row_count < 0) {
+    row_first = 0;
+    row_count = out.dim;
+  }
+  if (row_first < 0 || row_first + row_count > out.dim) return "edigpu_flat_build: bad shard";
+  out.row_first = row_first;
+  out.row_count = row_count;
+
+  // ---- operator strings; coefficient = what lands at (row i, col j=O|i>) ----
+  std::vector<OpTerm> terms;
+  auto hop = [&](int p, int q, cplx h) {  // c^+_p c_q with amplitude h: entry conj(h)
+    if (h == cplx(0.0)) return;
+    terms.push_back({2, {q, p, 0, 0}, {false, true, false, false}, std::conj(h)});
+  };
+  for (int a = 0; a < norb; a++)
+    for (int b = 0; b < norb; b++) {
+      if (a != b) {
+        hop(a, b, ix.hloc(0, 0, a, b));
+        hop(a + ns, b + ns, ix.hloc(sd, sd, a, b));
+      }
+      if (m.ed_mode == 2) {  // spin-flip local terms (ED_NONSU2/stored/Himp.f90:80-108)
+        hop(a, b + ns, ix.hloc(0, 1, a, b));
+        hop(a + ns, b, ix.hloc(1, 0, a, b));
+      }
+    }
+  for (int a = 0; a < norb; a++)
+    for (int k = 0; k < nbath; k++) {
+      const int p = ix.bath_pos(a, k);
+      const double vu = ix.bath(m.bv, 0, a, k), vd = ix.bath(m.bv, sd, a, k);
+      hop(p, a, vu);
+      hop(a, p, vu);
+      hop(p + ns, a + ns, vd);
+      hop(a + ns, p + ns, vd);
+      if (m.ed_mode == 2) {  // spin-flip hybridisation (ED_NONSU2/stored/Himp_bath.f90:77-136)
+        const double uu = ix.bath(m.bu, 0, a, k), ud = ix.bath(m.bu, sd, a, k);
+        hop(p + ns, a, uu);
+        hop(a, p + ns, uu);
+        hop(p, a + ns, ud);
+        hop(a + ns, p, ud);
+      }
+    }
+  if (m.ed_mode == 1) {
+    // bath pairing (ED_SUPERC/stored/Hbath.f90:94-128): d c_{dw} c_{up} and d c^+_{up} c^+_{dw}
+    for (int a = 0; a < ix.n_ebath_orb(); a++)
+      for (int k = 0; k < nbath; k++) {
+        const int p = ix.bath_pos(a, k);
+        const double d = ix.bath(m.bd, 0, a, k);
+        if (d == 0.0) continue;
+        terms.push_back({2, {p, p + ns, 0, 0}, {false, false, false, false}, cplx(d)});
+        terms.push_back({2, {p + ns, p, 0, 0}, {true, true, false, false}, cplx(d)});
+      }
+    // local pair field (ED_SUPERC/stored/Himp.f90:84-124)
+    for (int a = 0; a < norb; a++) {
+      const double f = m.pair_field[a];
+      if (f == 0.0) continue;
+      terms.push_back({2, {a, a + ns, 0, 0}, {false, false, false, false}, cplx(f)});
+      terms.push_back({2, {a + ns, a, 0, 0}, {true, true, false, false}, cplx(f)});
+    }
+  }
+  // spin exchange and pair hopping (ED_SUPERC/stored/Hint.f90:60-121 == ED_NONSU2/stored/Hint.f90)
+  if (norb > 1)
+    for (int a = 0; a < norb; a++)
+      for (int b = 0; b < norb; b++) {
+        if (a == b) continue;
+        if (ix.jx(a, b) != 0.0)
+          terms.push_back({4, {b, a + ns, b + ns, a}, {false, false, true, true}, cplx(ix.jx(a, b))});
+        if (ix.jp(a, b) != 0.0)
+          terms.push_back({4, {b, b + ns, a + ns, a}, {false, false, true, true}, cplx(ix.jp(a, b))});
+      }
+
+  // ---- diagonal pieces ----
+  std::vector<double> eps(2 * ns, 0.0);
+  for (int a = 0; a < norb; a++) {
+    double shift = -m.xmu;
+    if (m.hfmode) {
+      shift -= 0.5 * ix.uloc(a);
+      for (int b = 0; b < norb; b++) {
+        if (b == a) continue;
+        const int lo = std::min(a, b), hi = std::max(a, b);
+        shift -= 0.5 * ix.ust(lo, hi) + 0.5 * (ix.ust(lo, hi) - ix.jh(lo, hi));
+      }
+    }
+    eps[a] = ix.hloc(0, 0, a, a).real() + shift;
+    eps[a + ns] = ix.hloc(sd, sd, a, a).real() + shift;
+  }
+  for (int a = 0; a < ix.n_ebath_orb(); a++)
+    for (int k = 0; k < nbath; k++) {
+      eps[ix.bath_pos(a, k)] += ix.bath(m.be, 0, a, k);
+      eps[ix.bath_pos(a, k) + ns] += ix.bath(m.be, sd, a, k);
+    }
+  double cst = 0.0;
+  if (m.hfmode) {
+    for (int a = 0; a < norb; a++) cst += 0.25 * ix.uloc(a);
+    for (int a = 0; a < norb; a++)
+      for (int b = a + 1; b < norb; b++) cst += 0.5 * ix.ust(a, b) + 0.5 * (ix.ust(a, b) - ix.jh(a, b));
+  }
+
+  HostCsr& H = out.h;
+  H.nrow = row_count;
+  H.ncol = out.dim;
+  H.is_complex = true;
+  H.rowptr.assign(row_count + 1, 0);
+  H.col.clear();
+  H.val.clear();
+  H.col.reserve((size_t)row_count * 24);
+  H.val.reserve((size_t)row_count * 48);
+  std::vector<int32_t> rc;
+  std::vector<cplx> rv;
+  for (int64_t r = 0; r < row_count; r++) {
+    const int64_t i = row_first + r;
+    const uint32_t s = (uint32_t)sb.states[i];
+    rc.clear();
+    rv.clear();
+    double dg = cst;
+    for (int p = 0; p < 2 * ns; p++)
+      if ((s >> p) & 1u) dg += eps[p];
+    for (int a = 0; a < norb; a++) {
+      const int nu = (s >> a) & 1, nd = (s >> (a + ns)) & 1;
+      dg += ix.uloc(a) * nu * nd;
+      for (int b = a + 1; b < norb; b++) {
+        const int nub = (s >> b) & 1, ndb = (s >> (b + ns)) & 1;
+        dg += ix.ust(a, b) * (nu * ndb + nub * nd);
+        dg += (ix.ust(a, b) - ix.jh(a, b)) * (nu * nub + nd * ndb);
+      }
+    }
+    rc.push_back((int32_t)i);
+    rv.push_back(cplx(dg, 0.0));
+    for (const OpTerm& t : terms) {
+      uint32_t w = s;
+      double sg = 1.0;
+      bool ok = true;
+      for (int k = 0; k < t.n && ok; k++) ok = apply_op(w, t.pos[k], t.create[k], sg);
+      if (!ok) continue;
+      const int32_t j = (int32_t)sb.rank(w);
+      const cplx v = t.coef * sg;
+      bool merged = false;
+      for (size_t k = 0; k < rc.size(); k++)
+        if (rc[k] == j) {
+          rv[k] += v;
+          merged = true;
+          break;
+        }
+      if (!merged) {
+        rc.push_back(j);
+        rv.push_back(v);
+      }
+    }
+    for (size_t k = 0; k < rc.size(); k++) {
+      H.col.push_back(rc[k]);
+      H.val.push_back(rv[k].real());
+      H.val.push_back(rv[k].imag());
+    }
+    H.rowptr[r + 1] = (int64_t)H.col.size();
+  }
+  out.states = std::move(sb.states);
+  return "";
+}
+
+}  // namespace edigpu

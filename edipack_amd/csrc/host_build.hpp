@@ -1,0 +1,68 @@
+// host_build.hpp -- host-side construction of sector bases and sector Hamiltonians.
+//
+// Product code (not the oracle).  Functionally it takes the place of the reference's
+// build_sector (ED_SECTOR.f90:165-373) and ed_buildh_*_main (ED_NORMAL/
+// ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:26-267, ED_SUPERC/..:29-293, ED_NONSU2/..:29-175),
+// but it is organised differently: every spin species is described by a one-body
+// matrix A(p,q) (coefficient of c^+_p c_q), states are ranked with two lookup tables
+// instead of a binary search, fermionic signs come from popcounts of bit masks, and
+// CSR rows are emitted directly (no insert-and-search container).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/edigpu.h"
+
+namespace edigpu {
+
+struct HostCsr {
+  int64_t nrow = 0, ncol = 0;
+  bool is_complex = false;
+  std::vector<int64_t> rowptr;
+  std::vector<int32_t> col;
+  std::vector<double> val;  // nnz or 2*nnz
+  int64_t nnz() const { return (int64_t)col.size(); }
+};
+
+// Fixed-particle-number basis of `nbits` levels, ascending integer order
+// (the order build_sector produces, ED_SECTOR.f90:217-242), with O(1) ranking.
+struct CombBasis {
+  int nbits = 0, npart = 0, hbits = 0;
+  std::vector<int32_t> states;   // index -> bit pattern
+  std::vector<int32_t> off_hi;   // [2^(nbits-hbits)]
+  std::vector<int32_t> rank_lo;  // [2^hbits]
+  void init(int nbits_, int npart_);
+  int64_t size() const { return (int64_t)states.size(); }
+  inline int32_t rank(uint32_t m) const {
+    return off_hi[m >> hbits] + rank_lo[m & ((1u << hbits) - 1u)];
+  }
+};
+
+struct HostNormal {
+  int ns = 0, nup = 0, ndw = 0;
+  int64_t dim_up = 0, dim_dw = 0, dw_first = 0, dw_count = 0;
+  CombBasis bup, bdw;
+  std::vector<double> hd;  // local rows
+  HostCsr up, dw, nd;      // nd over local rows, global columns
+  bool has_nd = false;
+};
+
+struct HostFlat {
+  int ns = 0;
+  int64_t dim = 0, row_first = 0, row_count = 0;
+  std::vector<int32_t> states;
+  HostCsr h;  // complex, local rows, global columns
+};
+
+int model_ns(const edigpu_model& m);
+int64_t binomial(int n, int k);
+
+// returns "" on success, else an error message
+std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_first,
+                         int64_t dw_count, HostNormal& out);
+std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
+                       HostFlat& out);
+std::string sector_dim(const edigpu_model& m, int q1, int q2, int64_t& dim);
+
+}  // namespace edigpu

@@ -1,0 +1,110 @@
+// kernels_csr.hip -- flat row-CSR SpMV (real and complex) for gfx950.
+//
+// Takes the place of spMatVec_superc_main / spMatVec_mpi_superc_main (reference
+// ED_SUPERC/ED_HAMILTONIAN_SUPERC_STORED_HxV.f90:312-432), spMatVec_nonsu2_main /
+// spMatVec_mpi_nonsu2_main (ED_NONSU2/ED_HAMILTONIAN_NONSU2_STORED_HxV.f90:194-267)
+// and of the real sp_matvec (ED_SPARSE_MATRIX.f90:778-793).
+//
+// A group of LPR lanes (power of two, 2..64, chosen from the average row length)
+// owns one row: its (col,val) pairs are read coalesced, the x gathers go through
+// L2/Infinity Cache, and the partial sums are combined with wavefront shuffles
+// (64-wide waves: 64/LPR rows per wave).  No MFMA -- bandwidth bound.
+#include "kernels.hpp"
+
+namespace edigpu {
+
+constexpr int kCsrNT = 256;
+
+template <int LPR, bool CPLX, bool ACC, typename RP>
+__global__ void __launch_bounds__(kCsrNT)
+    csr_rows_kernel(int64_t nrow, const RP* __restrict__ rowptr, const int32_t* __restrict__ col,
+                    const double* __restrict__ val, const double* __restrict__ x,
+                    double* __restrict__ y) {
+  constexpr int RPB = kCsrNT / LPR;
+  const int lane = threadIdx.x % LPR;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+  double sr = 0.0, si = 0.0;
+  if (row < nrow) {
+    const int64_t b = rowptr[row], e = rowptr[row + 1];
+    for (int64_t k = b + lane; k < e; k += LPR) {
+      const int64_t c = col[k];
+      if (CPLX) {
+        const double2 a = reinterpret_cast<const double2*>(val)[k];
+        const double2 xv = reinterpret_cast<const double2*>(x)[c];
+        sr += a.x * xv.x - a.y * xv.y;
+        si += a.x * xv.y + a.y * xv.x;
+      } else {
+        sr += val[k] * x[c];
+      }
+    }
+  }
+#pragma unroll
+  for (int off = LPR / 2; off > 0; off >>= 1) {
+    sr += __shfl_down(sr, off, LPR);
+    if (CPLX) si += __shfl_down(si, off, LPR);
+  }
+  if (row < nrow && lane == 0) {
+    if (CPLX) {
+      double2* yy = reinterpret_cast<double2*>(y) + row;
+      double2 o = ACC ? *yy : make_double2(0.0, 0.0);
+      o.x += sr;
+      o.y += si;
+      *yy = o;
+    } else {
+      y[row] = (ACC ? y[row] : 0.0) + sr;
+    }
+  }
+}
+
+__global__ void zero_kernel(double* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = 0.0;
+}
+
+int launch_zero(double* y, int64_t n, hipStream_t st) {
+  if (n <= 0) return 0;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)nb), dim3(256), 0, st, y, n);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int LPR, bool CPLX, bool ACC>
+static int launch_lpr(const DevCsr& a, const double* x, double* y, hipStream_t st) {
+  constexpr int RPB = kCsrNT / LPR;
+  const int64_t nb = (a.nrow + RPB - 1) / RPB;
+  if (a.wide)
+    hipLaunchKernelGGL((csr_rows_kernel<LPR, CPLX, ACC, int64_t>), dim3((unsigned)nb),
+                       dim3(kCsrNT), 0, st, a.nrow, a.rowptr64, a.col, a.val, x, y);
+  else
+    hipLaunchKernelGGL((csr_rows_kernel<LPR, CPLX, ACC, int32_t>), dim3((unsigned)nb),
+                       dim3(kCsrNT), 0, st, a.nrow, a.rowptr32, a.col, a.val, x, y);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+template <bool CPLX, bool ACC>
+static int launch_pick(const DevCsr& a, const double* x, double* y, hipStream_t st) {
+  const double r = a.avg_row;
+  if (r <= 3.0) return launch_lpr<2, CPLX, ACC>(a, x, y, st);
+  if (r <= 6.0) return launch_lpr<4, CPLX, ACC>(a, x, y, st);
+  if (r <= 12.0) return launch_lpr<8, CPLX, ACC>(a, x, y, st);
+  if (r <= 24.0) return launch_lpr<16, CPLX, ACC>(a, x, y, st);
+  if (r <= 48.0) return launch_lpr<32, CPLX, ACC>(a, x, y, st);
+  return launch_lpr<64, CPLX, ACC>(a, x, y, st);
+}
+
+int launch_csr(const DevCsr& a, int cplx, const double* x, double* y, int accumulate,
+               hipStream_t st) {
+  if (a.nrow == 0) return 0;
+  if (a.nnz == 0) {
+    if (!accumulate) return launch_zero(y, a.nrow * (cplx ? 2 : 1), st);
+    return 0;
+  }
+  if (cplx) return accumulate ? launch_pick<true, true>(a, x, y, st) : launch_pick<true, false>(a, x, y, st);
+  return accumulate ? launch_pick<false, true>(a, x, y, st) : launch_pick<false, false>(a, x, y, st);
+}
+
+}  // namespace edigpu

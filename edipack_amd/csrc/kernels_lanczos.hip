@@ -1,0 +1,226 @@
+// kernels_lanczos.hip -- device-resident three-term recurrence for gfx950.
+//
+// Keeps the Lanczos vectors in HBM between H*v products; replaces the host loop
+// of SciFortran's sp_lanc_tridiag / sp_lanc_eigh that the reference drives through
+// spHtimesV_p (call sites: reference ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:360-365,
+// ED_NORMAL/ED_DIAG_NORMAL.f90:206-214).  alpha/beta stay on the device (scal[]), so
+// a whole tridiagonalisation is enqueued without a host synchronisation.
+//
+// Complex vectors are processed as 2n reals: only Re<a|b> and norms are needed
+// because H is Hermitian (alpha, beta real).
+//
+// Reductions are deterministic: a fixed grid writes one partial per workgroup
+// (wave shuffle + LDS), a single-workgroup kernel adds the partials in order.
+#include "kernels.hpp"
+
+namespace edigpu {
+
+constexpr int kLzNT = 256;
+
+__device__ inline double wave_sum(double x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  return x;
+}
+
+__device__ inline double block_sum(double x) {
+  __shared__ double ws[kLzNT / 64];
+  x = wave_sum(x);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) ws[w] = x;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < kLzNT / 64; i++) t += ws[i];
+  }
+  __syncthreads();
+  return t;  // valid on thread 0
+}
+
+// ---- norm of the start vector, then scale (first step of lanczos_iteration) ----
+__global__ void __launch_bounds__(kLzNT)
+    k_sumsq(const double* __restrict__ v, int64_t n, double* __restrict__ partial) {
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT)
+    s += v[i] * v[i];
+  s = block_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// mode 0: scal[SC_NORM] = sqrt(sum) ; stop if zero
+// mode 1: alpha -> scal[SC_ALPHA], scal[SC_AB+iter]
+// mode 2: beta = sqrt(sum) -> scal[SC_BETA], scal[SC_AB+nlanc+iter+1] ; stop if < thr
+__global__ void __launch_bounds__(1024)
+    k_finalize(const double* __restrict__ partial, int np, double* __restrict__ scal, int mode,
+               int iter, int nlanc) {
+  __shared__ double sh[1024];
+  if (mode != 0 && scal[SC_STOP] != 0.0) return;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < np; i += 1024) s += partial[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double tot = sh[0];
+    if (mode == 0) {
+      const double nrm = sqrt(tot);
+      scal[SC_NORM] = nrm;
+      scal[SC_STOP] = (nrm == 0.0) ? 1.0 : 0.0;
+      scal[SC_NDONE] = 0.0;
+    } else if (mode == 1) {
+      scal[SC_ALPHA] = tot;
+      scal[SC_AB + iter] = tot;
+      scal[SC_NDONE] = (double)(iter + 1);
+    } else {
+      const double b = sqrt(tot);
+      scal[SC_BETA] = b;
+      if (fabs(b) < scal[SC_THR])
+        scal[SC_STOP] = 1.0;
+      else if (iter + 1 < nlanc)
+        scal[SC_AB + nlanc + iter + 1] = b;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kLzNT)
+    k_scale_by_norm(double* __restrict__ v, int64_t n, const double* __restrict__ scal) {
+  if (scal[SC_STOP] != 0.0) return;
+  const double inv = 1.0 / scal[SC_NORM];
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT)
+    v[i] *= inv;
+}
+
+// (vin, vout) <- (vout/beta, -beta*vin)
+__global__ void __launch_bounds__(kLzNT)
+    k_rotate(double* __restrict__ vin, double* __restrict__ vout, int64_t n,
+             const double* __restrict__ scal) {
+  if (scal[SC_STOP] != 0.0) return;
+  const double b = scal[SC_BETA], ib = 1.0 / b;
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) {
+    const double t = vin[i];
+    vin[i] = vout[i] * ib;
+    vout[i] = -b * t;
+  }
+}
+
+// vout += tmp ; partial alpha = <vin|vout>
+__global__ void __launch_bounds__(kLzNT)
+    k_alpha(const double* __restrict__ vin, double* __restrict__ vout,
+            const double* __restrict__ tmp, int64_t n, double* __restrict__ partial,
+            const double* __restrict__ scal) {
+  if (scal[SC_STOP] != 0.0) return;
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) {
+    const double w = vout[i] + tmp[i];
+    vout[i] = w;
+    s += vin[i] * w;
+  }
+  s = block_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// vout -= alpha*vin ; partial beta^2 = <vout|vout>
+__global__ void __launch_bounds__(kLzNT)
+    k_beta(const double* __restrict__ vin, double* __restrict__ vout, int64_t n,
+           double* __restrict__ partial, const double* __restrict__ scal) {
+  if (scal[SC_STOP] != 0.0) return;
+  const double a = scal[SC_ALPHA];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) {
+    const double w = vout[i] - a * vin[i];
+    vout[i] = w;
+    s += w * w;
+  }
+  s = block_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// acc += coef * vin   (Ritz-vector accumulation in the second pass); skipped once iter >= ndone
+__global__ void __launch_bounds__(kLzNT)
+    k_axpy(double* __restrict__ acc, const double* __restrict__ vin, int64_t n, double coef,
+           const double* __restrict__ scal, int iter) {
+  if ((double)iter >= scal[SC_NDONE]) return;
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT)
+    acc[i] += coef * vin[i];
+}
+
+__device__ inline uint64_t splitmix(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ void __launch_bounds__(kLzNT)
+    k_fill_random(double* __restrict__ v, int64_t n, uint64_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) {
+    const uint64_t h = splitmix(seed ^ (uint64_t)i * 0xD1B54A32D192ED03ull);
+    v[i] = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+  }
+}
+
+static inline dim3 red_grid(int64_t n) {
+  int64_t nb = (n + kLzNT - 1) / kLzNT;
+  if (nb > kRedBlocks) nb = kRedBlocks;
+  if (nb < 1) nb = 1;
+  return dim3((unsigned)nb);
+}
+
+static inline dim3 ew_grid(int64_t n) {
+  int64_t nb = (n + kLzNT - 1) / kLzNT;
+  if (nb > 256 * 16) nb = 256 * 16;
+  if (nb < 1) nb = 1;
+  return dim3((unsigned)nb);
+}
+
+int lz_norm_begin(double* vin, int64_t n, double* partial, double* scal, hipStream_t st) {
+  dim3 g = red_grid(n);
+  hipLaunchKernelGGL(k_sumsq, g, dim3(kLzNT), 0, st, vin, n, partial);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, st, partial, (int)g.x, scal, 0, 0, 0);
+  hipLaunchKernelGGL(k_scale_by_norm, ew_grid(n), dim3(kLzNT), 0, st, vin, n, scal);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int lz_rotate(double* vin, double* vout, int64_t n, const double* scal, hipStream_t st) {
+  hipLaunchKernelGGL(k_rotate, ew_grid(n), dim3(kLzNT), 0, st, vin, vout, n, scal);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int lz_alpha(const double* vin, double* vout, const double* tmp, int64_t n, double* partial,
+             double* scal, int iter, int nlanc, hipStream_t st) {
+  dim3 g = red_grid(n);
+  hipLaunchKernelGGL(k_alpha, g, dim3(kLzNT), 0, st, vin, vout, tmp, n, partial, scal);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, st, partial, (int)g.x, scal, 1, iter, nlanc);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int lz_beta(const double* vin, double* vout, int64_t n, double* partial, double* scal, int iter,
+            int nlanc, hipStream_t st) {
+  dim3 g = red_grid(n);
+  hipLaunchKernelGGL(k_beta, g, dim3(kLzNT), 0, st, vin, vout, n, partial, scal);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, st, partial, (int)g.x, scal, 2, iter, nlanc);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int lz_axpy_coef(double* acc, const double* vin, int64_t n, double coef, const double* scal,
+                 int iter, hipStream_t st) {
+  hipLaunchKernelGGL(k_axpy, ew_grid(n), dim3(kLzNT), 0, st, acc, vin, n, coef, scal, iter);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int lz_fill_random(double* v, int64_t n, uint64_t seed, hipStream_t st) {
+  hipLaunchKernelGGL(k_fill_random, ew_grid(n), dim3(kLzNT), 0, st, v, n, seed);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace edigpu

@@ -1,0 +1,231 @@
+/*
+ * edigpu.h -- C ABI of the MI355X (gfx950) Lanczos H*v engine for EDIpack.
+ *
+ * This is the drop-in boundary for EDIpack's Hamiltonian-times-vector hot path.
+ * Reference paths below are relative to /root/reference/src/singlesite.
+ *
+ * In the reference the path sits behind two Fortran procedure pointers,
+ *   procedure(dd_sparse_HxV),pointer :: spHtimesV_p     (ED_VARS_GLOBAL.f90:111-122,196)
+ *   procedure(cc_sparse_HxV),pointer :: spHtimesV_cc    (ED_VARS_GLOBAL.f90:125-132,197)
+ * which build_Hv_sector_<mode> points at spMatVec_* / directMatVec_* and which
+ * SciFortran's sp_eigh / sp_lanc_eigh / sp_lanc_tridiag call once per iteration.
+ * A thin ISO_C_BINDING module (fortran/edigpu_shim.f90) binds
+ * the entry points below and is assigned to those pointers.
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on error; edigpu_last_error()
+ *    then holds a message (the Fortran shim does `if(ierr/=0) stop msg`, matching
+ *    the reference's `stop "..."` convention, e.g. ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:797).
+ *  - all indices are 0-based; row pointers are int64, column ids int32 (the
+ *    reference is limited to default 32-bit integers as well: Dim < 2^31).
+ *  - complex numbers are interleaved (re,im) doubles == Fortran complex(8).
+ *  - a handle describes ONE sector Hamiltonian (the reference keeps exactly one
+ *    live at a time in module globals, ED_VARS_GLOBAL.f90:190-195); several
+ *    handles may coexist here.
+ *  - "host" pointers are ordinary CPU memory; "dev" pointers are HIP device
+ *    memory on the handle's device; `stream` is a hipStream_t passed as void*
+ *    (NULL = the handle's own stream).
+ *  - There is NO CPU fallback: every entry point fails with an error if no
+ *    HIP device is usable.
+ */
+#ifndef EDIGPU_H
+#define EDIGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDIGPU_MAXORB 5
+#define EDIGPU_MAXBATH 16
+
+typedef struct edigpu_sector *edigpu_handle;
+
+/* ----------------------------------------------------------------------- */
+/* library / device                                                         */
+/* ----------------------------------------------------------------------- */
+const char *edigpu_last_error(void);
+int edigpu_version(void);
+/* number of visible HIP devices (0 and an error if the runtime is unusable) */
+int edigpu_device_count(int *count);
+/* select the device used by handles created afterwards from this thread
+ * (replaces nothing in the reference: it has no device notion; ED_MAIN.f90:164 is
+ * where a GPU-enabled ed_solve would call it once per rank). */
+int edigpu_init(int device);
+
+/* ----------------------------------------------------------------------- */
+/* normal mode: Kronecker-stored sector Hamiltonian                          */
+/*   H = diag(Hd) + 1 (x) Hup + Hdw (x) 1 + Hnd                              */
+/* replaces spH0d, spH0ups(1), spH0dws(1), spH0nd (ED_VARS_GLOBAL.f90:190-192) as */
+/* filled by ed_buildh_normal_main (ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:26-267) */
+/* ----------------------------------------------------------------------- */
+/*
+ * Vector layout (ED_SECTOR.f90:1705-1717): i = iup + idw*DimUp.
+ * A shard owns the down-index range [dw_first, dw_first+dw_count), i.e. vector
+ * rows [dw_first*DimUp, (dw_first+dw_count)*DimUp) -- the reference's MPI split
+ * of the down index (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:129-142).  hd and the rows
+ * of nd are given for the owned rows only (as the reference builds them,
+ * stored/H_local.f90:1, stored/H_non_local.f90:4); nd column ids are global.
+ * up/dw are the full DimUp x DimUp / DimDw x DimDw factors (replicated on every
+ * rank in the reference too).  nd_rowptr may be NULL (no spin-exchange /
+ * pair-hopping block).  Columns inside a row may come in any order.
+ */
+int edigpu_normal_create(edigpu_handle *h, int64_t dim_up, int64_t dim_dw, int64_t dw_first,
+                         int64_t dw_count, const double *hd, const int64_t *up_rowptr,
+                         const int32_t *up_col, const double *up_val, const int64_t *dw_rowptr,
+                         const int32_t *dw_col, const double *dw_val, const int64_t *nd_rowptr,
+                         const int32_t *nd_col, const double *nd_val);
+
+/* ----------------------------------------------------------------------- */
+/* superc / nonsu2 modes: one flat row-CSR matrix                            */
+/* replaces spH0 with its loc / non-loc row blocks (ED_SPARSE_MATRIX.f90:26-41,   */
+/* :462-470) as filled by ed_buildH_superc_main / ed_buildH_nonsu2_main       */
+/* ----------------------------------------------------------------------- */
+/*
+ * The shard owns global rows [row_first, row_first+nrow_local) of an
+ * ncol_global-column matrix.  One CSR with GLOBAL column ids is passed; the
+ * library splits it into the local diagonal block (columns inside the shard,
+ * multiplied before the exchanged vector arrives) and the non-local block,
+ * which is what sp_insert_element does on insertion in the reference.
+ * `_d` = real(8) values, `_z` = complex(8) values.
+ */
+int edigpu_csr_create_d(edigpu_handle *h, int64_t nrow_local, int64_t ncol_global,
+                        int64_t row_first, const int64_t *rowptr, const int32_t *col,
+                        const double *val);
+int edigpu_csr_create_z(edigpu_handle *h, int64_t nrow_local, int64_t ncol_global,
+                        int64_t row_first, const int64_t *rowptr, const int32_t *col,
+                        const double *val_re_im);
+
+/* ----------------------------------------------------------------------- */
+/* sector construction from model parameters                                 */
+/* replaces build_sector (ED_SECTOR.f90:165-373) + ed_buildh_*_main: the       */
+/* matrices are generated by the library instead of handed over.              */
+/* ----------------------------------------------------------------------- */
+typedef struct edigpu_model {
+  int32_t ed_mode;   /* 0 normal, 1 superc, 2 nonsu2          (ED_INPUT_VARS.f90 ED_MODE)   */
+  int32_t bath_type; /* 0 normal, 1 hybrid, 2 replica, 3 general (ED_INPUT_VARS.f90 BATH_TYPE) */
+  int32_t norb, nbath, nspin;
+  int32_t hfmode;
+  double xmu;
+  /* Uloc_internal(a), Ust/Jh/Jx/Jp_internal(a,b) (ED_VARS_GLOBAL.f90:216-220), row-major [a][b] */
+  double uloc[EDIGPU_MAXORB];
+  double ust[EDIGPU_MAXORB * EDIGPU_MAXORB];
+  double jh[EDIGPU_MAXORB * EDIGPU_MAXORB];
+  double jx[EDIGPU_MAXORB * EDIGPU_MAXORB];
+  double jp[EDIGPU_MAXORB * EDIGPU_MAXORB];
+  /* impHloc + mfHloc, [ispin][jspin][iorb][jorb][re,im] */
+  double hloc[2 * 2 * EDIGPU_MAXORB * EDIGPU_MAXORB * 2];
+  /* pair_field(a) (superc) */
+  double pair_field[EDIGPU_MAXORB];
+  /* dmft_bath%e,v,d,u [ispin][iorb][k]; hybrid: e,d use iorb=0 only */
+  double be[2 * EDIGPU_MAXORB * EDIGPU_MAXBATH];
+  double bv[2 * EDIGPU_MAXORB * EDIGPU_MAXBATH];
+  double bd[2 * EDIGPU_MAXORB * EDIGPU_MAXBATH];
+  double bu[2 * EDIGPU_MAXORB * EDIGPU_MAXBATH];
+} edigpu_model;
+
+/* normal mode sector (N_up, N_dw); the shard owns down-indices [dw_first, dw_first+dw_count)
+ * (dw_count < 0: all).  Equivalent to build_Hv_sector_normal(isector) with ed_sparse_H=T
+ * (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:31-206). */
+int edigpu_normal_build(edigpu_handle *h, const edigpu_model *model, int nup, int ndw,
+                        int64_t dw_first, int64_t dw_count);
+/* superc sector Sz / nonsu2 sector Ntot; the shard owns rows [row_first, row_first+row_count)
+ * (row_count < 0: all).  Equivalent to build_Hv_sector_superc / _nonsu2
+ * (ED_SUPERC/ED_HAMILTONIAN_SUPERC.f90:33-135, ED_NONSU2/ED_HAMILTONIAN_NONSU2.f90:31-128). */
+int edigpu_flat_build(edigpu_handle *h, const edigpu_model *model, int sector, int64_t row_first,
+                      int64_t row_count);
+
+/* sector dimensions (get_normal/superc/nonsu2_sector_dimension, ED_SETUP.f90:998-1033) */
+int edigpu_sector_dim(const edigpu_model *model, int q1, int q2, int64_t *dim);
+
+/* ----------------------------------------------------------------------- */
+/* queries                                                                    */
+/* ----------------------------------------------------------------------- */
+/* info[0]=global dim, [1]=local rows (vecDim_Hv_sector_*), [2]=first local row,
+ * [3]=is_complex, [4]=kind (0 normal Kronecker, 1 flat CSR), [5]=DimUp, [6]=DimDw,
+ * [7]=nnz(up)+nnz(dw) or nnz(loc), [8]=nnz(nd) or nnz(nonloc), [9]=device id */
+int edigpu_info(edigpu_handle h, int64_t info[10]);
+/* algorithmic bytes of one H*v in the reference's storage format */
+int edigpu_algorithmic_bytes(edigpu_handle h, double *bytes_hv, double *bytes_lanczos_step);
+/* copy the built matrices back to the host (tests: compare with the oracle).
+ * Any pointer may be NULL.  Normal kind: hd[local rows], up/dw/nd CSR (nd over local rows).
+ * Sizes come from edigpu_info. */
+int edigpu_normal_export(edigpu_handle h, double *hd, int64_t *up_rowptr, int32_t *up_col,
+                         double *up_val, int64_t *dw_rowptr, int32_t *dw_col, double *dw_val,
+                         int64_t *nd_rowptr, int32_t *nd_col, double *nd_val);
+/* flat kind: one CSR over the local rows with global columns (loc and non-loc merged) */
+int edigpu_csr_export(edigpu_handle h, int64_t *rowptr, int32_t *col, double *val);
+
+/* ----------------------------------------------------------------------- */
+/* H*v                                                                        */
+/* ----------------------------------------------------------------------- */
+/*
+ * Callback-compatible product with host vectors: same contract as
+ * dd_sparse_HxV / cc_sparse_HxV (ED_VARS_GLOBAL.f90:111-132): Hv is overwritten,
+ * v is untouched, nloc must equal the local row count.  Single-shard handles
+ * only (a sharded handle needs the gathered vector: use the _dev entry points).
+ * Replaces spMatVec_normal_main (ED_NORMAL/..._STORED_HxV.f90:517-650),
+ * spMatVec_superc_main (ED_SUPERC/..._STORED_HxV.f90:312-362),
+ * spMatVec_nonsu2_main (ED_NONSU2/..._STORED_HxV.f90:194-209).
+ */
+int edigpu_apply_d(edigpu_handle h, int64_t nloc, const double *v_host, double *hv_host);
+int edigpu_apply_z(edigpu_handle h, int64_t nloc, const double *v_host, double *hv_host);
+
+/*
+ * Device-resident product.  v_full_dev holds the WHOLE vector (global dim
+ * elements; for a single shard that is just the vector), hv_dev the local rows.
+ * Enqueued on `stream`, no host synchronisation.
+ */
+int edigpu_apply_dev(edigpu_handle h, const void *v_full_dev, void *hv_dev, void *stream);
+/*
+ * Two-phase form for sharded handles, mirroring spMatVec_mpi_* :
+ *  _local  : the terms that need only the shard's own slice of v (normal: diagonal
+ *            + up part, ..._STORED_HxV.f90:800-832; flat: the `loc` block, ED_SUPERC/
+ *            ..._STORED_HxV.f90:395-403).  Overwrites hv.  Runs while the exchange is in flight.
+ *  _remote : the terms that need the gathered vector (normal: down part + Hnd,
+ *            :847-927; flat: non-local block, :423-430).  Accumulates into hv.
+ */
+int edigpu_apply_local_dev(edigpu_handle h, const void *v_local_dev, void *hv_dev, void *stream);
+int edigpu_apply_remote_dev(edigpu_handle h, const void *v_full_dev, void *hv_dev, void *stream);
+
+/* ----------------------------------------------------------------------- */
+/* device-resident Lanczos                                                    */
+/* ----------------------------------------------------------------------- */
+/*
+ * Partial tridiagonalisation with the vector kept in HBM: replaces the
+ * sp_lanc_tridiag(spHtimesV_p, vvinit, alanc, blanc) call inside
+ * tridiag_Hv_sector_* (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:360-365,
+ * ED_SUPERC/ED_HAMILTONIAN_SUPERC.f90:263-268, ED_NONSU2/ED_HAMILTONIAN_NONSU2.f90:235-240).
+ * vin_host (local rows; real or complex per the handle) is normalised internally
+ * exactly as lanczos_iteration does on its first step; alanc/blanc have nlanc
+ * entries, blanc[0] is left 0 (the consumer reads blanc(2:N), ED_GF_NORMAL.f90:410-411).
+ * The recurrence stops early when |beta| < threshold; *niter_done is the number
+ * of alpha values produced.  Single-shard handles.
+ */
+int edigpu_lanczos_tridiag(edigpu_handle h, const double *vin_host, int nlanc, double *alanc,
+                           double *blanc, double threshold, int *niter_done);
+/*
+ * Lowest eigenpair by plain Lanczos (lanc_method="lanczos": sp_lanc_eigh call
+ * sites ED_NORMAL/ED_DIAG_NORMAL.f90:206-214): iterate until the lowest Ritz value
+ * moves by less than tol (checked every `check_every` steps) or nitermax, then
+ * rebuild the Ritz vector with a second pass.  evec_host may be NULL.
+ */
+int edigpu_lanczos_eigh(edigpu_handle h, int nitermax, double tol, int check_every,
+                        const double *v0_host, double *eval, double *evec_host,
+                        int *niter_done);
+
+/*
+ * Timing helper for bench.py: runs `warmup` untimed and `steps` timed H*v
+ * products (device-resident, random unit vector) on the handle's stream and
+ * returns the average duration of one H*v measured with HIP events on that
+ * stream, plus (if lanczos!=0) the same for full Lanczos steps.
+ */
+int edigpu_time_apply(edigpu_handle h, int warmup, int steps, int lanczos, double *ms_per_step);
+
+int edigpu_destroy(edigpu_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDIGPU_H */

@@ -1,0 +1,341 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Tolerances: index/integer data (maps, row pointers, columns) bit-exact; floating point
+<= 1e-10 relative (BASELINE.json north_star), in practice checked at 1e-12.
+"""
+import numpy as np
+import pytest
+
+from tests.common import csr_to_dense, make_models, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+def _oracle():
+    from oracle import oracle as O
+    return O
+
+
+# --------------------------------------------------------------------------------------------
+# normal mode (Kronecker): builder, H*v, create-from-arrays
+# --------------------------------------------------------------------------------------------
+NORMAL_CASES = [
+    # bath_type, norb, nbath, (nup, ndw)
+    ("normal", 1, 4, (2, 3)),      # BASELINE config 1: Ns=5, Dim=100
+    ("normal", 1, 4, (0, 5)),      # edge: 1 x 1 sector
+    ("normal", 2, 2, (3, 3)),      # reference test NORMAL_NORMAL largest sector (400)
+    ("hybrid", 2, 4, (3, 3)),      # reference test HYBRID_NORMAL
+    ("hybrid", 3, 5, (4, 4)),      # 3 orbitals: non-trivial signs in Hnd
+    ("normal", 2, 3, (4, 3)),      # rectangular DimUp != DimDw
+    ("normal", 2, 3, (8, 0)),      # edge: DimUp=1
+]
+
+
+@pytest.mark.parametrize("bath,norb,nbath,sec", NORMAL_CASES)
+def test_normal_builder_matches_oracle(gpu, bath, norb, nbath, sec):
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("normal", bath, norb, nbath, seed=3)
+    ho = O.HNormal(om, *sec)
+    hg = SectorHamiltonian.normal_from_model(pm, *sec)
+    assert (hg.dim_up, hg.dim_dw, hg.dim) == (ho.dimup, ho.dimdw, ho.dim)
+    hd, up, dw, nd = hg.export_normal()
+    assert rel_err(hd, ho.hd) < 1e-13
+    assert np.allclose(csr_to_dense(*up, ho.dimup), csr_to_dense(*ho.up, ho.dimup), rtol=0, atol=1e-14)
+    assert np.allclose(csr_to_dense(*dw, ho.dimdw), csr_to_dense(*ho.dw, ho.dimdw), rtol=0, atol=1e-14)
+    if ho.has_nd and ho.dim <= 4000:
+        assert np.allclose(csr_to_dense(*nd, ho.dim), csr_to_dense(*ho.nd, ho.dim), rtol=0, atol=1e-14)
+    hg.destroy()
+
+
+@pytest.mark.parametrize("bath,norb,nbath,sec", NORMAL_CASES)
+def test_normal_apply_matches_oracle(gpu, bath, norb, nbath, sec):
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("normal", bath, norb, nbath, seed=4)
+    ho = O.HNormal(om, *sec)
+    hg = SectorHamiltonian.normal_from_model(pm, *sec)
+    rng = np.random.default_rng(12345)
+    for _ in range(2):
+        v = rng.standard_normal(ho.dim)
+        assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
+    hg.destroy()
+
+
+def test_normal_create_from_reference_arrays(gpu):
+    """Drop-in boundary: hand over spH0d/spH0ups/spH0dws/spH0nd exactly as the (oracle-restated)
+    reference builds them -- unsorted columns in insertion order."""
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, _ = make_models("normal", "normal", 2, 3, seed=5)
+    ho = O.HNormal(om, 4, 4)
+    hg = SectorHamiltonian.normal_from_arrays(ho.dimup, ho.dimdw, ho.hd, ho.up, ho.dw, ho.nd)
+    v = np.random.default_rng(2).standard_normal(ho.dim)
+    assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
+    # linearity (size-independent property)
+    w = np.random.default_rng(3).standard_normal(ho.dim)
+    assert rel_err(hg.apply(2.0 * v - 3.0 * w), 2.0 * hg.apply(v) - 3.0 * hg.apply(w)) < 1e-12
+    hg.destroy()
+
+
+def test_normal_midsize_lds_paths(gpu):
+    """Ns=10 (5,5): DimUp=252, Dim=63504 -- several rows per workgroup and a multi-block grid."""
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("normal", "normal", 2, 4, seed=6)
+    ho = O.HNormal(om, 5, 5)
+    hg = SectorHamiltonian.normal_from_model(pm, 5, 5)
+    v = np.random.default_rng(9).standard_normal(ho.dim)
+    assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
+    hg.destroy()
+
+
+def test_normal_two_phase_equals_fused(gpu):
+    """edigpu_apply_local_dev + edigpu_apply_remote_dev on two dw-shards reproduce the fused product."""
+    import torch
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("normal", "normal", 2, 3, seed=8)
+    ho = O.HNormal(om, 4, 4)
+    v = np.random.default_rng(5).standard_normal(ho.dim)
+    ref = ho.matvec(v)
+    vd = torch.from_numpy(v).cuda()
+    out = []
+    half = ho.dimdw // 2
+    for first, cnt in ((0, half), (half, ho.dimdw - half)):
+        hs = SectorHamiltonian.normal_from_model(pm, 4, 4, dw_first=first, dw_count=cnt)
+        assert hs.nloc == cnt * ho.dimup and hs.row_first == first * ho.dimup
+        hv = torch.empty(hs.nloc, dtype=torch.float64, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        hs.apply_local_dev(vd[hs.row_first:].data_ptr(), hv.data_ptr(), st)
+        hs.apply_remote_dev(vd.data_ptr(), hv.data_ptr(), st)
+        hv2 = torch.empty_like(hv)
+        hs.apply_dev(vd.data_ptr(), hv2.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert rel_err(hv2.cpu().numpy(), hv.cpu().numpy()) < 1e-14
+        out.append(hv.cpu().numpy())
+        hs.destroy()
+    assert rel_err(np.concatenate(out), ref) < TOL
+
+
+# --------------------------------------------------------------------------------------------
+# flat CSR (real / complex), loc + non-loc split
+# --------------------------------------------------------------------------------------------
+def _random_csr(n, avg, cplx, seed, empty_rows=True):
+    rng = np.random.default_rng(seed)
+    cnt = rng.poisson(avg, n)
+    if empty_rows:
+        cnt[rng.integers(0, n, max(1, n // 10))] = 0
+    cnt = np.minimum(cnt, n)
+    rowptr = np.zeros(n + 1, np.int64)
+    rowptr[1:] = np.cumsum(cnt)
+    col = np.concatenate([rng.choice(n, c, replace=False) for c in cnt] + [np.zeros(0, np.int64)]).astype(np.int32)
+    val = rng.standard_normal(rowptr[-1])
+    if cplx:
+        val = val + 1j * rng.standard_normal(rowptr[-1])
+    return rowptr, col, val
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n,avg", [(1, 1), (257, 2.5), (1000, 7), (3000, 22), (500, 70)])
+def test_csr_apply_matches_oracle(gpu, cplx, n, avg):
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    rowptr, col, val = _random_csr(n, avg, cplx, seed=n)
+    hg = SectorHamiltonian.csr_from_arrays(rowptr, col, val)
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0)
+    assert rel_err(hg.apply(x), O.csr_matvec(rowptr, col, val, x)) < TOL
+    hg.destroy()
+
+
+def test_csr_empty_matrix(gpu):
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    hg = SectorHamiltonian.csr_from_arrays(np.zeros(6, np.int64), np.zeros(0, np.int32), np.zeros(0))
+    assert np.all(hg.apply(np.ones(5)) == 0.0)
+    hg.destroy()
+
+
+FLAT_CASES = [
+    ("superc", "normal", 2, 2, 0),   # reference test NORMAL_SUPERC, Sz=0: 924
+    ("superc", "hybrid", 2, 3, 1),
+    ("superc", "normal", 1, 3, -1),
+    ("nonsu2", "normal", 2, 2, 6),   # reference test NORMAL_NONSU2, N=6: 924
+    ("nonsu2", "hybrid", 2, 4, 5),
+    ("nonsu2", "hybrid", 3, 3, 6),   # 3 orbitals: signs across orbitals
+    ("nonsu2", "normal", 1, 2, 0),   # 1 x 1
+]
+
+
+@pytest.mark.parametrize("mode,bath,norb,nbath,sec", FLAT_CASES)
+def test_flat_builder_and_apply_match_oracle(gpu, mode, bath, norb, nbath, sec):
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models(mode, bath, norb, nbath, seed=11)
+    ho = O.HFlat(om, sec)
+    hg = SectorHamiltonian.flat_from_model(pm, sec)
+    assert hg.dim == ho.dim and hg.is_complex
+    rp, col, val = hg.export_csr()
+    dense_ref = ho.dense()
+    assert np.allclose(csr_to_dense(rp, col, val, ho.dim), dense_ref, rtol=0, atol=1e-14)
+    assert np.allclose(dense_ref, dense_ref.conj().T, atol=1e-14)   # Hermitian
+    rng = np.random.default_rng(4)
+    v = rng.standard_normal(ho.dim) + 1j * rng.standard_normal(ho.dim)
+    assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
+    hg.destroy()
+
+
+def test_flat_two_shards_loc_nonloc(gpu):
+    """Row shards with the loc / non-loc column split (spMatVec_mpi_superc_main data flow)."""
+    import torch
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("superc", "normal", 2, 2, seed=13)
+    ho = O.HFlat(om, 0)
+    v = np.random.default_rng(6).standard_normal(ho.dim) + 1j * np.random.default_rng(7).standard_normal(ho.dim)
+    ref = ho.matvec(v)
+    vd = torch.from_numpy(v).cuda()
+    q = ho.dim // 2
+    out = []
+    for first, cnt in ((0, q), (q, ho.dim - q)):      # remainder on the last shard, as the reference
+        hs = SectorHamiltonian.flat_from_model(pm, 0, row_first=first, row_count=cnt)
+        hv = torch.empty(cnt, dtype=torch.complex128, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        hs.apply_local_dev(vd[first:].data_ptr(), hv.data_ptr(), st)
+        hs.apply_remote_dev(vd.data_ptr(), hv.data_ptr(), st)
+        torch.cuda.synchronize()
+        out.append(hv.cpu().numpy())
+        hs.destroy()
+    assert rel_err(np.concatenate(out), ref) < TOL
+
+
+# --------------------------------------------------------------------------------------------
+# device-resident Lanczos
+# --------------------------------------------------------------------------------------------
+def _cf(alpha, beta, z):
+    """continued fraction <v|(z-H)^-1|v> from the tridiagonal (what the GF builder consumes)."""
+    g = 0.0
+    for k in range(len(alpha) - 1, -1, -1):
+        b2 = beta[k + 1] ** 2 if k + 1 < len(alpha) else 0.0
+        g = 1.0 / (z - alpha[k] - b2 * g)
+    return g
+
+
+@pytest.mark.parametrize("mode,bath,norb,nbath,sec", [
+    ("normal", "normal", 2, 3, (4, 4)),
+    ("superc", "normal", 2, 2, 0),
+    ("nonsu2", "normal", 2, 2, 6),
+])
+def test_lanczos_tridiag_matches_oracle(gpu, mode, bath, norb, nbath, sec):
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models(mode, bath, norb, nbath, seed=21)
+    if mode == "normal":
+        ho, hg = O.HNormal(om, *sec), SectorHamiltonian.normal_from_model(pm, *sec)
+    else:
+        ho, hg = O.HFlat(om, sec), SectorHamiltonian.flat_from_model(pm, sec)
+    rng = np.random.default_rng(12345)
+    v = rng.standard_normal(ho.dim) + (1j * rng.standard_normal(ho.dim) if mode != "normal" else 0)
+    n = 100
+    a_ref, b_ref, n_ref = ho.lanc_tridiag(v, n)
+    a, b, nd = hg.lanczos_tridiag(v, n)
+    assert nd == n_ref == n
+    # the first steps agree to rounding; later ones drift apart as in any two Lanczos runs
+    assert rel_err(a[:15], a_ref[:15]) < 1e-10 and rel_err(b[:15], b_ref[:15]) < 1e-10
+    # what the consumer uses (continued fraction away from the spectrum) agrees to 1e-10
+    for z in (40.0 + 0.1j, -40.0 + 0.1j, 25.0j):
+        g_ref, g = _cf(a_ref, b_ref, z), _cf(a, b, z)
+        assert abs(g - g_ref) / abs(g_ref) < 1e-10
+    # inside the spectrum both fractions are truncated Gauss quadratures of the same measure
+    g_ref, g = _cf(a_ref, b_ref, 0.5j), _cf(a, b, 0.5j)
+    assert abs(g - g_ref) / abs(g_ref) < 1e-6
+    hg.destroy()
+
+
+def test_lanczos_invariant_subspace_stops(gpu):
+    """A start vector inside a small invariant subspace: beta hits 0 and the recurrence stops,
+    as sp_lanc_tridiag does (edge case: Nlanc > rank of the Krylov space)."""
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    n = 6
+    rowptr = np.arange(n + 1, dtype=np.int64)
+    col = np.arange(n, dtype=np.int32)
+    val = np.array([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])
+    hg = SectorHamiltonian.csr_from_arrays(rowptr, col, val)
+    v = np.zeros(n)
+    v[1] = v[3] = 1.0          # spans a 2-dimensional invariant subspace
+    a, b, nd = hg.lanczos_tridiag(v, 6, threshold=1e-12)
+    assert nd == 2
+    ev = np.linalg.eigvalsh(np.diag(a[:2]) + np.diag(b[1:2], 1) + np.diag(b[1:2], -1))
+    assert np.allclose(ev, [2.0, 4.0], atol=1e-12)
+    hg.destroy()
+
+
+@pytest.mark.parametrize("mode,bath,norb,nbath,sec", [
+    ("normal", "normal", 2, 3, (4, 4)),     # 4900
+    ("normal", "hybrid", 3, 4, (3, 4)),     # 35*35
+    ("superc", "hybrid", 2, 3, 0),
+    ("nonsu2", "hybrid", 2, 3, 5),
+])
+def test_lanczos_eigh_matches_dense(gpu, mode, bath, norb, nbath, sec):
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models(mode, bath, norb, nbath, seed=31)
+    if mode == "normal":
+        ho, hg = O.HNormal(om, *sec), SectorHamiltonian.normal_from_model(pm, *sec)
+    else:
+        ho, hg = O.HFlat(om, sec), SectorHamiltonian.flat_from_model(pm, sec)
+    w, z = np.linalg.eigh(ho.dense())
+    e0, vec, nit = hg.lanczos_eigh(nitermax=300, tol=1e-13, check_every=10)
+    assert abs(e0 - w[0]) <= 1e-10 * max(1.0, abs(w[0]))
+    # eigenvector: residual and overlap with the dense ground space
+    r = ho.matvec(vec) - e0 * vec
+    assert np.linalg.norm(r) < 1e-6
+    deg = int(np.sum(w - w[0] < 1e-9))
+    ov = np.linalg.norm(z[:, :deg].conj().T @ vec)
+    assert abs(ov - 1.0) < 1e-8
+    hg.destroy()
+
+
+# --------------------------------------------------------------------------------------------
+# reference golden fixtures through the GPU path
+# --------------------------------------------------------------------------------------------
+GOLDEN = [
+    ("normal", "normal", 2, 2, dict(uloc=(2.0, 2.0), ust=2.0, jh=0.125, jx=0.125, jp=0.125), -10.533355749661421),
+    ("normal", "hybrid", 2, 4, dict(uloc=(2.0, 2.0), ust=2.0, jh=0.125, jx=0.125, jp=0.125), -7.1817468474675614),
+    ("superc", "normal", 2, 2, dict(uloc=(-2.0, -2.0), ust=-1.5, jh=0.25, jx=0.25, jp=0.25), -11.071617981308913),
+    ("superc", "hybrid", 2, 2, dict(uloc=(-2.0, -2.0), ust=-1.5, jh=0.25, jx=0.25, jp=0.25), -7.0681728592427708),
+    ("nonsu2", "normal", 2, 2, dict(uloc=(1.0, 1.0), ust=1.0, jh=0.01, jx=0.01, jp=0.01), -11.622869256525634),
+    ("nonsu2", "hybrid", 2, 4, dict(uloc=(1.0, 1.0), ust=1.0, jh=0.01, jx=0.01, jp=0.01), -8.1406794050893225),
+]
+
+
+@pytest.mark.parametrize("mode,bath,norb,nbath,par,e_gold", GOLDEN)
+def test_golden_ground_state_energy_on_gpu(gpu, mode, bath, norb, nbath, par, e_gold):
+    """evals.check of the reference's regression tests (test/src/<BATH>_<MODE>/evals.check, abs tol
+    1e-9, test/src/ASSERTING.f90:74-80), reproduced with GPU-built sectors + GPU Lanczos."""
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from tests.test_oracle_golden import golden_models
+    om, pm = golden_models(mode, bath, norb, nbath, par)
+    O = _oracle()
+    best = np.inf
+    for sec in O.sectors(om):
+        if mode == "normal":
+            if sec[0] < sec[1]:
+                continue                     # twin sectors (ed_twin=T): same spectrum
+            hg = SectorHamiltonian.normal_from_model(pm, *sec)
+        else:
+            try:
+                hg = SectorHamiltonian.flat_from_model(pm, sec)
+            except Exception:
+                continue                     # empty sector
+        if hg.dim <= 2:
+            v = np.eye(hg.dim, dtype=hg.dtype)
+            hm = np.stack([hg.apply(v[:, k].copy()) for k in range(hg.dim)], axis=1)
+            e0 = np.linalg.eigvalsh(hm)[0]
+        else:
+            e0, _, _ = hg.lanczos_eigh(nitermax=min(hg.dim, 400), tol=1e-14, check_every=20, want_vector=False)
+        best = min(best, e0)
+        hg.destroy()
+    assert abs(best - e_gold) < 1e-9
