@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- Lanczos H*v throughput of the MI355X engine on BASELINE.json's workload.
+
+    python bench.py --gpus N --steps K --warmup W [--workload cfg2]
+
+One "step" = one Lanczos iteration (H*v + three-term recurrence) on the largest sector of the
+workload, vectors resident in HBM.  N=1: single-shard device-resident loop inside libedigpu.so.
+N>1 (launched by torch.distributed.run, one rank per GPU): the vector is row-sharded, the exchange
+is an RCCL all-gather overlapped with the shard-local part of H*v; total work is fixed (strong
+scaling).  Rank 0 prints ONE JSON line.
+
+roofline  : algorithmic bytes of one H*v in the reference's storage format (SURVEY.md 8d,
+            edigpu_algorithmic_bytes) / average H*v launch duration from HIP events recorded
+            around every launch of the timed steps.
+cpu_baseline (N=1 only): the CPU oracle (a port of the reference algorithm, NOT the reference
+            binary) timed single-threaded on a bounded sample of the same matrices.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def _traffic_from_profiles(workload: str):
+    """HBM bytes per H*v launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json)."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        return json.load(open(p)).get(workload, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(h, workload, budget_s: float = 15.0):
+    """Time the oracle's spMatVec restatement on the SAME matrices (exported from the handle)."""
+    import numpy as np
+    from oracle import oracle as O
+    rng = np.random.default_rng(12345)
+    if h.kind == 0:
+        hd, up, dw, nd = h.export_normal()
+        ndarg = nd if nd[0][-1] > 0 else None
+        v = rng.standard_normal(h.dim)
+        v /= np.linalg.norm(v)
+        hv = np.empty_like(v)
+
+        def one():
+            O.normal_matvec_arrays(h.dim_up, h.dim_dw, hd, up, dw, ndarg, v, hv)
+    else:
+        rp, col, val = h.export_csr()
+        v = (rng.standard_normal(h.dim) + 1j * rng.standard_normal(h.dim)).astype(np.complex128)
+        v /= np.linalg.norm(v)
+
+        def one():
+            O.csr_matvec(rp, col, val, v)
+    t0 = time.perf_counter()
+    one()
+    t1 = time.perf_counter() - t0
+    n = int(max(2, min(200, budget_s / max(t1, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one()
+    dt = (time.perf_counter() - t0) / n
+    return {"value": 1.0 / dt, "unit": "H*v/s", "cores": 1, "kind": "port",
+            "sample": f"{n} H*v products of workload {workload} (same matrices as the GPU run), "
+                      f"oracle C restatement of spMatVec_*_main, 1 thread, {dt * 1e3:.1f} ms each"}
+
+
+def run_single(args):
+    import torch  # noqa: F401  (first: one HIP runtime per process, see edipack_amd/capi.py)
+    from edipack_amd import capi
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from edipack_amd.synthetic import WORKLOADS, synthetic_model
+
+    w = WORKLOADS[args.workload]
+    capi.init(0)
+    model = synthetic_model(w)
+    t0 = time.perf_counter()
+    if w.ed_mode == "normal":
+        h = SectorHamiltonian.normal_from_model(model, *w.sector)
+    else:
+        h = SectorHamiltonian.flat_from_model(model, w.sector)
+    t_build = time.perf_counter() - t0
+    bytes_hv, bytes_step = h.algorithmic_bytes()
+    ms_step, ms_hv = h.lanczos_bench(args.warmup, args.steps)
+    ms_hv_only = h.time_apply(max(2, args.warmup), args.steps, lanczos=False)
+    achieved = bytes_hv / (ms_hv * 1e-3) / 1e9
+    out = {
+        "metric": "Lanczos H*v iterations/sec, largest (Nup,Ndw) sector",
+        "value": 1e3 / ms_step, "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "c128" if h.is_complex else "f64", "data": "synthetic",
+        "config": {"workload": f"{w.name}: {w.ed_mode} mode, bath={w.bath_type}, Norb={w.norb}, Nbath={w.nbath}, "
+                               f"sector={w.sector}, Dim={h.dim} ({w.note})",
+                   "storage": "Kronecker (Hd,Hup,Hdw,Hnd)" if h.kind == 0 else "flat CSR",
+                   "parallelism": "1 GPU, device-resident Lanczos", "build_s": round(t_build, 3),
+                   "hv_only_ms": ms_hv_only, "lanczos_step_GBs": bytes_step / (ms_step * 1e-3) / 1e9},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profiles(w.name),
+                     "kernel": "normal_rows_kernel" if h.kind == 0 else "csr_rows_kernel",
+                     "algorithmic_bytes_per_launch": bytes_hv, "ms_per_launch": ms_hv},
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(h, w.name, args.cpu_seconds)
+    h.destroy()
+    print(json.dumps(out), flush=True)
+
+
+def run_multi(args):
+    import torch
+    import torch.distributed as dist
+    from edipack_amd import capi
+    from edipack_amd.sharding import gpu_sharded_hamiltonian
+    from edipack_amd.synthetic import WORKLOADS, synthetic_model
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    capi.init(local)
+    w = WORKLOADS[args.workload]
+    model = synthetic_model(w)
+    plan, h, lz = gpu_sharded_hamiltonian(model, w.sector, world, rank)
+    bytes_hv, _ = h.algorithmic_bytes()   # this shard's share of the algorithmic bytes
+    gen = torch.Generator(device="cuda").manual_seed(12345 + rank)
+    v0 = torch.randn(plan.nloc, dtype=torch.float64, device="cuda", generator=gen)
+    if lz.dtype.is_complex:
+        v0 = v0.to(lz.dtype)
+    lz.tridiag(v0, max(1, args.warmup))
+    # timed region: K Lanczos steps, barrier + synchronize on both sides
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    hv_orig = lz.hv
+    counter = {"k": 0}
+
+    def hv_timed():
+        k = counter["k"]
+        ev[k][0].record()
+        hv_orig()
+        ev[k][1].record()
+        counter["k"] = k + 1
+
+    lz.hv = hv_timed
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lz.tridiag(v0, args.steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    ms_hv = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    t = torch.tensor([dt, ms_hv, bytes_hv], dtype=torch.float64, device="cuda")
+    tmax = t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tsum = t.clone()
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        dt_max, ms_hv_max, bytes_total = float(tmax[0]), float(tmax[1]), float(tsum[2])
+        ms_step = dt_max * 1e3 / args.steps
+        achieved = bytes_total / (ms_hv_max * 1e-3) / 1e9
+        out = {
+            "metric": "Lanczos H*v iterations/sec, largest (Nup,Ndw) sector",
+            "value": 1e3 / ms_step, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "c128" if lz.dtype.is_complex else "f64", "data": "synthetic",
+            "config": {"workload": f"{w.name}: {w.ed_mode} mode, bath={w.bath_type}, Norb={w.norb}, "
+                                   f"Nbath={w.nbath}, sector={w.sector}, Dim={h.dim} ({w.note})",
+                       "parallelism": f"row-sharded over {world} GPUs, RCCL all-gather of v overlapped with the "
+                                      f"shard-local part of H*v"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                         "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
+                         "note": "whole-job: sum of shard algorithmic bytes / slowest rank's H*v time "
+                                 "(exchange included)", "ms_per_launch": ms_hv_max},
+        }
+        print(json.dumps(out), flush=True)
+    h.destroy()
+    dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        run_multi(args)
+    else:
+        run_single(args)
+
+
+if __name__ == "__main__":
+    main()

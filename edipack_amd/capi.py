@@ -77,6 +77,7 @@ SIGNATURES = {
     "edigpu_lanczos_tridiag": (C.c_int, [_vp, _pd, C.c_int, _pd, _pd, C.c_double, _pint]),
     "edigpu_lanczos_eigh": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int, _pd, _pd, _pd, _pint]),
     "edigpu_time_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _pd]),
+    "edigpu_lanczos_bench": (C.c_int, [_vp, C.c_int, C.c_int, _pd, _pd]),
     "edigpu_destroy": (C.c_int, [_vp]),
 }
 
@@ -90,6 +91,15 @@ def lib() -> C.CDLL:
         raise EdigpuError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so (SONAME
+    # libamdhip64.so.7) and looks it up by file name, so if libedigpu.so pulled in /opt/rocm's copy
+    # first, torch would load a second runtime that cannot see the GPU.  Importing torch first makes
+    # the dynamic loader resolve our NEEDED libamdhip64.so.7 to the copy torch already mapped.
+    # Without torch (e.g. the Fortran host) the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional plumbing
+        pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)

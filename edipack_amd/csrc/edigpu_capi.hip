@@ -4,6 +4,7 @@
 // sequencing on the handle's HIP stream, the device-resident Lanczos driver.
 // There is no CPU compute path: without a usable HIP device every entry point fails.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -816,6 +817,54 @@ int edigpu_time_apply(edigpu_handle s, int warmup, int steps, int lanczos, doubl
     return 1;
   }
   *ms_per_step = (double)ms / (double)steps;
+  return 0;
+}
+
+int edigpu_lanczos_bench(edigpu_handle s, int warmup, int steps, double* ms_wall_per_step,
+                         double* ms_hv_per_launch) {
+  if (!s || steps <= 0 || warmup < 0 || !ms_wall_per_step || !ms_hv_per_launch) {
+    set_error("edigpu_lanczos_bench: bad argument");
+    return 1;
+  }
+  if (single_shard(s, "edigpu_lanczos_bench")) return 1;
+  EDIGPU_HIP(hipSetDevice(s->device));
+  if (ensure_workspace(s)) return 1;
+  hipStream_t st = s->stream;
+  const int64_t len = s->ws_len;
+  const int total = warmup + steps;
+  if (lanczos_prepare(s, total, 0.0, st)) return 1;
+  if (lz_fill_random(s->d_vin, len, 12345ull, st)) return 1;
+  if (lz_norm_begin(s->d_vin, len, s->d_partial, s->d_scal, st)) return 1;
+  std::vector<hipEvent_t> ev(2 * (size_t)steps);
+  for (auto& e : ev) EDIGPU_HIP(hipEventCreate(&e));
+  int rc = 0;
+  for (int it = 0; it < warmup && !rc; it++) rc |= lanczos_step(s, it, total, st);
+  if (!rc) rc |= (hipStreamSynchronize(st) != hipSuccess);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < steps && !rc; k++) {
+    const int it = warmup + k;
+    if (it > 0) rc |= lz_rotate(s->d_vin, s->d_vout, len, s->d_scal, st);
+    rc |= (hipEventRecord(ev[2 * k], st) != hipSuccess);
+    rc |= apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st);
+    rc |= (hipEventRecord(ev[2 * k + 1], st) != hipSuccess);
+    rc |= lz_alpha(s->d_vin, s->d_vout, s->d_tmp, len, s->d_partial, s->d_scal, it, total, st);
+    rc |= lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, it, total, st);
+  }
+  if (!rc) rc |= (hipStreamSynchronize(st) != hipSuccess);
+  const auto t1 = std::chrono::steady_clock::now();
+  double hv = 0.0;
+  for (int k = 0; k < steps && !rc; k++) {
+    float ms = 0.f;
+    rc |= (hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]) != hipSuccess);
+    hv += ms;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (rc) {
+    if (g_err.empty()) set_error("edigpu_lanczos_bench: HIP failure");
+    return 1;
+  }
+  *ms_wall_per_step = std::chrono::duration<double, std::milli>(t1 - t0).count() / steps;
+  *ms_hv_per_launch = hv / steps;
   return 0;
 }
 

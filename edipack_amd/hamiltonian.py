@@ -261,6 +261,13 @@ class SectorHamiltonian:
                    "edigpu_time_apply")
         return ms.value
 
+    def lanczos_bench(self, warmup: int, steps: int):
+        """(ms wall per Lanczos step, ms per H*v launch from HIP events)."""
+        a, b = C.c_double(), C.c_double()
+        capi.check(capi.lib().edigpu_lanczos_bench(self._h, warmup, steps, C.byref(a), C.byref(b)),
+                   "edigpu_lanczos_bench")
+        return a.value, b.value
+
     def destroy(self) -> None:
         if self._h:
             capi.lib().edigpu_destroy(self._h)

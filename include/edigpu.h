@@ -223,6 +223,16 @@ int edigpu_lanczos_eigh(edigpu_handle h, int nitermax, double tol, int check_eve
  */
 int edigpu_time_apply(edigpu_handle h, int warmup, int steps, int lanczos, double *ms_per_step);
 
+/*
+ * Measurement helper for bench.py: `warmup` + `steps` full Lanczos steps (H*v + the vector
+ * recurrence) on a random unit start vector.  *ms_wall_per_step = host wall clock of the timed
+ * steps (stream synchronised on both sides) / steps; *ms_hv_per_launch = average duration of the
+ * H*v launches alone inside the timed steps, from HIP events recorded around every launch on the
+ * stream they are launched on.
+ */
+int edigpu_lanczos_bench(edigpu_handle h, int warmup, int steps, double *ms_wall_per_step,
+                         double *ms_hv_per_launch);
+
 int edigpu_destroy(edigpu_handle h);
 
 #ifdef __cplusplus

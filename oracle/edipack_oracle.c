@@ -569,6 +569,33 @@ void orc_spmatvec_normal_main(const orc_hnormal *h, const double *v, double *hv)
         hv[i] = hv[i] + h->nd.val[jj] * v[h->nd.col[jj]];
 }
 
+void orc_spmatvec_normal_arrays(int64_t dimup, int64_t dimdw, const double *hd,
+                                const int64_t *up_rowptr, const int32_t *up_col, const double *up_val,
+                                const int64_t *dw_rowptr, const int32_t *dw_col, const double *dw_val,
+                                const int64_t *nd_rowptr, const int32_t *nd_col, const double *nd_val,
+                                const double *v, double *hv) {
+  orc_hnormal h;
+  memset(&h, 0, sizeof(h));
+  h.dimup = dimup;
+  h.dimdw = dimdw;
+  h.dim = dimup * dimdw;
+  h.hd = (double *)hd;
+  h.up.nrow = dimup;
+  h.up.rowptr = (int64_t *)up_rowptr;
+  h.up.col = (int32_t *)up_col;
+  h.up.val = (double *)up_val;
+  h.dw.nrow = dimdw;
+  h.dw.rowptr = (int64_t *)dw_rowptr;
+  h.dw.col = (int32_t *)dw_col;
+  h.dw.val = (double *)dw_val;
+  h.has_nd = nd_rowptr != NULL;
+  h.nd.nrow = h.dim;
+  h.nd.rowptr = (int64_t *)nd_rowptr;
+  h.nd.col = (int32_t *)nd_col;
+  h.nd.val = (double *)nd_val;
+  orc_spmatvec_normal_main(&h, v, hv);
+}
+
 /* ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:209-262 (Hmat dump), row-major. */
 void orc_hnormal_dense(const orc_hnormal *h, double *hmat) {
   int64_t N = h->dim, DimUp = h->dimup, DimDw = h->dimdw;

@@ -105,6 +105,14 @@ void orc_spmatvec_normal_main(const orc_hnormal *h, const double *v, double *hv)
 /* dense dump: ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:209-262 (column-major nothing: symmetric, row-major out) */
 void orc_hnormal_dense(const orc_hnormal *h, double *hmat);
 
+/* same product on caller-owned arrays (bench.py cpu_baseline leg: the matrices of the timed
+ * workload are handed over so that CPU and GPU multiply the identical Hamiltonian) */
+void orc_spmatvec_normal_arrays(int64_t dimup, int64_t dimdw, const double *hd,
+                                const int64_t *up_rowptr, const int32_t *up_col, const double *up_val,
+                                const int64_t *dw_rowptr, const int32_t *dw_col, const double *dw_val,
+                                const int64_t *nd_rowptr, const int32_t *nd_col, const double *nd_val,
+                                const double *v, double *hv);
+
 /* flat CSR modes: ED_SUPERC/ED_HAMILTONIAN_SUPERC_STORED_HxV.f90:29-293, ED_NONSU2/..._STORED_HxV.f90:29-175 */
 typedef struct {
   int ns;

@@ -212,6 +212,8 @@ def lib() -> C.CDLL:
     L.orc_hflat_dense.argtypes = [vp, dp]
     L.orc_lanc_tridiag_flat.restype = C.c_int
     L.orc_lanc_tridiag_flat.argtypes = [vp, dp, C.c_int, dp, dp, C.c_double]
+    L.orc_spmatvec_normal_arrays.argtypes = [C.c_int64, C.c_int64, dp, i64p, i32p, dp, i64p, i32p, dp,
+                                             i64p, i32p, dp, dp, dp]
     L.orc_csr_matvec_d.argtypes = [vp, dp, dp]
     L.orc_csr_matvec_z.argtypes = [vp, dp, dp]
     _lib = L
@@ -353,6 +355,19 @@ class HFlat:
             self.close()
         except Exception:
             pass
+
+
+def normal_matvec_arrays(dimup, dimdw, hd, up, dw, nd, v, hv=None):
+    """spMatVec_normal_main (reference loop order) on caller-owned arrays; nd may be None."""
+    L = lib()
+    i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))  # noqa: E731
+    i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
+    if hv is None:
+        hv = np.empty_like(v)
+    ndargs = (i64(nd[0]), i32(nd[1]), _dp(nd[2])) if nd is not None else (None, None, None)
+    L.orc_spmatvec_normal_arrays(dimup, dimdw, _dp(hd), i64(up[0]), i32(up[1]), _dp(up[2]),
+                                 i64(dw[0]), i32(dw[1]), _dp(dw[2]), *ndargs, _dp(v), _dp(hv))
+    return hv
 
 
 # ----------------------------------------------------------------------------
