@@ -82,6 +82,39 @@ static int upload_ell(DevEll& e, const HostCsr& a) {
   for (int64_t i = 0; i < a.nrow; i++) w = std::max<int>(w, (int)(a.rowptr[i + 1] - a.rowptr[i]));
   e.width = w;
   if (w == 0 || a.nrow == 0) return 0;
+  // distinct |values| -> coefficient table (slot 0 = 0.0 for padding)
+  std::vector<double> coef(1, 0.0);
+  bool packable = a.nrow < ((int64_t)1 << 24);
+  std::vector<uint8_t> cid((size_t)a.nnz());
+  for (int64_t p = 0; p < a.nnz() && packable; p++) {
+    const double m = std::fabs(a.val[p]);
+    size_t k = 0;
+    for (; k < coef.size(); k++)
+      if (coef[k] == m) break;
+    if (k == coef.size()) {
+      if (coef.size() >= 128) {
+        packable = false;
+        break;
+      }
+      coef.push_back(m);
+    }
+    cid[p] = (uint8_t)k;
+  }
+  if (packable) {
+    coef.resize(128, 0.0);
+    std::vector<uint32_t> pk((size_t)w * e.pitch);
+    for (int k = 0; k < w; k++)
+      for (int64_t i = 0; i < e.pitch; i++) pk[(size_t)k * e.pitch + i] = (uint32_t)std::min(i, a.nrow - 1);
+    for (int64_t i = 0; i < a.nrow; i++) {
+      int k = 0;
+      for (int64_t p = a.rowptr[i]; p < a.rowptr[i + 1]; p++, k++)
+        pk[(size_t)k * e.pitch + i] = (uint32_t)a.col[p] | ((uint32_t)cid[p] << 24) |
+                                      (std::signbit(a.val[p]) ? 0x80000000u : 0u);
+    }
+    if (dev_upload(&e.pk, pk.data(), pk.size())) return 1;
+    if (dev_upload(&e.coef, coef.data(), coef.size())) return 1;
+    return 0;
+  }
   std::vector<int32_t> col((size_t)w * e.pitch);
   std::vector<double> val((size_t)w * e.pitch, 0.0);
   for (int k = 0; k < w; k++)
@@ -876,6 +909,8 @@ int edigpu_destroy(edigpu_handle s) {
     (void)hipStreamDestroy(s->stream);
   }
   dev_free(s->d_hd);
+  dev_free(s->up_ell.pk);
+  dev_free(s->up_ell.coef);
   dev_free(s->up_ell.col);
   dev_free(s->up_ell.val);
   free_csr(s->dw);

@@ -39,6 +39,10 @@ struct DevCsr {
 struct DevEll {
   int64_t nrow = 0, pitch = 0;
   int width = 0;
+  // packed image (preferred): 24-bit column | 7-bit coefficient id | sign; coef[128] table
+  uint32_t* pk = nullptr;
+  double* coef = nullptr;
+  // plain image (fallback when > 127 distinct |values| or nrow >= 2^24)
   int32_t* col = nullptr;   // width*pitch, padding: col=row, val=0
   double* val = nullptr;
 };
