@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -149,9 +150,15 @@ static int finish_handle(edigpu_sector* s) {
   return 0;
 }
 
+static bool env_flag(const char* name) {
+  const char* e = getenv(name);
+  return e && e[0] == '1';
+}
+
 static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_t dw_first,
                         int64_t dw_count, const double* hd, const HostCsr& up, const HostCsr& dw,
-                        const int64_t* nd_rowptr, const int32_t* nd_col, const double* nd_val) {
+                        const int64_t* nd_rowptr, const int32_t* nd_col, const double* nd_val,
+                        HostNormal* built = nullptr) {
   s->kind = 0;
   s->is_complex = 0;
   s->device = g_device;
@@ -164,11 +171,33 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
   s->row_first = dw_first * dim_up;
   s->h_up = up;
   s->h_dw = dw;
-  if (dev_upload(&s->d_hd, hd, (size_t)s->nloc)) return 1;
   if (upload_ell(s->up_ell, up)) return 1;
   if (upload_csr(s->dw, dim_dw, dw.rowptr.data(), dw.col.data(), dw.val.data(), 0)) return 1;
+  for (int64_t i = 0; i < dim_dw; i++)
+    s->dw_maxrow = std::max<int>(s->dw_maxrow, (int)(dw.rowptr[i + 1] - dw.rowptr[i]));
   s->has_nd = nd_rowptr != nullptr && nd_rowptr[s->nloc] > 0;
-  if (s->has_nd && upload_csr(s->nd, s->nloc, nd_rowptr, nd_col, nd_val, 0)) return 1;
+  s->nd_nnz = s->has_nd ? nd_rowptr[s->nloc] : 0;
+  // library-built sectors keep the diagonal and Hnd in factored form on the device (the explicit
+  // arrays stay on the host for export); EDIGPU_NORMAL_EXPLICIT=1 forces the explicit image.
+  if (built && built->fac.valid && built->fac.nterms <= 16 && !env_flag("EDIGPU_NORMAL_EXPLICIT")) {
+    const HostFactored& f = built->fac;
+    s->factored = 1;
+    s->fac_nimp = f.nimp;
+    s->fac_nterms = f.nterms;
+    if (dev_upload(&s->d_eux, f.eux.data(), f.eux.size())) return 1;
+    if (dev_upload(&s->d_ed, f.ed.data(), f.ed.size())) return 1;
+    if (dev_upload(&s->d_impd, f.impd.data(), f.impd.size())) return 1;
+    if (f.nterms > 0) {
+      if (dev_upload(&s->d_ndcoef, f.coef.data(), f.coef.size())) return 1;
+      if (dev_upload(&s->d_jup, f.jup.data(), f.jup.size())) return 1;
+      if (dev_upload(&s->d_jdw, f.jdw.data(), f.jdw.size())) return 1;
+    }
+    s->h_hd = std::move(built->hd);
+    s->h_nd = std::move(built->nd);
+  } else {
+    if (dev_upload(&s->d_hd, hd, (size_t)s->nloc)) return 1;
+    if (s->has_nd && upload_csr(s->nd, s->nloc, nd_rowptr, nd_col, nd_val, 0)) return 1;
+  }
   s->rows_per_block = normal_pick_rows_per_block(dim_up, dw_count);
   return finish_handle(s);
 }
@@ -460,7 +489,7 @@ int edigpu_normal_build(edigpu_handle* h, const edigpu_model* model, int nup, in
   std::unique_ptr<edigpu_sector> s(new edigpu_sector());
   if (setup_normal(s.get(), hn.dim_up, hn.dim_dw, hn.dw_first, hn.dw_count, hn.hd.data(), hn.up,
                    hn.dw, hn.has_nd ? hn.nd.rowptr.data() : nullptr, hn.nd.col.data(),
-                   hn.nd.val.data())) {
+                   hn.nd.val.data(), &hn)) {
     edigpu_destroy(s.release());
     return 1;
   }
@@ -523,7 +552,7 @@ int edigpu_info(edigpu_handle s, int64_t info[10]) {
   info[6] = s->dim_dw;
   if (s->kind == 0) {
     info[7] = s->h_up.nnz() + s->h_dw.nnz();
-    info[8] = s->has_nd ? s->nd.nnz : 0;
+    info[8] = s->nd_nnz;
   } else {
     info[7] = s->loc.nnz;
     info[8] = s->nonloc.nnz;
@@ -543,7 +572,7 @@ int edigpu_algorithmic_bytes(edigpu_handle s, double* bytes_hv, double* bytes_st
   if (s->kind == 0) {
     const double n = (double)s->nloc;
     b = 3.0 * sz * n;
-    if (s->has_nd) b += (sz + 4.0) * (double)s->nd.nnz + 4.0 * (n + 1.0);
+    if (s->has_nd) b += (sz + 4.0) * (double)s->nd_nnz + 4.0 * (n + 1.0);
     b += (sz + 4.0) * (double)(s->h_up.nnz() + s->h_dw.nnz()) + 4.0 * (double)(s->dim_up + s->dim_dw + 2);
   } else {
     const double n = (double)s->nloc;
@@ -579,7 +608,12 @@ int edigpu_normal_export(edigpu_handle s, double* hd, int64_t* up_rowptr, int32_
     return 1;
   }
   EDIGPU_HIP(hipSetDevice(s->device));
-  if (hd && s->nloc) EDIGPU_HIP(hipMemcpy(hd, s->d_hd, (size_t)s->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  if (hd && s->nloc) {
+    if (s->factored)
+      std::copy(s->h_hd.begin(), s->h_hd.end(), hd);
+    else
+      EDIGPU_HIP(hipMemcpy(hd, s->d_hd, (size_t)s->nloc * sizeof(double), hipMemcpyDeviceToHost));
+  }
   auto cp = [](const HostCsr& a, int64_t* rp, int32_t* c, double* v) {
     if (rp) std::copy(a.rowptr.begin(), a.rowptr.end(), rp);
     if (c) std::copy(a.col.begin(), a.col.end(), c);
@@ -587,6 +621,10 @@ int edigpu_normal_export(edigpu_handle s, double* hd, int64_t* up_rowptr, int32_
   };
   cp(s->h_up, up_rowptr, up_col, up_val);
   cp(s->h_dw, dw_rowptr, dw_col, dw_val);
+  if (s->has_nd && s->factored) {
+    cp(s->h_nd, nd_rowptr, nd_col, nd_val);
+    return 0;
+  }
   if (s->has_nd) return download_csr(s->nd, nd_rowptr, nd_col, nd_val, 1);
   if (nd_rowptr)
     for (int64_t i = 0; i <= s->nloc; i++) nd_rowptr[i] = 0;
@@ -909,6 +947,12 @@ int edigpu_destroy(edigpu_handle s) {
     (void)hipStreamDestroy(s->stream);
   }
   dev_free(s->d_hd);
+  dev_free(s->d_eux);
+  dev_free(s->d_ed);
+  dev_free(s->d_impd);
+  dev_free(s->d_ndcoef);
+  dev_free(s->d_jup);
+  dev_free(s->d_jdw);
   dev_free(s->up_ell.pk);
   dev_free(s->up_ell.coef);
   dev_free(s->up_ell.col);

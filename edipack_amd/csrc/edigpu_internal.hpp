@@ -60,10 +60,23 @@ struct edigpu_sector {
   double* d_hd = nullptr;
   edigpu::DevEll up_ell;
   edigpu::DevCsr dw;          // DimDw rows
+  int dw_maxrow = 0;
   edigpu::DevCsr nd;          // local rows, global columns
   int has_nd = 0;
   edigpu::HostCsr h_up, h_dw; // kept for export (tiny)
   int rows_per_block = 1;     // TD of the LDS row-block kernel (0: generic kernel)
+  // factored diagonal / non-local block (library-built sectors; see HostFactored)
+  int factored = 0;
+  int fac_nimp = 0, fac_nterms = 0;
+  double* d_eux = nullptr;      // nimp * dim_up
+  double* d_ed = nullptr;       // dim_dw
+  uint8_t* d_impd = nullptr;    // dim_dw
+  double* d_ndcoef = nullptr;   // nterms
+  uint32_t* d_jup = nullptr;    // nterms * dim_up
+  uint32_t* d_jdw = nullptr;    // nterms * dim_dw
+  int64_t nd_nnz = 0;           // nnz of the (possibly host-only) CSR image of Hnd
+  std::vector<double> h_hd;     // host copies kept for export when the device holds the factored form
+  edigpu::HostCsr h_nd;
   // ---- flat ----
   edigpu::DevCsr loc, nonloc; // local rows; loc columns are shard-relative, nonloc global
   // ---- Lanczos workspace (lazily allocated) ----

@@ -260,6 +260,20 @@ std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_fir
       }
       xt[(iu << norb) | id] = x;
     }
+  // factored diagonal tables
+  HostFactored& fac = out.fac;
+  fac = HostFactored();
+  fac.valid = true;
+  fac.nimp = 1 << norb;
+  fac.eux.resize((size_t)fac.nimp * DimUp);
+  for (uint32_t id = 0; id <= impmask; id++)
+    for (int64_t iup = 0; iup < DimUp; iup++) {
+      const uint32_t mu = (uint32_t)out.bup.states[iup];
+      fac.eux[(size_t)id * DimUp + iup] = eu[iup] + xt[((mu & impmask) << norb) | id];
+    }
+  fac.ed = ed;
+  fac.impd.resize(out.dim_dw);
+  for (int64_t idw = 0; idw < out.dim_dw; idw++) fac.impd[idw] = (uint8_t)((uint32_t)out.bdw.states[idw] & impmask);
   out.hd.resize((size_t)(dw_count * DimUp));
   for (int64_t r = 0; r < dw_count; r++) {
     const int64_t idw = dw_first + r;
@@ -283,6 +297,36 @@ std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_fir
   out.has_nd = norb > 1 && (any_jx || any_jp);
   out.nd = HostCsr();
   if (out.has_nd) {
+    // factored form: one (Pdw (x) Pup) pair per (kind, a, b)
+    auto partner = [&](const CombBasis& bs, int from, int to, std::vector<uint32_t>& dst) {
+      // c^+_to c_from on every basis state: partner index | sign
+      const uint32_t bf = 1u << from, bt = 1u << to, btw = between_mask(from, to);
+      for (int64_t i = 0; i < bs.size(); i++) {
+        const uint32_t st = (uint32_t)bs.states[i];
+        if ((st & bf) && !(st & bt)) {
+          const uint32_t j = (uint32_t)bs.rank(st ^ bf ^ bt);
+          dst.push_back(j | ((popc(st & btw) & 1) ? 0x80000000u : 0u));
+        } else {
+          dst.push_back(0xFFFFFFFFu);
+        }
+      }
+    };
+    for (int a = 0; a < norb; a++)
+      for (int b = 0; b < norb; b++) {
+        if (a == b) continue;
+        if (ix.jx(a, b) != 0.0) {  // up b->a, down a->b
+          fac.coef.push_back(ix.jx(a, b));
+          partner(out.bup, b, a, fac.jup);
+          partner(out.bdw, a, b, fac.jdw);
+          fac.nterms++;
+        }
+        if (ix.jp(a, b) != 0.0) {  // up b->a, down b->a
+          fac.coef.push_back(ix.jp(a, b));
+          partner(out.bup, b, a, fac.jup);
+          partner(out.bdw, b, a, fac.jdw);
+          fac.nterms++;
+        }
+      }
     struct Term { uint32_t xu, xd; double val; };
     std::vector<std::vector<Term>> terms((size_t)1 << (2 * norb));
     for (uint32_t iu = 0; iu <= impmask; iu++)

@@ -39,7 +39,25 @@ struct CombBasis {
   }
 };
 
+// Factored image of the diagonal and of the non-local block (what the library generates when it
+// builds the sector itself; nothing in the reference stores it this way):
+//   Hd(iup,idw)  = eux[impd(idw)][iup] + ed[idw]
+//   Hnd          = sum_t coef[t] * (Pdw_t (x) Pup_t), P = signed partial permutations
+// Partner entries: bits 0..30 partner index, bit 31 set = negative sign, 0xFFFFFFFF = no partner.
+struct HostFactored {
+  bool valid = false;
+  int nimp = 0;                 // 2^norb
+  std::vector<double> eux;      // nimp * dim_up
+  std::vector<double> ed;       // dim_dw
+  std::vector<uint8_t> impd;    // dim_dw
+  int nterms = 0;
+  std::vector<double> coef;     // nterms
+  std::vector<uint32_t> jup;    // nterms * dim_up
+  std::vector<uint32_t> jdw;    // nterms * dim_dw
+};
+
 struct HostNormal {
+  HostFactored fac;
   int ns = 0, nup = 0, ndw = 0;
   int64_t dim_up = 0, dim_dw = 0, dw_first = 0, dw_count = 0;
   CombBasis bup, bdw;

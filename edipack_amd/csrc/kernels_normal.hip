@@ -7,19 +7,23 @@
 // spMatVec_mpi_normal_main (:765-929).  The state vector is viewed as the matrix
 // V[idw][iup] (iup contiguous, ED_SECTOR.f90:1705-1717).
 //
-// Mapping to the hardware (one workgroup = TD consecutive idw rows, all iup):
-//  * the TD rows of V are staged once into LDS (coalesced HBM read); the Hup term is
-//    a gather inside a row and is served from LDS, not from L1/L2;
-//  * Hup is held as ELL, column-major, so that the 64 lanes of a wave read
-//    consecutive slots -- coalesced, L2-resident, shared by the TD rows; a slot is
-//    one packed 32-bit word (24-bit column, 7-bit coefficient id, sign) when the
-//    matrix has <= 127 distinct |values| (always true for bath hybridisations);
-//  * the Hdw term reads whole neighbour rows V[jdw][:], contiguous along iup:
-//    coalesced; the neighbour list of each row is broadcast from LDS;
-//  * every thread owns E columns per pass so that E independent loads are in flight
-//    per neighbour row / ELL slot (memory-level parallelism instead of occupancy);
-//  * Hd is streamed, Hnd (0.3 nnz/row) is a short per-row CSR gather.
-// No MFMA: ~0.25 flop/byte, HBM/L2 bound.
+// Two kernels, each with its irregular accesses served on-chip:
+//
+//  A. normal_rows_kernel -- one workgroup = TD consecutive idw rows, all iup.
+//     The TD rows of V are staged once into LDS (coalesced 16-byte HBM reads); the Hup term
+//     is a gather inside a row and is served from LDS.  Hup is held as ELL, column-major,
+//     one packed 32-bit word per slot (24-bit column, 7-bit coefficient id, sign) so that a
+//     lane fetches the slots of its 4 adjacent columns with one 16-byte load, shared by the
+//     TD rows.  The diagonal is streamed (explicit Hd) or regenerated from three small tables
+//     (sectors built by the library).
+//
+//  B. normal_dw_panel_kernel -- (Hdw (x) 1) + Hnd as a column-panel sweep.  A panel of <= 64
+//     columns over all DimDw rows fits one XCD's 4 MiB L2; all workgroups of an XCD sweep the
+//     same panel, so the ~6.5 neighbour-row reads per output row are L2 hits and the fabric
+//     sees V once.  Hnd is applied in factored form (signed partial permutations of the
+//     impurity bits: partners are adjacent rows / columns) or as CSR in kernel A.
+//
+// No MFMA: ~0.25 flop/byte, bandwidth bound.
 #include <cstdlib>
 #include <string>
 
@@ -28,8 +32,12 @@
 namespace edigpu {
 
 struct NormalArgs {
-  int64_t dim_up, dw_first, dw_count;
+  int64_t dim_up, dim_dw, dw_first, dw_count;
+  // diagonal: explicit (hd) or factored (eux[impd[g]][iup] + ed[g])
   const double* hd;
+  const double* eux;
+  const double* ed;
+  const uint8_t* impd;
   // Hup as ELL: packed (pk + coef table) or plain (col,val)
   const uint32_t* ell_pk;
   const double* ell_coef;  // 128 entries
@@ -40,17 +48,41 @@ struct NormalArgs {
   const int32_t* dw_rowptr;
   const int32_t* dw_col;
   const double* dw_val;
+  // Hnd: CSR over the local rows (explicit) or factored terms
   const int32_t* nd_rp32;
   const int64_t* nd_rp64;
   const int32_t* nd_col;
   const double* nd_val;
+  int dw_maxrow;  // longest row of Hdw
   int has_nd;
+  int nterms;
+  const double* nd_coef;
+  const uint32_t* jup;  // nterms * dim_up
+  const uint32_t* jdw;  // nterms * dim_dw
 };
 
 constexpr int kNT = 512;
 constexpr int kMaxNbr = 64;  // neighbour-list slots per row kept in LDS
+constexpr int kE = 4;        // adjacent columns owned by one thread per pass (16/32-byte accesses)
 
-template <int TD, int E, bool USE_LDS, bool LOCAL, bool DW, bool ND, bool PACKED>
+// VEC: DimUp even => every (row, 2-column pair) is 16-byte aligned and never straddles a row end
+template <bool VEC>
+__device__ inline void load4(const double* __restrict__ base, int64_t i0, const bool* ok, double* out) {
+  if (VEC) {
+    const double2 a = ok[0] ? *reinterpret_cast<const double2*>(base + i0) : make_double2(0.0, 0.0);
+    const double2 b = ok[2] ? *reinterpret_cast<const double2*>(base + i0 + 2) : make_double2(0.0, 0.0);
+    out[0] = a.x;
+    out[1] = a.y;
+    out[2] = b.x;
+    out[3] = b.y;
+  } else {
+#pragma unroll
+    for (int e = 0; e < kE; e++) out[e] = ok[e] ? base[i0 + e] : 0.0;
+  }
+}
+
+// HDF: diagonal from the factored tables instead of the explicit hd array
+template <int TD, bool USE_LDS, bool LOCAL, bool DW, bool ND, bool PACKED, bool VEC, bool HDF>
 __global__ void __launch_bounds__(kNT)
     normal_rows_kernel(NormalArgs a, const double* __restrict__ v_local,
                        const double* __restrict__ v_full, double* __restrict__ hv) {
@@ -84,22 +116,58 @@ __global__ void __launch_bounds__(kNT)
     }
   }
   if (LOCAL && USE_LDS) {
-    for (int r = 0; r < nr; r++) {
-      const double* src = v_local + (r0 + r) * DimUp;
-      for (int64_t iup = tid; iup < DimUp; iup += kNT) vs[r * DimUp + iup] = src[iup];
+    // stage the TD rows: 4 independent loads in flight per thread and row
+    if (VEC) {
+      const int64_t n2 = DimUp >> 1;
+      for (int64_t j0 = 0; j0 < n2; j0 += 4 * kNT) {
+        double2 t[TD][4];
+#pragma unroll
+        for (int r = 0; r < TD; r++)
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int64_t j = j0 + tid + u * kNT;
+            const int rr = r < nr ? r : 0;  // clamped: always a valid address
+            t[r][u] = reinterpret_cast<const double2*>(v_local + (r0 + rr) * DimUp)[j < n2 ? j : n2 - 1];
+          }
+#pragma unroll
+        for (int r = 0; r < TD; r++)
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int64_t j = j0 + tid + u * kNT;
+            if (r < nr && j < n2) reinterpret_cast<double2*>(vs + r * DimUp)[j] = t[r][u];
+          }
+      }
+    } else {
+      for (int64_t j0 = 0; j0 < DimUp; j0 += 4 * kNT) {
+        double t[TD][4];
+#pragma unroll
+        for (int r = 0; r < TD; r++)
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int64_t j = j0 + tid + u * kNT;
+            const int rr = r < nr ? r : 0;
+            t[r][u] = v_local[(r0 + rr) * DimUp + (j < DimUp ? j : DimUp - 1)];
+          }
+#pragma unroll
+        for (int r = 0; r < TD; r++)
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int64_t j = j0 + tid + u * kNT;
+            if (r < nr && j < DimUp) vs[r * DimUp + j] = t[r][u];
+          }
+      }
     }
   }
   __syncthreads();
 
-  for (int64_t c0 = 0; c0 < DimUp; c0 += (int64_t)kNT * E) {
-    double acc[TD][E];
-    int64_t col[E];
-    bool ok[E];
+  for (int64_t c0 = 0; c0 < DimUp; c0 += (int64_t)kNT * kE) {
+    const int64_t col0 = c0 + (int64_t)tid * kE;
+    if (col0 >= DimUp) break;  // no barrier below: safe to leave
+    double acc[TD][kE];
+    bool ok[kE];
 #pragma unroll
-    for (int e = 0; e < E; e++) {
-      col[e] = c0 + tid + (int64_t)e * kNT;
-      ok[e] = col[e] < DimUp;
-      if (!ok[e]) col[e] = DimUp - 1;  // clamp: loads stay in bounds, result discarded
+    for (int e = 0; e < kE; e++) {
+      ok[e] = col0 + e < DimUp;
 #pragma unroll
       for (int r = 0; r < TD; r++) acc[r][e] = 0.0;
     }
@@ -109,34 +177,52 @@ __global__ void __launch_bounds__(kNT)
 #pragma unroll
       for (int r = 0; r < TD; r++)
         if (r < nr) {
+          double h[kE], x[kE];
+          if (HDF) {
+            const int64_t g = a.dw_first + r0 + r;
+            const double edr = a.ed[g];
+            load4<VEC>(a.eux, (int64_t)a.impd[g] * DimUp + col0, ok, h);
 #pragma unroll
-          for (int e = 0; e < E; e++) {
-            const int64_t i = (r0 + r) * DimUp + col[e];
-            const double x = USE_LDS ? vs[r * DimUp + col[e]] : v_local[i];
-            acc[r][e] = a.hd[i] * x;
-          }
-        }
-      // ---- (1 (x) Hup): gather inside the row ----
-      for (int k = 0; k < a.ell_w; k++) {
-        int32_t cc[E];
-        double ww[E];
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-          if (PACKED) {
-            const uint32_t p = a.ell_pk[(int64_t)k * a.ell_pitch + col[e]];
-            cc[e] = (int32_t)(p & 0xFFFFFFu);
-            const double m = coef_s[(p >> 24) & 0x7Fu];
-            ww[e] = (p >> 31) ? -m : m;
+            for (int e = 0; e < kE; e++) h[e] += edr;
           } else {
-            cc[e] = a.ell_col[(int64_t)k * a.ell_pitch + col[e]];
-            ww[e] = a.ell_val[(int64_t)k * a.ell_pitch + col[e]];
+            load4<VEC>(a.hd, (r0 + r) * DimUp + col0, ok, h);
           }
+          if (USE_LDS) {
+#pragma unroll
+            for (int e = 0; e < kE; e++) x[e] = ok[e] ? vs[r * DimUp + col0 + e] : 0.0;
+          } else {
+            load4<VEC>(v_local, (r0 + r) * DimUp + col0, ok, x);
+          }
+#pragma unroll
+          for (int e = 0; e < kE; e++) acc[r][e] = h[e] * x[e];
+        }
+      // ---- (1 (x) Hup): gather inside the row; one 16-byte load brings 4 packed slots ----
+#pragma unroll 2
+      for (int k = 0; k < a.ell_w; k++) {
+        int32_t cc[kE];
+        double ww[kE];
+        const int64_t o = (int64_t)k * a.ell_pitch + col0;  // multiple of 4, inside the pitch
+        if (PACKED) {
+          const uint4 p4 = *reinterpret_cast<const uint4*>(a.ell_pk + o);
+          const uint32_t p[kE] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+          for (int e = 0; e < kE; e++) {
+            cc[e] = (int32_t)(p[e] & 0xFFFFFFu);
+            const double m = coef_s[(p[e] >> 24) & 0x7Fu];
+            ww[e] = (p[e] >> 31) ? -m : m;
+          }
+        } else {
+          const int4 c4 = *reinterpret_cast<const int4*>(a.ell_col + o);
+          const double2 w0 = *reinterpret_cast<const double2*>(a.ell_val + o);
+          const double2 w1 = *reinterpret_cast<const double2*>(a.ell_val + o + 2);
+          cc[0] = c4.x; cc[1] = c4.y; cc[2] = c4.z; cc[3] = c4.w;
+          ww[0] = w0.x; ww[1] = w0.y; ww[2] = w1.x; ww[3] = w1.y;
         }
 #pragma unroll
         for (int r = 0; r < TD; r++)
           if (r < nr) {
 #pragma unroll
-            for (int e = 0; e < E; e++) {
+            for (int e = 0; e < kE; e++) {
               const double x = USE_LDS ? vs[r * DimUp + cc[e]] : v_local[(r0 + r) * DimUp + cc[e]];
               acc[r][e] += ww[e] * x;
             }
@@ -153,17 +239,19 @@ __global__ void __launch_bounds__(kNT)
 #pragma unroll 4
             for (int jj = 0; jj < n; jj++) {
               const double w = nb_val[r][jj];
-              const double* row = v_full + (int64_t)nb_col[r][jj] * DimUp;
+              double x[kE];
+              load4<VEC>(v_full, (int64_t)nb_col[r][jj] * DimUp + col0, ok, x);
 #pragma unroll
-              for (int e = 0; e < E; e++) acc[r][e] += w * row[col[e]];
+              for (int e = 0; e < kE; e++) acc[r][e] += w * x[e];
             }
           } else {
             const int64_t g = a.dw_first + r0 + r;
             for (int32_t jj = a.dw_rowptr[g]; jj < a.dw_rowptr[g + 1]; jj++) {
               const double w = a.dw_val[jj];
-              const double* row = v_full + (int64_t)a.dw_col[jj] * DimUp;
+              double x[kE];
+              load4<VEC>(v_full, (int64_t)a.dw_col[jj] * DimUp + col0, ok, x);
 #pragma unroll
-              for (int e = 0; e < E; e++) acc[r][e] += w * row[col[e]];
+              for (int e = 0; e < kE; e++) acc[r][e] += w * x[e];
             }
           }
         }
@@ -171,101 +259,131 @@ __global__ void __launch_bounds__(kNT)
     if (ND) {
       // ---- Hnd: short CSR rows with global columns ----
       if (a.has_nd) {
+        int64_t rp[TD][kE + 1];
 #pragma unroll
         for (int r = 0; r < TD; r++)
           if (r < nr) {
-            int64_t b[E], en[E];
+            const int64_t i0 = (r0 + r) * DimUp + col0;
 #pragma unroll
-            for (int e = 0; e < E; e++) {
-              const int64_t i = (r0 + r) * DimUp + col[e];
-              if (a.nd_rp64) {
-                b[e] = a.nd_rp64[i];
-                en[e] = a.nd_rp64[i + 1];
-              } else {
-                b[e] = a.nd_rp32[i];
-                en[e] = a.nd_rp32[i + 1];
+            for (int e = 0; e <= kE; e++) {
+              const int64_t i = (e == 0 || ok[e - 1]) ? i0 + e : i0;  // stays inside the row pointers
+              rp[r][e] = a.nd_rp64 ? a.nd_rp64[i] : (int64_t)a.nd_rp32[i];
+            }
+          }
+#pragma unroll
+        for (int r = 0; r < TD; r++)
+          if (r < nr) {
+#pragma unroll
+            for (int e = 0; e < kE; e++)
+              if (ok[e]) {
+                double s = 0.0;
+                for (int64_t jj = rp[r][e]; jj < rp[r][e + 1]; jj++)
+                  s += a.nd_val[jj] * v_full[a.nd_col[jj]];
+                acc[r][e] += s;
               }
-            }
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-              double s = 0.0;
-              for (int64_t jj = b[e]; jj < en[e]; jj++) s += a.nd_val[jj] * v_full[a.nd_col[jj]];
-              acc[r][e] += s;
-            }
           }
       }
     }
 #pragma unroll
     for (int r = 0; r < TD; r++)
       if (r < nr) {
+        double* dst = hv + (r0 + r) * DimUp + col0;
+        if (!LOCAL) {
+          double old[kE];
+          load4<VEC>(hv, (r0 + r) * DimUp + col0, ok, old);
 #pragma unroll
-        for (int e = 0; e < E; e++)
-          if (ok[e]) {
-            const int64_t i = (r0 + r) * DimUp + col[e];
-            if (LOCAL)
-              hv[i] = acc[r][e];
-            else
-              hv[i] += acc[r][e];
-          }
+          for (int e = 0; e < kE; e++) acc[r][e] += old[e];
+        }
+        if (VEC) {
+          if (ok[0]) *reinterpret_cast<double2*>(dst) = make_double2(acc[r][0], acc[r][1]);
+          if (ok[2]) *reinterpret_cast<double2*>(dst + 2) = make_double2(acc[r][2], acc[r][3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < kE; e++)
+            if (ok[e]) dst[e] = acc[r][e];
+        }
       }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// (Hdw (x) 1) as a column-panel sweep:  hv[:, panel] += Hdw * V[:, panel]
+// B. column-panel sweep:  hv[:, panel] += Hdw * V[:, panel]  (+ factored Hnd)
 //
-// The down term touches ~6.5 other rows of V per output row.  V (94 MB for config 2) does not
-// fit the 8 x 4 MiB L2s, but one panel of W <= 64 columns over all DimDw rows does (1.7 MB for
-// config 2).  All workgroups that share an XCD (blockIdx % 8, the observed round-robin dispatch;
-// a different placement only costs speed) sweep the same panel at the same time, so every
-// neighbour-row read after the first touch is an L2 hit and HBM sees V exactly once.
-// A wave owns one output row at a time (64 lanes = 64 panel columns, one 512-B segment);
-// the row's neighbour list is wave-uniform and is fetched with scalar loads.
+// All workgroups that share an XCD (blockIdx % 8, the observed round-robin dispatch; a different
+// placement only costs speed) sweep the same panel at the same time.  A wave owns one output row
+// at a time (64 lanes = 64 panel columns, one 512-B segment); the row's neighbour list is
+// wave-uniform and is fetched with scalar loads.
 // ------------------------------------------------------------------------------------------
 struct PanelArgs {
-  int64_t dim_up, dw_first, dw_count;
   int npanels, width, blocks_per_panel, rows_per_block;
-  const int32_t* dw_rowptr;
-  const int32_t* dw_col;
-  const double* dw_val;
 };
 
 constexpr int kPanelNT = 512;
+constexpr int kMaxNdTerms = 16;
 
-__global__ void __launch_bounds__(kPanelNT, 2)
-    normal_dw_panel_kernel(PanelArgs a, const double* __restrict__ v_full, double* __restrict__ hv) {
+template <bool DO_DW, bool DO_ND>
+__global__ void __launch_bounds__(kPanelNT)
+    normal_dw_panel_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full,
+                           double* __restrict__ hv) {
   const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
-  const int panel = (k / a.blocks_per_panel) * 8 + x;
-  if (panel >= a.npanels) return;
-  const int chunk = k % a.blocks_per_panel;
+  const int panel = (k / p.blocks_per_panel) * 8 + x;
+  if (panel >= p.npanels) return;
+  const int chunk = k % p.blocks_per_panel;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t DimUp = a.dim_up;
-  const int64_t c = (int64_t)panel * a.width + lane;
-  const bool ok = lane < a.width && c < DimUp;
+  const int64_t c = (int64_t)panel * p.width + lane;
+  const bool ok = lane < p.width && c < DimUp;
   const int64_t cc = ok ? c : DimUp - 1;
-  int64_t rend = (int64_t)(chunk + 1) * a.rows_per_block;
+  int64_t rend = (int64_t)(chunk + 1) * p.rows_per_block;
   if (rend > a.dw_count) rend = a.dw_count;
   constexpr int NW = kPanelNT / 64;
-  for (int64_t r = (int64_t)chunk * a.rows_per_block + wave; r < rend; r += 2 * NW) {
+  // the lane's partner columns of every Hnd term (depends on the column only)
+  uint32_t ju[kMaxNdTerms];
+  if (DO_ND) {
+#pragma unroll
+    for (int t = 0; t < kMaxNdTerms; t++) ju[t] = t < a.nterms ? a.jup[(int64_t)t * DimUp + cc] : 0xFFFFFFFFu;
+  }
+  for (int64_t r = (int64_t)chunk * p.rows_per_block + wave; r < rend; r += 2 * NW) {
     // two rows per iteration: independent load streams in flight
     const int64_t r2 = r + NW;
     const bool two = r2 < rend;
     const int64_t g = a.dw_first + r;
-    const int32_t b0 = a.dw_rowptr[g], e0 = a.dw_rowptr[g + 1];
-    int32_t b1 = 0, e1 = 0;
-    if (two) {
-      b1 = a.dw_rowptr[g + NW];
-      e1 = a.dw_rowptr[g + NW + 1];
-    }
     double acc0 = hv[r * DimUp + cc];
     double acc1 = two ? hv[r2 * DimUp + cc] : 0.0;
+    if (DO_DW) {
+      const int32_t b0 = a.dw_rowptr[g], e0 = a.dw_rowptr[g + 1];
+      int32_t b1 = 0, e1 = 0;
+      if (two) {
+        b1 = a.dw_rowptr[g + NW];
+        e1 = a.dw_rowptr[g + NW + 1];
+      }
 #pragma unroll 4
-    for (int32_t jj = b0; jj < e0; jj++)
-      acc0 += a.dw_val[jj] * v_full[(int64_t)a.dw_col[jj] * DimUp + cc];
+      for (int32_t jj = b0; jj < e0; jj++)
+        acc0 += a.dw_val[jj] * v_full[(int64_t)a.dw_col[jj] * DimUp + cc];
 #pragma unroll 4
-    for (int32_t jj = b1; jj < e1; jj++)
-      acc1 += a.dw_val[jj] * v_full[(int64_t)a.dw_col[jj] * DimUp + cc];
+      for (int32_t jj = b1; jj < e1; jj++)
+        acc1 += a.dw_val[jj] * v_full[(int64_t)a.dw_col[jj] * DimUp + cc];
+    }
+    if (DO_ND) {
+#pragma unroll
+      for (int t = 0; t < kMaxNdTerms; t++)
+        if (t < a.nterms) {
+          const double cf = a.nd_coef[t];
+          const uint32_t jd0 = a.jdw[(int64_t)t * a.dim_dw + g];
+          if (jd0 != 0xFFFFFFFFu && ju[t] != 0xFFFFFFFFu) {
+            const double w = ((jd0 ^ ju[t]) >> 31) ? -cf : cf;
+            acc0 += w * v_full[(int64_t)(jd0 & 0x7FFFFFFFu) * DimUp + (ju[t] & 0x7FFFFFFFu)];
+          }
+          if (two) {
+            const uint32_t jd1 = a.jdw[(int64_t)t * a.dim_dw + g + NW];
+            if (jd1 != 0xFFFFFFFFu && ju[t] != 0xFFFFFFFFu) {
+              const double w = ((jd1 ^ ju[t]) >> 31) ? -cf : cf;
+              acc1 += w * v_full[(int64_t)(jd1 & 0x7FFFFFFFu) * DimUp + (ju[t] & 0x7FFFFFFFu)];
+            }
+          }
+        }
+    }
     if (ok) {
       hv[r * DimUp + c] = acc0;
       if (two) hv[r2 * DimUp + c] = acc1;
@@ -273,29 +391,169 @@ __global__ void __launch_bounds__(kPanelNT, 2)
   }
 }
 
-static int launch_dw_panels(const NormalArgs& a, const double* v_full, double* hv, hipStream_t st) {
+// Variant with the neighbour lists of the workgroup's rows preloaded into LDS (one latency round
+// instead of two dependent scalar-load rounds per row) and 4 output rows in flight per wave.
+constexpr int kPanelRowsMax = 64;  // rows per workgroup held in LDS lists
+
+template <int MAXN, bool DO_DW, bool DO_ND>
+__global__ void __launch_bounds__(kPanelNT)
+    normal_dw_panel_lds_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full,
+                               double* __restrict__ hv) {
+  __shared__ int32_t l_col[kPanelRowsMax][MAXN];
+  __shared__ double l_val[kPanelRowsMax][MAXN];
+  __shared__ int l_cnt[kPanelRowsMax];
+  __shared__ uint32_t l_jdw[kPanelRowsMax][kMaxNdTerms];
+  const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const int panel = (k / p.blocks_per_panel) * 8 + x;
+  if (panel >= p.npanels) return;
+  const int chunk = k % p.blocks_per_panel;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t DimUp = a.dim_up;
+  const int64_t c = (int64_t)panel * p.width + lane;
+  const bool ok = lane < p.width && c < DimUp;
+  const int64_t cc = ok ? c : DimUp - 1;
+  const int64_t rbeg = (int64_t)chunk * p.rows_per_block;
+  int64_t rend = rbeg + p.rows_per_block;
+  if (rend > a.dw_count) rend = a.dw_count;
+  const int nrows = (int)(rend - rbeg);
+  // ---- cooperative preload of the lists ----
+  if (DO_DW) {
+    for (int idx = threadIdx.x; idx < nrows * MAXN; idx += kPanelNT) {
+      const int r = idx / MAXN, j = idx % MAXN;
+      const int64_t g = a.dw_first + rbeg + r;
+      const int32_t b = a.dw_rowptr[g], n = a.dw_rowptr[g + 1] - b;
+      if (j < n) {
+        l_col[r][j] = a.dw_col[b + j];
+        l_val[r][j] = a.dw_val[b + j];
+      }
+      if (j == 0) l_cnt[r] = n;
+    }
+  }
+  if (DO_ND) {
+    for (int idx = threadIdx.x; idx < nrows * a.nterms; idx += kPanelNT) {
+      const int r = idx / a.nterms, t = idx % a.nterms;
+      l_jdw[r][t] = a.jdw[(int64_t)t * a.dim_dw + a.dw_first + rbeg + r];
+    }
+  }
+  uint32_t ju[kMaxNdTerms];
+  if (DO_ND) {
+#pragma unroll
+    for (int t = 0; t < kMaxNdTerms; t++) ju[t] = t < a.nterms ? a.jup[(int64_t)t * DimUp + cc] : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  constexpr int NW = kPanelNT / 64;
+  constexpr int R = 4;  // output rows in flight per wave
+  for (int base = wave * R; base < nrows; base += NW * R) {
+    double acc[R];
+    int n[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      acc[q] = 0.0;
+      n[q] = (DO_DW && base + q < nrows) ? l_cnt[base + q] : 0;
+    }
+    if (DO_DW) {
+      int nmax = n[0];
+#pragma unroll
+      for (int q = 1; q < R; q++) nmax = n[q] > nmax ? n[q] : nmax;
+#pragma unroll 2
+      for (int jj = 0; jj < nmax; jj++) {
+#pragma unroll
+        for (int q = 0; q < R; q++)
+          if (jj < n[q])
+            acc[q] += l_val[base + q][jj] * v_full[(int64_t)l_col[base + q][jj] * DimUp + cc];
+      }
+    }
+    if (DO_ND) {
+#pragma unroll
+      for (int q = 0; q < R; q++)
+        if (base + q < nrows) {
+          for (int t = 0; t < a.nterms; t++) {
+            const uint32_t jd = l_jdw[base + q][t];
+            if (jd != 0xFFFFFFFFu) {
+              const double cf = a.nd_coef[t];
+              uint32_t jt = 0xFFFFFFFFu;
+#pragma unroll
+              for (int tt = 0; tt < kMaxNdTerms; tt++)
+                if (tt == t) jt = ju[tt];
+              if (jt != 0xFFFFFFFFu) {
+                const double w = ((jd ^ jt) >> 31) ? -cf : cf;
+                acc[q] += w * v_full[(int64_t)(jd & 0x7FFFFFFFu) * DimUp + (jt & 0x7FFFFFFFu)];
+              }
+            }
+          }
+        }
+    }
+    // read-modify-write of the output rows last: the long-latency stream load is consumed last
+#pragma unroll
+    for (int q = 0; q < R; q++)
+      if (base + q < nrows) {
+        const int64_t i = (rbeg + base + q) * DimUp + cc;
+        const double old = hv[i];
+        if (ok) hv[i] = old + acc[q];
+      }
+  }
+}
+
+static int panel_resident_blocks() {
+  // EDIGPU_PANEL_BPP: workgroups per panel (tuning knob); default = what one XCD keeps resident
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("EDIGPU_PANEL_BPP");
+    v = e ? atoi(e) : 128;
+    if (v < 1) v = 128;
+  }
+  return v;
+}
+
+static int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* v_full,
+                            double* hv, hipStream_t st) {
+  if (!do_dw && !do_nd) return 0;
+  if (do_nd && a.nterms > kMaxNdTerms) {
+    set_error("launch_dw_panels: too many factored Hnd terms");
+    return 1;
+  }
   PanelArgs p;
-  p.dim_up = a.dim_up;
-  p.dw_first = a.dw_first;
-  p.dw_count = a.dw_count;
-  p.dw_rowptr = a.dw_rowptr;
-  p.dw_col = a.dw_col;
-  p.dw_val = a.dw_val;
   // panels: a multiple of 8 (one stream of panels per XCD), at most 64 columns wide
-  int np = (int)((a.dim_up + 511) / 512) * 8;
+  int wmax = 64;
+  if (const char* e = getenv("EDIGPU_PANEL_W")) {
+    wmax = atoi(e);
+    if (wmax < 1 || wmax > 64) wmax = 64;
+  }
+  int np = (int)((a.dim_up + 8 * wmax - 1) / (8 * wmax)) * 8;
   if (np < 8) np = 8;
   p.width = (int)((a.dim_up + np - 1) / np);
   if (p.width < 1) p.width = 1;
   p.npanels = (int)((a.dim_up + p.width - 1) / p.width);
-  // ~64 workgroups per panel = what one XCD keeps resident (32 CUs x 2): one panel in flight per XCD
-  int bpp = 64;
+  int bpp = panel_resident_blocks();
   p.rows_per_block = (int)((a.dw_count + bpp - 1) / bpp);
   if (p.rows_per_block < 16) p.rows_per_block = 16;
   bpp = (int)((a.dw_count + p.rows_per_block - 1) / p.rows_per_block);
   p.blocks_per_panel = bpp;
   const int panel_groups = (p.npanels + 7) / 8;
-  const int64_t nblk = (int64_t)panel_groups * bpp * 8;
-  hipLaunchKernelGGL(normal_dw_panel_kernel, dim3((unsigned)nblk), dim3(kPanelNT), 0, st, p, v_full, hv);
+  const dim3 grid((unsigned)((int64_t)panel_groups * bpp * 8)), block(kPanelNT);
+  const bool lds_ok = a.dw_maxrow <= 64 && p.rows_per_block <= kPanelRowsMax && !getenv("EDIGPU_PANEL_NOLDS");
+#define EDIGPU_PANEL_LAUNCH(KERN) hipLaunchKernelGGL((KERN), grid, block, 0, st, a, p, v_full, hv)
+  if (lds_ok) {
+    if (a.dw_maxrow <= 16) {
+      if (do_dw && do_nd) EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<16, true, true>));
+      else if (do_dw) EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<16, true, false>));
+      else EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<16, false, true>));
+    } else if (a.dw_maxrow <= 32) {
+      if (do_dw && do_nd) EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<32, true, true>));
+      else if (do_dw) EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<32, true, false>));
+      else EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<32, false, true>));
+    } else {
+      if (do_dw && do_nd) EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<64, true, true>));
+      else if (do_dw) EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<64, true, false>));
+      else EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<64, false, true>));
+    }
+  } else {
+    if (do_dw && do_nd) EDIGPU_PANEL_LAUNCH((normal_dw_panel_kernel<true, true>));
+    else if (do_dw) EDIGPU_PANEL_LAUNCH((normal_dw_panel_kernel<true, false>));
+    else EDIGPU_PANEL_LAUNCH((normal_dw_panel_kernel<false, true>));
+  }
+#undef EDIGPU_PANEL_LAUNCH
   EDIGPU_HIP(hipGetLastError());
   return 0;
 }
@@ -314,28 +572,29 @@ int normal_pick_rows_per_block(int64_t dim_up, int64_t dw_count) {
   return td;
 }
 
-// what: bit0 = diagonal+up (overwrite), bit1 = down term inside the row kernel, bit2 = Hnd
-template <int TD, int E, bool USE_LDS, bool PACKED>
+// what: bit0 = diagonal+up (overwrite), bit1 = down term inside the row kernel, bit2 = CSR Hnd
+template <int TD, bool USE_LDS, bool PACKED, bool VEC, bool HDF>
 static int launch_te(const NormalArgs& a, const double* vl, const double* vf, double* hv,
                      int what, hipStream_t st) {
   const int64_t nblk = (a.dw_count + TD - 1) / TD;
   const size_t lds = USE_LDS ? (size_t)TD * a.dim_up * sizeof(double) : 0;
   dim3 grid((unsigned)nblk), block(kNT);
-#define EDIGPU_LAUNCH_ROWS(LOC, DWF, NDF, LDSB, UL, PK)                                          \
+#define EDIGPU_LAUNCH_ROWS(LOC, DWF, NDF, LDSB, UL, PK, HF)                                      \
   do {                                                                                           \
-    auto kern = normal_rows_kernel<TD, E, UL, LOC, DWF, NDF, PK>;                                \
+    auto kern = normal_rows_kernel<TD, UL, LOC, DWF, NDF, PK, VEC, HF>;                          \
     if ((LDSB) > 48 * 1024)                                                                      \
       EDIGPU_HIP(hipFuncSetAttribute((const void*)kern,                                          \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB)));  \
     hipLaunchKernelGGL(kern, grid, block, (LDSB), st, a, vl, vf, hv);                            \
   } while (0)
   switch (what) {
-    case 1: EDIGPU_LAUNCH_ROWS(true, false, false, lds, USE_LDS, PACKED); break;
-    case 5: EDIGPU_LAUNCH_ROWS(true, false, true, lds, USE_LDS, PACKED); break;
-    case 7: EDIGPU_LAUNCH_ROWS(true, true, true, lds, USE_LDS, PACKED); break;
-    case 4: EDIGPU_LAUNCH_ROWS(false, false, true, (size_t)0, false, false); break;
-    case 6: EDIGPU_LAUNCH_ROWS(false, true, true, (size_t)0, false, false); break;
-    case 2: EDIGPU_LAUNCH_ROWS(false, true, false, (size_t)0, false, false); break;
+    case 1: EDIGPU_LAUNCH_ROWS(true, false, false, lds, USE_LDS, PACKED, HDF); break;
+    case 5: EDIGPU_LAUNCH_ROWS(true, false, true, lds, USE_LDS, PACKED, HDF); break;
+    case 7: EDIGPU_LAUNCH_ROWS(true, true, true, lds, USE_LDS, PACKED, HDF); break;
+    case 3: EDIGPU_LAUNCH_ROWS(true, true, false, lds, USE_LDS, PACKED, HDF); break;
+    case 4: EDIGPU_LAUNCH_ROWS(false, false, true, (size_t)0, false, false, false); break;
+    case 6: EDIGPU_LAUNCH_ROWS(false, true, true, (size_t)0, false, false, false); break;
+    case 2: EDIGPU_LAUNCH_ROWS(false, true, false, (size_t)0, false, false, false); break;
     default: set_error("launch_normal: bad term mask"); return 1;
   }
 #undef EDIGPU_LAUNCH_ROWS
@@ -344,30 +603,27 @@ static int launch_te(const NormalArgs& a, const double* vl, const double* vf, do
 }
 
 template <int TD, bool USE_LDS>
-static int launch_td(const NormalArgs& a, bool packed, const double* vl, const double* vf,
+static int launch_td(const NormalArgs& a, bool packed, bool hdf, const double* vl, const double* vf,
                      double* hv, int what, hipStream_t st) {
-  // E columns per thread and pass: enough to cover the row in few passes, capped by registers
-  const int64_t per_thread = (a.dim_up + kNT - 1) / kNT;
-  constexpr int EMAX = (TD >= 4) ? 2 : 4;
-  if (per_thread >= 3 && EMAX >= 4)
-    return packed ? launch_te<TD, 4, USE_LDS, true>(a, vl, vf, hv, what, st)
-                  : launch_te<TD, 4, USE_LDS, false>(a, vl, vf, hv, what, st);
-  if (per_thread >= 2)
-    return packed ? launch_te<TD, 2, USE_LDS, true>(a, vl, vf, hv, what, st)
-                  : launch_te<TD, 2, USE_LDS, false>(a, vl, vf, hv, what, st);
-  return packed ? launch_te<TD, 1, USE_LDS, true>(a, vl, vf, hv, what, st)
-                : launch_te<TD, 1, USE_LDS, false>(a, vl, vf, hv, what, st);
+  const bool vec = (a.dim_up % 2) == 0;
+#define EDIGPU_TD(PK, VC)                                                           \
+  (hdf ? launch_te<TD, USE_LDS, PK, VC, true>(a, vl, vf, hv, what, st)             \
+       : launch_te<TD, USE_LDS, PK, VC, false>(a, vl, vf, hv, what, st))
+  if (vec) return packed ? EDIGPU_TD(true, true) : EDIGPU_TD(false, true);
+  return packed ? EDIGPU_TD(true, false) : EDIGPU_TD(false, false);
+#undef EDIGPU_TD
 }
 
 static int launch_rows(const edigpu_sector* s, const NormalArgs& a, const double* vl,
                        const double* vf, double* hv, int what, hipStream_t st) {
   const bool packed = s->up_ell.pk != nullptr;
+  const bool hdf = s->factored != 0;
   switch (s->rows_per_block) {
-    case 0: return launch_td<1, false>(a, packed, vl, vf, hv, what, st);
-    case 1: return launch_td<1, true>(a, packed, vl, vf, hv, what, st);
-    case 2: return launch_td<2, true>(a, packed, vl, vf, hv, what, st);
-    case 4: return launch_td<4, true>(a, packed, vl, vf, hv, what, st);
-    case 8: return launch_td<8, true>(a, packed, vl, vf, hv, what, st);
+    case 0: return launch_td<1, false>(a, packed, hdf, vl, vf, hv, what, st);
+    case 1: return launch_td<1, true>(a, packed, hdf, vl, vf, hv, what, st);
+    case 2: return launch_td<2, true>(a, packed, hdf, vl, vf, hv, what, st);
+    case 4: return launch_td<4, true>(a, packed, hdf, vl, vf, hv, what, st);
+    case 8: return launch_td<8, true>(a, packed, hdf, vl, vf, hv, what, st);
     default: set_error("launch_normal: bad rows_per_block"); return 1;
   }
 }
@@ -387,9 +643,13 @@ int launch_normal(const edigpu_sector* s, const double* v_local, const double* v
                   int phase, hipStream_t st) {
   NormalArgs a;
   a.dim_up = s->dim_up;
+  a.dim_dw = s->dim_dw;
   a.dw_first = s->dw_first;
   a.dw_count = s->dw_count;
   a.hd = s->d_hd;
+  a.eux = s->d_eux;
+  a.ed = s->d_ed;
+  a.impd = s->d_impd;
   a.ell_pk = s->up_ell.pk;
   a.ell_coef = s->up_ell.coef;
   a.ell_col = s->up_ell.col;
@@ -399,23 +659,40 @@ int launch_normal(const edigpu_sector* s, const double* v_local, const double* v
   a.dw_rowptr = s->dw.rowptr32;
   a.dw_col = s->dw.col;
   a.dw_val = s->dw.val;
+  a.dw_maxrow = s->dw_maxrow;
   a.nd_rp32 = s->nd.rowptr32;
   a.nd_rp64 = s->nd.wide ? s->nd.rowptr64 : nullptr;
   a.nd_col = s->nd.col;
   a.nd_val = s->nd.val;
   a.has_nd = s->has_nd;
+  a.nterms = s->factored ? s->fac_nterms : 0;
+  a.nd_coef = s->d_ndcoef;
+  a.jup = s->d_jup;
+  a.jdw = s->d_jdw;
   if (s->dw_count == 0) return 0;
+  const bool fac = s->factored != 0;
+  const bool csr_nd = !fac && s->has_nd;       // Hnd applied by the row kernel from CSR
+  const bool fac_nd = fac && a.nterms > 0;     // Hnd applied by the panel kernel from the factored terms
+  // timing-only ablations (results are wrong on purpose)
+  if (const char* ab = getenv("EDIGPU_ABLATE_ELL")) {
+    if (ab[0] == '1') a.ell_w = 0;
+  }
+  if (const char* ab = getenv("EDIGPU_ABLATE_TERMS")) {
+    if (std::string(ab) == "panels") return launch_dw_panels(a, true, fac_nd, v_full, hv, st);
+    if (std::string(ab) == "panels_dw") return launch_dw_panels(a, true, false, v_full, hv, st);
+    return launch_rows(s, a, v_local, v_full, hv, atoi(ab), st);
+  }
   const bool rows = dw_in_rows();
   if (phase == 1) return launch_rows(s, a, v_local, v_full, hv, 1, st);
   if (phase == 3) {
-    if (rows) return launch_rows(s, a, v_local, v_full, hv, 7, st);
-    if (launch_rows(s, a, v_local, v_full, hv, s->has_nd ? 5 : 1, st)) return 1;
-    return launch_dw_panels(a, v_full, hv, st);
+    const int what = 1 | (rows ? 2 : 0) | (csr_nd ? 4 : 0);
+    if (launch_rows(s, a, v_local, v_full, hv, what, st)) return 1;
+    return launch_dw_panels(a, !rows, fac_nd, v_full, hv, st);
   }
   // phase 2: the terms that need the gathered vector, accumulated into hv
-  if (rows) return launch_rows(s, a, v_local, v_full, hv, s->has_nd ? 6 : 2, st);
-  if (s->has_nd && launch_rows(s, a, v_local, v_full, hv, 4, st)) return 1;
-  return launch_dw_panels(a, v_full, hv, st);
+  const int what = (rows ? 2 : 0) | (csr_nd ? 4 : 0);
+  if (what && launch_rows(s, a, v_local, v_full, hv, what, st)) return 1;
+  return launch_dw_panels(a, !rows, fac_nd, v_full, hv, st);
 }
 
 }  // namespace edigpu
