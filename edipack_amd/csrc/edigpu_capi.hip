@@ -101,6 +101,36 @@ static int upload_ell(DevEll& e, const HostCsr& a) {
     }
     cid[p] = (uint8_t)k;
   }
+  // typed layout: every row holds at most one entry per distinct |value| -> slot = value id
+  bool typed = packable && coef.size() > 1 && !getenv("EDIGPU_ELL_UNTYPED");
+  for (int64_t i = 0; i < a.nrow && typed; i++) {
+    uint64_t seen[2] = {0, 0};
+    for (int64_t p = a.rowptr[i]; p < a.rowptr[i + 1]; p++) {
+      const int id = cid[p];
+      if (id == 0 || (seen[id >> 6] >> (id & 63)) & 1) {
+        typed = false;
+        break;
+      }
+      seen[id >> 6] |= (uint64_t)1 << (id & 63);
+    }
+  }
+  if (typed) {
+    const int nt = (int)coef.size() - 1;
+    e.width = nt;
+    e.typed = 1;
+    std::vector<double> tc(128, 0.0);
+    for (int k = 0; k < nt; k++) tc[k] = coef[k + 1];
+    std::vector<uint32_t> pk((size_t)nt * e.pitch);
+    for (int k = 0; k < nt; k++)
+      for (int64_t i = 0; i < e.pitch; i++) pk[(size_t)k * e.pitch + i] = (uint32_t)std::min(i, a.nrow - 1);
+    for (int64_t i = 0; i < a.nrow; i++)
+      for (int64_t p = a.rowptr[i]; p < a.rowptr[i + 1]; p++)
+        pk[(size_t)(cid[p] - 1) * e.pitch + i] = (uint32_t)a.col[p] | (1u << 24) |
+                                                 (std::signbit(a.val[p]) ? 0x80000000u : 0u);
+    if (dev_upload(&e.pk, pk.data(), pk.size())) return 1;
+    if (dev_upload(&e.coef, tc.data(), tc.size())) return 1;
+    return 0;
+  }
   if (packable) {
     coef.resize(128, 0.0);
     std::vector<uint32_t> pk((size_t)w * e.pitch);
@@ -191,6 +221,29 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
       if (dev_upload(&s->d_ndcoef, f.coef.data(), f.coef.size())) return 1;
       if (dev_upload(&s->d_jup, f.jup.data(), f.jup.size())) return 1;
       if (dev_upload(&s->d_jdw, f.jdw.data(), f.jdw.size())) return 1;
+      // merged per-local-row list for the panel kernel: Hdw entries (tag 0) + applicable Hnd terms
+      if (dim_dw < ((int64_t)1 << 24) && f.nterms < 127) {
+        std::vector<int32_t> mp((size_t)dw_count + 1, 0), mc;
+        std::vector<double> mv;
+        for (int64_t r = 0; r < dw_count; r++) {
+          const int64_t g = dw_first + r;
+          for (int64_t q = dw.rowptr[g]; q < dw.rowptr[g + 1]; q++) {
+            mc.push_back(dw.col[q]);
+            mv.push_back(dw.val[q]);
+          }
+          for (int t = 0; t < f.nterms; t++) {
+            const uint32_t jd = f.jdw[(size_t)t * dim_dw + g];
+            if (jd != 0xFFFFFFFFu) {
+              mc.push_back((int32_t)((jd & 0xFFFFFFu) | ((uint32_t)(t + 1) << 24)));
+              mv.push_back((jd >> 31) ? -f.coef[t] : f.coef[t]);
+            }
+          }
+          mp[r + 1] = (int32_t)mc.size();
+        }
+        if (dev_upload(&s->d_mx_rowptr, mp.data(), mp.size())) return 1;
+        if (dev_upload(&s->d_mx_col, mc.data(), mc.size())) return 1;
+        if (dev_upload(&s->d_mx_val, mv.data(), mv.size())) return 1;
+      }
     }
     s->h_hd = std::move(built->hd);
     s->h_nd = std::move(built->nd);
@@ -947,6 +1000,9 @@ int edigpu_destroy(edigpu_handle s) {
     (void)hipStreamDestroy(s->stream);
   }
   dev_free(s->d_hd);
+  dev_free(s->d_mx_rowptr);
+  dev_free(s->d_mx_col);
+  dev_free(s->d_mx_val);
   dev_free(s->d_eux);
   dev_free(s->d_ed);
   dev_free(s->d_impd);

@@ -39,6 +39,7 @@ struct DevCsr {
 struct DevEll {
   int64_t nrow = 0, pitch = 0;
   int width = 0;
+  int typed = 0;            // packed image with one hop amplitude per slot (coef[k])
   // packed image (preferred): 24-bit column | 7-bit coefficient id | sign; coef[128] table
   uint32_t* pk = nullptr;
   double* coef = nullptr;
@@ -74,6 +75,9 @@ struct edigpu_sector {
   double* d_ndcoef = nullptr;   // nterms
   uint32_t* d_jup = nullptr;    // nterms * dim_up
   uint32_t* d_jdw = nullptr;    // nterms * dim_dw
+  int32_t* d_mx_rowptr = nullptr;  // per local row: Hdw entries + applicable Hnd terms
+  int32_t* d_mx_col = nullptr;
+  double* d_mx_val = nullptr;
   int64_t nd_nnz = 0;           // nnz of the (possibly host-only) CSR image of Hnd
   std::vector<double> h_hd;     // host copies kept for export when the device holds the factored form
   edigpu::HostCsr h_nd;

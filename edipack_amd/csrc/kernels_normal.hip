@@ -44,6 +44,7 @@ struct NormalArgs {
   const int32_t* ell_col;
   const double* ell_val;
   int ell_w;
+  int ell_typed;  // packed ELL whose slot k holds the hop with amplitude ell_coef[k]
   int64_t ell_pitch;
   const int32_t* dw_rowptr;
   const int32_t* dw_col;
@@ -59,6 +60,10 @@ struct NormalArgs {
   const double* nd_coef;
   const uint32_t* jup;  // nterms * dim_up
   const uint32_t* jdw;  // nterms * dim_dw
+  // per LOCAL row: Hdw entries + applicable Hnd terms in one list (panel kernel)
+  const int32_t* mx_rowptr;  // merged list: ptr[dw_count+1]
+  const int32_t* mx_col;     // partner row (24 bit) | tag << 24
+  const double* mx_val;
 };
 
 constexpr int kNT = 512;
@@ -205,11 +210,22 @@ __global__ void __launch_bounds__(kNT)
         if (PACKED) {
           const uint4 p4 = *reinterpret_cast<const uint4*>(a.ell_pk + o);
           const uint32_t p[kE] = {p4.x, p4.y, p4.z, p4.w};
+          if (a.ell_typed) {
+            // slot k = one hop type: the amplitude is wave-uniform, no table lookup
+            const double tk = a.ell_coef[k];
 #pragma unroll
-          for (int e = 0; e < kE; e++) {
-            cc[e] = (int32_t)(p[e] & 0xFFFFFFu);
-            const double m = coef_s[(p[e] >> 24) & 0x7Fu];
-            ww[e] = (p[e] >> 31) ? -m : m;
+            for (int e = 0; e < kE; e++) {
+              cc[e] = (int32_t)(p[e] & 0xFFFFFFu);
+              const double m = ((p[e] >> 24) & 0x7Fu) ? tk : 0.0;
+              ww[e] = (p[e] >> 31) ? -m : m;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < kE; e++) {
+              cc[e] = (int32_t)(p[e] & 0xFFFFFFu);
+              const double m = coef_s[(p[e] >> 24) & 0x7Fu];
+              ww[e] = (p[e] >> 31) ? -m : m;
+            }
           }
         } else {
           const int4 c4 = *reinterpret_cast<const int4*>(a.ell_col + o);
@@ -351,7 +367,7 @@ __global__ void __launch_bounds__(kPanelNT)
     const int64_t g = a.dw_first + r;
     double acc0 = hv[r * DimUp + cc];
     double acc1 = two ? hv[r2 * DimUp + cc] : 0.0;
-    if (DO_DW) {
+    if (DO_DW && !DO_ND) {
       const int32_t b0 = a.dw_rowptr[g], e0 = a.dw_rowptr[g + 1];
       int32_t b1 = 0, e1 = 0;
       if (two) {
@@ -366,132 +382,57 @@ __global__ void __launch_bounds__(kPanelNT)
         acc1 += a.dw_val[jj] * v_full[(int64_t)a.dw_col[jj] * DimUp + cc];
     }
     if (DO_ND) {
+      // merged per-LOCAL-row list: down hops (tag 0) followed by the applicable Hnd terms
+      // (tag = term id + 1 in bits 24..30 of the column word, weight = +-coef of the down side)
+      const int32_t b0 = a.mx_rowptr[r], e0 = a.mx_rowptr[r + 1];
+      int32_t b1 = 0, e1 = 0;
+      if (two) {
+        b1 = a.mx_rowptr[r2];
+        e1 = a.mx_rowptr[r2 + 1];
+      }
+#pragma unroll 2
+      for (int32_t jj = b0; jj < e0; jj++) {
+        const uint32_t cw = (uint32_t)a.mx_col[jj];
+        const int tag = (int)(cw >> 24);
+        double w = a.mx_val[jj];
+        int64_t col = cc;
+        if (tag) {
+          uint32_t jt = 0xFFFFFFFFu;
 #pragma unroll
-      for (int t = 0; t < kMaxNdTerms; t++)
-        if (t < a.nterms) {
-          const double cf = a.nd_coef[t];
-          const uint32_t jd0 = a.jdw[(int64_t)t * a.dim_dw + g];
-          if (jd0 != 0xFFFFFFFFu && ju[t] != 0xFFFFFFFFu) {
-            const double w = ((jd0 ^ ju[t]) >> 31) ? -cf : cf;
-            acc0 += w * v_full[(int64_t)(jd0 & 0x7FFFFFFFu) * DimUp + (ju[t] & 0x7FFFFFFFu)];
-          }
-          if (two) {
-            const uint32_t jd1 = a.jdw[(int64_t)t * a.dim_dw + g + NW];
-            if (jd1 != 0xFFFFFFFFu && ju[t] != 0xFFFFFFFFu) {
-              const double w = ((jd1 ^ ju[t]) >> 31) ? -cf : cf;
-              acc1 += w * v_full[(int64_t)(jd1 & 0x7FFFFFFFu) * DimUp + (ju[t] & 0x7FFFFFFFu)];
-            }
-          }
+          for (int tt = 0; tt < kMaxNdTerms; tt++)
+            if (tt == tag - 1) jt = ju[tt];
+          const bool v = jt != 0xFFFFFFFFu;
+          w = v ? ((jt >> 31) ? -w : w) : 0.0;
+          col = v ? (int64_t)(jt & 0x7FFFFFFFu) : cc;
+        } else if (!DO_DW) {
+          w = 0.0;
         }
+        acc0 += w * v_full[(int64_t)(cw & 0xFFFFFFu) * DimUp + col];
+      }
+#pragma unroll 2
+      for (int32_t jj = b1; jj < e1; jj++) {
+        const uint32_t cw = (uint32_t)a.mx_col[jj];
+        const int tag = (int)(cw >> 24);
+        double w = a.mx_val[jj];
+        int64_t col = cc;
+        if (tag) {
+          uint32_t jt = 0xFFFFFFFFu;
+#pragma unroll
+          for (int tt = 0; tt < kMaxNdTerms; tt++)
+            if (tt == tag - 1) jt = ju[tt];
+          const bool v = jt != 0xFFFFFFFFu;
+          w = v ? ((jt >> 31) ? -w : w) : 0.0;
+          col = v ? (int64_t)(jt & 0x7FFFFFFFu) : cc;
+        } else if (!DO_DW) {
+          w = 0.0;
+        }
+        acc1 += w * v_full[(int64_t)(cw & 0xFFFFFFu) * DimUp + col];
+      }
     }
     if (ok) {
       hv[r * DimUp + c] = acc0;
       if (two) hv[r2 * DimUp + c] = acc1;
     }
-  }
-}
-
-// Variant with the neighbour lists of the workgroup's rows preloaded into LDS (one latency round
-// instead of two dependent scalar-load rounds per row) and 4 output rows in flight per wave.
-constexpr int kPanelRowsMax = 64;  // rows per workgroup held in LDS lists
-
-template <int MAXN, bool DO_DW, bool DO_ND>
-__global__ void __launch_bounds__(kPanelNT)
-    normal_dw_panel_lds_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full,
-                               double* __restrict__ hv) {
-  __shared__ int32_t l_col[kPanelRowsMax][MAXN];
-  __shared__ double l_val[kPanelRowsMax][MAXN];
-  __shared__ int l_cnt[kPanelRowsMax];
-  __shared__ uint32_t l_jdw[kPanelRowsMax][kMaxNdTerms];
-  const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
-  const int panel = (k / p.blocks_per_panel) * 8 + x;
-  if (panel >= p.npanels) return;
-  const int chunk = k % p.blocks_per_panel;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t DimUp = a.dim_up;
-  const int64_t c = (int64_t)panel * p.width + lane;
-  const bool ok = lane < p.width && c < DimUp;
-  const int64_t cc = ok ? c : DimUp - 1;
-  const int64_t rbeg = (int64_t)chunk * p.rows_per_block;
-  int64_t rend = rbeg + p.rows_per_block;
-  if (rend > a.dw_count) rend = a.dw_count;
-  const int nrows = (int)(rend - rbeg);
-  // ---- cooperative preload of the lists ----
-  if (DO_DW) {
-    for (int idx = threadIdx.x; idx < nrows * MAXN; idx += kPanelNT) {
-      const int r = idx / MAXN, j = idx % MAXN;
-      const int64_t g = a.dw_first + rbeg + r;
-      const int32_t b = a.dw_rowptr[g], n = a.dw_rowptr[g + 1] - b;
-      if (j < n) {
-        l_col[r][j] = a.dw_col[b + j];
-        l_val[r][j] = a.dw_val[b + j];
-      }
-      if (j == 0) l_cnt[r] = n;
-    }
-  }
-  if (DO_ND) {
-    for (int idx = threadIdx.x; idx < nrows * a.nterms; idx += kPanelNT) {
-      const int r = idx / a.nterms, t = idx % a.nterms;
-      l_jdw[r][t] = a.jdw[(int64_t)t * a.dim_dw + a.dw_first + rbeg + r];
-    }
-  }
-  uint32_t ju[kMaxNdTerms];
-  if (DO_ND) {
-#pragma unroll
-    for (int t = 0; t < kMaxNdTerms; t++) ju[t] = t < a.nterms ? a.jup[(int64_t)t * DimUp + cc] : 0xFFFFFFFFu;
-  }
-  __syncthreads();
-  constexpr int NW = kPanelNT / 64;
-  constexpr int R = 4;  // output rows in flight per wave
-  for (int base = wave * R; base < nrows; base += NW * R) {
-    double acc[R];
-    int n[R];
-#pragma unroll
-    for (int q = 0; q < R; q++) {
-      acc[q] = 0.0;
-      n[q] = (DO_DW && base + q < nrows) ? l_cnt[base + q] : 0;
-    }
-    if (DO_DW) {
-      int nmax = n[0];
-#pragma unroll
-      for (int q = 1; q < R; q++) nmax = n[q] > nmax ? n[q] : nmax;
-#pragma unroll 2
-      for (int jj = 0; jj < nmax; jj++) {
-#pragma unroll
-        for (int q = 0; q < R; q++)
-          if (jj < n[q])
-            acc[q] += l_val[base + q][jj] * v_full[(int64_t)l_col[base + q][jj] * DimUp + cc];
-      }
-    }
-    if (DO_ND) {
-#pragma unroll
-      for (int q = 0; q < R; q++)
-        if (base + q < nrows) {
-          for (int t = 0; t < a.nterms; t++) {
-            const uint32_t jd = l_jdw[base + q][t];
-            if (jd != 0xFFFFFFFFu) {
-              const double cf = a.nd_coef[t];
-              uint32_t jt = 0xFFFFFFFFu;
-#pragma unroll
-              for (int tt = 0; tt < kMaxNdTerms; tt++)
-                if (tt == t) jt = ju[tt];
-              if (jt != 0xFFFFFFFFu) {
-                const double w = ((jd ^ jt) >> 31) ? -cf : cf;
-                acc[q] += w * v_full[(int64_t)(jd & 0x7FFFFFFFu) * DimUp + (jt & 0x7FFFFFFFu)];
-              }
-            }
-          }
-        }
-    }
-    // read-modify-write of the output rows last: the long-latency stream load is consumed last
-#pragma unroll
-    for (int q = 0; q < R; q++)
-      if (base + q < nrows) {
-        const int64_t i = (rbeg + base + q) * DimUp + cc;
-        const double old = hv[i];
-        if (ok) hv[i] = old + acc[q];
-      }
   }
 }
 
@@ -532,28 +473,12 @@ static int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const d
   p.blocks_per_panel = bpp;
   const int panel_groups = (p.npanels + 7) / 8;
   const dim3 grid((unsigned)((int64_t)panel_groups * bpp * 8)), block(kPanelNT);
-  const bool lds_ok = a.dw_maxrow <= 64 && p.rows_per_block <= kPanelRowsMax && !getenv("EDIGPU_PANEL_NOLDS");
-#define EDIGPU_PANEL_LAUNCH(KERN) hipLaunchKernelGGL((KERN), grid, block, 0, st, a, p, v_full, hv)
-  if (lds_ok) {
-    if (a.dw_maxrow <= 16) {
-      if (do_dw && do_nd) EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<16, true, true>));
-      else if (do_dw) EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<16, true, false>));
-      else EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<16, false, true>));
-    } else if (a.dw_maxrow <= 32) {
-      if (do_dw && do_nd) EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<32, true, true>));
-      else if (do_dw) EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<32, true, false>));
-      else EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<32, false, true>));
-    } else {
-      if (do_dw && do_nd) EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<64, true, true>));
-      else if (do_dw) EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<64, true, false>));
-      else EDIGPU_PANEL_LAUNCH((normal_dw_panel_lds_kernel<64, false, true>));
-    }
-  } else {
-    if (do_dw && do_nd) EDIGPU_PANEL_LAUNCH((normal_dw_panel_kernel<true, true>));
-    else if (do_dw) EDIGPU_PANEL_LAUNCH((normal_dw_panel_kernel<true, false>));
-    else EDIGPU_PANEL_LAUNCH((normal_dw_panel_kernel<false, true>));
-  }
-#undef EDIGPU_PANEL_LAUNCH
+  if (do_dw && do_nd)
+    hipLaunchKernelGGL((normal_dw_panel_kernel<true, true>), grid, block, 0, st, a, p, v_full, hv);
+  else if (do_dw)
+    hipLaunchKernelGGL((normal_dw_panel_kernel<true, false>), grid, block, 0, st, a, p, v_full, hv);
+  else
+    hipLaunchKernelGGL((normal_dw_panel_kernel<false, true>), grid, block, 0, st, a, p, v_full, hv);
   EDIGPU_HIP(hipGetLastError());
   return 0;
 }
@@ -562,10 +487,14 @@ static int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const d
 // workgroups per CU when possible (<= 64 KiB each of the 160 KiB LDS).
 int normal_pick_rows_per_block(int64_t dim_up, int64_t dw_count) {
   const int64_t row_bytes = dim_up * 8;
+  if (const char* e = getenv("EDIGPU_ROWS_TD")) {  // tuning override
+    const int td = atoi(e);
+    if ((td == 1 || td == 2 || td == 4 || td == 8) && td * row_bytes <= 150 * 1024) return td;
+  }
   if (row_bytes > 150 * 1024) return 0;  // generic (no LDS) kernel
   int td = 1;
   for (int cand : {2, 4, 8}) {
-    if (cand * row_bytes > 64 * 1024) break;
+    if (cand * row_bytes > 24 * 1024) break;  // measured (config 2): 4 workgroups/CU beat 2 rows/workgroup
     if ((dw_count + cand - 1) / cand < 1024) break;  // keep >= 4 workgroups per CU in the grid
     td = cand;
   }
@@ -655,6 +584,7 @@ int launch_normal(const edigpu_sector* s, const double* v_local, const double* v
   a.ell_col = s->up_ell.col;
   a.ell_val = s->up_ell.val;
   a.ell_w = s->up_ell.width;
+  a.ell_typed = s->up_ell.typed;
   a.ell_pitch = s->up_ell.pitch;
   a.dw_rowptr = s->dw.rowptr32;
   a.dw_col = s->dw.col;
@@ -669,10 +599,13 @@ int launch_normal(const edigpu_sector* s, const double* v_local, const double* v
   a.nd_coef = s->d_ndcoef;
   a.jup = s->d_jup;
   a.jdw = s->d_jdw;
+  a.mx_rowptr = s->d_mx_rowptr;
+  a.mx_col = s->d_mx_col;
+  a.mx_val = s->d_mx_val;
   if (s->dw_count == 0) return 0;
   const bool fac = s->factored != 0;
   const bool csr_nd = !fac && s->has_nd;       // Hnd applied by the row kernel from CSR
-  const bool fac_nd = fac && a.nterms > 0;     // Hnd applied by the panel kernel from the factored terms
+  const bool fac_nd = fac && a.nterms > 0 && s->d_mx_rowptr != nullptr;     // Hnd applied by the panel kernel from the factored terms
   // timing-only ablations (results are wrong on purpose)
   if (const char* ab = getenv("EDIGPU_ABLATE_ELL")) {
     if (ab[0] == '1') a.ell_w = 0;
