@@ -307,7 +307,7 @@ static int ensure_workspace(edigpu_sector* s) {
   EDIGPU_HIP(hipMalloc((void**)&s->d_vin, n * sizeof(double)));
   EDIGPU_HIP(hipMalloc((void**)&s->d_vout, n * sizeof(double)));
   EDIGPU_HIP(hipMalloc((void**)&s->d_tmp, n * sizeof(double)));
-  EDIGPU_HIP(hipMalloc((void**)&s->d_partial, kRedBlocks * sizeof(double)));
+  EDIGPU_HIP(hipMalloc((void**)&s->d_partial, kMaxPartials * sizeof(double)));
   s->ws_len = len;
   return 0;
 }
@@ -387,6 +387,17 @@ static int tql2(int n, std::vector<double>& d, std::vector<double>& e, std::vect
 // enqueue one Lanczos step (iter is 0-based); vin/vout/tmp live in the workspace
 static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
   const int64_t len = s->ws_len;
+  if (normal_lanczos_fusable(s)) {
+    // rotate fused into the row kernel, alpha into the panel sweep (kernels_normal.hip)
+    int np = 0;
+    if (launch_normal_lanczos(s, s->d_vin, s->d_vout, s->d_scal, s->d_partial, iter == 0, st, &np)) return 1;
+    if (np > kMaxPartials) {
+      set_error("lanczos_step: partial buffer too small");
+      return 1;
+    }
+    if (lz_finalize_alpha(s->d_partial, np, s->d_scal, iter, nlanc, st)) return 1;
+    return lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, iter, nlanc, st);
+  }
   if (iter > 0 && lz_rotate(s->d_vin, s->d_vout, len, s->d_scal, st)) return 1;
   if (apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st)) return 1;
   if (lz_alpha(s->d_vin, s->d_vout, s->d_tmp, len, s->d_partial, s->d_scal, iter, nlanc, st)) return 1;
@@ -881,13 +892,9 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
     }
     int rc = 0;
     for (int it = 0; it < ndone && !rc; it++) {
-      if (it > 0) rc |= lz_rotate(s->d_vin, s->d_vout, len, s->d_scal, st);
+      // same kernels, same order as the first pass => bitwise the same Lanczos vectors
+      rc |= lanczos_step(s, it, ndone, st);
       rc |= lz_axpy_coef(d_acc, s->d_vin, len, y[it], s->d_scal, -1, st);
-      if (it + 1 < ndone) {
-        rc |= apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st);
-        rc |= lz_alpha(s->d_vin, s->d_vout, s->d_tmp, len, s->d_partial, s->d_scal, it, ndone, st);
-        rc |= lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, it, ndone, st);
-      }
     }
     // normalise
     if (!rc) rc |= lz_norm_begin(d_acc, len, s->d_partial, s->d_scal, st);
@@ -959,23 +966,23 @@ int edigpu_lanczos_bench(edigpu_handle s, int warmup, int steps, double* ms_wall
   if (lanczos_prepare(s, total, 0.0, st)) return 1;
   if (lz_fill_random(s->d_vin, len, 12345ull, st)) return 1;
   if (lz_norm_begin(s->d_vin, len, s->d_partial, s->d_scal, st)) return 1;
-  std::vector<hipEvent_t> ev(2 * (size_t)steps);
-  for (auto& e : ev) EDIGPU_HIP(hipEventCreate(&e));
   int rc = 0;
   for (int it = 0; it < warmup && !rc; it++) rc |= lanczos_step(s, it, total, st);
   if (!rc) rc |= (hipStreamSynchronize(st) != hipSuccess);
   const auto t0 = std::chrono::steady_clock::now();
+  for (int k = 0; k < steps && !rc; k++) rc |= lanczos_step(s, warmup + k, total, st);
+  if (!rc) rc |= (hipStreamSynchronize(st) != hipSuccess);
+  const auto t1 = std::chrono::steady_clock::now();
+  // H*v launches alone (the Lanczos vector of the last step as input), HIP events around each
+  std::vector<hipEvent_t> ev(2 * (size_t)steps);
+  for (auto& e : ev) EDIGPU_HIP(hipEventCreate(&e));
+  for (int k = 0; k < 3 && !rc; k++) rc |= apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st);
   for (int k = 0; k < steps && !rc; k++) {
-    const int it = warmup + k;
-    if (it > 0) rc |= lz_rotate(s->d_vin, s->d_vout, len, s->d_scal, st);
     rc |= (hipEventRecord(ev[2 * k], st) != hipSuccess);
     rc |= apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st);
     rc |= (hipEventRecord(ev[2 * k + 1], st) != hipSuccess);
-    rc |= lz_alpha(s->d_vin, s->d_vout, s->d_tmp, len, s->d_partial, s->d_scal, it, total, st);
-    rc |= lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, it, total, st);
   }
   if (!rc) rc |= (hipStreamSynchronize(st) != hipSuccess);
-  const auto t1 = std::chrono::steady_clock::now();
   double hv = 0.0;
   for (int k = 0; k < steps && !rc; k++) {
     float ms = 0.f;

@@ -4,12 +4,22 @@
 
 namespace edigpu {
 
+// device-resident Lanczos scalars (kernels_lanczos.hip)
+enum { SC_ALPHA = 0, SC_BETA = 1, SC_STOP = 2, SC_NDONE = 3, SC_NORM = 4, SC_THR = 5, SC_AB = 8 };
+constexpr int kRedBlocks = 1024;
+constexpr int kMaxPartials = 1 << 16;  // capacity of the per-workgroup partial buffer
+
 // ---- normal mode (kernels_normal.hip) ----
 // phase: 3 = fused (local+remote, overwrite), 1 = local only (overwrite), 2 = remote only (accumulate)
 // v_local : first element of the shard's own rows, v_full : element 0 of the whole vector.
 int launch_normal(const edigpu_sector* s, const double* v_local, const double* v_full, double* hv,
                   int phase, hipStream_t st);
 int normal_pick_rows_per_block(int64_t dim_up, int64_t dw_count);
+// fused Lanczos step (normal, single shard): P = Lanczos vector, Q = work vector, see kernels_normal.hip
+bool normal_lanczos_fusable(const edigpu_sector* s);
+int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const double* scal,
+                          double* partial, bool first, hipStream_t st, int* npartial);
+int lz_finalize_alpha(const double* partial, int np, double* scal, int iter, int nlanc, hipStream_t st);
 
 // ---- flat CSR (kernels_csr.hip) ----
 // y[0:nrow] (=|+=) A x ; T = double (cplx=0) or (re,im) pairs (cplx=1)
@@ -18,8 +28,6 @@ int launch_csr(const DevCsr& a, int cplx, const double* x, double* y, int accumu
 int launch_zero(double* y, int64_t n, hipStream_t st);
 
 // ---- Lanczos vector kernels (kernels_lanczos.hip); n counts doubles ----
-enum { SC_ALPHA = 0, SC_BETA = 1, SC_STOP = 2, SC_NDONE = 3, SC_NORM = 4, SC_THR = 5, SC_AB = 8 };
-constexpr int kRedBlocks = 1024;
 int lz_norm_begin(double* vin, int64_t n, double* partial, double* scal, hipStream_t st);
 int lz_rotate(double* vin, double* vout, int64_t n, const double* scal, hipStream_t st);
 int lz_alpha(const double* vin, double* vout, const double* tmp, int64_t n, double* partial,

@@ -201,6 +201,12 @@ int lz_alpha(const double* vin, double* vout, const double* tmp, int64_t n, doub
   return 0;
 }
 
+int lz_finalize_alpha(const double* partial, int np, double* scal, int iter, int nlanc, hipStream_t st) {
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, st, partial, np, scal, 1, iter, nlanc);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 int lz_beta(const double* vin, double* vout, int64_t n, double* partial, double* scal, int iter,
             int nlanc, hipStream_t st) {
   dim3 g = red_grid(n);

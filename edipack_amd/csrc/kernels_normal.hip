@@ -61,6 +61,9 @@ struct NormalArgs {
   const uint32_t* jup;  // nterms * dim_up
   const uint32_t* jdw;  // nterms * dim_dw
   // per LOCAL row: Hdw entries + applicable Hnd terms in one list (panel kernel)
+  // fused Lanczos step (device scalars, see kernels.hpp SC_*) and per-workgroup alpha partials
+  const double* scal;
+  double* partial;
   const int32_t* mx_rowptr;  // merged list: ptr[dw_count+1]
   const int32_t* mx_col;     // partner row (24 bit) | tag << 24
   const double* mx_val;
@@ -87,10 +90,13 @@ __device__ inline void load4(const double* __restrict__ base, int64_t i0, const 
 }
 
 // HDF: diagonal from the factored tables instead of the explicit hd array
-template <int TD, bool USE_LDS, bool LOCAL, bool DW, bool ND, bool PACKED, bool VEC, bool HDF>
+// FUSE (Lanczos step fused into the row kernel, v_local = P = previous Lanczos vector, hv = Q):
+//   0: plain H*v.   1: first step: x = P, Q <- (Hd+Hup) x.
+//   2: x = Q/beta (the new Lanczos vector), P <- x, Q <- (Hd+Hup) x - beta*P_old.
+template <int TD, bool USE_LDS, bool LOCAL, bool DW, bool ND, bool PACKED, bool VEC, bool HDF, int FUSE>
 __global__ void __launch_bounds__(kNT)
-    normal_rows_kernel(NormalArgs a, const double* __restrict__ v_local,
-                       const double* __restrict__ v_full, double* __restrict__ hv) {
+    normal_rows_kernel(NormalArgs a, const double* v_local, const double* __restrict__ v_full,
+                       double* hv) {
   extern __shared__ double vs[];  // TD*DimUp staged rows (LOCAL && USE_LDS)
   __shared__ int32_t nb_col[TD][kMaxNbr];
   __shared__ double nb_val[TD][kMaxNbr];
@@ -102,6 +108,16 @@ __global__ void __launch_bounds__(kNT)
   const int tid = threadIdx.x;
   int nr = TD;
   if (r0 + nr > a.dw_count) nr = (int)(a.dw_count - r0);
+  double beta = 0.0, ibeta = 1.0;
+  if (FUSE != 0) {
+    if (a.scal[SC_STOP] != 0.0) return;  // recurrence already terminated (uniform)
+    if (FUSE == 2) {
+      beta = a.scal[SC_BETA];
+      ibeta = 1.0 / beta;
+    }
+  }
+  // source of the staged rows: the vector itself, or Q (scaled by 1/beta) in the fused rotate
+  const double* __restrict__ v_src = (FUSE == 2) ? hv : v_local;
 
   if (LOCAL && PACKED && tid < 128) coef_s[tid] = a.ell_coef[tid];
   if (DW) {
@@ -132,7 +148,11 @@ __global__ void __launch_bounds__(kNT)
           for (int u = 0; u < 4; u++) {
             const int64_t j = j0 + tid + u * kNT;
             const int rr = r < nr ? r : 0;  // clamped: always a valid address
-            t[r][u] = reinterpret_cast<const double2*>(v_local + (r0 + rr) * DimUp)[j < n2 ? j : n2 - 1];
+            t[r][u] = reinterpret_cast<const double2*>(v_src + (r0 + rr) * DimUp)[j < n2 ? j : n2 - 1];
+            if (FUSE == 2) {
+              t[r][u].x *= ibeta;
+              t[r][u].y *= ibeta;
+            }
           }
 #pragma unroll
         for (int r = 0; r < TD; r++)
@@ -151,7 +171,8 @@ __global__ void __launch_bounds__(kNT)
           for (int u = 0; u < 4; u++) {
             const int64_t j = j0 + tid + u * kNT;
             const int rr = r < nr ? r : 0;
-            t[r][u] = v_local[(r0 + rr) * DimUp + (j < DimUp ? j : DimUp - 1)];
+            t[r][u] = v_src[(r0 + rr) * DimUp + (j < DimUp ? j : DimUp - 1)];
+            if (FUSE == 2) t[r][u] *= ibeta;
           }
 #pragma unroll
         for (int r = 0; r < TD; r++)
@@ -310,6 +331,22 @@ __global__ void __launch_bounds__(kNT)
 #pragma unroll
           for (int e = 0; e < kE; e++) acc[r][e] += old[e];
         }
+        if (FUSE == 2) {
+          // Q <- acc - beta * P_old ; P <- x (the staged, normalised vector)
+          double pold[kE];
+          load4<VEC>(v_local, (r0 + r) * DimUp + col0, ok, pold);
+          double* pdst = const_cast<double*>(v_local) + (r0 + r) * DimUp + col0;
+#pragma unroll
+          for (int e = 0; e < kE; e++) acc[r][e] -= beta * pold[e];
+          if (VEC) {
+            if (ok[0]) *reinterpret_cast<double2*>(pdst) = make_double2(vs[r * DimUp + col0], vs[r * DimUp + col0 + 1]);
+            if (ok[2]) *reinterpret_cast<double2*>(pdst + 2) = make_double2(vs[r * DimUp + col0 + 2], vs[r * DimUp + col0 + 3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < kE; e++)
+              if (ok[e]) pdst[e] = vs[r * DimUp + col0 + e];
+          }
+        }
         if (VEC) {
           if (ok[0]) *reinterpret_cast<double2*>(dst) = make_double2(acc[r][0], acc[r][1]);
           if (ok[2]) *reinterpret_cast<double2*>(dst + 2) = make_double2(acc[r][2], acc[r][3]);
@@ -337,13 +374,23 @@ struct PanelArgs {
 constexpr int kPanelNT = 512;
 constexpr int kMaxNdTerms = 16;
 
-template <bool DO_DW, bool DO_ND>
+// ALPHA: also accumulate <v|hv_new> over the local rows (v = v_full rows of this shard) and write
+// one partial per workgroup (deterministic two-stage reduction, see kernels_lanczos.hip)
+template <bool DO_DW, bool DO_ND, bool ALPHA>
 __global__ void __launch_bounds__(kPanelNT)
     normal_dw_panel_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full,
                            double* __restrict__ hv) {
+  __shared__ double red[kPanelNT / 64];
   const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
   const int panel = (k / p.blocks_per_panel) * 8 + x;
+  if (ALPHA) {
+    if (panel >= p.npanels || a.scal[SC_STOP] != 0.0) {
+      if (threadIdx.x == 0) a.partial[blockIdx.x] = 0.0;
+      return;
+    }
+  }
   if (panel >= p.npanels) return;
+  double asum = 0.0;
   const int chunk = k % p.blocks_per_panel;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -432,6 +479,22 @@ __global__ void __launch_bounds__(kPanelNT)
     if (ok) {
       hv[r * DimUp + c] = acc0;
       if (two) hv[r2 * DimUp + c] = acc1;
+      if (ALPHA) {
+        asum += v_full[(a.dw_first + r) * DimUp + c] * acc0;
+        if (two) asum += v_full[(a.dw_first + r2) * DimUp + c] * acc1;
+      }
+    }
+  }
+  if (ALPHA) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) asum += __shfl_down(asum, off, 64);
+    if (lane == 0) red[wave] = asum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < kPanelNT / 64; i++) t += red[i];
+      a.partial[blockIdx.x] = t;
     }
   }
 }
@@ -448,8 +511,8 @@ static int panel_resident_blocks() {
 }
 
 static int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* v_full,
-                            double* hv, hipStream_t st) {
-  if (!do_dw && !do_nd) return 0;
+                            double* hv, hipStream_t st, bool alpha = false, int* nblocks = nullptr) {
+  if (!do_dw && !do_nd && !alpha) return 0;
   if (do_nd && a.nterms > kMaxNdTerms) {
     set_error("launch_dw_panels: too many factored Hnd terms");
     return 1;
@@ -473,12 +536,18 @@ static int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const d
   p.blocks_per_panel = bpp;
   const int panel_groups = (p.npanels + 7) / 8;
   const dim3 grid((unsigned)((int64_t)panel_groups * bpp * 8)), block(kPanelNT);
-  if (do_dw && do_nd)
-    hipLaunchKernelGGL((normal_dw_panel_kernel<true, true>), grid, block, 0, st, a, p, v_full, hv);
+  if (nblocks) *nblocks = (int)grid.x;
+  if (alpha) {
+    if (do_nd)
+      hipLaunchKernelGGL((normal_dw_panel_kernel<true, true, true>), grid, block, 0, st, a, p, v_full, hv);
+    else
+      hipLaunchKernelGGL((normal_dw_panel_kernel<true, false, true>), grid, block, 0, st, a, p, v_full, hv);
+  } else if (do_dw && do_nd)
+    hipLaunchKernelGGL((normal_dw_panel_kernel<true, true, false>), grid, block, 0, st, a, p, v_full, hv);
   else if (do_dw)
-    hipLaunchKernelGGL((normal_dw_panel_kernel<true, false>), grid, block, 0, st, a, p, v_full, hv);
+    hipLaunchKernelGGL((normal_dw_panel_kernel<true, false, false>), grid, block, 0, st, a, p, v_full, hv);
   else
-    hipLaunchKernelGGL((normal_dw_panel_kernel<false, true>), grid, block, 0, st, a, p, v_full, hv);
+    hipLaunchKernelGGL((normal_dw_panel_kernel<false, true, false>), grid, block, 0, st, a, p, v_full, hv);
   EDIGPU_HIP(hipGetLastError());
   return 0;
 }
@@ -510,7 +579,7 @@ static int launch_te(const NormalArgs& a, const double* vl, const double* vf, do
   dim3 grid((unsigned)nblk), block(kNT);
 #define EDIGPU_LAUNCH_ROWS(LOC, DWF, NDF, LDSB, UL, PK, HF)                                      \
   do {                                                                                           \
-    auto kern = normal_rows_kernel<TD, UL, LOC, DWF, NDF, PK, VEC, HF>;                          \
+    auto kern = normal_rows_kernel<TD, UL, LOC, DWF, NDF, PK, VEC, HF, 0>;                       \
     if ((LDSB) > 48 * 1024)                                                                      \
       EDIGPU_HIP(hipFuncSetAttribute((const void*)kern,                                          \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB)));  \
@@ -521,6 +590,20 @@ static int launch_te(const NormalArgs& a, const double* vl, const double* vf, do
     case 5: EDIGPU_LAUNCH_ROWS(true, false, true, lds, USE_LDS, PACKED, HDF); break;
     case 7: EDIGPU_LAUNCH_ROWS(true, true, true, lds, USE_LDS, PACKED, HDF); break;
     case 3: EDIGPU_LAUNCH_ROWS(true, true, false, lds, USE_LDS, PACKED, HDF); break;
+    case 101: {  // fused Lanczos, first step
+      auto kern = normal_rows_kernel<TD, USE_LDS, true, false, false, PACKED, VEC, HDF, 1>;
+      if (lds > 48 * 1024)
+        EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, block, lds, st, a, vl, vf, hv);
+      break;
+    }
+    case 102: {  // fused Lanczos, rotate + H*v
+      auto kern = normal_rows_kernel<TD, USE_LDS, true, false, false, PACKED, VEC, HDF, 2>;
+      if (lds > 48 * 1024)
+        EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, block, lds, st, a, vl, vf, hv);
+      break;
+    }
     case 4: EDIGPU_LAUNCH_ROWS(false, false, true, (size_t)0, false, false, false); break;
     case 6: EDIGPU_LAUNCH_ROWS(false, true, true, (size_t)0, false, false, false); break;
     case 2: EDIGPU_LAUNCH_ROWS(false, true, false, (size_t)0, false, false, false); break;
@@ -568,9 +651,7 @@ static bool dw_in_rows() {
   return mode == 1;
 }
 
-int launch_normal(const edigpu_sector* s, const double* v_local, const double* v_full, double* hv,
-                  int phase, hipStream_t st) {
-  NormalArgs a;
+static void fill_args(const edigpu_sector* s, NormalArgs& a) {
   a.dim_up = s->dim_up;
   a.dim_dw = s->dim_dw;
   a.dw_first = s->dw_first;
@@ -602,6 +683,14 @@ int launch_normal(const edigpu_sector* s, const double* v_local, const double* v
   a.mx_rowptr = s->d_mx_rowptr;
   a.mx_col = s->d_mx_col;
   a.mx_val = s->d_mx_val;
+  a.scal = nullptr;
+  a.partial = nullptr;
+}
+
+int launch_normal(const edigpu_sector* s, const double* v_local, const double* v_full, double* hv,
+                  int phase, hipStream_t st) {
+  NormalArgs a;
+  fill_args(s, a);
   if (s->dw_count == 0) return 0;
   const bool fac = s->factored != 0;
   const bool csr_nd = !fac && s->has_nd;       // Hnd applied by the row kernel from CSR
@@ -626,6 +715,29 @@ int launch_normal(const edigpu_sector* s, const double* v_local, const double* v
   const int what = (rows ? 2 : 0) | (csr_nd ? 4 : 0);
   if (what && launch_rows(s, a, v_local, v_full, hv, what, st)) return 1;
   return launch_dw_panels(a, !rows, fac_nd, v_full, hv, st);
+}
+
+// One fused Lanczos step on a single-shard normal handle (see normal_rows_kernel FUSE):
+//   row kernel : [rotate] + Q <- (Hd+Hup) v [- beta*P_old]
+//   panel sweep: Q += (Hdw + Hnd) v ; per-workgroup partials of alpha = <v|Q>
+// Returns the number of partials written.  The caller finalises alpha and runs the beta kernel.
+bool normal_lanczos_fusable(const edigpu_sector* s) {
+  if (s->kind != 0 || s->nloc != s->dim || s->dw_count == 0) return false;
+  if (s->rows_per_block == 0) return false;               // needs the LDS row kernel
+  if (!s->factored && s->has_nd) return false;             // CSR Hnd needs the complete new vector
+  if (getenv("EDIGPU_LANCZOS_UNFUSED")) return false;
+  return true;
+}
+
+int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const double* scal,
+                          double* partial, bool first, hipStream_t st, int* npartial) {
+  NormalArgs a;
+  fill_args(s, a);
+  a.scal = scal;
+  a.partial = partial;
+  if (launch_rows(s, a, P, P, Q, first ? 101 : 102, st)) return 1;
+  const bool fac_nd = s->factored && a.nterms > 0 && s->d_mx_rowptr != nullptr;
+  return launch_dw_panels(a, true, fac_nd, P, Q, st, true, npartial);
 }
 
 }  // namespace edigpu

@@ -1,0 +1,239 @@
+!> EDIGPU_SHIM -- thin ISO_C_BINDING layer between EDIpack's Fortran host and libedigpu.so
+!!
+!! The reference keeps its H*v behind two procedure pointers,
+!!   procedure(dd_sparse_HxV),pointer :: spHtimesV_p    (ED_VARS_GLOBAL.f90:111-122,196)
+!!   procedure(cc_sparse_HxV),pointer :: spHtimesV_cc   (ED_VARS_GLOBAL.f90:125-132,197)
+!! assigned in build_Hv_sector_<mode> (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:177-203,
+!! ED_SUPERC/ED_HAMILTONIAN_SUPERC.f90:118-132, ED_NONSU2/ED_HAMILTONIAN_NONSU2.f90:111-125).
+!! This module provides procedures with exactly those interfaces,
+!!   spMatVec_gpu_d(Nloc,v,Hv)   and   spMatVec_gpu_c(Nloc,v,Hv),
+!! which forward to the C ABI (include/edigpu.h), plus the calls that hand the sector
+!! Hamiltonian over (flattened sparse_matrix_csr rows) and the device-resident replacement of
+!! sp_lanc_tridiag.  Error convention of the reference: `stop "message"`.
+!!
+!! One sector is live at a time (module variable `gpu_sector`), like Hsector/spH0* in the
+!! reference (ED_VARS_GLOBAL.f90:190-197).  See INTEGRATION.md for the three-line patch of
+!! build_Hv_sector_* / delete_Hv_sector_* / tridiag_Hv_sector_* that uses it.
+module EDIGPU_SHIM
+  use, intrinsic :: iso_c_binding
+  implicit none
+  private
+
+  type(c_ptr), save :: gpu_sector = c_null_ptr   !< the live edigpu_handle
+
+  interface
+     function edigpu_last_error() bind(C, name="edigpu_last_error") result(msg)
+       import :: c_ptr
+       type(c_ptr) :: msg
+     end function edigpu_last_error
+     function edigpu_init(device) bind(C, name="edigpu_init") result(ierr)
+       import :: c_int
+       integer(c_int), value :: device
+       integer(c_int) :: ierr
+     end function edigpu_init
+     function edigpu_normal_create(h, dim_up, dim_dw, dw_first, dw_count, hd, &
+          up_rowptr, up_col, up_val, dw_rowptr, dw_col, dw_val, nd_rowptr, nd_col, nd_val) &
+          bind(C, name="edigpu_normal_create") result(ierr)
+       import :: c_ptr, c_int, c_int64_t
+       type(c_ptr) :: h                                   ! edigpu_handle* (by reference)
+       integer(c_int64_t), value :: dim_up, dim_dw, dw_first, dw_count
+       type(c_ptr), value :: hd, up_rowptr, up_col, up_val, dw_rowptr, dw_col, dw_val
+       type(c_ptr), value :: nd_rowptr, nd_col, nd_val
+       integer(c_int) :: ierr
+     end function edigpu_normal_create
+     function edigpu_csr_create_d(h, nrow_local, ncol_global, row_first, rowptr, col, val) &
+          bind(C, name="edigpu_csr_create_d") result(ierr)
+       import :: c_ptr, c_int, c_int64_t
+       type(c_ptr) :: h
+       integer(c_int64_t), value :: nrow_local, ncol_global, row_first
+       type(c_ptr), value :: rowptr, col, val
+       integer(c_int) :: ierr
+     end function edigpu_csr_create_d
+     function edigpu_csr_create_z(h, nrow_local, ncol_global, row_first, rowptr, col, val) &
+          bind(C, name="edigpu_csr_create_z") result(ierr)
+       import :: c_ptr, c_int, c_int64_t
+       type(c_ptr) :: h
+       integer(c_int64_t), value :: nrow_local, ncol_global, row_first
+       type(c_ptr), value :: rowptr, col, val
+       integer(c_int) :: ierr
+     end function edigpu_csr_create_z
+     function edigpu_apply_d(h, nloc, v, hv) bind(C, name="edigpu_apply_d") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, c_double
+       type(c_ptr), value :: h
+       integer(c_int64_t), value :: nloc
+       real(c_double), intent(in) :: v(*)
+       real(c_double), intent(inout) :: hv(*)
+       integer(c_int) :: ierr
+     end function edigpu_apply_d
+     function edigpu_apply_z(h, nloc, v, hv) bind(C, name="edigpu_apply_z") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, c_double_complex
+       type(c_ptr), value :: h
+       integer(c_int64_t), value :: nloc
+       complex(c_double_complex), intent(in) :: v(*)
+       complex(c_double_complex), intent(inout) :: hv(*)
+       integer(c_int) :: ierr
+     end function edigpu_apply_z
+     function edigpu_lanczos_tridiag(h, vin, nlanc, alanc, blanc, threshold, niter) &
+          bind(C, name="edigpu_lanczos_tridiag") result(ierr)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h, vin
+       integer(c_int), value :: nlanc
+       real(c_double), intent(inout) :: alanc(*), blanc(*)
+       real(c_double), value :: threshold
+       integer(c_int), intent(out) :: niter
+       integer(c_int) :: ierr
+     end function edigpu_lanczos_tridiag
+     function edigpu_destroy(h) bind(C, name="edigpu_destroy") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: h
+       integer(c_int) :: ierr
+     end function edigpu_destroy
+     function c_strlen(s) bind(C, name="strlen") result(n)
+       import :: c_ptr, c_size_t
+       type(c_ptr), value :: s
+       integer(c_size_t) :: n
+     end function c_strlen
+  end interface
+
+  public :: gpu_init, gpu_delete_sector
+  public :: gpu_set_normal, gpu_set_csr_d, gpu_set_csr_c
+  public :: spMatVec_gpu_d, spMatVec_gpu_c
+  public :: gpu_lanc_tridiag_d, gpu_lanc_tridiag_c
+  public :: flatten_rows_count
+
+contains
+
+  !> `stop` with the library's message: the reference's error convention
+  !! (e.g. ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:797).
+  subroutine gpu_check(ierr, where)
+    integer(c_int), intent(in) :: ierr
+    character(len=*), intent(in) :: where
+    type(c_ptr) :: cmsg
+    character(kind=c_char), pointer :: fmsg(:)
+    character(len=512) :: msg
+    integer :: i, n
+    if (ierr == 0) return
+    msg = ""
+    cmsg = edigpu_last_error()
+    if (c_associated(cmsg)) then
+       n = min(int(c_strlen(cmsg)), len(msg))
+       call c_f_pointer(cmsg, fmsg, [n])
+       do i = 1, n
+          msg(i:i) = fmsg(i)
+       end do
+    end if
+    write(*,"(A)") "EDIGPU ERROR in "//trim(where)//": "//trim(msg)
+    error stop "EDIGPU error"
+  end subroutine gpu_check
+
+  !> once per rank, e.g. from ed_solve (ED_MAIN.f90:164): device = local MPI rank
+  subroutine gpu_init(device)
+    integer, intent(in) :: device
+    call gpu_check(edigpu_init(int(device, c_int)), "gpu_init")
+  end subroutine gpu_init
+
+  !> helper for the flattening of sparse_matrix_csr rows (ED_SPARSE_MATRIX.f90:16-41):
+  !! rowptr(0:n) from the per-row sizes, 0-based as the C side wants it
+  subroutine flatten_rows_count(sizes, rowptr)
+    integer, intent(in) :: sizes(:)
+    integer(c_int64_t), intent(out) :: rowptr(0:)
+    integer :: i
+    rowptr(0) = 0_c_int64_t
+    do i = 1, size(sizes)
+       rowptr(i) = rowptr(i-1) + int(sizes(i), c_int64_t)
+    end do
+  end subroutine flatten_rows_count
+
+  !> hand over spH0d / spH0ups(1) / spH0dws(1) / spH0nd (already flattened, 0-based columns).
+  !! dw_first/dw_count = the rank's share of the down index (mpiIshift/DimUp, mpiQdw;
+  !! ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:129-142).  Pass has_nd=.false. when spH0nd is not built.
+  subroutine gpu_set_normal(DimUp, DimDw, dw_first, dw_count, hd, up_rowptr, up_col, up_val, &
+       dw_rowptr, dw_col, dw_val, has_nd, nd_rowptr, nd_col, nd_val)
+    integer, intent(in) :: DimUp, DimDw, dw_first, dw_count
+    real(c_double), intent(in), target :: hd(:), up_val(:), dw_val(:), nd_val(:)
+    integer(c_int64_t), intent(in), target :: up_rowptr(0:), dw_rowptr(0:), nd_rowptr(0:)
+    integer(c_int32_t), intent(in), target :: up_col(:), dw_col(:), nd_col(:)
+    logical, intent(in) :: has_nd
+    type(c_ptr) :: pr, pc, pv
+    if (c_associated(gpu_sector)) stop "gpu_set_normal: a sector is already allocated"
+    pr = c_null_ptr; pc = c_null_ptr; pv = c_null_ptr
+    if (has_nd) then
+       pr = c_loc(nd_rowptr); pc = c_loc(nd_col); pv = c_loc(nd_val)
+    end if
+    call gpu_check(edigpu_normal_create(gpu_sector, int(DimUp, c_int64_t), int(DimDw, c_int64_t), &
+         int(dw_first, c_int64_t), int(dw_count, c_int64_t), c_loc(hd), &
+         c_loc(up_rowptr), c_loc(up_col), c_loc(up_val), &
+         c_loc(dw_rowptr), c_loc(dw_col), c_loc(dw_val), pr, pc, pv), "gpu_set_normal")
+  end subroutine gpu_set_normal
+
+  !> hand over a flat real CSR (sp_matvec-type use, e.g. a real spH0)
+  subroutine gpu_set_csr_d(nrow_local, ncol_global, row_first, rowptr, col, val)
+    integer, intent(in) :: nrow_local, ncol_global, row_first
+    integer(c_int64_t), intent(in), target :: rowptr(0:)
+    integer(c_int32_t), intent(in), target :: col(:)
+    real(c_double), intent(in), target :: val(:)
+    if (c_associated(gpu_sector)) stop "gpu_set_csr_d: a sector is already allocated"
+    call gpu_check(edigpu_csr_create_d(gpu_sector, int(nrow_local, c_int64_t), &
+         int(ncol_global, c_int64_t), int(row_first, c_int64_t), &
+         c_loc(rowptr), c_loc(col), c_loc(val)), "gpu_set_csr_d")
+  end subroutine gpu_set_csr_d
+
+  !> hand over spH0 of the superc / nonsu2 modes: the rank's rows (loc and non-loc entries merged
+  !! back into one row, global 0-based columns); row_first = mpiIshift
+  !! (ED_SUPERC/ED_HAMILTONIAN_SUPERC.f90:82-88, ED_NONSU2/ED_HAMILTONIAN_NONSU2.f90:73-79)
+  subroutine gpu_set_csr_c(nrow_local, ncol_global, row_first, rowptr, col, val)
+    integer, intent(in) :: nrow_local, ncol_global, row_first
+    integer(c_int64_t), intent(in), target :: rowptr(0:)
+    integer(c_int32_t), intent(in), target :: col(:)
+    complex(c_double_complex), intent(in), target :: val(:)
+    if (c_associated(gpu_sector)) stop "gpu_set_csr_c: a sector is already allocated"
+    call gpu_check(edigpu_csr_create_z(gpu_sector, int(nrow_local, c_int64_t), &
+         int(ncol_global, c_int64_t), int(row_first, c_int64_t), &
+         c_loc(rowptr), c_loc(col), c_loc(val)), "gpu_set_csr_c")
+  end subroutine gpu_set_csr_c
+
+  !> dd_sparse_HxV-compatible (ED_VARS_GLOBAL.f90:111-122): assign with  spHtimesV_p => spMatVec_gpu_d
+  subroutine spMatVec_gpu_d(Nloc, v, Hv)
+    integer :: Nloc
+    real(8), dimension(Nloc) :: v, Hv
+    if (.not. c_associated(gpu_sector)) stop "spMatVec_gpu_d: Hsector NOT allocated"
+    call gpu_check(edigpu_apply_d(gpu_sector, int(Nloc, c_int64_t), v, Hv), "spMatVec_gpu_d")
+  end subroutine spMatVec_gpu_d
+
+  !> cc_sparse_HxV-compatible (ED_VARS_GLOBAL.f90:125-132): spHtimesV_cc => spMatVec_gpu_c
+  subroutine spMatVec_gpu_c(Nloc, v, Hv)
+    integer :: Nloc
+    complex(8), dimension(Nloc) :: v, Hv
+    if (.not. c_associated(gpu_sector)) stop "spMatVec_gpu_c: Hsector NOT allocated"
+    call gpu_check(edigpu_apply_z(gpu_sector, int(Nloc, c_int64_t), v, Hv), "spMatVec_gpu_c")
+  end subroutine spMatVec_gpu_c
+
+  !> device-resident replacement of  call sp_lanc_tridiag(spHtimesV_p, vvinit, alanc, blanc)
+  !! (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:360-365): the vector never leaves HBM between steps
+  subroutine gpu_lanc_tridiag_d(vin, alanc, blanc)
+    real(8), intent(in), target :: vin(:)
+    real(8), intent(inout) :: alanc(:), blanc(:)
+    integer(c_int) :: niter
+    if (.not. c_associated(gpu_sector)) stop "gpu_lanc_tridiag_d: Hsector NOT allocated"
+    call gpu_check(edigpu_lanczos_tridiag(gpu_sector, c_loc(vin), int(size(alanc), c_int), &
+         alanc, blanc, 0.0_c_double, niter), "gpu_lanc_tridiag_d")
+  end subroutine gpu_lanc_tridiag_d
+
+  subroutine gpu_lanc_tridiag_c(vin, alanc, blanc)
+    complex(8), intent(in), target :: vin(:)
+    real(8), intent(inout) :: alanc(:), blanc(:)
+    integer(c_int) :: niter
+    if (.not. c_associated(gpu_sector)) stop "gpu_lanc_tridiag_c: Hsector NOT allocated"
+    call gpu_check(edigpu_lanczos_tridiag(gpu_sector, c_loc(vin), int(size(alanc), c_int), &
+         alanc, blanc, 0.0_c_double, niter), "gpu_lanc_tridiag_c")
+  end subroutine gpu_lanc_tridiag_c
+
+  !> delete_Hv_sector_* counterpart (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:212-279)
+  subroutine gpu_delete_sector()
+    if (c_associated(gpu_sector)) then
+       call gpu_check(edigpu_destroy(gpu_sector), "gpu_delete_sector")
+       gpu_sector = c_null_ptr
+    end if
+  end subroutine gpu_delete_sector
+
+end module EDIGPU_SHIM
