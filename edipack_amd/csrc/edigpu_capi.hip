@@ -763,7 +763,7 @@ int edigpu_apply_dev(edigpu_handle s, const void* v_full_dev, void* hv_dev, void
     set_error("edigpu_apply_dev: NULL argument");
     return 1;
   }
-  hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default (null) stream
   const int w = s->is_complex ? 2 : 1;
   const double* vf = (const double*)v_full_dev;
   return apply_any(s, vf + s->row_first * w, vf, (double*)hv_dev, 3, st);
@@ -774,7 +774,7 @@ int edigpu_apply_local_dev(edigpu_handle s, const void* v_local_dev, void* hv_de
     set_error("edigpu_apply_local_dev: NULL argument");
     return 1;
   }
-  hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default (null) stream
   return apply_any(s, (const double*)v_local_dev, nullptr, (double*)hv_dev, 1, st);
 }
 
@@ -783,7 +783,7 @@ int edigpu_apply_remote_dev(edigpu_handle s, const void* v_full_dev, void* hv_de
     set_error("edigpu_apply_remote_dev: NULL argument");
     return 1;
   }
-  hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default (null) stream
   return apply_any(s, nullptr, (const double*)v_full_dev, (double*)hv_dev, 2, st);
 }
 

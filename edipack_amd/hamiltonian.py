@@ -219,14 +219,14 @@ class SectorHamiltonian:
         return hv
 
     def apply_dev(self, v_full_ptr: int, hv_ptr: int, stream: int = 0) -> None:
-        capi.check(capi.lib().edigpu_apply_dev(self._h, v_full_ptr, hv_ptr, stream or None), "edigpu_apply_dev")
+        capi.check(capi.lib().edigpu_apply_dev(self._h, v_full_ptr, hv_ptr, stream if stream else None), "edigpu_apply_dev")
 
     def apply_local_dev(self, v_local_ptr: int, hv_ptr: int, stream: int = 0) -> None:
-        capi.check(capi.lib().edigpu_apply_local_dev(self._h, v_local_ptr, hv_ptr, stream or None),
+        capi.check(capi.lib().edigpu_apply_local_dev(self._h, v_local_ptr, hv_ptr, stream if stream else None),
                    "edigpu_apply_local_dev")
 
     def apply_remote_dev(self, v_full_ptr: int, hv_ptr: int, stream: int = 0) -> None:
-        capi.check(capi.lib().edigpu_apply_remote_dev(self._h, v_full_ptr, hv_ptr, stream or None),
+        capi.check(capi.lib().edigpu_apply_remote_dev(self._h, v_full_ptr, hv_ptr, stream if stream else None),
                    "edigpu_apply_remote_dev")
 
     # ---- Lanczos ------------------------------------------------------------------------------

@@ -24,7 +24,8 @@
  *    handles may coexist here.
  *  - "host" pointers are ordinary CPU memory; "dev" pointers are HIP device
  *    memory on the handle's device; `stream` is a hipStream_t passed as void*
- *    (NULL = the handle's own stream).
+ *    (NULL = the HIP default stream, as in every HIP API; the host-pointer entry
+ *    points use a private stream of the handle and synchronise it before returning).
  *  - There is NO CPU fallback: every entry point fails with an error if no
  *    HIP device is usable.
  */

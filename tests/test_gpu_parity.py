@@ -339,3 +339,26 @@ def test_golden_ground_state_energy_on_gpu(gpu, mode, bath, norb, nbath, par, e_
         best = min(best, e0)
         hg.destroy()
     assert abs(best - e_gold) < 1e-9
+
+
+# --------------------------------------------------------------------------------------------
+# sharded driver glue on one GPU (world = 1: no collective, same code path as bench.py --gpus N)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,bath,norb,nbath,sec", [
+    ("normal", "normal", 2, 3, (4, 4)),
+    ("superc", "normal", 2, 2, 0),
+])
+def test_sharded_lanczos_gpu_world1(gpu, mode, bath, norb, nbath, sec):
+    import torch
+    O = _oracle()
+    from edipack_amd.sharding import gpu_sharded_hamiltonian
+    om, pm = make_models(mode, bath, norb, nbath, seed=51)
+    ho = O.HNormal(om, *sec) if mode == "normal" else O.HFlat(om, sec)
+    plan, h, lz = gpu_sharded_hamiltonian(pm, sec, world=1, rank=0)
+    assert plan.nloc == ho.dim and h.nloc == ho.dim
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(ho.dim) + (1j * rng.standard_normal(ho.dim) if mode != "normal" else 0)
+    a, b, n = lz.tridiag(torch.from_numpy(v).cuda(), 30)
+    a_ref, b_ref, _ = ho.lanc_tridiag(v, 30)
+    assert rel_err(a[:12], a_ref[:12]) < 1e-10 and rel_err(b[:12], b_ref[:12]) < 1e-10
+    h.destroy()
