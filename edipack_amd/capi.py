@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libedigpu.so")
+LIB_PATH = os.environ.get("EDIGPU_LIB", os.path.join(HERE, "lib", "libedigpu.so"))  # override: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "edigpu.h")
 
 MAXORB = 5

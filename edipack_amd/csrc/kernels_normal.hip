@@ -222,48 +222,65 @@ __global__ void __launch_bounds__(kNT)
 #pragma unroll
           for (int e = 0; e < kE; e++) acc[r][e] = h[e] * x[e];
         }
-      // ---- (1 (x) Hup): gather inside the row; one 16-byte load brings 4 packed slots ----
-#pragma unroll 2
-      for (int k = 0; k < a.ell_w; k++) {
-        int32_t cc[kE];
-        double ww[kE];
-        const int64_t o = (int64_t)k * a.ell_pitch + col0;  // multiple of 4, inside the pitch
-        if (PACKED) {
-          const uint4 p4 = *reinterpret_cast<const uint4*>(a.ell_pk + o);
-          const uint32_t p[kE] = {p4.x, p4.y, p4.z, p4.w};
-          if (a.ell_typed) {
-            // slot k = one hop type: the amplitude is wave-uniform, no table lookup
-            const double tk = a.ell_coef[k];
+      // ---- (1 (x) Hup): gather inside the row; one 16-byte load brings 4 packed slots.
+      // Slots are fetched KU at a time into registers first, so that KU independent L2 loads are
+      // in flight per lane before the first LDS gather is issued. ----
+      constexpr int KU = 6;
+      for (int k0 = 0; k0 < a.ell_w; k0 += KU) {
+        uint4 pk4[KU];
+        int4 pc4[KU];
+        double2 pw0[KU], pw1[KU];
 #pragma unroll
-            for (int e = 0; e < kE; e++) {
-              cc[e] = (int32_t)(p[e] & 0xFFFFFFu);
-              const double m = ((p[e] >> 24) & 0x7Fu) ? tk : 0.0;
-              ww[e] = (p[e] >> 31) ? -m : m;
-            }
+        for (int u = 0; u < KU; u++) {
+          const int k = k0 + u < a.ell_w ? k0 + u : a.ell_w - 1;       // clamped, weight zeroed below
+          const int64_t o = (int64_t)k * a.ell_pitch + col0;           // multiple of 4, inside the pitch
+          if (PACKED) {
+            pk4[u] = *reinterpret_cast<const uint4*>(a.ell_pk + o);
           } else {
-#pragma unroll
-            for (int e = 0; e < kE; e++) {
-              cc[e] = (int32_t)(p[e] & 0xFFFFFFu);
-              const double m = coef_s[(p[e] >> 24) & 0x7Fu];
-              ww[e] = (p[e] >> 31) ? -m : m;
-            }
+            pc4[u] = *reinterpret_cast<const int4*>(a.ell_col + o);
+            pw0[u] = *reinterpret_cast<const double2*>(a.ell_val + o);
+            pw1[u] = *reinterpret_cast<const double2*>(a.ell_val + o + 2);
           }
-        } else {
-          const int4 c4 = *reinterpret_cast<const int4*>(a.ell_col + o);
-          const double2 w0 = *reinterpret_cast<const double2*>(a.ell_val + o);
-          const double2 w1 = *reinterpret_cast<const double2*>(a.ell_val + o + 2);
-          cc[0] = c4.x; cc[1] = c4.y; cc[2] = c4.z; cc[3] = c4.w;
-          ww[0] = w0.x; ww[1] = w0.y; ww[2] = w1.x; ww[3] = w1.y;
         }
 #pragma unroll
-        for (int r = 0; r < TD; r++)
-          if (r < nr) {
+        for (int u = 0; u < KU; u++) {
+          const bool live = k0 + u < a.ell_w;
+          int32_t cc[kE];
+          double ww[kE];
+          if (PACKED) {
+            const uint32_t p[kE] = {pk4[u].x, pk4[u].y, pk4[u].z, pk4[u].w};
+            if (a.ell_typed) {
+              // slot k = one hop type: the amplitude is wave-uniform, no table lookup
+              const double tk = live ? a.ell_coef[k0 + u] : 0.0;
 #pragma unroll
-            for (int e = 0; e < kE; e++) {
-              const double x = USE_LDS ? vs[r * DimUp + cc[e]] : v_local[(r0 + r) * DimUp + cc[e]];
-              acc[r][e] += ww[e] * x;
+              for (int e = 0; e < kE; e++) {
+                cc[e] = (int32_t)(p[e] & 0xFFFFFFu);
+                const double m = ((p[e] >> 24) & 0x7Fu) ? tk : 0.0;
+                ww[e] = (p[e] >> 31) ? -m : m;
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < kE; e++) {
+                cc[e] = (int32_t)(p[e] & 0xFFFFFFu);
+                const double m = live ? coef_s[(p[e] >> 24) & 0x7Fu] : 0.0;
+                ww[e] = (p[e] >> 31) ? -m : m;
+              }
             }
+          } else {
+            cc[0] = pc4[u].x; cc[1] = pc4[u].y; cc[2] = pc4[u].z; cc[3] = pc4[u].w;
+            ww[0] = live ? pw0[u].x : 0.0; ww[1] = live ? pw0[u].y : 0.0;
+            ww[2] = live ? pw1[u].x : 0.0; ww[3] = live ? pw1[u].y : 0.0;
           }
+#pragma unroll
+          for (int r = 0; r < TD; r++)
+            if (r < nr) {
+#pragma unroll
+              for (int e = 0; e < kE; e++) {
+                const double x = USE_LDS ? vs[r * DimUp + cc[e]] : v_local[(r0 + r) * DimUp + cc[e]];
+                acc[r][e] += ww[e] * x;
+              }
+            }
+        }
       }
     }
     if (DW) {
