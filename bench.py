@@ -78,17 +78,12 @@ def cpu_baseline(h, workload, budget_s: float = 15.0):
 def run_single(args):
     import torch  # noqa: F401  (first: one HIP runtime per process, see edipack_amd/capi.py)
     from edipack_amd import capi
-    from edipack_amd.hamiltonian import SectorHamiltonian
-    from edipack_amd.synthetic import WORKLOADS, synthetic_model
+    from edipack_amd.synthetic import WORKLOADS, build_workload
 
     w = WORKLOADS[args.workload]
     capi.init(0)
-    model = synthetic_model(w)
     t0 = time.perf_counter()
-    if w.ed_mode == "normal":
-        h = SectorHamiltonian.normal_from_model(model, *w.sector)
-    else:
-        h = SectorHamiltonian.flat_from_model(model, w.sector)
+    h = build_workload(w)
     t_build = time.perf_counter() - t0
     bytes_hv, bytes_step = h.algorithmic_bytes()
     ms_step, ms_hv = h.lanczos_bench(args.warmup, args.steps)
@@ -101,15 +96,16 @@ def run_single(args):
         "dtype": "c128" if h.is_complex else "f64", "data": "synthetic",
         "config": {"workload": f"{w.name}: {w.ed_mode} mode, bath={w.bath_type}, Norb={w.norb}, Nbath={w.nbath}, "
                                f"sector={w.sector}, Dim={h.dim} ({w.note})",
-                   "storage": "Kronecker (Hd,Hup,Hdw,Hnd)" if h.kind == 0 else "flat CSR",
+                   "storage": {0: "Kronecker (Hd,Hup,Hdw,Hnd)", 1: "flat CSR", 2: "direct (on-the-fly)"}[h.kind],
                    "parallelism": "1 GPU, device-resident Lanczos", "build_s": round(t_build, 3),
                    "hv_only_ms": ms_hv_only, "lanczos_step_GBs": bytes_step / (ms_step * 1e-3) / 1e9},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profiles(w.name),
-                     "kernel": "normal_rows_kernel" if h.kind == 0 else "csr_rows_kernel",
+                     "kernel": {0: "normal_rows_kernel + normal_dw_panel_kernel", 1: "csr_rows_kernel",
+                                2: "direct_rows_kernel"}[h.kind],
                      "algorithmic_bytes_per_launch": bytes_hv, "ms_per_launch": ms_hv},
     }
-    if not args.no_cpu:
+    if not args.no_cpu and h.kind != 2:
         out["cpu_baseline"] = cpu_baseline(h, w.name, args.cpu_seconds)
     h.destroy()
     print(json.dumps(out), flush=True)

@@ -315,6 +315,12 @@ static int ensure_workspace(edigpu_sector* s) {
 static int apply_any(edigpu_sector* s, const double* v_local, const double* v_full, double* hv,
                      int phase, hipStream_t st) {
   if (s->kind == 0) return launch_normal(s, v_local, v_full, hv, phase, st);
+  if (s->kind == 2) {
+    // on-the-fly: like directMatVec_MPI_* the whole product needs the gathered vector
+    // (reference ED_NONSU2/ED_HAMILTONIAN_NONSU2_DIRECT_HxV.f90:220-223: gather first, then compute)
+    if (phase == 1) return launch_zero(hv, s->nloc * 2, st);
+    return launch_direct(s, v_full, hv, st);
+  }
   // flat: loc block then non-local block
   if (phase & 1) {
     if (launch_csr(s->loc, s->is_complex, v_local, hv, 0, st)) return 1;
@@ -589,6 +595,44 @@ int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, i
   return 0;
 }
 
+int edigpu_direct_build(edigpu_handle* h, const edigpu_model* model, int sector, int64_t row_first,
+                        int64_t row_count) {
+  if (!h || !model) {
+    set_error("edigpu_direct_build: NULL argument");
+    return 1;
+  }
+  *h = nullptr;
+  if (ensure_device()) return 1;
+  HostDirect hd;
+  std::string e = build_direct(*model, sector, row_first, row_count, hd);
+  if (!e.empty()) {
+    set_error(e);
+    return 1;
+  }
+  std::unique_ptr<edigpu_sector> s(new edigpu_sector());
+  s->kind = 2;
+  s->is_complex = 1;
+  s->device = g_device;
+  s->dim = hd.dim;
+  s->nloc = hd.row_count;
+  s->row_first = hd.row_first;
+  s->dir_ns = hd.ns;
+  s->dir_norb = hd.norb;
+  s->dir_nterms = (int)hd.terms.size();
+  int rc = dev_upload(&s->d_dir_states, hd.states.data(), hd.states.size());
+  rc |= dev_upload(&s->d_dir_offdw, hd.off_dw.data(), hd.off_dw.size());
+  rc |= dev_upload(&s->d_dir_rkup, hd.rk_up.data(), hd.rk_up.size());
+  rc |= dev_upload(&s->d_dir_terms, hd.terms.data(), hd.terms.size());
+  rc |= dev_upload(&s->d_dir_dtab, hd.dtab.data(), hd.dtab.size());
+  rc |= dev_upload(&s->d_dir_xtab, hd.xtab.data(), hd.xtab.size());
+  if (rc || finish_handle(s.get())) {
+    edigpu_destroy(s.release());
+    return 1;
+  }
+  *h = s.release();
+  return 0;
+}
+
 int edigpu_sector_dim(const edigpu_model* model, int q1, int q2, int64_t* dim) {
   if (!model || !dim) {
     set_error("edigpu_sector_dim: NULL argument");
@@ -617,6 +661,9 @@ int edigpu_info(edigpu_handle s, int64_t info[10]) {
   if (s->kind == 0) {
     info[7] = s->h_up.nnz() + s->h_dw.nnz();
     info[8] = s->nd_nnz;
+  } else if (s->kind == 2) {
+    info[7] = s->dir_nterms;
+    info[8] = 0;
   } else {
     info[7] = s->loc.nnz;
     info[8] = s->nonloc.nnz;
@@ -638,6 +685,9 @@ int edigpu_algorithmic_bytes(edigpu_handle s, double* bytes_hv, double* bytes_st
     b = 3.0 * sz * n;
     if (s->has_nd) b += (sz + 4.0) * (double)s->nd_nnz + 4.0 * (n + 1.0);
     b += (sz + 4.0) * (double)(s->h_up.nnz() + s->h_dw.nnz()) + 4.0 * (double)(s->dim_up + s->dim_dw + 2);
+  } else if (s->kind == 2) {
+    // direct: 2 vectors + the sector map (B = 2*s*Dim + 4*DimEl)
+    b = 2.0 * sz * (double)s->nloc + 4.0 * (double)s->nloc;
   } else {
     const double n = (double)s->nloc;
     b = (sz + 4.0) * (double)(s->loc.nnz + s->nonloc.nnz) + 4.0 * (n + 1.0) + 2.0 * sz * n;
@@ -697,7 +747,7 @@ int edigpu_normal_export(edigpu_handle s, double* hd, int64_t* up_rowptr, int32_
 
 int edigpu_csr_export(edigpu_handle s, int64_t* rowptr, int32_t* col, double* val) {
   if (!s || s->kind != 1) {
-    set_error("edigpu_csr_export: not a flat-CSR handle");
+    set_error("edigpu_csr_export: not a flat-CSR handle (direct handles store no matrix)");
     return 1;
   }
   EDIGPU_HIP(hipSetDevice(s->device));
@@ -1024,6 +1074,12 @@ int edigpu_destroy(edigpu_handle s) {
   free_csr(s->nd);
   free_csr(s->loc);
   free_csr(s->nonloc);
+  dev_free(s->d_dir_states);
+  dev_free(s->d_dir_offdw);
+  dev_free(s->d_dir_rkup);
+  dev_free(s->d_dir_terms);
+  dev_free(s->d_dir_dtab);
+  dev_free(s->d_dir_xtab);
   dev_free(s->d_vin);
   dev_free(s->d_vout);
   dev_free(s->d_tmp);

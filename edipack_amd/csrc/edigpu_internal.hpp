@@ -51,7 +51,7 @@ struct DevEll {
 }  // namespace edigpu
 
 struct edigpu_sector {
-  int kind = 0;        // 0 normal (Kronecker), 1 flat CSR
+  int kind = 0;        // 0 normal (Kronecker), 1 flat CSR, 2 direct (on-the-fly superc/nonsu2)
   int is_complex = 0;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -83,6 +83,14 @@ struct edigpu_sector {
   edigpu::HostCsr h_nd;
   // ---- flat ----
   edigpu::DevCsr loc, nonloc; // local rows; loc columns are shard-relative, nonloc global
+  // ---- direct (on-the-fly) ----
+  int dir_ns = 0, dir_norb = 0, dir_nterms = 0;
+  int32_t* d_dir_states = nullptr;
+  int32_t* d_dir_offdw = nullptr;
+  int32_t* d_dir_rkup = nullptr;
+  edigpu::DirectTerm* d_dir_terms = nullptr;
+  double* d_dir_dtab = nullptr;
+  double* d_dir_xtab = nullptr;
   // ---- Lanczos workspace (lazily allocated) ----
   double* d_vin = nullptr;
   double* d_vout = nullptr;

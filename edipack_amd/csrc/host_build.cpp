@@ -443,30 +443,14 @@ struct OpTerm {           // coef * op[n-1] ... op[1] op[0]  (op[0] acts first)
 
 }  // namespace
 
-std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
-                       HostFlat& out) {
-  std::string e = check_model(m);
-  if (!e.empty()) return e;
-  if (m.ed_mode != 1 && m.ed_mode != 2) return "edigpu_flat_build: model.ed_mode must be superc or nonsu2";
-  if (m.ed_mode == 2 && m.nspin != 2) return "edigpu_flat_build: nonsu2 needs nspin=2";
+// Operator strings and diagonal data of the superc / nonsu2 Hamiltonians over the 2*Ns spin-orbital
+// levels (up: 0..Ns-1, down: Ns..2Ns-1); shared by the stored (CSR) and the direct (on-the-fly) builders.
+static void flat_physics(const edigpu_model& m, std::vector<OpTerm>& terms, std::vector<double>& eps_out,
+                         double& cst_out) {
   Idx ix(m);
   const int ns = model_ns(m), norb = m.norb, nbath = m.nbath;
-  if (2 * ns > 30) return "edigpu_flat_build: 2*Ns > 30 bits (the reference's integer range)";
   const int sd = m.nspin - 1;  // spin index used for the down species
-  SpinBasis sb;
-  sb.init(ns, m.ed_mode, sector);
-  out.ns = ns;
-  out.dim = (int64_t)sb.states.size();
-  if (row_count < 0) {
-    row_first = 0;
-    row_count = out.dim;
-  }
-  if (row_first < 0 || row_first + row_count > out.dim) return "edigpu_flat_build: bad shard";
-  out.row_first = row_first;
-  out.row_count = row_count;
-
   // ---- operator strings; coefficient = what lands at (row i, col j=O|i>) ----
-  std::vector<OpTerm> terms;
   auto hop = [&](int p, int q, cplx h) {  // c^+_p c_q with amplitude h: entry conj(h)
     if (h == cplx(0.0)) return;
     terms.push_back({2, {q, p, 0, 0}, {false, true, false, false}, std::conj(h)});
@@ -528,7 +512,8 @@ std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int
       }
 
   // ---- diagonal pieces ----
-  std::vector<double> eps(2 * ns, 0.0);
+  std::vector<double>& eps = eps_out;
+  eps.assign(2 * ns, 0.0);
   for (int a = 0; a < norb; a++) {
     double shift = -m.xmu;
     if (m.hfmode) {
@@ -547,12 +532,42 @@ std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int
       eps[ix.bath_pos(a, k)] += ix.bath(m.be, 0, a, k);
       eps[ix.bath_pos(a, k) + ns] += ix.bath(m.be, sd, a, k);
     }
-  double cst = 0.0;
+  double& cst = cst_out;
+  cst = 0.0;
   if (m.hfmode) {
     for (int a = 0; a < norb; a++) cst += 0.25 * ix.uloc(a);
     for (int a = 0; a < norb; a++)
       for (int b = a + 1; b < norb; b++) cst += 0.5 * ix.ust(a, b) + 0.5 * (ix.ust(a, b) - ix.jh(a, b));
   }
+
+}
+
+std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
+                       HostFlat& out) {
+  std::string e = check_model(m);
+  if (!e.empty()) return e;
+  if (m.ed_mode != 1 && m.ed_mode != 2) return "edigpu_flat_build: model.ed_mode must be superc or nonsu2";
+  if (m.ed_mode == 2 && m.nspin != 2) return "edigpu_flat_build: nonsu2 needs nspin=2";
+  Idx ix(m);
+  const int ns = model_ns(m), norb = m.norb, nbath = m.nbath;
+  if (2 * ns > 30) return "edigpu_flat_build: 2*Ns > 30 bits (the reference's integer range)";
+  const int sd = m.nspin - 1;  // spin index used for the down species
+  SpinBasis sb;
+  sb.init(ns, m.ed_mode, sector);
+  out.ns = ns;
+  out.dim = (int64_t)sb.states.size();
+  if (row_count < 0) {
+    row_first = 0;
+    row_count = out.dim;
+  }
+  if (row_first < 0 || row_first + row_count > out.dim) return "edigpu_flat_build: bad shard";
+  out.row_first = row_first;
+  out.row_count = row_count;
+
+  std::vector<OpTerm> terms;
+  std::vector<double> eps;
+  double cst = 0.0;
+  flat_physics(m, terms, eps, cst);
 
   HostCsr& H = out.h;
   H.nrow = row_count;
@@ -612,6 +627,86 @@ std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int
     H.rowptr[r + 1] = (int64_t)H.col.size();
   }
   out.states = std::move(sb.states);
+  return "";
+}
+
+std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
+                         HostDirect& out) {
+  std::string e = check_model(m);
+  if (!e.empty()) return e;
+  if (m.ed_mode != 1 && m.ed_mode != 2) return "edigpu_direct_build: model.ed_mode must be superc or nonsu2";
+  if (m.ed_mode == 2 && m.nspin != 2) return "edigpu_direct_build: nonsu2 needs nspin=2";
+  Idx ix(m);
+  const int ns = model_ns(m), norb = m.norb;
+  if (2 * ns > 30) return "edigpu_direct_build: 2*Ns > 30 bits (the reference's integer range)";
+  SpinBasis sb;
+  sb.init(ns, m.ed_mode, sector);
+  out.ns = ns;
+  out.norb = norb;
+  out.dim = (int64_t)sb.states.size();
+  if (out.dim == 0) return "edigpu_direct_build: empty sector";
+  if (row_count < 0) {
+    row_first = 0;
+    row_count = out.dim;
+  }
+  if (row_first < 0 || row_first + row_count > out.dim) return "edigpu_direct_build: bad shard";
+  out.row_first = row_first;
+  out.row_count = row_count;
+  out.states.assign(sb.states.begin() + row_first, sb.states.begin() + row_first + row_count);
+  out.off_dw = sb.off_dw;
+  out.rk_up = sb.rk_up;
+
+  std::vector<OpTerm> terms;
+  std::vector<double> eps;
+  double cst = 0.0;
+  flat_physics(m, terms, eps, cst);
+  out.terms.clear();
+  for (const OpTerm& t : terms) {
+    DirectTerm d{};
+    uint32_t flipped = 0;
+    int cs = 0;
+    for (int k = 0; k < t.n; k++) {
+      const uint32_t b = 1u << t.pos[k];
+      if (flipped & b) return "edigpu_direct_build: operator string touches a level twice";
+      if (t.create[k]) d.need_clear |= b; else d.need_set |= b;
+      // popc((s ^ flipped) & below) = popc(s & below) + popc(flipped & below)  (mod 2)
+      d.sign_mask ^= (b - 1u);
+      cs ^= popc(flipped & (b - 1u)) & 1;
+      flipped |= b;
+    }
+    d.flip = flipped;
+    d.csign = cs;
+    d.cre = t.coef.real();
+    d.cim = t.coef.imag();
+    out.terms.push_back(d);
+  }
+  // diagonal: byte-wise sums of the one-body energies + impurity interaction table
+  out.dtab.assign(4 * 256, 0.0);
+  for (int byte = 0; byte < 4; byte++)
+    for (int v = 0; v < 256; v++) {
+      double x = 0.0;
+      for (int bit = 0; bit < 8; bit++) {
+        const int p = byte * 8 + bit;
+        if (p < 2 * ns && ((v >> bit) & 1)) x += eps[p];
+      }
+      out.dtab[byte * 256 + v] = x;
+    }
+  const uint32_t impmask = (1u << norb) - 1u;
+  out.xtab.assign((size_t)1 << (2 * norb), 0.0);
+  for (uint32_t iu = 0; iu <= impmask; iu++)
+    for (uint32_t id = 0; id <= impmask; id++) {
+      double x = cst;
+      for (int a = 0; a < norb; a++) {
+        const int nu = (iu >> a) & 1, nd = (id >> a) & 1;
+        x += ix.uloc(a) * nu * nd;
+        for (int b = a + 1; b < norb; b++) {
+          const int nub = (iu >> b) & 1, ndb = (id >> b) & 1;
+          x += ix.ust(a, b) * (nu * ndb + nub * nd);
+          x += (ix.ust(a, b) - ix.jh(a, b)) * (nu * nub + nd * ndb);
+        }
+      }
+      out.xtab[(id << norb) | iu] = x;
+    }
   return "";
 }
 

@@ -73,6 +73,29 @@ struct HostFlat {
   HostCsr h;  // complex, local rows, global columns
 };
 
+// On-the-fly ("direct", ed_sparse_H=F) image of a superc / nonsu2 sector: nothing of H is stored, only
+// the sector map, two ranking tables and the operator-term list from which every H*v regenerates the
+// matrix elements (the reference's directMatVec_*_main, ED_NONSU2/ED_HAMILTONIAN_NONSU2_DIRECT_HxV.f90:22-252).
+struct DirectTerm {          // coef * (-1)^{popc(s & sign_mask) + csign} at column rank(s ^ flip),
+  uint32_t need_set;         // applicable iff (s & need_set) == need_set && (s & need_clear) == 0
+  uint32_t need_clear;
+  uint32_t flip;
+  uint32_t sign_mask;
+  int32_t csign;
+  int32_t pad;
+  double cre, cim;
+};
+
+struct HostDirect {
+  int ns = 0, norb = 0;
+  int64_t dim = 0, row_first = 0, row_count = 0;
+  std::vector<int32_t> states;          // local rows
+  std::vector<int32_t> off_dw, rk_up;   // rank(s) = off_dw[s >> ns] + rk_up[s & (2^ns - 1)]
+  std::vector<DirectTerm> terms;
+  std::vector<double> dtab;             // 4 * 256: sum of one-body energies per byte of s
+  std::vector<double> xtab;             // 2^(2 norb): interaction energy of the impurity bits (+ constant)
+};
+
 int model_ns(const edigpu_model& m);
 int64_t binomial(int n, int k);
 
@@ -81,6 +104,8 @@ std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_fir
                          int64_t dw_count, HostNormal& out);
 std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
                        HostFlat& out);
+std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
+                         HostDirect& out);
 std::string sector_dim(const edigpu_model& m, int q1, int q2, int64_t& dim);
 
 }  // namespace edigpu

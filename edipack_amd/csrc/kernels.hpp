@@ -27,6 +27,9 @@ int launch_csr(const DevCsr& a, int cplx, const double* x, double* y, int accumu
                hipStream_t st);
 int launch_zero(double* y, int64_t n, hipStream_t st);
 
+// ---- direct / on-the-fly (kernels_direct.hip): hv[local rows] = H v_full ----
+int launch_direct(const edigpu_sector* s, const double* v_full, double* hv, hipStream_t st);
+
 // ---- Lanczos vector kernels (kernels_lanczos.hip); n counts doubles ----
 int lz_norm_begin(double* vin, int64_t n, double* partial, double* scal, hipStream_t st);
 int lz_rotate(double* vin, double* vout, int64_t n, const double* scal, hipStream_t st);

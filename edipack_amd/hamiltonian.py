@@ -137,6 +137,16 @@ class SectorHamiltonian:
         return cls(h)
 
     @classmethod
+    def direct_from_model(cls, model: ImpurityModel, sector: int, row_first: int = 0,
+                          row_count: int = -1) -> "SectorHamiltonian":
+        """ed_sparse_H=F: on-the-fly H*v, nothing stored (directMatVec_*_main)."""
+        h = C.c_void_p()
+        cm = model.to_c()
+        capi.check(capi.lib().edigpu_direct_build(C.byref(h), C.byref(cm), sector, row_first, row_count),
+                   "edigpu_direct_build")
+        return cls(h)
+
+    @classmethod
     def normal_from_arrays(cls, dim_up, dim_dw, hd, up, dw, nd=None, dw_first=0, dw_count=None):
         """Hand over spH0d / spH0ups(1) / spH0dws(1) / spH0nd as (rowptr, col, val) triples."""
         if dw_count is None:

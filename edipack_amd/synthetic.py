@@ -24,6 +24,7 @@ class Workload:
     nbath: int
     sector: tuple | int
     note: str
+    direct: bool = False   # ed_sparse_H=F: on-the-fly H*v
 
 
 WORKLOADS = {
@@ -38,8 +39,22 @@ WORKLOADS = {
     "cfg3_ns17": Workload("cfg3_ns17", 3, "normal", "hybrid", 3, 14, (8, 9), "Ns=17, Dim=590 976 100"),
     # scale-up of the flat-CSR modes
     "cfg4_ns12": Workload("cfg4_ns12", 4, "superc", "hybrid", 2, 10, 0, "Ns=12, Sz=0, Dim=2 704 156"),
+    # BASELINE.json configs[4]: 3 orbitals, Nbath=10 (hybrid), nonsu2, on-the-fly kernel
+    "cfg5": Workload("cfg5", 5, "nonsu2", "hybrid", 3, 10, 13, "Ns=13, N=13, Dim=10 400 600, complex, direct", True),
+    "cfg5_ns11": Workload("cfg5_ns11", 5, "nonsu2", "hybrid", 3, 8, 11, "Ns=11, N=11, Dim=705 432, direct", True),
     "cfg5_stored_ns11": Workload("cfg5_stored_ns11", 5, "nonsu2", "hybrid", 3, 8, 11, "Ns=11, N=11, Dim=705 432"),
 }
+
+
+def build_workload(w: Workload, **shard):
+    """SectorHamiltonian of a workload (single shard unless dw_first/dw_count or row_first/row_count given)."""
+    from .hamiltonian import SectorHamiltonian
+    m = synthetic_model(w)
+    if w.ed_mode == "normal":
+        return SectorHamiltonian.normal_from_model(m, *w.sector, **shard)
+    if w.direct:
+        return SectorHamiltonian.direct_from_model(m, w.sector, **shard)
+    return SectorHamiltonian.flat_from_model(m, w.sector, **shard)
 
 
 def synthetic_model(w: Workload) -> ImpurityModel:

@@ -137,6 +137,17 @@ int edigpu_normal_build(edigpu_handle *h, const edigpu_model *model, int nup, in
 int edigpu_flat_build(edigpu_handle *h, const edigpu_model *model, int sector, int64_t row_first,
                       int64_t row_count);
 
+/*
+ * On-the-fly ("direct", ED_SPARSE_H=F) sector: nothing of H is stored; every H*v regenerates the
+ * matrix elements from the sector map, as directMatVec_nonsu2_main / directMatVec_MPI_nonsu2_main
+ * (ED_NONSU2/ED_HAMILTONIAN_NONSU2_DIRECT_HxV.f90:22-252) and directMatVec_[MPI_]superc_main
+ * (ED_SUPERC/ED_HAMILTONIAN_SUPERC_DIRECT_HxV.f90:22-311) do.  superc: sector = Sz, nonsu2: sector = Ntot.
+ * Sharded handles need the gathered vector for the whole product (the reference gathers first, :220-223):
+ * edigpu_apply_local_dev only zeroes hv, edigpu_apply_remote_dev does the work.
+ */
+int edigpu_direct_build(edigpu_handle *h, const edigpu_model *model, int sector, int64_t row_first,
+                        int64_t row_count);
+
 /* sector dimensions (get_normal/superc/nonsu2_sector_dimension, ED_SETUP.f90:998-1033) */
 int edigpu_sector_dim(const edigpu_model *model, int q1, int q2, int64_t *dim);
 
@@ -144,7 +155,7 @@ int edigpu_sector_dim(const edigpu_model *model, int q1, int q2, int64_t *dim);
 /* queries                                                                    */
 /* ----------------------------------------------------------------------- */
 /* info[0]=global dim, [1]=local rows (vecDim_Hv_sector_*), [2]=first local row,
- * [3]=is_complex, [4]=kind (0 normal Kronecker, 1 flat CSR), [5]=DimUp, [6]=DimDw,
+ * [3]=is_complex, [4]=kind (0 normal Kronecker, 1 flat CSR, 2 direct), [5]=DimUp, [6]=DimDw,
  * [7]=nnz(up)+nnz(dw) or nnz(loc), [8]=nnz(nd) or nnz(nonloc), [9]=device id */
 int edigpu_info(edigpu_handle h, int64_t info[10]);
 /* algorithmic bytes of one H*v in the reference's storage format */

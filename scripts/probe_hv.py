@@ -18,13 +18,10 @@ def main():
     a = ap.parse_args()
     import torch  # noqa: F401
     from edipack_amd import capi
-    from edipack_amd.hamiltonian import SectorHamiltonian
-    from edipack_amd.synthetic import WORKLOADS, synthetic_model
+    from edipack_amd.synthetic import WORKLOADS, build_workload
     capi.init(0)
     w = WORKLOADS[a.workload]
-    m = synthetic_model(w)
-    h = (SectorHamiltonian.normal_from_model(m, *w.sector) if w.ed_mode == "normal"
-         else SectorHamiltonian.flat_from_model(m, w.sector))
+    h = build_workload(w)
     b_hv, b_step = h.algorithmic_bytes()
     if a.lanczos:
         ms_step, ms_hv = h.lanczos_bench(a.warmup, a.steps)

@@ -362,3 +362,48 @@ def test_sharded_lanczos_gpu_world1(gpu, mode, bath, norb, nbath, sec):
     a_ref, b_ref, _ = ho.lanc_tridiag(v, 30)
     assert rel_err(a[:12], a_ref[:12]) < 1e-10 and rel_err(b[:12], b_ref[:12]) < 1e-10
     h.destroy()
+
+
+# --------------------------------------------------------------------------------------------
+# direct (on-the-fly, ed_sparse_H=F) kernels: must agree with the stored matrices, as the reference's
+# own regression tests require (they run every fixture with ED_SPARSE_H = T and F)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,bath,norb,nbath,sec", FLAT_CASES + [("superc", "hybrid", 3, 3, -1)])
+def test_direct_matches_oracle_stored(gpu, mode, bath, norb, nbath, sec):
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models(mode, bath, norb, nbath, seed=61)
+    ho = O.HFlat(om, sec)
+    hg = SectorHamiltonian.direct_from_model(pm, sec)
+    assert hg.dim == ho.dim and hg.kind == 2
+    rng = np.random.default_rng(8)
+    v = rng.standard_normal(ho.dim) + 1j * rng.standard_normal(ho.dim)
+    assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
+    if ho.dim > 50:
+        a_ref, b_ref, _ = ho.lanc_tridiag(v, 20)
+        a, b, _ = hg.lanczos_tridiag(v, 20)
+        assert rel_err(a[:10], a_ref[:10]) < 1e-10 and rel_err(b[:10], b_ref[:10]) < 1e-10
+    hg.destroy()
+
+
+def test_direct_two_shards(gpu):
+    """directMatVec_MPI_* data flow: gather first, then every rank computes its rows."""
+    import torch
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("nonsu2", "hybrid", 2, 3, seed=62)
+    ho = O.HFlat(om, 5)
+    v = np.random.default_rng(1).standard_normal(ho.dim) + 1j * np.random.default_rng(2).standard_normal(ho.dim)
+    vd = torch.from_numpy(v).cuda()
+    q = (ho.dim + 1) // 2
+    out = []
+    for first, cnt in ((0, q), (q, ho.dim - q)):
+        hs = SectorHamiltonian.direct_from_model(pm, 5, row_first=first, row_count=cnt)
+        hv = torch.full((cnt,), 7.0, dtype=torch.complex128, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        hs.apply_local_dev(vd[first:].data_ptr(), hv.data_ptr(), st)
+        hs.apply_remote_dev(vd.data_ptr(), hv.data_ptr(), st)
+        torch.cuda.synchronize()
+        out.append(hv.cpu().numpy())
+        hs.destroy()
+    assert rel_err(np.concatenate(out), ho.matvec(v)) < TOL
