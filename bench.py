@@ -120,12 +120,19 @@ def run_multi(args):
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", rank))
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    capi.init(local)
+    # one rank per GPU; EDIGPU_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the
+    # N>1 data flow on a single-GPU box; the timed configuration is always nccl = RCCL over xGMI)
+    backend = os.environ.get("EDIGPU_DIST_BACKEND", "nccl")
+    dev = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group(backend)
+    capi.init(dev)
     w = WORKLOADS[args.workload]
     model = synthetic_model(w)
-    plan, h, lz = gpu_sharded_hamiltonian(model, w.sector, world, rank)
+    plan, h, lz = gpu_sharded_hamiltonian(model, w.sector, world, rank, direct=w.direct)
     bytes_hv, _ = h.algorithmic_bytes()   # this shard's share of the algorithmic bytes
     gen = torch.Generator(device="cuda").manual_seed(12345 + rank)
     v0 = torch.randn(plan.nloc, dtype=torch.float64, device="cuda", generator=gen)
@@ -153,7 +160,7 @@ def run_multi(args):
     dist.barrier()
     dt = time.perf_counter() - t0
     ms_hv = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    t = torch.tensor([dt, ms_hv, bytes_hv], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt, ms_hv, bytes_hv], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     tmax = t.clone()
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tsum = t.clone()

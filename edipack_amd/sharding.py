@@ -96,7 +96,10 @@ class ShardedLanczos:
         """tmp <- (H vin) restricted to the local rows, exchange overlapped with the local part."""
         work = None
         if self.plan.world > 1:
-            work = dist.all_gather_into_tensor(self.vfull, self.vin, group=self.group, async_op=True)
+            # complex vectors travel as (re,im) pairs: every backend handles real tensors
+            src = torch.view_as_real(self.vin) if self.vin.is_complex() else self.vin
+            dst = torch.view_as_real(self.vfull) if self.vfull.is_complex() else self.vfull
+            work = dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)
         else:
             self.vfull.copy_(self.vin)
         self.apply_local(self.vin, self.tmp)
@@ -147,7 +150,7 @@ class ShardedLanczos:
         return alanc, blanc, ndone
 
 
-def gpu_sharded_hamiltonian(model, workload_sector, world: int, rank: int):
+def gpu_sharded_hamiltonian(model, workload_sector, world: int, rank: int, direct: bool = False):
     """Build this rank's shard on its GPU and return (plan, SectorHamiltonian, ShardedLanczos)."""
     from . import capi
     from .hamiltonian import SectorHamiltonian
@@ -158,11 +161,9 @@ def gpu_sharded_hamiltonian(model, workload_sector, world: int, rank: int):
     if model.ed_mode == "normal":
         nup, ndw = workload_sector
         d_up, d_dw = C.c_int64(), C.c_int64()
-        # DimUp, DimDw from the library's own sector arithmetic (q2 unused -> use two calls)
-        one = C.c_int64()
+        # DimUp = dim(nup, 0), DimDw = dim(0, ndw): the library's own sector arithmetic
         capi.check(L.edigpu_sector_dim(C.byref(cm), nup, 0, C.byref(d_up)))
         capi.check(L.edigpu_sector_dim(C.byref(cm), 0, ndw, C.byref(d_dw)))
-        del one
         plan = ShardPlan(units=d_dw.value, unit_len=d_up.value, world=world, rank=rank)
         h = SectorHamiltonian.normal_from_model(model, nup, ndw, dw_first=plan.first, dw_count=plan.count)
         dtype = torch.float64
@@ -170,8 +171,8 @@ def gpu_sharded_hamiltonian(model, workload_sector, world: int, rank: int):
         dim = C.c_int64()
         capi.check(L.edigpu_sector_dim(C.byref(cm), int(workload_sector), 0, C.byref(dim)))
         plan = ShardPlan(units=dim.value, unit_len=1, world=world, rank=rank)
-        h = SectorHamiltonian.flat_from_model(model, int(workload_sector), row_first=plan.first,
-                                              row_count=plan.count)
+        build = SectorHamiltonian.direct_from_model if direct else SectorHamiltonian.flat_from_model
+        h = build(model, int(workload_sector), row_first=plan.first, row_count=plan.count)
         dtype = torch.complex128
 
     def apply_local(v_chunk, out):
