@@ -394,15 +394,21 @@ static int tql2(int n, std::vector<double>& d, std::vector<double>& e, std::vect
 static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
   const int64_t len = s->ws_len;
   if (normal_lanczos_fusable(s)) {
-    // rotate fused into the row kernel, alpha into the panel sweep (kernels_normal.hip)
+    // rotate (and the pending axpy) fused into the row kernel, alpha and <Q|Q> into the panel sweep
+    // (kernels_normal.hip); EDIGPU_LANCZOS_EXACTBETA=1 keeps the separate axpy+norm kernel
+    static const bool exactbeta = getenv("EDIGPU_LANCZOS_EXACTBETA") != nullptr;
     int np = 0;
-    if (launch_normal_lanczos(s, s->d_vin, s->d_vout, s->d_scal, s->d_partial, iter == 0, st, &np)) return 1;
-    if (np > kMaxPartials) {
+    if (launch_normal_lanczos(s, s->d_vin, s->d_vout, s->d_scal, s->d_partial, iter == 0, !exactbeta, st, &np))
+      return 1;
+    if (2 * np > kMaxPartials) {
       set_error("lanczos_step: partial buffer too small");
       return 1;
     }
-    if (lz_finalize_alpha(s->d_partial, np, s->d_scal, iter, nlanc, st)) return 1;
-    return lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, iter, nlanc, st);
+    if (exactbeta) {
+      if (lz_finalize_alpha(s->d_partial, np, s->d_scal, iter, nlanc, st)) return 1;
+      return lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, iter, nlanc, st);
+    }
+    return lz_finalize_alpha_beta(s->d_vin, s->d_vout, len, s->d_partial, np, s->d_scal, iter, nlanc, st);
   }
   if (iter > 0 && lz_rotate(s->d_vin, s->d_vout, len, s->d_scal, st)) return 1;
   if (apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st)) return 1;

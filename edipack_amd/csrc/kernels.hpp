@@ -5,7 +5,7 @@
 namespace edigpu {
 
 // device-resident Lanczos scalars (kernels_lanczos.hip)
-enum { SC_ALPHA = 0, SC_BETA = 1, SC_STOP = 2, SC_NDONE = 3, SC_NORM = 4, SC_THR = 5, SC_AB = 8 };
+enum { SC_ALPHA = 0, SC_BETA = 1, SC_STOP = 2, SC_NDONE = 3, SC_NORM = 4, SC_THR = 5, SC_EXACT = 6, SC_AB = 8 };
 constexpr int kRedBlocks = 1024;
 constexpr int kMaxPartials = 1 << 16;  // capacity of the per-workgroup partial buffer
 
@@ -18,7 +18,10 @@ int normal_pick_rows_per_block(int64_t dim_up, int64_t dw_count);
 // fused Lanczos step (normal, single shard): P = Lanczos vector, Q = work vector, see kernels_normal.hip
 bool normal_lanczos_fusable(const edigpu_sector* s);
 int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const double* scal,
-                          double* partial, bool first, hipStream_t st, int* npartial);
+                          double* partial, bool first, bool lazy_axpy, hipStream_t st, int* npartial);
+// alpha = sum(partial[0:np]), beta = sqrt(sum(partial[np:2np]) - alpha^2) with an exact fallback pass
+int lz_finalize_alpha_beta(const double* P, const double* Q, int64_t n, double* partial, int np,
+                           double* scal, int iter, int nlanc, hipStream_t st);
 int lz_finalize_alpha(const double* partial, int np, double* scal, int iter, int nlanc, hipStream_t st);
 
 // ---- flat CSR (kernels_csr.hip) ----

@@ -201,6 +201,97 @@ int lz_alpha(const double* vin, double* vout, const double* tmp, int64_t n, doub
   return 0;
 }
 
+// alpha and beta from the panel-sweep partials: beta^2 = <Q|Q> - alpha^2 (|v| = 1).  When that
+// difference loses more than ~3 digits to cancellation SC_EXACT is raised and the (otherwise idle)
+// exact pass recomputes beta^2 = |Q - alpha v|^2 directly.
+__global__ void __launch_bounds__(1024)
+    k_finalize_ab(const double* __restrict__ partial, int np, double* __restrict__ scal, int iter, int nlanc) {
+  __shared__ double sa[1024], sq[1024];
+  if (scal[SC_STOP] != 0.0) return;
+  double a = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < np; i += 1024) {
+    a += partial[i];
+    q += partial[np + i];
+  }
+  sa[threadIdx.x] = a;
+  sq[threadIdx.x] = q;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      sa[threadIdx.x] += sa[threadIdx.x + off];
+      sq[threadIdx.x] += sq[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double alpha = sa[0], qq = sq[0];
+    double b2 = qq - alpha * alpha;
+    scal[SC_ALPHA] = alpha;
+    scal[SC_AB + iter] = alpha;
+    scal[SC_NDONE] = (double)(iter + 1);
+    if (b2 < 1e-3 * qq) {
+      scal[SC_EXACT] = 1.0;  // beta written by the exact pass
+    } else {
+      scal[SC_EXACT] = 0.0;
+      const double b = sqrt(b2);
+      scal[SC_BETA] = b;
+      if (fabs(b) < scal[SC_THR])
+        scal[SC_STOP] = 1.0;
+      else if (iter + 1 < nlanc)
+        scal[SC_AB + nlanc + iter + 1] = b;
+    }
+  }
+}
+
+// exact |Q - alpha*P|^2 (only when SC_EXACT is raised; Q is left untouched: the axpy stays pending)
+__global__ void __launch_bounds__(kLzNT)
+    k_beta_exact(const double* __restrict__ P, const double* __restrict__ Q, int64_t n,
+                 double* __restrict__ partial, const double* __restrict__ scal) {
+  if (scal[SC_STOP] != 0.0 || scal[SC_EXACT] == 0.0) return;
+  const double a = scal[SC_ALPHA];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) {
+    const double w = Q[i] - a * P[i];
+    s += w * w;
+  }
+  s = block_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(1024)
+    k_finalize_exact(const double* __restrict__ partial, int np, double* __restrict__ scal, int iter, int nlanc) {
+  __shared__ double sh[1024];
+  if (scal[SC_STOP] != 0.0 || scal[SC_EXACT] == 0.0) return;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < np; i += 1024) s += partial[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double b = sqrt(sh[0]);
+    scal[SC_BETA] = b;
+    scal[SC_EXACT] = 0.0;
+    if (fabs(b) < scal[SC_THR])
+      scal[SC_STOP] = 1.0;
+    else if (iter + 1 < nlanc)
+      scal[SC_AB + nlanc + iter + 1] = b;
+  }
+}
+
+int lz_finalize_alpha_beta(const double* P, const double* Q, int64_t n, double* partial, int np,
+                           double* scal, int iter, int nlanc, hipStream_t st) {
+  hipLaunchKernelGGL(k_finalize_ab, dim3(1), dim3(1024), 0, st, partial, np, scal, iter, nlanc);
+  // exact fallback: both kernels return immediately unless SC_EXACT was raised
+  dim3 g = red_grid(n);
+  hipLaunchKernelGGL(k_beta_exact, g, dim3(kLzNT), 0, st, P, Q, n, partial, scal);
+  hipLaunchKernelGGL(k_finalize_exact, dim3(1), dim3(1024), 0, st, partial, (int)g.x, scal, iter, nlanc);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 int lz_finalize_alpha(const double* partial, int np, double* scal, int iter, int nlanc, hipStream_t st) {
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, st, partial, np, scal, 1, iter, nlanc);
   EDIGPU_HIP(hipGetLastError());

@@ -93,6 +93,7 @@ __device__ inline void load4(const double* __restrict__ base, int64_t i0, const 
 // FUSE (Lanczos step fused into the row kernel, v_local = P = previous Lanczos vector, hv = Q):
 //   0: plain H*v.   1: first step: x = P, Q <- (Hd+Hup) x.
 //   2: x = Q/beta (the new Lanczos vector), P <- x, Q <- (Hd+Hup) x - beta*P_old.
+//   3: as 2 with the pending axpy folded in: x = (Q - alpha*P)/beta  (no separate beta kernel).
 template <int TD, bool USE_LDS, bool LOCAL, bool DW, bool ND, bool PACKED, bool VEC, bool HDF, int FUSE>
 __global__ void __launch_bounds__(kNT)
     normal_rows_kernel(NormalArgs a, const double* v_local, const double* __restrict__ v_full,
@@ -111,13 +112,14 @@ __global__ void __launch_bounds__(kNT)
   double beta = 0.0, ibeta = 1.0;
   if (FUSE != 0) {
     if (a.scal[SC_STOP] != 0.0) return;  // recurrence already terminated (uniform)
-    if (FUSE == 2) {
+    if (FUSE >= 2) {
       beta = a.scal[SC_BETA];
       ibeta = 1.0 / beta;
     }
   }
+  const double alpha = (FUSE == 3) ? a.scal[SC_ALPHA] : 0.0;
   // source of the staged rows: the vector itself, or Q (scaled by 1/beta) in the fused rotate
-  const double* __restrict__ v_src = (FUSE == 2) ? hv : v_local;
+  const double* __restrict__ v_src = (FUSE >= 2) ? hv : v_local;
 
   if (LOCAL && PACKED && tid < 128) coef_s[tid] = a.ell_coef[tid];
   if (DW) {
@@ -149,7 +151,12 @@ __global__ void __launch_bounds__(kNT)
             const int64_t j = j0 + tid + u * kNT;
             const int rr = r < nr ? r : 0;  // clamped: always a valid address
             t[r][u] = reinterpret_cast<const double2*>(v_src + (r0 + rr) * DimUp)[j < n2 ? j : n2 - 1];
-            if (FUSE == 2) {
+            if (FUSE == 3) {
+              const double2 pp = reinterpret_cast<const double2*>(v_local + (r0 + rr) * DimUp)[j < n2 ? j : n2 - 1];
+              t[r][u].x -= alpha * pp.x;
+              t[r][u].y -= alpha * pp.y;
+            }
+            if (FUSE >= 2) {
               t[r][u].x *= ibeta;
               t[r][u].y *= ibeta;
             }
@@ -172,7 +179,8 @@ __global__ void __launch_bounds__(kNT)
             const int64_t j = j0 + tid + u * kNT;
             const int rr = r < nr ? r : 0;
             t[r][u] = v_src[(r0 + rr) * DimUp + (j < DimUp ? j : DimUp - 1)];
-            if (FUSE == 2) t[r][u] *= ibeta;
+            if (FUSE == 3) t[r][u] -= alpha * v_local[(r0 + rr) * DimUp + (j < DimUp ? j : DimUp - 1)];
+            if (FUSE >= 2) t[r][u] *= ibeta;
           }
 #pragma unroll
         for (int r = 0; r < TD; r++)
@@ -348,7 +356,7 @@ __global__ void __launch_bounds__(kNT)
 #pragma unroll
           for (int e = 0; e < kE; e++) acc[r][e] += old[e];
         }
-        if (FUSE == 2) {
+        if (FUSE >= 2) {
           // Q <- acc - beta * P_old ; P <- x (the staged, normalised vector)
           double pold[kE];
           load4<VEC>(v_local, (r0 + r) * DimUp + col0, ok, pold);
@@ -397,17 +405,20 @@ template <bool DO_DW, bool DO_ND, bool ALPHA>
 __global__ void __launch_bounds__(kPanelNT)
     normal_dw_panel_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full,
                            double* __restrict__ hv) {
-  __shared__ double red[kPanelNT / 64];
+  __shared__ double red[2 * (kPanelNT / 64)];
   const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
   const int panel = (k / p.blocks_per_panel) * 8 + x;
   if (ALPHA) {
     if (panel >= p.npanels || a.scal[SC_STOP] != 0.0) {
-      if (threadIdx.x == 0) a.partial[blockIdx.x] = 0.0;
+      if (threadIdx.x == 0) {
+        a.partial[blockIdx.x] = 0.0;
+        a.partial[gridDim.x + blockIdx.x] = 0.0;
+      }
       return;
     }
   }
   if (panel >= p.npanels) return;
-  double asum = 0.0;
+  double asum = 0.0, qsum = 0.0;
   const int chunk = k % p.blocks_per_panel;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -498,20 +509,35 @@ __global__ void __launch_bounds__(kPanelNT)
       if (two) hv[r2 * DimUp + c] = acc1;
       if (ALPHA) {
         asum += v_full[(a.dw_first + r) * DimUp + c] * acc0;
-        if (two) asum += v_full[(a.dw_first + r2) * DimUp + c] * acc1;
+        qsum += acc0 * acc0;
+        if (two) {
+          asum += v_full[(a.dw_first + r2) * DimUp + c] * acc1;
+          qsum += acc1 * acc1;
+        }
       }
     }
   }
   if (ALPHA) {
+    // per-workgroup partials of <v|Q> and <Q|Q> (the latter gives beta^2 = <Q|Q> - alpha^2)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) asum += __shfl_down(asum, off, 64);
-    if (lane == 0) red[wave] = asum;
+    for (int off = 32; off > 0; off >>= 1) {
+      asum += __shfl_down(asum, off, 64);
+      qsum += __shfl_down(qsum, off, 64);
+    }
+    if (lane == 0) {
+      red[wave] = asum;
+      red[kPanelNT / 64 + wave] = qsum;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-      double t = 0.0;
+      double t = 0.0, q = 0.0;
 #pragma unroll
-      for (int i = 0; i < kPanelNT / 64; i++) t += red[i];
+      for (int i = 0; i < kPanelNT / 64; i++) {
+        t += red[i];
+        q += red[kPanelNT / 64 + i];
+      }
       a.partial[blockIdx.x] = t;
+      a.partial[gridDim.x + blockIdx.x] = q;
     }
   }
 }
@@ -616,6 +642,13 @@ static int launch_te(const NormalArgs& a, const double* vl, const double* vf, do
     }
     case 102: {  // fused Lanczos, rotate + H*v
       auto kern = normal_rows_kernel<TD, USE_LDS, true, false, false, PACKED, VEC, HDF, 2>;
+      if (lds > 48 * 1024)
+        EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, grid, block, lds, st, a, vl, vf, hv);
+      break;
+    }
+    case 103: {  // fused Lanczos, pending axpy + rotate + H*v
+      auto kern = normal_rows_kernel<TD, USE_LDS, true, false, false, PACKED, VEC, HDF, 3>;
       if (lds > 48 * 1024)
         EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid, block, lds, st, a, vl, vf, hv);
@@ -747,12 +780,12 @@ bool normal_lanczos_fusable(const edigpu_sector* s) {
 }
 
 int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const double* scal,
-                          double* partial, bool first, hipStream_t st, int* npartial) {
+                          double* partial, bool first, bool lazy_axpy, hipStream_t st, int* npartial) {
   NormalArgs a;
   fill_args(s, a);
   a.scal = scal;
   a.partial = partial;
-  if (launch_rows(s, a, P, P, Q, first ? 101 : 102, st)) return 1;
+  if (launch_rows(s, a, P, P, Q, first ? 101 : (lazy_axpy ? 103 : 102), st)) return 1;
   const bool fac_nd = s->factored && a.nterms > 0 && s->d_mx_rowptr != nullptr;
   return launch_dw_panels(a, true, fac_nd, P, Q, st, true, npartial);
 }
