@@ -94,8 +94,9 @@ __device__ inline void load4(const double* __restrict__ base, int64_t i0, const 
 //   0: plain H*v.   1: first step: x = P, Q <- (Hd+Hup) x.
 //   2: x = Q/beta (the new Lanczos vector), P <- x, Q <- (Hd+Hup) x - beta*P_old.
 //   3: as 2 with the pending axpy folded in: x = (Q - alpha*P)/beta  (no separate beta kernel).
-template <int TD, bool USE_LDS, bool LOCAL, bool DW, bool ND, bool PACKED, bool VEC, bool HDF, int FUSE>
-__global__ void __launch_bounds__(kNT)
+// NT: threads per workgroup (512; 1024 when the staged rows leave room for one workgroup per CU only)
+template <int NT, int TD, bool USE_LDS, bool LOCAL, bool DW, bool ND, bool PACKED, bool VEC, bool HDF, int FUSE>
+__global__ void __launch_bounds__(NT)
     normal_rows_kernel(NormalArgs a, const double* v_local, const double* __restrict__ v_full,
                        double* hv) {
   extern __shared__ double vs[];  // TD*DimUp staged rows (LOCAL && USE_LDS)
@@ -142,13 +143,13 @@ __global__ void __launch_bounds__(kNT)
     // stage the TD rows: 4 independent loads in flight per thread and row
     if (VEC) {
       const int64_t n2 = DimUp >> 1;
-      for (int64_t j0 = 0; j0 < n2; j0 += 4 * kNT) {
+      for (int64_t j0 = 0; j0 < n2; j0 += 4 * NT) {
         double2 t[TD][4];
 #pragma unroll
         for (int r = 0; r < TD; r++)
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            const int64_t j = j0 + tid + u * kNT;
+            const int64_t j = j0 + tid + u * NT;
             const int rr = r < nr ? r : 0;  // clamped: always a valid address
             t[r][u] = reinterpret_cast<const double2*>(v_src + (r0 + rr) * DimUp)[j < n2 ? j : n2 - 1];
             if (FUSE == 3) {
@@ -165,18 +166,18 @@ __global__ void __launch_bounds__(kNT)
         for (int r = 0; r < TD; r++)
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            const int64_t j = j0 + tid + u * kNT;
+            const int64_t j = j0 + tid + u * NT;
             if (r < nr && j < n2) reinterpret_cast<double2*>(vs + r * DimUp)[j] = t[r][u];
           }
       }
     } else {
-      for (int64_t j0 = 0; j0 < DimUp; j0 += 4 * kNT) {
+      for (int64_t j0 = 0; j0 < DimUp; j0 += 4 * NT) {
         double t[TD][4];
 #pragma unroll
         for (int r = 0; r < TD; r++)
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            const int64_t j = j0 + tid + u * kNT;
+            const int64_t j = j0 + tid + u * NT;
             const int rr = r < nr ? r : 0;
             t[r][u] = v_src[(r0 + rr) * DimUp + (j < DimUp ? j : DimUp - 1)];
             if (FUSE == 3) t[r][u] -= alpha * v_local[(r0 + rr) * DimUp + (j < DimUp ? j : DimUp - 1)];
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(kNT)
         for (int r = 0; r < TD; r++)
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            const int64_t j = j0 + tid + u * kNT;
+            const int64_t j = j0 + tid + u * NT;
             if (r < nr && j < DimUp) vs[r * DimUp + j] = t[r][u];
           }
       }
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(kNT)
   }
   __syncthreads();
 
-  for (int64_t c0 = 0; c0 < DimUp; c0 += (int64_t)kNT * kE) {
+  for (int64_t c0 = 0; c0 < DimUp; c0 += (int64_t)NT * kE) {
     const int64_t col0 = c0 + (int64_t)tid * kE;
     if (col0 >= DimUp) break;  // no barrier below: safe to leave
     double acc[TD][kE];
@@ -614,15 +615,15 @@ int normal_pick_rows_per_block(int64_t dim_up, int64_t dw_count) {
 }
 
 // what: bit0 = diagonal+up (overwrite), bit1 = down term inside the row kernel, bit2 = CSR Hnd
-template <int TD, bool USE_LDS, bool PACKED, bool VEC, bool HDF>
+template <int NT, int TD, bool USE_LDS, bool PACKED, bool VEC, bool HDF>
 static int launch_te(const NormalArgs& a, const double* vl, const double* vf, double* hv,
                      int what, hipStream_t st) {
   const int64_t nblk = (a.dw_count + TD - 1) / TD;
   const size_t lds = USE_LDS ? (size_t)TD * a.dim_up * sizeof(double) : 0;
-  dim3 grid((unsigned)nblk), block(kNT);
+  dim3 grid((unsigned)nblk), block(NT);
 #define EDIGPU_LAUNCH_ROWS(LOC, DWF, NDF, LDSB, UL, PK, HF)                                      \
   do {                                                                                           \
-    auto kern = normal_rows_kernel<TD, UL, LOC, DWF, NDF, PK, VEC, HF, 0>;                       \
+    auto kern = normal_rows_kernel<NT, TD, UL, LOC, DWF, NDF, PK, VEC, HF, 0>;                       \
     if ((LDSB) > 48 * 1024)                                                                      \
       EDIGPU_HIP(hipFuncSetAttribute((const void*)kern,                                          \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB)));  \
@@ -634,21 +635,21 @@ static int launch_te(const NormalArgs& a, const double* vl, const double* vf, do
     case 7: EDIGPU_LAUNCH_ROWS(true, true, true, lds, USE_LDS, PACKED, HDF); break;
     case 3: EDIGPU_LAUNCH_ROWS(true, true, false, lds, USE_LDS, PACKED, HDF); break;
     case 101: {  // fused Lanczos, first step
-      auto kern = normal_rows_kernel<TD, USE_LDS, true, false, false, PACKED, VEC, HDF, 1>;
+      auto kern = normal_rows_kernel<NT, TD, USE_LDS, true, false, false, PACKED, VEC, HDF, 1>;
       if (lds > 48 * 1024)
         EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid, block, lds, st, a, vl, vf, hv);
       break;
     }
     case 102: {  // fused Lanczos, rotate + H*v
-      auto kern = normal_rows_kernel<TD, USE_LDS, true, false, false, PACKED, VEC, HDF, 2>;
+      auto kern = normal_rows_kernel<NT, TD, USE_LDS, true, false, false, PACKED, VEC, HDF, 2>;
       if (lds > 48 * 1024)
         EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid, block, lds, st, a, vl, vf, hv);
       break;
     }
     case 103: {  // fused Lanczos, pending axpy + rotate + H*v
-      auto kern = normal_rows_kernel<TD, USE_LDS, true, false, false, PACKED, VEC, HDF, 3>;
+      auto kern = normal_rows_kernel<NT, TD, USE_LDS, true, false, false, PACKED, VEC, HDF, 3>;
       if (lds > 48 * 1024)
         EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid, block, lds, st, a, vl, vf, hv);
@@ -668,9 +669,14 @@ template <int TD, bool USE_LDS>
 static int launch_td(const NormalArgs& a, bool packed, bool hdf, const double* vl, const double* vf,
                      double* hv, int what, hipStream_t st) {
   const bool vec = (a.dim_up % 2) == 0;
-#define EDIGPU_TD(PK, VC)                                                           \
-  (hdf ? launch_te<TD, USE_LDS, PK, VC, true>(a, vl, vf, hv, what, st)             \
-       : launch_te<TD, USE_LDS, PK, VC, false>(a, vl, vf, hv, what, st))
+  // one workgroup per CU by LDS (a single row > 80 KiB): use all 1024 threads of it
+  const bool big = TD == 1 && USE_LDS && (size_t)a.dim_up * sizeof(double) > 80 * 1024;
+  constexpr int NTBIG = (TD == 1 && USE_LDS) ? 1024 : 512;  // only TD=1 instantiates the 1024 variant
+#define EDIGPU_TD(PK, VC)                                                                  \
+  (big ? (hdf ? launch_te<NTBIG, TD, USE_LDS, PK, VC, true>(a, vl, vf, hv, what, st)       \
+              : launch_te<NTBIG, TD, USE_LDS, PK, VC, false>(a, vl, vf, hv, what, st))     \
+       : (hdf ? launch_te<512, TD, USE_LDS, PK, VC, true>(a, vl, vf, hv, what, st)         \
+              : launch_te<512, TD, USE_LDS, PK, VC, false>(a, vl, vf, hv, what, st)))
   if (vec) return packed ? EDIGPU_TD(true, true) : EDIGPU_TD(false, true);
   return packed ? EDIGPU_TD(true, false) : EDIGPU_TD(false, false);
 #undef EDIGPU_TD
