@@ -33,6 +33,13 @@ struct DevCsr {
   int32_t* col = nullptr;
   double* val = nullptr;    // nnz (real) or 2*nnz (complex)
   double avg_row = 0.0;
+  // SELL-64 image (sliced ELL, 64 rows per slice, entries sorted by column inside a row):
+  // entry (slice s, slot k, lane l) at sell_ptr[s]*64 + k*64 + l; padding = own row, value 0
+  int sell = 0;
+  int64_t nslice = 0;
+  int32_t* sell_ptr = nullptr;   // nslice+1, in units of 64 entries
+  int32_t* sell_col = nullptr;
+  double* sell_val = nullptr;
 };
 
 // ELL (column-major [slot][row]) image of a small square factor matrix
