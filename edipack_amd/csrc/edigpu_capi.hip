@@ -70,6 +70,9 @@ static int upload_csr(DevCsr& d, int64_t nrow, const int64_t* rowptr, const int3
 
 static void free_csr(DevCsr& d) {
   dev_free(d.sell_ptr);
+  dev_free(d.sell_pk);
+  dev_free(d.sell_dict);
+  dev_free(d.sell_diag);
   dev_free(d.sell_col);
   dev_free(d.sell_val);
   dev_free(d.rowptr32);
@@ -167,41 +170,86 @@ static int upload_ell(DevEll& e, const HostCsr& a) {
 
 // SELL-64 image of a CSR block (kernels_csr.hip, sell_rows_kernel): rows sorted by column, 64 rows per
 // slice, column-major inside the slice.  Built when the padding stays below 60 % of the entries.
-static int upload_sell(DevCsr& d, int64_t nrow, const int64_t* rowptr, const int32_t* col, const double* val,
-                       int cplx, int64_t own_col_shift) {
+static int upload_sell(DevCsr& d, int64_t nrow, int64_t ncol, const int64_t* rowptr, const int32_t* col,
+                       const double* val, int cplx, bool is_loc) {
   if (nrow == 0 || rowptr[nrow] == 0 || getenv("EDIGPU_CSR_NOSELL")) return 0;
   const int w = cplx ? 2 : 1;
+  // ---- value dictionary (off-diagonal entries; the loc block's diagonal goes to its own array) ----
+  bool packed = ncol < ((int64_t)1 << 24) && !getenv("EDIGPU_CSR_UNPACKED");
+  std::vector<double> dict(w, 0.0);  // id 0 = zero (padding)
+  std::vector<uint8_t> ids;
+  std::vector<double> diag;
+  if (packed) {
+    ids.assign((size_t)rowptr[nrow], 0);
+    if (is_loc) diag.assign((size_t)nrow * w, 0.0);
+    for (int64_t i = 0; i < nrow && packed; i++)
+      for (int64_t k = rowptr[i]; k < rowptr[i + 1]; k++) {
+        if (is_loc && col[k] == i) {
+          for (int q = 0; q < w; q++) diag[i * w + q] += val[k * w + q];
+          continue;
+        }
+        const size_t n = dict.size() / w;
+        size_t id = 0;
+        for (; id < n; id++)
+          if (memcmp(&dict[id * w], &val[k * w], sizeof(double) * w) == 0) break;
+        if (id == n) {
+          if (n >= 256) {
+            packed = false;
+            break;
+          }
+          for (int q = 0; q < w; q++) dict.push_back(val[k * w + q]);
+        }
+        ids[k] = (uint8_t)id;
+      }
+  }
+  const bool skip_diag = packed && is_loc;
   const int64_t ns = (nrow + 63) / 64;
   std::vector<int32_t> sp((size_t)ns + 1, 0);
-  int64_t tot = 0;
+  int64_t tot = 0, nent = 0;
   for (int64_t s = 0; s < ns; s++) {
     int64_t mx = 0;
-    for (int64_t i = s * 64; i < std::min<int64_t>(nrow, s * 64 + 64); i++) mx = std::max(mx, rowptr[i + 1] - rowptr[i]);
+    for (int64_t i = s * 64; i < std::min<int64_t>(nrow, s * 64 + 64); i++) {
+      int64_t n = rowptr[i + 1] - rowptr[i];
+      if (skip_diag)
+        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; k++)
+          if (col[k] == i) n--;
+      mx = std::max(mx, n);
+      nent += n;
+    }
     tot += mx;
     if (tot >= ((int64_t)1 << 31) / 64) return 0;
     sp[s + 1] = (int32_t)tot;
   }
-  if ((double)tot * 64.0 > 1.6 * (double)rowptr[nrow]) return 0;  // too ragged: keep the CSR kernel
-  std::vector<int32_t> sc((size_t)tot * 64);
-  std::vector<double> sv((size_t)tot * 64 * w, 0.0);
+  if (nent > 0 && (double)tot * 64.0 > 1.6 * (double)nent) return 0;  // too ragged: keep the CSR kernel
+  std::vector<int32_t> sc;
+  std::vector<uint32_t> spk;
+  std::vector<double> sv;
+  if (packed) spk.assign((size_t)tot * 64, 0u);
+  else {
+    sc.assign((size_t)tot * 64, 0);
+    sv.assign((size_t)tot * 64 * w, 0.0);
+  }
   std::vector<std::pair<int32_t, int64_t>> ord;
   for (int64_t s = 0; s < ns; s++) {
     const int64_t width = sp[s + 1] - sp[s];
     for (int l = 0; l < 64; l++) {
       const int64_t i = s * 64 + l;
-      const int32_t own = (int32_t)std::min<int64_t>(i, nrow - 1);  // a valid x index of this block's source
-      (void)own_col_shift;
       ord.clear();
       if (i < nrow)
-        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; k++) ord.emplace_back(col[k], k);
+        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; k++)
+          if (!(skip_diag && col[k] == i)) ord.emplace_back(col[k], k);
       std::sort(ord.begin(), ord.end());
       for (int64_t k = 0; k < width; k++) {
         const size_t o = ((size_t)sp[s] + k) * 64 + l;
-        if (k < (int64_t)ord.size()) {
-          sc[o] = ord[k].first;
-          for (int q = 0; q < w; q++) sv[o * w + q] = val[ord[k].second * w + q];
+        const bool live = k < (int64_t)ord.size();
+        // padding: repeat the last column (same cache line), value 0 / dictionary id 0
+        const int32_t c = live ? ord[k].first : (ord.empty() ? 0 : ord.back().first);
+        if (packed) {
+          spk[o] = (uint32_t)c | ((uint32_t)(live ? ids[ord[k].second] : 0) << 24);
         } else {
-          sc[o] = ord.empty() ? 0 : ord.back().first;  // padding: repeat the last column (same cache line), value 0
+          sc[o] = c;
+          if (live)
+            for (int q = 0; q < w; q++) sv[o * w + q] = val[ord[k].second * w + q];
         }
       }
     }
@@ -209,8 +257,16 @@ static int upload_sell(DevCsr& d, int64_t nrow, const int64_t* rowptr, const int
   d.sell = 1;
   d.nslice = ns;
   if (dev_upload(&d.sell_ptr, sp.data(), sp.size())) return 1;
-  if (dev_upload(&d.sell_col, sc.data(), sc.size())) return 1;
-  if (dev_upload(&d.sell_val, sv.data(), sv.size())) return 1;
+  if (packed) {
+    d.sell_packed = 1;
+    dict.resize((size_t)256 * w, 0.0);
+    if (dev_upload(&d.sell_pk, spk.data(), spk.size())) return 1;
+    if (dev_upload(&d.sell_dict, dict.data(), dict.size())) return 1;
+    if (is_loc && dev_upload(&d.sell_diag, diag.data(), diag.size())) return 1;
+  } else {
+    if (dev_upload(&d.sell_col, sc.data(), sc.size())) return 1;
+    if (dev_upload(&d.sell_val, sv.data(), sv.size())) return 1;
+  }
   return 0;
 }
 
@@ -344,8 +400,8 @@ static int setup_flat(edigpu_sector* s, int64_t nrow_local, int64_t ncol_global,
   }
   if (upload_csr(s->loc, nrow_local, rpl.data(), cl.data(), vl.data(), cplx)) return 1;
   if (upload_csr(s->nonloc, nrow_local, rpn.data(), cn.data(), vn.data(), cplx)) return 1;
-  if (upload_sell(s->loc, nrow_local, rpl.data(), cl.data(), vl.data(), cplx, 0)) return 1;
-  if (upload_sell(s->nonloc, nrow_local, rpn.data(), cn.data(), vn.data(), cplx, 0)) return 1;
+  if (upload_sell(s->loc, nrow_local, nrow_local, rpl.data(), cl.data(), vl.data(), cplx, true)) return 1;
+  if (upload_sell(s->nonloc, nrow_local, ncol_global, rpn.data(), cn.data(), vn.data(), cplx, false)) return 1;
   return finish_handle(s);
 }
 

@@ -40,6 +40,12 @@ struct DevCsr {
   int32_t* sell_ptr = nullptr;   // nslice+1, in units of 64 entries
   int32_t* sell_col = nullptr;
   double* sell_val = nullptr;
+  // value-dictionary form of the SELL image: 4 B/entry = column (24 bit) | id (8 bit), values in a
+  // <= 256-entry table (id 0 = 0.0), diagonal kept apart (one value per row, loc block only)
+  int sell_packed = 0;
+  uint32_t* sell_pk = nullptr;
+  double* sell_dict = nullptr;
+  double* sell_diag = nullptr;
 };
 
 // ELL (column-major [slot][row]) image of a small square factor matrix

@@ -97,6 +97,60 @@ __global__ void __launch_bounds__(kCsrNT)
   }
 }
 
+// SELL-64 with the value dictionary: 4 bytes per entry, values from a <= 256-entry LDS table, the
+// diagonal of the loc block as a separate stream.
+template <bool CPLX, bool ACC>
+__global__ void __launch_bounds__(kCsrNT)
+    sell_rows_packed_kernel(int64_t nrow, int64_t nslice, const int32_t* __restrict__ sptr,
+                            const uint32_t* __restrict__ pk, const double* __restrict__ dict,
+                            const double* __restrict__ diag, const double* __restrict__ x,
+                            double* __restrict__ y) {
+  __shared__ double dict_s[CPLX ? 512 : 256];
+  for (int i = threadIdx.x; i < (CPLX ? 512 : 256); i += kCsrNT) dict_s[i] = dict[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t slice = (int64_t)blockIdx.x * (kCsrNT / 64) + (threadIdx.x >> 6);
+  if (slice >= nslice) return;
+  const int64_t row = slice * 64 + lane;
+  const int32_t b = sptr[slice], e = sptr[slice + 1];
+  double sr = 0.0, si = 0.0;
+#pragma unroll 4
+  for (int32_t k = b; k < e; k++) {
+    const uint32_t p = pk[(int64_t)k * 64 + lane];
+    const int64_t c = p & 0xFFFFFFu;
+    const int id = p >> 24;
+    if (CPLX) {
+      const double ar = dict_s[2 * id], ai = dict_s[2 * id + 1];
+      const double2 xv = reinterpret_cast<const double2*>(x)[c];
+      sr += ar * xv.x - ai * xv.y;
+      si += ar * xv.y + ai * xv.x;
+    } else {
+      sr += dict_s[id] * x[c];
+    }
+  }
+  if (row < nrow) {
+    if (diag != nullptr) {
+      if (CPLX) {
+        const double2 d = reinterpret_cast<const double2*>(diag)[row];
+        const double2 xv = reinterpret_cast<const double2*>(x)[row];
+        sr += d.x * xv.x - d.y * xv.y;
+        si += d.x * xv.y + d.y * xv.x;
+      } else {
+        sr += diag[row] * x[row];
+      }
+    }
+    if (CPLX) {
+      double2* yy = reinterpret_cast<double2*>(y) + row;
+      double2 o2 = ACC ? *yy : make_double2(0.0, 0.0);
+      o2.x += sr;
+      o2.y += si;
+      *yy = o2;
+    } else {
+      y[row] = (ACC ? y[row] : 0.0) + sr;
+    }
+  }
+}
+
 __global__ void zero_kernel(double* __restrict__ y, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x)
@@ -131,6 +185,12 @@ static int launch_pick(const DevCsr& a, const double* x, double* y, hipStream_t 
   const double r = a.avg_row;
   if (a.sell) {
     const int64_t nb = (a.nslice + kCsrNT / 64 - 1) / (kCsrNT / 64);
+    if (a.sell_packed) {
+      hipLaunchKernelGGL((sell_rows_packed_kernel<CPLX, ACC>), dim3((unsigned)nb), dim3(kCsrNT), 0, st, a.nrow,
+                         a.nslice, a.sell_ptr, a.sell_pk, a.sell_dict, a.sell_diag, x, y);
+      EDIGPU_HIP(hipGetLastError());
+      return 0;
+    }
     hipLaunchKernelGGL((sell_rows_kernel<CPLX, ACC>), dim3((unsigned)nb), dim3(kCsrNT), 0, st, a.nrow, a.nslice,
                        a.sell_ptr, a.sell_col, a.sell_val, x, y);
     EDIGPU_HIP(hipGetLastError());
