@@ -82,8 +82,9 @@ struct DirectTerm {          // coef * (-1)^{popc(s & sign_mask) + csign} at col
   uint32_t flip;
   uint32_t sign_mask;
   int32_t csign;
-  int32_t pad;
-  double cre, cim;
+  int32_t pair;              // 1: a hop merged with its reverse: applicable iff exactly one of the two
+  double cre, cim;           //    levels in `flip` is occupied; (cre,cim) if (s & need_set) != 0,
+  double c2re, c2im;         //    (c2re,c2im) otherwise; csign2 in the upper half-word of csign
 };
 
 struct HostDirect {

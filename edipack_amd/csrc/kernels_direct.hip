@@ -17,15 +17,27 @@
 
 namespace edigpu {
 
-constexpr int kDirNT = 256;
+constexpr int kDirNT = 1024;  // 2 workgroups/CU with the 2 x 2^Ns-entry rank tables staged in LDS (Ns <= 13)
 
+template <bool LDS_TABLES>
 __global__ void __launch_bounds__(kDirNT)
     direct_rows_kernel(int64_t nrow, int64_t row_first, int ns, int norb, int nterms,
                        const int32_t* __restrict__ states, const int32_t* __restrict__ off_dw,
                        const int32_t* __restrict__ rk_up, const DirectTerm* __restrict__ terms,
                        const double* __restrict__ dtab, const double* __restrict__ xtab,
                        const double2* __restrict__ v_full, double2* __restrict__ hv) {
+  extern __shared__ int32_t tabs[];  // [off_dw | rk_up] when LDS_TABLES
   const uint32_t lomask = (1u << ns) - 1u, impmask = (1u << norb) - 1u;
+  if (LDS_TABLES) {
+    const int n = 1 << ns;
+    for (int i = threadIdx.x; i < n; i += kDirNT) {
+      tabs[i] = off_dw[i];
+      tabs[n + i] = rk_up[i];
+    }
+    __syncthreads();
+  }
+  const int32_t* __restrict__ t_off = LDS_TABLES ? tabs : off_dw;
+  const int32_t* __restrict__ t_rk = LDS_TABLES ? tabs + (1 << ns) : rk_up;
   for (int64_t r = (int64_t)blockIdx.x * kDirNT + threadIdx.x; r < nrow; r += (int64_t)gridDim.x * kDirNT) {
     const uint32_t s = (uint32_t)states[r];
     // diagonal: one-body energies byte by byte + impurity interaction table
@@ -35,11 +47,29 @@ __global__ void __launch_bounds__(kDirNT)
     double ar = dg * x0.x, ai = dg * x0.y;
     for (int t = 0; t < nterms; t++) {
       const DirectTerm tm = terms[t];  // wave-uniform
-      if ((s & tm.need_set) == tm.need_set && (s & tm.need_clear) == 0u) {
+      bool on;
+      double cr, ci;
+      int cs;
+      if (tm.pair) {
+        // hop merged with its reverse: exactly one of the two levels occupied
+        const bool fwd = (s & tm.need_set) != 0u;
+        on = fwd != ((s & tm.need_clear) != 0u);
+        cr = fwd ? tm.cre : tm.c2re;
+        ci = fwd ? tm.cim : tm.c2im;
+        cs = fwd ? (tm.csign & 1) : ((tm.csign >> 16) & 1);
+      } else {
+        on = (s & tm.need_set) == tm.need_set && (s & tm.need_clear) == 0u;
+        cr = tm.cre;
+        ci = tm.cim;
+        cs = tm.csign & 1;
+      }
+      if (on) {
         const uint32_t w = s ^ tm.flip;
-        const int64_t j = (int64_t)off_dw[w >> ns] + rk_up[w & lomask];
-        const bool neg = ((__popc(s & tm.sign_mask) + tm.csign) & 1) != 0;
-        const double cr = neg ? -tm.cre : tm.cre, ci = neg ? -tm.cim : tm.cim;
+        const int64_t j = (int64_t)t_off[w >> ns] + t_rk[w & lomask];
+        if ((__popc(s & tm.sign_mask) + cs) & 1) {
+          cr = -cr;
+          ci = -ci;
+        }
         const double2 x = v_full[j];
         ar += cr * x.x - ci * x.y;
         ai += cr * x.y + ci * x.x;
@@ -52,11 +82,22 @@ __global__ void __launch_bounds__(kDirNT)
 int launch_direct(const edigpu_sector* s, const double* v_full, double* hv, hipStream_t st) {
   if (s->nloc == 0) return 0;
   int64_t nb = (s->nloc + kDirNT - 1) / kDirNT;
-  if (nb > 256 * 32) nb = 256 * 32;
-  hipLaunchKernelGGL(direct_rows_kernel, dim3((unsigned)nb), dim3(kDirNT), 0, st, s->nloc, s->row_first,
-                     s->dir_ns, s->dir_norb, s->dir_nterms, s->d_dir_states, s->d_dir_offdw, s->d_dir_rkup,
-                     s->d_dir_terms, s->d_dir_dtab, s->d_dir_xtab, reinterpret_cast<const double2*>(v_full),
-                     reinterpret_cast<double2*>(hv));
+  if (nb > 256 * 2) nb = 256 * 2;  // persistent: two workgroups per CU sweep the rows
+  const size_t tab_bytes = (size_t)2 * sizeof(int32_t) << s->dir_ns;
+  const double2* v2 = reinterpret_cast<const double2*>(v_full);
+  double2* h2 = reinterpret_cast<double2*>(hv);
+  if (tab_bytes <= 64 * 1024) {
+    auto kern = direct_rows_kernel<true>;
+    if (tab_bytes > 48 * 1024)
+      EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kDirNT), tab_bytes, st, s->nloc, s->row_first, s->dir_ns,
+                       s->dir_norb, s->dir_nterms, s->d_dir_states, s->d_dir_offdw, s->d_dir_rkup, s->d_dir_terms,
+                       s->d_dir_dtab, s->d_dir_xtab, v2, h2);
+  } else {
+    hipLaunchKernelGGL(direct_rows_kernel<false>, dim3((unsigned)nb), dim3(kDirNT), 0, st, s->nloc, s->row_first,
+                       s->dir_ns, s->dir_norb, s->dir_nterms, s->d_dir_states, s->d_dir_offdw, s->d_dir_rkup,
+                       s->d_dir_terms, s->d_dir_dtab, s->d_dir_xtab, v2, h2);
+  }
   EDIGPU_HIP(hipGetLastError());
   return 0;
 }
