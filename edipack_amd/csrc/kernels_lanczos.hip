@@ -243,27 +243,20 @@ __global__ void __launch_bounds__(1024)
   }
 }
 
-// exact |Q - alpha*P|^2 (only when SC_EXACT is raised; Q is left untouched: the axpy stays pending)
-__global__ void __launch_bounds__(kLzNT)
-    k_beta_exact(const double* __restrict__ P, const double* __restrict__ Q, int64_t n,
-                 double* __restrict__ partial, const double* __restrict__ scal) {
+// exact |Q - alpha*P|^2 (only when SC_EXACT is raised; Q is left untouched: the axpy stays pending).
+// One workgroup: the launch costs ~2 us when idle; when it does run (near-invariant subspace, rare) it
+// sweeps the vectors alone.
+__global__ void __launch_bounds__(1024)
+    k_beta_exact_single(const double* __restrict__ P, const double* __restrict__ Q, int64_t n,
+                        double* __restrict__ scal, int iter, int nlanc) {
+  __shared__ double sh[1024];
   if (scal[SC_STOP] != 0.0 || scal[SC_EXACT] == 0.0) return;
   const double a = scal[SC_ALPHA];
   double s = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) {
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
     const double w = Q[i] - a * P[i];
     s += w * w;
   }
-  s = block_sum(s);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
-}
-
-__global__ void __launch_bounds__(1024)
-    k_finalize_exact(const double* __restrict__ partial, int np, double* __restrict__ scal, int iter, int nlanc) {
-  __shared__ double sh[1024];
-  if (scal[SC_STOP] != 0.0 || scal[SC_EXACT] == 0.0) return;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < np; i += 1024) s += partial[i];
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int off = 512; off > 0; off >>= 1) {
@@ -284,10 +277,8 @@ __global__ void __launch_bounds__(1024)
 int lz_finalize_alpha_beta(const double* P, const double* Q, int64_t n, double* partial, int np,
                            double* scal, int iter, int nlanc, hipStream_t st) {
   hipLaunchKernelGGL(k_finalize_ab, dim3(1), dim3(1024), 0, st, partial, np, scal, iter, nlanc);
-  // exact fallback: both kernels return immediately unless SC_EXACT was raised
-  dim3 g = red_grid(n);
-  hipLaunchKernelGGL(k_beta_exact, g, dim3(kLzNT), 0, st, P, Q, n, partial, scal);
-  hipLaunchKernelGGL(k_finalize_exact, dim3(1), dim3(1024), 0, st, partial, (int)g.x, scal, iter, nlanc);
+  // exact fallback: returns immediately unless SC_EXACT was raised
+  hipLaunchKernelGGL(k_beta_exact_single, dim3(1), dim3(1024), 0, st, P, Q, n, scal, iter, nlanc);
   EDIGPU_HIP(hipGetLastError());
   return 0;
 }

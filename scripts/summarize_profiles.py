@@ -23,7 +23,8 @@ def main():
     for f in glob.glob(os.path.join(out, "pmc_*", "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
-            key = "panel" if "panel" in kn else "rows" if "normal_rows" in kn else "csr" if "csr_rows" in kn else None
+            key = ("panel" if "panel" in kn else "rows" if "normal_rows" in kn else
+                   "csr" if ("csr_rows" in kn or "sell_rows" in kn) else "direct" if "direct_rows" in kn else None)
             if key:
                 agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     pmc = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
