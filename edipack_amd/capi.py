@@ -77,6 +77,11 @@ SIGNATURES = {
     "edigpu_apply_remote_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
     "edigpu_lanczos_tridiag": (C.c_int, [_vp, _pd, C.c_int, _pd, _pd, C.c_double, _pint]),
     "edigpu_lanczos_eigh": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int, _pd, _pd, _pd, _pint]),
+    "edigpu_vec_work_doubles": (C.c_int, []),
+    "edigpu_vec_rotate": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
+    "edigpu_vec_add_dot": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "edigpu_vec_axpy_nrm2": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "edigpu_vec_scale": (C.c_int, [_i64, _vp, _vp, _vp]),
     "edigpu_time_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _pd]),
     "edigpu_lanczos_bench": (C.c_int, [_vp, C.c_int, C.c_int, _pd, _pd]),
     "edigpu_destroy": (C.c_int, [_vp]),

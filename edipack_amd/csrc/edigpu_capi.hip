@@ -1076,6 +1076,42 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
   return 0;
 }
 
+int edigpu_vec_work_doubles(void) { return kRedBlocks; }
+
+int edigpu_vec_rotate(int64_t n, double* vin_dev, double* vout_dev, const double* beta2_dev, void* stream) {
+  if (n < 0 || !vin_dev || !vout_dev || !beta2_dev) {
+    set_error("edigpu_vec_rotate: bad argument");
+    return 1;
+  }
+  return vec_rotate(n, vin_dev, vout_dev, beta2_dev, (hipStream_t)stream);
+}
+
+int edigpu_vec_add_dot(int64_t n, const double* vin_dev, double* vout_dev, const double* tmp_dev,
+                       double* out_dev, double* work_dev, void* stream) {
+  if (n < 0 || !vin_dev || !vout_dev || !tmp_dev || !out_dev || !work_dev) {
+    set_error("edigpu_vec_add_dot: bad argument");
+    return 1;
+  }
+  return vec_add_dot(n, vin_dev, vout_dev, tmp_dev, out_dev, work_dev, (hipStream_t)stream);
+}
+
+int edigpu_vec_axpy_nrm2(int64_t n, const double* vin_dev, double* vout_dev, const double* alpha_dev,
+                         double* out_dev, double* work_dev, void* stream) {
+  if (n < 0 || !vin_dev || !vout_dev || !alpha_dev || !out_dev || !work_dev) {
+    set_error("edigpu_vec_axpy_nrm2: bad argument");
+    return 1;
+  }
+  return vec_axpy_nrm2(n, vin_dev, vout_dev, alpha_dev, out_dev, work_dev, (hipStream_t)stream);
+}
+
+int edigpu_vec_scale(int64_t n, double* v_dev, const double* nrm2_dev, void* stream) {
+  if (n < 0 || !v_dev || !nrm2_dev) {
+    set_error("edigpu_vec_scale: bad argument");
+    return 1;
+  }
+  return vec_scale(n, v_dev, nrm2_dev, (hipStream_t)stream);
+}
+
 int edigpu_time_apply(edigpu_handle s, int warmup, int steps, int lanczos, double* ms_per_step) {
   if (!s || steps <= 0 || !ms_per_step) {
     set_error("edigpu_time_apply: bad argument");

@@ -43,5 +43,10 @@ int lz_beta(const double* vin, double* vout, int64_t n, double* partial, double*
 int lz_axpy_coef(double* acc, const double* vin, int64_t n, double coef, const double* scal,
                  int iter, hipStream_t st);
 int lz_fill_random(double* v, int64_t n, uint64_t seed, hipStream_t st);
+// stand-alone vector kernels with explicit device scalars (sharded loop)
+int vec_rotate(int64_t n, double* vin, double* vout, const double* beta2, hipStream_t st);
+int vec_add_dot(int64_t n, const double* vin, double* vout, const double* tmp, double* out, double* work, hipStream_t st);
+int vec_axpy_nrm2(int64_t n, const double* vin, double* vout, const double* alpha, double* out, double* work, hipStream_t st);
+int vec_scale(int64_t n, double* v, const double* nrm2, hipStream_t st);
 
 }  // namespace edigpu

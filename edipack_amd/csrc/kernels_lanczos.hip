@@ -311,4 +311,92 @@ int lz_fill_random(double* v, int64_t n, uint64_t seed, hipStream_t st) {
   return 0;
 }
 
+// ---- stand-alone vector kernels with explicit device scalars (sharded N>1 loop) ----
+__global__ void __launch_bounds__(kLzNT)
+    kv_rotate(int64_t n, double* __restrict__ vin, double* __restrict__ vout, const double* __restrict__ beta2) {
+  const double b = sqrt(beta2[0]), ib = 1.0 / b;
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) {
+    const double t = vin[i];
+    vin[i] = vout[i] * ib;
+    vout[i] = -b * t;
+  }
+}
+
+__global__ void __launch_bounds__(kLzNT)
+    kv_add_dot(int64_t n, const double* __restrict__ vin, double* __restrict__ vout,
+               const double* __restrict__ tmp, double* __restrict__ partial) {
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) {
+    const double w = vout[i] + tmp[i];
+    vout[i] = w;
+    s += vin[i] * w;
+  }
+  s = block_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(kLzNT)
+    kv_axpy_nrm2(int64_t n, const double* __restrict__ vin, double* __restrict__ vout,
+                 const double* __restrict__ alpha, double* __restrict__ partial) {
+  const double a = alpha[0];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) {
+    const double w = vout[i] - a * vin[i];
+    vout[i] = w;
+    s += w * w;
+  }
+  s = block_sum(s);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(1024) kv_sum(const double* __restrict__ partial, int np, double* __restrict__ out) {
+  __shared__ double sh[1024];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < np; i += 1024) s += partial[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+__global__ void __launch_bounds__(kLzNT) kv_scale(int64_t n, double* __restrict__ v, const double* __restrict__ nrm2) {
+  const double inv = 1.0 / sqrt(nrm2[0]);
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) v[i] *= inv;
+}
+
+int vec_rotate(int64_t n, double* vin, double* vout, const double* beta2, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(kv_rotate, ew_grid(n), dim3(kLzNT), 0, st, n, vin, vout, beta2);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int vec_add_dot(int64_t n, const double* vin, double* vout, const double* tmp, double* out, double* work,
+                hipStream_t st) {
+  dim3 g = red_grid(n > 0 ? n : 1);
+  hipLaunchKernelGGL(kv_add_dot, g, dim3(kLzNT), 0, st, n, vin, vout, tmp, work);
+  hipLaunchKernelGGL(kv_sum, dim3(1), dim3(1024), 0, st, work, (int)g.x, out);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int vec_axpy_nrm2(int64_t n, const double* vin, double* vout, const double* alpha, double* out, double* work,
+                  hipStream_t st) {
+  dim3 g = red_grid(n > 0 ? n : 1);
+  hipLaunchKernelGGL(kv_axpy_nrm2, g, dim3(kLzNT), 0, st, n, vin, vout, alpha, work);
+  hipLaunchKernelGGL(kv_sum, dim3(1), dim3(1024), 0, st, work, (int)g.x, out);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int vec_scale(int64_t n, double* v, const double* nrm2, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(kv_scale, ew_grid(n), dim3(kLzNT), 0, st, n, v, nrm2);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace edigpu

@@ -63,18 +63,94 @@ class ShardPlan:
                 for r in range(self.world)]
 
 
+class TorchVecOps:
+    """Elementwise part of the recurrence with torch ops (CPU / gloo tests and any device)."""
+
+    @staticmethod
+    def _real(t):
+        return torch.view_as_real(t) if t.is_complex() else t
+
+    def rotate(self, vin, vout, beta2):
+        b = torch.sqrt(beta2)
+        b = b.to(vin.dtype) if vin.is_complex() else b
+        t = vin.clone()
+        torch.div(vout, b, out=vin)
+        torch.mul(t, -b, out=vout)
+
+    def add_dot(self, vin, vout, tmp, out):
+        vout.add_(tmp)
+        out.copy_(torch.sum(self._real(vin) * self._real(vout)).reshape(1))
+
+    def axpy_nrm2(self, vin, vout, alpha, out):
+        a = alpha.to(vin.dtype) if vin.is_complex() else alpha
+        vout.addcmul_(vin, -a)
+        r = self._real(vout)
+        out.copy_(torch.sum(r * r).reshape(1))
+
+    def nrm2(self, v, out):
+        r = self._real(v)
+        out.copy_(torch.sum(r * r).reshape(1))
+
+    def scale(self, v, nrm2):
+        b = torch.sqrt(nrm2)
+        v.div_(b.to(v.dtype) if v.is_complex() else b)
+
+
+class NativeVecOps:
+    """The same through the library's fused vector kernels (edigpu_vec_*, include/edigpu.h): one
+    launch per update instead of 3-4 torch ops, no temporaries, no host synchronisation."""
+
+    def __init__(self, device="cuda"):
+        from . import capi
+        self.L, self.check = capi.lib(), capi.check
+        self.work = torch.zeros(self.L.edigpu_vec_work_doubles(), dtype=torch.float64, device=device)
+        self.zero = None
+
+    @staticmethod
+    def _n(t):
+        return t.numel() * (2 if t.is_complex() else 1)
+
+    @staticmethod
+    def _st():
+        return torch.cuda.current_stream().cuda_stream
+
+    def rotate(self, vin, vout, beta2):
+        self.check(self.L.edigpu_vec_rotate(self._n(vin), vin.data_ptr(), vout.data_ptr(), beta2.data_ptr(),
+                                            self._st()))
+
+    def add_dot(self, vin, vout, tmp, out):
+        self.check(self.L.edigpu_vec_add_dot(self._n(vin), vin.data_ptr(), vout.data_ptr(), tmp.data_ptr(),
+                                             out.data_ptr(), self.work.data_ptr(), self._st()))
+
+    def axpy_nrm2(self, vin, vout, alpha, out):
+        self.check(self.L.edigpu_vec_axpy_nrm2(self._n(vin), vin.data_ptr(), vout.data_ptr(), alpha.data_ptr(),
+                                               out.data_ptr(), self.work.data_ptr(), self._st()))
+
+    def nrm2(self, v, out):
+        # sum(v^2) = the norm partial of (v - 0*v)
+        if self.zero is None:
+            self.zero = torch.zeros(1, dtype=torch.float64, device=v.device)
+        self.check(self.L.edigpu_vec_axpy_nrm2(self._n(v), v.data_ptr(), v.data_ptr(), self.zero.data_ptr(),
+                                               out.data_ptr(), self.work.data_ptr(), self._st()))
+
+    def scale(self, v, nrm2):
+        self.check(self.L.edigpu_vec_scale(self._n(v), v.data_ptr(), nrm2.data_ptr(), self._st()))
+
+
 class ShardedLanczos:
     """Three-term recurrence on a row-sharded vector (sp_lanc_tridiag semantics, MPI variant).
 
     ``apply_local(v_chunk, out)`` computes the shard-local part of H*v from the rank's own (padded)
     chunk and overwrites ``out``; ``apply_remote(v_full, out)`` adds the part that needs the
-    gathered vector.  Both operate on torch tensors that live on ``device``.
+    gathered vector.  Both operate on torch tensors that live on ``device``.  ``vec_ops`` supplies
+    the elementwise updates (TorchVecOps by default, NativeVecOps on the GPU).
     """
 
     def __init__(self, plan: ShardPlan, apply_local: Callable, apply_remote: Callable,
-                 dtype=torch.float64, device="cpu", group=None):
+                 dtype=torch.float64, device="cpu", group=None, vec_ops=None):
         self.plan, self.apply_local, self.apply_remote = plan, apply_local, apply_remote
         self.dtype, self.device, self.group = dtype, device, group
+        self.ops = vec_ops if vec_ops is not None else TorchVecOps()
         n = plan.chunk
         self.vin = torch.zeros(n, dtype=dtype, device=device)     # padded chunk; tail stays zero
         self.vout = torch.zeros(n, dtype=dtype, device=device)
@@ -86,11 +162,6 @@ class ShardedLanczos:
         if self.plan.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
-
-    def _dot_real(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-        if a.is_complex():
-            a, b = torch.view_as_real(a), torch.view_as_real(b)
-        return self._allreduce(torch.sum(a * b).reshape(1))
 
     def hv(self) -> None:
         """tmp <- (H vin) restricted to the local rows, exchange overlapped with the local part."""
@@ -107,34 +178,35 @@ class ShardedLanczos:
             work.wait()
         self.apply_remote(self.vfull, self.tmp)
 
+    def step(self, it: int, alphas: torch.Tensor, beta2s: torch.Tensor) -> None:
+        """One lanczos_iteration; alpha_it and beta_it^2 land in alphas[it], beta2s[it] (device)."""
+        ops = self.ops
+        if it > 0:
+            ops.rotate(self.vin, self.vout, beta2s[it - 1:it])
+        self.hv()
+        ops.add_dot(self.vin, self.vout, self.tmp, alphas[it:it + 1])
+        self._allreduce(alphas[it:it + 1])
+        ops.axpy_nrm2(self.vin, self.vout, alphas[it:it + 1], beta2s[it:it + 1])
+        self._allreduce(beta2s[it:it + 1])
+
     # -- sp_lanc_tridiag ------------------------------------------------------------------------
     def tridiag(self, v_local: torch.Tensor, nlanc: int, threshold: float = 0.0):
         """v_local: this rank's slice (length plan.nloc).  Returns (alanc, blanc, niter) on the host."""
+        import numpy as np
         nl = self.plan.nloc
         self.vin.zero_()
         self.vin[:nl].copy_(v_local)
         self.vout.zero_()
-        alphas, betas = [], []
-        nrm = torch.sqrt(self._dot_real(self.vin, self.vin))
-        self.vin.div_(nrm.to(self.vin.dtype) if self.vin.is_complex() else nrm)
-        beta = None
+        alphas = torch.zeros(nlanc, dtype=torch.float64, device=self.device)
+        beta2s = torch.zeros(nlanc, dtype=torch.float64, device=self.device)
+        nrm2 = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.ops.nrm2(self.vin, nrm2)
+        self._allreduce(nrm2)
+        self.ops.scale(self.vin, nrm2)
         for it in range(nlanc):
-            if it > 0:
-                b = beta.to(self.vin.dtype) if self.vin.is_complex() else beta
-                self.tmp.copy_(self.vin)
-                torch.div(self.vout, b, out=self.vin)
-                torch.mul(self.tmp, -b, out=self.vout)
-            self.hv()
-            self.vout.add_(self.tmp)
-            alpha = self._dot_real(self.vin, self.vout)
-            a = alpha.to(self.vin.dtype) if self.vin.is_complex() else alpha
-            self.vout.addcmul_(self.vin, -a)
-            beta = torch.sqrt(self._dot_real(self.vout, self.vout))
-            alphas.append(alpha)
-            betas.append(beta)
-        al = torch.cat(alphas).cpu().numpy()
-        be = torch.cat(betas).cpu().numpy()
-        import numpy as np
+            self.step(it, alphas, beta2s)
+        al = alphas.cpu().numpy()
+        be = np.sqrt(beta2s.cpu().numpy())
         alanc = np.zeros(nlanc)
         blanc = np.zeros(nlanc)
         ndone = nlanc
@@ -181,5 +253,5 @@ def gpu_sharded_hamiltonian(model, workload_sector, world: int, rank: int, direc
     def apply_remote(v_full, out):
         h.apply_remote_dev(v_full.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
-    lz = ShardedLanczos(plan, apply_local, apply_remote, dtype=dtype, device="cuda")
+    lz = ShardedLanczos(plan, apply_local, apply_remote, dtype=dtype, device="cuda", vec_ops=NativeVecOps())
     return plan, h, lz

@@ -228,6 +228,25 @@ int edigpu_lanczos_eigh(edigpu_handle h, int nitermax, double tol, int check_eve
                         int *niter_done);
 
 /*
+ * Vector kernels of the three-term recurrence on caller-owned device buffers (the sharded N>1 loop:
+ * the scalars cross ranks with a 1-element all-reduce, everything else stays on the device).
+ * n counts doubles (2 per complex element).  Scalars are device pointers; no host synchronisation.
+ * They restate the elementwise part of SciFortran's lanczos_iteration (see edigpu_lanczos_tridiag).
+ *   edigpu_vec_rotate   : (vin, vout) <- (vout/beta, -beta*vin),  beta = sqrt(*beta2_dev)
+ *   edigpu_vec_add_dot  : vout += tmp ; *out_dev = sum(vin*vout)          (local partial of alpha)
+ *   edigpu_vec_axpy_nrm2: vout -= (*alpha_dev)*vin ; *out_dev = sum(vout^2) (local partial of beta^2)
+ *   edigpu_vec_scale    : v *= 1/sqrt(*nrm2_dev)
+ * `work_dev` must hold at least edigpu_vec_work_doubles() doubles.
+ */
+int edigpu_vec_work_doubles(void);
+int edigpu_vec_rotate(int64_t n, double *vin_dev, double *vout_dev, const double *beta2_dev, void *stream);
+int edigpu_vec_add_dot(int64_t n, const double *vin_dev, double *vout_dev, const double *tmp_dev,
+                       double *out_dev, double *work_dev, void *stream);
+int edigpu_vec_axpy_nrm2(int64_t n, const double *vin_dev, double *vout_dev, const double *alpha_dev,
+                         double *out_dev, double *work_dev, void *stream);
+int edigpu_vec_scale(int64_t n, double *v_dev, const double *nrm2_dev, void *stream);
+
+/*
  * Timing helper for bench.py: runs `warmup` untimed and `steps` timed H*v
  * products (device-resident, random unit vector) on the handle's stream and
  * returns the average duration of one H*v measured with HIP events on that

@@ -407,3 +407,34 @@ def test_direct_two_shards(gpu):
         out.append(hv.cpu().numpy())
         hs.destroy()
     assert rel_err(np.concatenate(out), ho.matvec(v)) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 63, 4097, 1_000_003])
+def test_vec_kernels_match_torch(gpu, n):
+    """edigpu_vec_* (sharded-loop vector kernels) against the torch formulation of the same updates."""
+    import torch
+    from edipack_amd.sharding import NativeVecOps, TorchVecOps
+    g = torch.Generator().manual_seed(n)
+    vin0 = torch.randn(n, dtype=torch.float64, generator=g).cuda()
+    vout0 = torch.randn(n, dtype=torch.float64, generator=g).cuda()
+    tmp = torch.randn(n, dtype=torch.float64, generator=g).cuda()
+    beta2 = torch.tensor([1.7], dtype=torch.float64).cuda()
+    res = []
+    for ops in (TorchVecOps(), NativeVecOps()):
+        vin, vout = vin0.clone(), vout0.clone()
+        o1 = torch.zeros(1, dtype=torch.float64).cuda()
+        o2 = torch.zeros(1, dtype=torch.float64).cuda()
+        o3 = torch.zeros(1, dtype=torch.float64).cuda()
+        ops.rotate(vin, vout, beta2)
+        ops.add_dot(vin, vout, tmp, o1)
+        ops.axpy_nrm2(vin, vout, o1, o2)
+        ops.nrm2(vin, o3)
+        ops.scale(vin, o3)
+        torch.cuda.synchronize()
+        res.append((vin.cpu().numpy(), vout.cpu().numpy(), o1.item(), o2.item(), o3.item()))
+    t, h = res
+    assert np.allclose(t[0], h[0], rtol=1e-14, atol=1e-300)
+    assert np.allclose(t[1], h[1], rtol=1e-12, atol=1e-13)
+    for k in (2, 3, 4):
+        assert abs(t[k] - h[k]) <= 1e-12 * max(1.0, abs(t[k]))
