@@ -81,8 +81,11 @@ static void free_csr(DevCsr& d) {
   dev_free(d.val);
 }
 
-static int upload_ell(DevEll& e, const HostCsr& a) {
+// lds: the sector's row kernel stages V rows in LDS; the packed layouts then hold byte offsets into
+// the staged row instead of columns, and dead typed slots name its zero slot (index nrow).
+static int upload_ell(DevEll& e, const HostCsr& a, bool lds) {
   e = DevEll();
+  const uint32_t cmul = lds ? 8u : 1u;
   e.nrow = a.nrow;
   e.pitch = (a.nrow + 63) / 64 * 64;
   int w = 0;
@@ -91,7 +94,7 @@ static int upload_ell(DevEll& e, const HostCsr& a) {
   if (w == 0 || a.nrow == 0) return 0;
   // distinct |values| -> coefficient table (slot 0 = 0.0 for padding)
   std::vector<double> coef(1, 0.0);
-  bool packable = a.nrow < ((int64_t)1 << 24);
+  bool packable = (a.nrow + 1) * (int64_t)cmul < ((int64_t)1 << 24);
   std::vector<uint8_t> cid((size_t)a.nnz());
   for (int64_t p = 0; p < a.nnz() && packable; p++) {
     const double m = std::fabs(a.val[p]);
@@ -107,32 +110,41 @@ static int upload_ell(DevEll& e, const HostCsr& a) {
     }
     cid[p] = (uint8_t)k;
   }
-  // typed layout: every row holds at most one entry per distinct |value| -> slot = value id
+  // typed layout: slot = (distinct |value|, occurrence of it inside the row), so that every slot has one
+  // wave-uniform amplitude.  With generic bath parameters each hop has its own amplitude and a row
+  // holds it at most once; symmetric baths repeat amplitudes and get one slot per repetition.
   bool typed = packable && coef.size() > 1 && !getenv("EDIGPU_ELL_UNTYPED");
-  for (int64_t i = 0; i < a.nrow && typed; i++) {
-    uint64_t seen[2] = {0, 0};
-    for (int64_t p = a.rowptr[i]; p < a.rowptr[i + 1]; p++) {
-      const int id = cid[p];
-      if (id == 0 || (seen[id >> 6] >> (id & 63)) & 1) {
-        typed = false;
-        break;
-      }
-      seen[id >> 6] |= (uint64_t)1 << (id & 63);
+  std::vector<int> maxmult(coef.size(), 0), base(coef.size() + 1, 0);
+  if (typed) {
+    std::vector<int> cnt(coef.size());
+    for (int64_t i = 0; i < a.nrow; i++) {
+      std::fill(cnt.begin(), cnt.end(), 0);
+      for (int64_t p = a.rowptr[i]; p < a.rowptr[i + 1]; p++) cnt[cid[p]]++;
+      for (size_t v = 1; v < coef.size(); v++) maxmult[v] = std::max(maxmult[v], cnt[v]);
     }
+    for (size_t v = 1; v < coef.size(); v++) base[v + 1] = base[v] + maxmult[v];
+    const int nt = base[coef.size()];
+    typed = nt >= 1 && nt <= 127 && nt <= std::max(2 * w, w + 8);  // else too many dead slots
   }
   if (typed) {
-    const int nt = (int)coef.size() - 1;
+    const int nt = base[coef.size()];
     e.width = nt;
     e.typed = 1;
     std::vector<double> tc(128, 0.0);
-    for (int k = 0; k < nt; k++) tc[k] = coef[k + 1];
-    std::vector<uint32_t> pk((size_t)nt * e.pitch);
-    for (int k = 0; k < nt; k++)
-      for (int64_t i = 0; i < e.pitch; i++) pk[(size_t)k * e.pitch + i] = (uint32_t)std::min(i, a.nrow - 1);
-    for (int64_t i = 0; i < a.nrow; i++)
-      for (int64_t p = a.rowptr[i]; p < a.rowptr[i + 1]; p++)
-        pk[(size_t)(cid[p] - 1) * e.pitch + i] = (uint32_t)a.col[p] | (1u << 24) |
-                                                 (std::signbit(a.val[p]) ? 0x80000000u : 0u);
+    for (size_t v = 1; v < coef.size(); v++)
+      for (int j = 0; j < maxmult[v]; j++) tc[base[v] + j] = coef[v];
+    // dead slots: the zero slot of the staged row / column 0 with the live bit (24) clear
+    std::vector<uint32_t> pk((size_t)nt * e.pitch, lds ? (uint32_t)a.nrow * 8u : 0u);
+    std::vector<int> occ(coef.size());
+    for (int64_t i = 0; i < a.nrow; i++) {
+      std::fill(occ.begin(), occ.end(), 0);
+      for (int64_t p = a.rowptr[i]; p < a.rowptr[i + 1]; p++) {
+        if (cid[p] == 0) continue;  // explicit zero
+        const int slot = base[cid[p]] + occ[cid[p]]++;
+        pk[(size_t)slot * e.pitch + i] = (uint32_t)a.col[p] * cmul | (lds ? 0u : 1u << 24) |
+                                         (std::signbit(a.val[p]) ? 0x80000000u : 0u);
+      }
+    }
     if (dev_upload(&e.pk, pk.data(), pk.size())) return 1;
     if (dev_upload(&e.coef, tc.data(), tc.size())) return 1;
     return 0;
@@ -141,11 +153,11 @@ static int upload_ell(DevEll& e, const HostCsr& a) {
     coef.resize(128, 0.0);
     std::vector<uint32_t> pk((size_t)w * e.pitch);
     for (int k = 0; k < w; k++)
-      for (int64_t i = 0; i < e.pitch; i++) pk[(size_t)k * e.pitch + i] = (uint32_t)std::min(i, a.nrow - 1);
+      for (int64_t i = 0; i < e.pitch; i++) pk[(size_t)k * e.pitch + i] = (uint32_t)std::min(i, a.nrow - 1) * cmul;
     for (int64_t i = 0; i < a.nrow; i++) {
       int k = 0;
       for (int64_t p = a.rowptr[i]; p < a.rowptr[i + 1]; p++, k++)
-        pk[(size_t)k * e.pitch + i] = (uint32_t)a.col[p] | ((uint32_t)cid[p] << 24) |
+        pk[(size_t)k * e.pitch + i] = (uint32_t)a.col[p] * cmul | ((uint32_t)cid[p] << 24) |
                                       (std::signbit(a.val[p]) ? 0x80000000u : 0u);
     }
     if (dev_upload(&e.pk, pk.data(), pk.size())) return 1;
@@ -309,7 +321,8 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
   s->row_first = dw_first * dim_up;
   s->h_up = up;
   s->h_dw = dw;
-  if (upload_ell(s->up_ell, up)) return 1;
+  s->rows_per_block = normal_pick_rows_per_block(dim_up, dw_count);
+  if (upload_ell(s->up_ell, up, s->rows_per_block != 0)) return 1;
   if (upload_csr(s->dw, dim_dw, dw.rowptr.data(), dw.col.data(), dw.val.data(), 0)) return 1;
   for (int64_t i = 0; i < dim_dw; i++)
     s->dw_maxrow = std::max<int>(s->dw_maxrow, (int)(dw.rowptr[i + 1] - dw.rowptr[i]));
@@ -359,7 +372,6 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
     if (dev_upload(&s->d_hd, hd, (size_t)s->nloc)) return 1;
     if (s->has_nd && upload_csr(s->nd, s->nloc, nd_rowptr, nd_col, nd_val, 0)) return 1;
   }
-  s->rows_per_block = normal_pick_rows_per_block(dim_up, dw_count);
   return finish_handle(s);
 }
 

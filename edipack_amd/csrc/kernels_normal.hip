@@ -89,6 +89,12 @@ __device__ inline void load4(const double* __restrict__ base, int64_t i0, const 
   }
 }
 
+// LDS read at an absolute byte address: and + ds_read_b64, no base add.  Valid for the staged rows
+// because the row kernel's dynamic LDS starts at address 0 (no static LDS in those instantiations;
+// checked once per workgroup).
+typedef const double __attribute__((address_space(3))) lds_cdouble;
+__device__ inline double lds_abs_read(uint32_t byte_addr) { return *reinterpret_cast<lds_cdouble*>(byte_addr); }
+
 // HDF: diagonal from the factored tables instead of the explicit hd array
 // FUSE (Lanczos step fused into the row kernel, v_local = P = previous Lanczos vector, hv = Q):
 //   0: plain H*v.   1: first step: x = P, Q <- (Hd+Hup) x.
@@ -99,13 +105,18 @@ template <int NT, int TD, bool USE_LDS, bool LOCAL, bool DW, bool ND, bool PACKE
 __global__ void __launch_bounds__(NT)
     normal_rows_kernel(NormalArgs a, const double* v_local, const double* __restrict__ v_full,
                        double* hv) {
-  extern __shared__ double vs[];  // TD*DimUp staged rows (LOCAL && USE_LDS)
+  // dynamic LDS: TD staged rows (LOCAL && USE_LDS) at offset 0 -- the packed ELL holds byte offsets
+  // into them, so no base has to be added per gather -- followed by the 128 hop amplitudes
+  extern __shared__ double vs[];
   __shared__ int32_t nb_col[TD][kMaxNbr];
   __shared__ double nb_val[TD][kMaxNbr];
   __shared__ int nb_cnt[TD];
-  __shared__ double coef_s[128];
 
   const int64_t DimUp = a.dim_up;
+  // staged row stride: DimUp columns + a zero slot at index DimUp (target of the dead ELL slots), even
+  const int S = ((int)DimUp + 2) & ~1;
+  const int rowB = S * 8;
+  double* coef_s = vs + (USE_LDS ? TD * S : 0);
   const int64_t r0 = (int64_t)blockIdx.x * TD;  // first local row of this block
   const int tid = threadIdx.x;
   int nr = TD;
@@ -140,6 +151,8 @@ __global__ void __launch_bounds__(NT)
     }
   }
   if (LOCAL && USE_LDS) {
+    if (!DW && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)vs != 0u) __builtin_trap();
+    if (tid < TD) vs[tid * S + DimUp] = 0.0;
     // stage the TD rows: 4 independent loads in flight per thread and row
     if (VEC) {
       const int64_t n2 = DimUp >> 1;
@@ -167,7 +180,7 @@ __global__ void __launch_bounds__(NT)
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const int64_t j = j0 + tid + u * NT;
-            if (r < nr && j < n2) reinterpret_cast<double2*>(vs + r * DimUp)[j] = t[r][u];
+            if (r < nr && j < n2) reinterpret_cast<double2*>(vs + r * S)[j] = t[r][u];
           }
       }
     } else {
@@ -188,7 +201,7 @@ __global__ void __launch_bounds__(NT)
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const int64_t j = j0 + tid + u * NT;
-            if (r < nr && j < DimUp) vs[r * DimUp + j] = t[r][u];
+            if (r < nr && j < DimUp) vs[r * S + j] = t[r][u];
           }
       }
     }
@@ -224,7 +237,7 @@ __global__ void __launch_bounds__(NT)
           }
           if (USE_LDS) {
 #pragma unroll
-            for (int e = 0; e < kE; e++) x[e] = ok[e] ? vs[r * DimUp + col0 + e] : 0.0;
+            for (int e = 0; e < kE; e++) x[e] = ok[e] ? vs[r * S + col0 + e] : 0.0;
           } else {
             load4<VEC>(v_local, (r0 + r) * DimUp + col0, ok, x);
           }
@@ -235,7 +248,40 @@ __global__ void __launch_bounds__(NT)
       // Slots are fetched KU at a time into registers first, so that KU independent L2 loads are
       // in flight per lane before the first LDS gather is issued. ----
       constexpr int KU = 6;
-      for (int k0 = 0; k0 < a.ell_w; k0 += KU) {
+      // Typed ELL of an LDS sector (the normal case): slot k = one hop type with a wave-uniform
+      // amplitude; an entry is (byte offset in the staged row) | sign << 31, dead entries name the
+      // row's zero slot.  Per gather: v_and, ds_read_b64, v_bitop3 (sign), v_fma_f64.
+      const bool fast = PACKED && USE_LDS && !DW && a.ell_typed != 0;
+      if (fast) {
+        const uint32_t* __restrict__ epk = a.ell_pk + col0;
+        const int epitch = (int)a.ell_pitch;
+        for (int k0 = 0; k0 < a.ell_w; k0 += KU) {
+          uint4 pk4[KU];
+          double tk[KU];
+#pragma unroll
+          for (int u = 0; u < KU; u++) {
+            // slots past the width: clamped address, amplitude 0 (the table is zero from ell_w on)
+            const int k = k0 + u < a.ell_w ? k0 + u : a.ell_w - 1;
+            pk4[u] = *reinterpret_cast<const uint4*>(epk + k * epitch);  // 32-bit: staged rows are short
+            tk[u] = coef_s[k0 + u < 127 ? k0 + u : 127];                 // LDS broadcast
+          }
+#pragma unroll
+          for (int u = 0; u < KU; u++) {
+            const uint32_t p[kE] = {pk4[u].x, pk4[u].y, pk4[u].z, pk4[u].w};
+#pragma unroll
+            for (int r = 0; r < TD; r++)
+              if (TD == 1 || r < nr) {
+#pragma unroll
+                for (int e = 0; e < kE; e++) {
+                  double x = lds_abs_read((uint32_t)(r * rowB) + (p[e] & 0xFFFFFFu));
+                  x = __hiloint2double(__double2hiint(x) ^ (int)(p[e] & 0x80000000u), __double2loint(x));
+                  acc[r][e] = fma(tk[u], x, acc[r][e]);
+                }
+              }
+          }
+        }
+      }
+      for (int k0 = fast ? a.ell_w : 0; k0 < a.ell_w; k0 += KU) {
         uint4 pk4[KU];
         int4 pc4[KU];
         double2 pw0[KU], pw1[KU];
@@ -260,12 +306,22 @@ __global__ void __launch_bounds__(NT)
             const uint32_t p[kE] = {pk4[u].x, pk4[u].y, pk4[u].z, pk4[u].w};
             if (a.ell_typed) {
               // slot k = one hop type: the amplitude is wave-uniform, no table lookup
-              const double tk = live ? a.ell_coef[k0 + u] : 0.0;
+              const double tk = live ? coef_s[k0 + u] : 0.0;  // LDS broadcast (a global load here stalls on vmcnt)
+              if (USE_LDS) {
+                // low 24 bits = byte offset inside the staged row (dead slots name the zero slot, so
+                // there is no live test), bit 31 = sign: and + and + xor + fma per gather
 #pragma unroll
-              for (int e = 0; e < kE; e++) {
-                cc[e] = (int32_t)(p[e] & 0xFFFFFFu);
-                const double m = ((p[e] >> 24) & 0x7Fu) ? tk : 0.0;
-                ww[e] = (p[e] >> 31) ? -m : m;
+                for (int e = 0; e < kE; e++) {
+                  cc[e] = (int32_t)(p[e] & 0xFFFFFFu);
+                  ww[e] = __hiloint2double(__double2hiint(tk) ^ (int)(p[e] & 0x80000000u), __double2loint(tk));
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < kE; e++) {
+                  cc[e] = (int32_t)(p[e] & 0xFFFFFFu);
+                  const double m = ((p[e] >> 24) & 0x7Fu) ? tk : 0.0;
+                  ww[e] = (p[e] >> 31) ? -m : m;
+                }
               }
             } else {
 #pragma unroll
@@ -285,8 +341,12 @@ __global__ void __launch_bounds__(NT)
             if (r < nr) {
 #pragma unroll
               for (int e = 0; e < kE; e++) {
-                const double x = USE_LDS ? vs[r * DimUp + cc[e]] : v_local[(r0 + r) * DimUp + cc[e]];
-                acc[r][e] += ww[e] * x;
+                // packed ELL of an LDS sector holds byte offsets (upload_ell), the plain one columns
+                const double x = USE_LDS ? (PACKED ? *reinterpret_cast<const double*>(
+                                                         reinterpret_cast<const char*>(vs) + r * rowB + cc[e])
+                                                   : vs[r * S + cc[e]])
+                                         : v_local[(r0 + r) * DimUp + cc[e]];
+                acc[r][e] = fma(ww[e], x, acc[r][e]);
               }
             }
         }
@@ -365,12 +425,12 @@ __global__ void __launch_bounds__(NT)
 #pragma unroll
           for (int e = 0; e < kE; e++) acc[r][e] -= beta * pold[e];
           if (VEC) {
-            if (ok[0]) *reinterpret_cast<double2*>(pdst) = make_double2(vs[r * DimUp + col0], vs[r * DimUp + col0 + 1]);
-            if (ok[2]) *reinterpret_cast<double2*>(pdst + 2) = make_double2(vs[r * DimUp + col0 + 2], vs[r * DimUp + col0 + 3]);
+            if (ok[0]) *reinterpret_cast<double2*>(pdst) = make_double2(vs[r * S + col0], vs[r * S + col0 + 1]);
+            if (ok[2]) *reinterpret_cast<double2*>(pdst + 2) = make_double2(vs[r * S + col0 + 2], vs[r * S + col0 + 3]);
           } else {
 #pragma unroll
             for (int e = 0; e < kE; e++)
-              if (ok[e]) pdst[e] = vs[r * DimUp + col0 + e];
+              if (ok[e]) pdst[e] = vs[r * S + col0 + e];
           }
         }
         if (VEC) {
@@ -599,7 +659,7 @@ static int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const d
 // TD rows of V (8 B/elem) must fit the LDS budget of one workgroup.  Keep two
 // workgroups per CU when possible (<= 64 KiB each of the 160 KiB LDS).
 int normal_pick_rows_per_block(int64_t dim_up, int64_t dw_count) {
-  const int64_t row_bytes = dim_up * 8;
+  const int64_t row_bytes = ((dim_up + 2) & ~(int64_t)1) * 8;  // staged row: columns + zero slot
   if (const char* e = getenv("EDIGPU_ROWS_TD")) {  // tuning override
     const int td = atoi(e);
     if ((td == 1 || td == 2 || td == 4 || td == 8) && td * row_bytes <= 150 * 1024) return td;
@@ -619,7 +679,7 @@ template <int NT, int TD, bool USE_LDS, bool PACKED, bool VEC, bool HDF>
 static int launch_te(const NormalArgs& a, const double* vl, const double* vf, double* hv,
                      int what, hipStream_t st) {
   const int64_t nblk = (a.dw_count + TD - 1) / TD;
-  const size_t lds = USE_LDS ? (size_t)TD * a.dim_up * sizeof(double) : 0;
+  const size_t lds = (USE_LDS ? (size_t)TD * ((a.dim_up + 2) & ~(int64_t)1) * sizeof(double) : 0) + 128 * sizeof(double);
   dim3 grid((unsigned)nblk), block(NT);
 #define EDIGPU_LAUNCH_ROWS(LOC, DWF, NDF, LDSB, UL, PK, HF)                                      \
   do {                                                                                           \
