@@ -1,0 +1,220 @@
+// kernels_panel.hip -- normal mode, kernel B: hv[:, panel] += (Hdw (x) 1) V[:, panel] + factored Hnd.
+//
+// Takes the place of the "down" and "non-local" loops of spMatVec_normal_main (reference
+// ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:517-650; MPI form :765-929, where the reference
+// transposes the vector with MPI_Alltoallv to make this term contiguous).
+//
+// The down term couples whole rows of V[idw][iup]: output row idw reads ~7 neighbour rows at the
+// same columns.  A panel of <= 64 columns over all DimDw rows fits one XCD's 4 MiB L2, so all
+// workgroups of an XCD (blockIdx % 8, the observed round-robin dispatch; another placement only
+// costs speed) sweep the same panel at the same time: the neighbour reads are L2 hits and the
+// fabric sees V once.  A wave owns one output row at a time (64 lanes = 64 panel columns, one
+// 512-byte segment); its neighbour list is wave-uniform (scalar loads).
+//
+// Measured (round 1, cfg2): issuing the whole list of two rows as one batch of independent loads
+// (6..8 in flight per row) is 10-20 % SLOWER than this two-entries-at-a-time loop: the kernel is
+// bound by the fabric/L2 traffic of the sweep, not by load latency, and a deeper queue only spreads
+// the workgroups of a panel further apart.
+#include <cstdlib>
+
+#include "normal_args.hpp"
+
+namespace edigpu {
+
+struct PanelArgs {
+  int npanels, width, blocks_per_panel, rows_per_block;
+};
+
+constexpr int kPanelNT = 512;
+constexpr int kMaxNdTerms = 16;
+
+// ALPHA: also accumulate <v|hv_new> over the local rows (v = v_full rows of this shard) and write
+// one partial per workgroup (deterministic two-stage reduction, see kernels_lanczos.hip)
+template <bool DO_DW, bool DO_ND, bool ALPHA>
+__global__ void __launch_bounds__(kPanelNT)
+    normal_dw_panel_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full,
+                           double* __restrict__ hv) {
+  __shared__ double red[2 * (kPanelNT / 64)];
+  const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const int panel = (k / p.blocks_per_panel) * 8 + x;
+  if (ALPHA) {
+    if (panel >= p.npanels || a.scal[SC_STOP] != 0.0) {
+      if (threadIdx.x == 0) {
+        a.partial[blockIdx.x] = 0.0;
+        a.partial[gridDim.x + blockIdx.x] = 0.0;
+      }
+      return;
+    }
+  }
+  if (panel >= p.npanels) return;
+  double asum = 0.0, qsum = 0.0;
+  const int chunk = k % p.blocks_per_panel;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t DimUp = a.dim_up;
+  const int64_t c = (int64_t)panel * p.width + lane;
+  const bool ok = lane < p.width && c < DimUp;
+  const int64_t cc = ok ? c : DimUp - 1;
+  int64_t rend = (int64_t)(chunk + 1) * p.rows_per_block;
+  if (rend > a.dw_count) rend = a.dw_count;
+  constexpr int NW = kPanelNT / 64;
+  // the lane's partner column of every Hnd term (depends on the column only) in LDS; a thread reads
+  // back its own words only, so no barrier is needed
+  __shared__ uint32_t ju_s[(DO_ND ? kMaxNdTerms : 1) * kPanelNT];
+  if (DO_ND)
+    for (int t = 0; t < a.nterms; t++) ju_s[t * kPanelNT + threadIdx.x] = a.jup[(int64_t)t * DimUp + cc];
+  for (int64_t r = (int64_t)chunk * p.rows_per_block + wave; r < rend; r += 2 * NW) {
+    // two rows per iteration: independent load streams in flight
+    const int64_t r2 = r + NW;
+    const bool two = r2 < rend;
+    const int64_t g = a.dw_first + r;
+    double acc0 = hv[r * DimUp + cc];
+    double acc1 = two ? hv[r2 * DimUp + cc] : 0.0;
+    if (DO_DW && !DO_ND) {
+      const int32_t b0 = a.dw_rowptr[g], e0 = a.dw_rowptr[g + 1];
+      int32_t b1 = 0, e1 = 0;
+      if (two) {
+        b1 = a.dw_rowptr[g + NW];
+        e1 = a.dw_rowptr[g + NW + 1];
+      }
+#pragma unroll 4
+      for (int32_t jj = b0; jj < e0; jj++)
+        acc0 += a.dw_val[jj] * v_full[(int64_t)a.dw_col[jj] * DimUp + cc];
+#pragma unroll 4
+      for (int32_t jj = b1; jj < e1; jj++)
+        acc1 += a.dw_val[jj] * v_full[(int64_t)a.dw_col[jj] * DimUp + cc];
+    }
+    if (DO_ND) {
+      // merged per-LOCAL-row list: down hops (tag 0) followed by the applicable Hnd terms
+      // (tag = term id + 1 in bits 24..30 of the column word, weight = +-coef of the down side)
+      const int32_t b0 = a.mx_rowptr[r], e0 = a.mx_rowptr[r + 1];
+      int32_t b1 = 0, e1 = 0;
+      if (two) {
+        b1 = a.mx_rowptr[r2];
+        e1 = a.mx_rowptr[r2 + 1];
+      }
+#pragma unroll 2
+      for (int32_t jj = b0; jj < e0; jj++) {
+        const uint32_t cw = (uint32_t)a.mx_col[jj];
+        const int tag = (int)(cw >> 24);
+        double w = a.mx_val[jj];
+        int64_t col = cc;
+        if (tag) {
+          const uint32_t jt = ju_s[(tag - 1) * kPanelNT + threadIdx.x];
+          const bool v = jt != 0xFFFFFFFFu;
+          w = v ? ((jt >> 31) ? -w : w) : 0.0;
+          col = v ? (int64_t)(jt & 0x7FFFFFFFu) : cc;
+        } else if (!DO_DW) {
+          w = 0.0;
+        }
+        acc0 += w * v_full[(int64_t)(cw & 0xFFFFFFu) * DimUp + col];
+      }
+#pragma unroll 2
+      for (int32_t jj = b1; jj < e1; jj++) {
+        const uint32_t cw = (uint32_t)a.mx_col[jj];
+        const int tag = (int)(cw >> 24);
+        double w = a.mx_val[jj];
+        int64_t col = cc;
+        if (tag) {
+          const uint32_t jt = ju_s[(tag - 1) * kPanelNT + threadIdx.x];
+          const bool v = jt != 0xFFFFFFFFu;
+          w = v ? ((jt >> 31) ? -w : w) : 0.0;
+          col = v ? (int64_t)(jt & 0x7FFFFFFFu) : cc;
+        } else if (!DO_DW) {
+          w = 0.0;
+        }
+        acc1 += w * v_full[(int64_t)(cw & 0xFFFFFFu) * DimUp + col];
+      }
+    }
+    if (ok) {
+      hv[r * DimUp + c] = acc0;
+      if (two) hv[r2 * DimUp + c] = acc1;
+      if (ALPHA) {
+        asum += v_full[(a.dw_first + r) * DimUp + c] * acc0;
+        qsum += acc0 * acc0;
+        if (two) {
+          asum += v_full[(a.dw_first + r2) * DimUp + c] * acc1;
+          qsum += acc1 * acc1;
+        }
+      }
+    }
+  }
+  if (ALPHA) {
+    // per-workgroup partials of <v|Q> and <Q|Q> (the latter gives beta^2 = <Q|Q> - alpha^2)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      asum += __shfl_down(asum, off, 64);
+      qsum += __shfl_down(qsum, off, 64);
+    }
+    if (lane == 0) {
+      red[wave] = asum;
+      red[kPanelNT / 64 + wave] = qsum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0, q = 0.0;
+#pragma unroll
+      for (int i = 0; i < kPanelNT / 64; i++) {
+        t += red[i];
+        q += red[kPanelNT / 64 + i];
+      }
+      a.partial[blockIdx.x] = t;
+      a.partial[gridDim.x + blockIdx.x] = q;
+    }
+  }
+}
+
+static int panel_resident_blocks() {
+  // EDIGPU_PANEL_BPP: workgroups per panel (tuning knob); default = what one XCD keeps resident
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("EDIGPU_PANEL_BPP");
+    v = e ? atoi(e) : 128;
+    if (v < 1) v = 128;
+  }
+  return v;
+}
+
+int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* v_full, double* hv,
+                     hipStream_t st, bool alpha, int* nblocks) {
+  if (!do_dw && !do_nd && !alpha) return 0;
+  if (do_nd && a.nterms > kMaxNdTerms) {
+    set_error("launch_dw_panels: too many factored Hnd terms");
+    return 1;
+  }
+  PanelArgs p;
+  // panels: a multiple of 8 (one stream of panels per XCD), at most 64 columns wide
+  int wmax = 64;
+  if (const char* e = getenv("EDIGPU_PANEL_W")) {
+    wmax = atoi(e);
+    if (wmax < 1 || wmax > 64) wmax = 64;
+  }
+  int np = (int)((a.dim_up + 8 * wmax - 1) / (8 * wmax)) * 8;
+  if (np < 8) np = 8;
+  p.width = (int)((a.dim_up + np - 1) / np);
+  if (p.width < 1) p.width = 1;
+  p.npanels = (int)((a.dim_up + p.width - 1) / p.width);
+  int bpp = panel_resident_blocks();
+  p.rows_per_block = (int)((a.dw_count + bpp - 1) / bpp);
+  if (p.rows_per_block < 16) p.rows_per_block = 16;
+  bpp = (int)((a.dw_count + p.rows_per_block - 1) / p.rows_per_block);
+  p.blocks_per_panel = bpp;
+  const int panel_groups = (p.npanels + 7) / 8;
+  const dim3 grid((unsigned)((int64_t)panel_groups * bpp * 8)), block(kPanelNT);
+  if (nblocks) *nblocks = (int)grid.x;
+  if (alpha) {
+    if (do_nd)
+      hipLaunchKernelGGL((normal_dw_panel_kernel<true, true, true>), grid, block, 0, st, a, p, v_full, hv);
+    else
+      hipLaunchKernelGGL((normal_dw_panel_kernel<true, false, true>), grid, block, 0, st, a, p, v_full, hv);
+  } else if (do_dw && do_nd)
+    hipLaunchKernelGGL((normal_dw_panel_kernel<true, true, false>), grid, block, 0, st, a, p, v_full, hv);
+  else if (do_dw)
+    hipLaunchKernelGGL((normal_dw_panel_kernel<true, false, false>), grid, block, 0, st, a, p, v_full, hv);
+  else
+    hipLaunchKernelGGL((normal_dw_panel_kernel<false, true, false>), grid, block, 0, st, a, p, v_full, hv);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace edigpu

@@ -1,0 +1,53 @@
+// normal_args.hpp -- kernel argument block shared by the normal-mode kernels
+// (kernels_normal.hip: row kernel A, kernels_panel.hip: column-panel kernel B).
+#pragma once
+#include <cstdint>
+
+#include "kernels.hpp"
+
+namespace edigpu {
+
+struct NormalArgs {
+  int64_t dim_up, dim_dw, dw_first, dw_count;
+  // diagonal: explicit (hd) or factored (eux[impd[g]][iup] + ed[g])
+  const double* hd;
+  const double* eux;
+  const double* ed;
+  const uint8_t* impd;
+  // Hup as ELL: packed (pk + coef table) or plain (col,val)
+  const uint32_t* ell_pk;
+  const double* ell_coef;  // 128 entries
+  const int32_t* ell_col;
+  const double* ell_val;
+  int ell_w;
+  int ell_typed;  // packed ELL whose slot k holds the hop with amplitude ell_coef[k]
+  int64_t ell_pitch;
+  const int32_t* dw_rowptr;
+  const int32_t* dw_col;
+  const double* dw_val;
+  // Hnd: CSR over the local rows (explicit) or factored terms
+  const int32_t* nd_rp32;
+  const int64_t* nd_rp64;
+  const int32_t* nd_col;
+  const double* nd_val;
+  int dw_maxrow;  // longest row of Hdw
+  int has_nd;
+  int nterms;
+  const double* nd_coef;
+  const uint32_t* jup;  // nterms * dim_up
+  const uint32_t* jdw;  // nterms * dim_dw
+  // per LOCAL row: Hdw entries + applicable Hnd terms in one list (panel kernel)
+  // fused Lanczos step (device scalars, see kernels.hpp SC_*) and per-workgroup alpha partials
+  const double* scal;
+  double* partial;
+  const int32_t* mx_rowptr;  // merged list: ptr[dw_count+1]
+  const int32_t* mx_col;     // partner row (24 bit) | tag << 24
+  const double* mx_val;
+};
+
+// B: (Hdw (x) 1) + factored Hnd as an L2-blocked column-panel sweep (kernels_panel.hip).
+// alpha: also write the per-workgroup partials of <v|hv> and <hv|hv> (fused Lanczos step).
+int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* v_full, double* hv,
+                     hipStream_t st, bool alpha = false, int* nblocks = nullptr);
+
+}  // namespace edigpu
