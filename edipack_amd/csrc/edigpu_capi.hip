@@ -513,6 +513,13 @@ static int tql2(int n, std::vector<double>& d, std::vector<double>& e, std::vect
 }
 
 // enqueue one Lanczos step (iter is 0-based); vin/vout/tmp live in the workspace
+static bool flat_lanczos_fusable(const edigpu_sector* s) {
+  static const bool off = getenv("EDIGPU_LANCZOS_UNFUSED") != nullptr;
+  if (off || s->nloc != s->dim || s->nloc == 0) return false;
+  if (s->kind == 2) return true;
+  return s->kind == 1 && csr_lanczos_fusable(s->loc) && s->nonloc.nnz == 0;
+}
+
 static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
   const int64_t len = s->ws_len;
   if (normal_lanczos_fusable(s)) {
@@ -529,6 +536,22 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
     if (exactbeta) {
       if (lz_finalize_alpha(s->d_partial, np, s->d_scal, iter, nlanc, st)) return 1;
       return lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, iter, nlanc, st);
+    }
+    return lz_finalize_alpha_beta(s->d_vin, s->d_vout, len, s->d_partial, np, s->d_scal, iter, nlanc, st);
+  }
+  if (flat_lanczos_fusable(s)) {
+    // flat / direct sectors held whole on this GPU: rotate with the pending axpy, then Q += H*v with
+    // the alpha and <Q|Q> partials in the product's epilogue (no tmp vector, no separate dot kernels)
+    int np = 0;
+    if (iter > 0 && lz_rotate_lazy(s->d_vin, s->d_vout, len, s->d_scal, st)) return 1;
+    if (s->kind == 2) {
+      if (launch_direct_lanczos(s, s->d_vin, s->d_vout, s->d_partial, &np, st)) return 1;
+    } else if (launch_csr_lanczos(s->loc, s->is_complex, s->d_vin, s->d_vout, s->d_partial, &np, st)) {
+      return 1;
+    }
+    if (2 * np > kMaxPartials) {
+      set_error("lanczos_step: partial buffer too small");
+      return 1;
     }
     return lz_finalize_alpha_beta(s->d_vin, s->d_vout, len, s->d_partial, np, s->d_scal, iter, nlanc, st);
   }

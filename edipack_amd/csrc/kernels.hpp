@@ -31,6 +31,13 @@ int launch_csr(const DevCsr& a, int cplx, const double* x, double* y, int accumu
 int launch_zero(double* y, int64_t n, hipStream_t st);
 
 // ---- direct / on-the-fly (kernels_direct.hip): hv[local rows] = H v_full ----
+int launch_direct_lanczos(const edigpu_sector* s, const double* v_full, double* q, double* partial, int* np,
+                          hipStream_t st);
+bool csr_lanczos_fusable(const DevCsr& a);
+int launch_csr_lanczos(const DevCsr& a, int cplx, const double* x, double* y, double* partial, int* np,
+                       hipStream_t st);
+// (P, Q) <- ((Q - alpha*P)/beta, -beta*P): rotate with the pending axpy of the fused step folded in
+int lz_rotate_lazy(double* P, double* Q, int64_t n, const double* scal, hipStream_t st);
 int launch_direct(const edigpu_sector* s, const double* v_full, double* hv, hipStream_t st);
 
 // ---- Lanczos vector kernels (kernels_lanczos.hip); n counts doubles ----

@@ -56,21 +56,49 @@ __global__ void __launch_bounds__(kCsrNT)
   }
 }
 
+// DOT epilogue (fused Lanczos step, y = Q accumulates H*x on top of -beta*v_prev): per-workgroup
+// partials of <x|y_new> and <y_new|y_new> over the real view, written to partial[blockIdx] and
+// partial[gridDim + blockIdx] (deterministic two-stage reduction, finalised by k_finalize_ab).
+__device__ inline void block_dot_partials(double a, double q, double* __restrict__ partial) {
+  __shared__ double red_a[kCsrNT / 64], red_q[kCsrNT / 64];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off, 64);
+    q += __shfl_down(q, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red_a[threadIdx.x >> 6] = a;
+    red_q[threadIdx.x >> 6] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0.0, tq = 0.0;
+#pragma unroll
+    for (int i = 0; i < kCsrNT / 64; i++) {
+      ta += red_a[i];
+      tq += red_q[i];
+    }
+    partial[blockIdx.x] = ta;
+    partial[gridDim.x + blockIdx.x] = tq;
+  }
+}
+
 // SELL-64: one lane = one row of a 64-row slice, slot k of all 64 rows is contiguous.  Rows are sorted by
 // column, so the 64 gathers of a slot land on few cache lines (adjacent rows of these Hamiltonians
 // reach adjacent columns through the same hop): ~3x fewer L1 accesses than the lane-group CSR kernel,
 // whose slot k mixes unrelated hops of neighbouring rows.  No cross-lane reduction.
-template <bool CPLX, bool ACC>
+template <bool CPLX, bool ACC, bool DOT>
 __global__ void __launch_bounds__(kCsrNT)
     sell_rows_kernel(int64_t nrow, int64_t nslice, const int32_t* __restrict__ sptr,
                      const int32_t* __restrict__ col, const double* __restrict__ val,
-                     const double* __restrict__ x, double* __restrict__ y) {
+                     const double* __restrict__ x, double* __restrict__ y, double* __restrict__ partial) {
   const int lane = threadIdx.x & 63;
   const int64_t slice = (int64_t)blockIdx.x * (kCsrNT / 64) + (threadIdx.x >> 6);
-  if (slice >= nslice) return;
+  if (!DOT && slice >= nslice) return;
   const int64_t row = slice * 64 + lane;
-  const int32_t b = sptr[slice], e = sptr[slice + 1];
-  double sr = 0.0, si = 0.0;
+  const bool in = slice < nslice;
+  const int32_t b = in ? sptr[slice] : 0, e = in ? sptr[slice + 1] : 0;
+  double sr = 0.0, si = 0.0, da = 0.0, dq = 0.0;
 #pragma unroll 4
   for (int32_t k = b; k < e; k++) {
     const int64_t o = (int64_t)k * 64 + lane;
@@ -84,36 +112,48 @@ __global__ void __launch_bounds__(kCsrNT)
       sr += val[o] * x[c];
     }
   }
-  if (row < nrow) {
+  if (in && row < nrow) {
     if (CPLX) {
       double2* yy = reinterpret_cast<double2*>(y) + row;
       double2 o2 = ACC ? *yy : make_double2(0.0, 0.0);
       o2.x += sr;
       o2.y += si;
       *yy = o2;
+      if (DOT) {
+        const double2 xo = reinterpret_cast<const double2*>(x)[row];
+        da = xo.x * o2.x + xo.y * o2.y;
+        dq = o2.x * o2.x + o2.y * o2.y;
+      }
     } else {
-      y[row] = (ACC ? y[row] : 0.0) + sr;
+      const double o = (ACC ? y[row] : 0.0) + sr;
+      y[row] = o;
+      if (DOT) {
+        da = x[row] * o;
+        dq = o * o;
+      }
     }
   }
+  if (DOT) block_dot_partials(da, dq, partial);
 }
 
 // SELL-64 with the value dictionary: 4 bytes per entry, values from a <= 256-entry LDS table, the
 // diagonal of the loc block as a separate stream.
-template <bool CPLX, bool ACC>
+template <bool CPLX, bool ACC, bool DOT>
 __global__ void __launch_bounds__(kCsrNT)
     sell_rows_packed_kernel(int64_t nrow, int64_t nslice, const int32_t* __restrict__ sptr,
                             const uint32_t* __restrict__ pk, const double* __restrict__ dict,
                             const double* __restrict__ diag, const double* __restrict__ x,
-                            double* __restrict__ y) {
+                            double* __restrict__ y, double* __restrict__ partial) {
   __shared__ double dict_s[CPLX ? 512 : 256];
   for (int i = threadIdx.x; i < (CPLX ? 512 : 256); i += kCsrNT) dict_s[i] = dict[i];
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int64_t slice = (int64_t)blockIdx.x * (kCsrNT / 64) + (threadIdx.x >> 6);
-  if (slice >= nslice) return;
+  if (!DOT && slice >= nslice) return;
   const int64_t row = slice * 64 + lane;
-  const int32_t b = sptr[slice], e = sptr[slice + 1];
-  double sr = 0.0, si = 0.0;
+  const bool in = slice < nslice;
+  const int32_t b = in ? sptr[slice] : 0, e = in ? sptr[slice + 1] : 0;
+  double sr = 0.0, si = 0.0, da = 0.0, dq = 0.0;
 #pragma unroll 4
   for (int32_t k = b; k < e; k++) {
     const uint32_t p = pk[(int64_t)k * 64 + lane];
@@ -128,7 +168,7 @@ __global__ void __launch_bounds__(kCsrNT)
       sr += dict_s[id] * x[c];
     }
   }
-  if (row < nrow) {
+  if (in && row < nrow) {
     if (diag != nullptr) {
       if (CPLX) {
         const double2 d = reinterpret_cast<const double2*>(diag)[row];
@@ -145,10 +185,21 @@ __global__ void __launch_bounds__(kCsrNT)
       o2.x += sr;
       o2.y += si;
       *yy = o2;
+      if (DOT) {
+        const double2 xo = reinterpret_cast<const double2*>(x)[row];
+        da = xo.x * o2.x + xo.y * o2.y;
+        dq = o2.x * o2.x + o2.y * o2.y;
+      }
     } else {
-      y[row] = (ACC ? y[row] : 0.0) + sr;
+      const double o = (ACC ? y[row] : 0.0) + sr;
+      y[row] = o;
+      if (DOT) {
+        da = x[row] * o;
+        dq = o * o;
+      }
     }
   }
+  if (DOT) block_dot_partials(da, dq, partial);
 }
 
 __global__ void zero_kernel(double* __restrict__ y, int64_t n) {
@@ -186,13 +237,13 @@ static int launch_pick(const DevCsr& a, const double* x, double* y, hipStream_t 
   if (a.sell) {
     const int64_t nb = (a.nslice + kCsrNT / 64 - 1) / (kCsrNT / 64);
     if (a.sell_packed) {
-      hipLaunchKernelGGL((sell_rows_packed_kernel<CPLX, ACC>), dim3((unsigned)nb), dim3(kCsrNT), 0, st, a.nrow,
-                         a.nslice, a.sell_ptr, a.sell_pk, a.sell_dict, a.sell_diag, x, y);
+      hipLaunchKernelGGL((sell_rows_packed_kernel<CPLX, ACC, false>), dim3((unsigned)nb), dim3(kCsrNT), 0, st,
+                         a.nrow, a.nslice, a.sell_ptr, a.sell_pk, a.sell_dict, a.sell_diag, x, y, nullptr);
       EDIGPU_HIP(hipGetLastError());
       return 0;
     }
-    hipLaunchKernelGGL((sell_rows_kernel<CPLX, ACC>), dim3((unsigned)nb), dim3(kCsrNT), 0, st, a.nrow, a.nslice,
-                       a.sell_ptr, a.sell_col, a.sell_val, x, y);
+    hipLaunchKernelGGL((sell_rows_kernel<CPLX, ACC, false>), dim3((unsigned)nb), dim3(kCsrNT), 0, st, a.nrow,
+                       a.nslice, a.sell_ptr, a.sell_col, a.sell_val, x, y, nullptr);
     EDIGPU_HIP(hipGetLastError());
     return 0;
   }
@@ -213,6 +264,38 @@ int launch_csr(const DevCsr& a, int cplx, const double* x, double* y, int accumu
   }
   if (cplx) return accumulate ? launch_pick<true, true>(a, x, y, st) : launch_pick<true, false>(a, x, y, st);
   return accumulate ? launch_pick<false, true>(a, x, y, st) : launch_pick<false, false>(a, x, y, st);
+}
+
+// Fused Lanczos step on a SELL block that holds whole rows of a square matrix (one shard):
+// y += A x with the <x|y>, <y|y> partials.  Returns the number of partial pairs in *np.
+bool csr_lanczos_fusable(const DevCsr& a) { return a.sell != 0 && a.nrow > 0 && a.nnz > 0; }
+
+int launch_csr_lanczos(const DevCsr& a, int cplx, const double* x, double* y, double* partial, int* np,
+                       hipStream_t st) {
+  const int64_t nb = (a.nslice + kCsrNT / 64 - 1) / (kCsrNT / 64);
+  *np = (int)nb;
+  if (2 * nb > kMaxPartials) {
+    set_error("launch_csr_lanczos: partial buffer too small");
+    return 1;
+  }
+  const dim3 g((unsigned)nb), blk(kCsrNT);
+  if (a.sell_packed) {
+    if (cplx)
+      hipLaunchKernelGGL((sell_rows_packed_kernel<true, true, true>), g, blk, 0, st, a.nrow, a.nslice, a.sell_ptr,
+                         a.sell_pk, a.sell_dict, a.sell_diag, x, y, partial);
+    else
+      hipLaunchKernelGGL((sell_rows_packed_kernel<false, true, true>), g, blk, 0, st, a.nrow, a.nslice, a.sell_ptr,
+                         a.sell_pk, a.sell_dict, a.sell_diag, x, y, partial);
+  } else {
+    if (cplx)
+      hipLaunchKernelGGL((sell_rows_kernel<true, true, true>), g, blk, 0, st, a.nrow, a.nslice, a.sell_ptr,
+                         a.sell_col, a.sell_val, x, y, partial);
+    else
+      hipLaunchKernelGGL((sell_rows_kernel<false, true, true>), g, blk, 0, st, a.nrow, a.nslice, a.sell_ptr,
+                         a.sell_col, a.sell_val, x, y, partial);
+  }
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
 }
 
 }  // namespace edigpu

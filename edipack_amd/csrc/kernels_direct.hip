@@ -19,14 +19,19 @@ namespace edigpu {
 
 constexpr int kDirNT = 1024;  // 2 workgroups/CU with the 2 x 2^Ns-entry rank tables staged in LDS (Ns <= 13)
 
-template <bool LDS_TABLES>
+// LZ (fused Lanczos step): hv = Q accumulates H*v on top of -beta*v_prev, and the workgroup writes its
+// partials of <v|Q_new> and <Q_new|Q_new> (real view) to partial[blockIdx], partial[gridDim + blockIdx].
+template <bool LDS_TABLES, bool LZ>
 __global__ void __launch_bounds__(kDirNT)
     direct_rows_kernel(int64_t nrow, int64_t row_first, int ns, int norb, int nterms,
                        const int32_t* __restrict__ states, const int32_t* __restrict__ off_dw,
                        const int32_t* __restrict__ rk_up, const DirectTerm* __restrict__ terms,
                        const double* __restrict__ dtab, const double* __restrict__ xtab,
-                       const double2* __restrict__ v_full, double2* __restrict__ hv) {
+                       const double2* __restrict__ v_full, double2* __restrict__ hv,
+                       double* __restrict__ partial) {
   extern __shared__ int32_t tabs[];  // [off_dw | rk_up] when LDS_TABLES
+  __shared__ double red_a[kDirNT / 64], red_q[kDirNT / 64];
+  double da = 0.0, dq = 0.0;
   const uint32_t lomask = (1u << ns) - 1u, impmask = (1u << norb) - 1u;
   if (LDS_TABLES) {
     const int n = 1 << ns;
@@ -75,31 +80,73 @@ __global__ void __launch_bounds__(kDirNT)
         ai += cr * x.y + ci * x.x;
       }
     }
+    if (LZ) {
+      const double2 q = hv[r];
+      ar += q.x;
+      ai += q.y;
+      da += x0.x * ar + x0.y * ai;
+      dq += ar * ar + ai * ai;
+    }
     hv[r] = make_double2(ar, ai);
+  }
+  if (LZ) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      da += __shfl_down(da, off, 64);
+      dq += __shfl_down(dq, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      red_a[threadIdx.x >> 6] = da;
+      red_q[threadIdx.x >> 6] = dq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double ta = 0.0, tq = 0.0;
+#pragma unroll
+      for (int i = 0; i < kDirNT / 64; i++) {
+        ta += red_a[i];
+        tq += red_q[i];
+      }
+      partial[blockIdx.x] = ta;
+      partial[gridDim.x + blockIdx.x] = tq;
+    }
   }
 }
 
-int launch_direct(const edigpu_sector* s, const double* v_full, double* hv, hipStream_t st) {
-  if (s->nloc == 0) return 0;
+template <bool LZ>
+static int launch_direct_t(const edigpu_sector* s, const double* v_full, double* hv, double* partial, int* np,
+                           hipStream_t st) {
   int64_t nb = (s->nloc + kDirNT - 1) / kDirNT;
   if (nb > 256 * 2) nb = 256 * 2;  // persistent: two workgroups per CU sweep the rows
+  if (np) *np = (int)nb;
   const size_t tab_bytes = (size_t)2 * sizeof(int32_t) << s->dir_ns;
   const double2* v2 = reinterpret_cast<const double2*>(v_full);
   double2* h2 = reinterpret_cast<double2*>(hv);
   if (tab_bytes <= 64 * 1024) {
-    auto kern = direct_rows_kernel<true>;
+    auto kern = direct_rows_kernel<true, LZ>;
     if (tab_bytes > 48 * 1024)
       EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kDirNT), tab_bytes, st, s->nloc, s->row_first, s->dir_ns,
                        s->dir_norb, s->dir_nterms, s->d_dir_states, s->d_dir_offdw, s->d_dir_rkup, s->d_dir_terms,
-                       s->d_dir_dtab, s->d_dir_xtab, v2, h2);
+                       s->d_dir_dtab, s->d_dir_xtab, v2, h2, partial);
   } else {
-    hipLaunchKernelGGL(direct_rows_kernel<false>, dim3((unsigned)nb), dim3(kDirNT), 0, st, s->nloc, s->row_first,
-                       s->dir_ns, s->dir_norb, s->dir_nterms, s->d_dir_states, s->d_dir_offdw, s->d_dir_rkup,
-                       s->d_dir_terms, s->d_dir_dtab, s->d_dir_xtab, v2, h2);
+    hipLaunchKernelGGL((direct_rows_kernel<false, LZ>), dim3((unsigned)nb), dim3(kDirNT), 0, st, s->nloc,
+                       s->row_first, s->dir_ns, s->dir_norb, s->dir_nterms, s->d_dir_states, s->d_dir_offdw,
+                       s->d_dir_rkup, s->d_dir_terms, s->d_dir_dtab, s->d_dir_xtab, v2, h2, partial);
   }
   EDIGPU_HIP(hipGetLastError());
   return 0;
+}
+
+int launch_direct(const edigpu_sector* s, const double* v_full, double* hv, hipStream_t st) {
+  if (s->nloc == 0) return 0;
+  return launch_direct_t<false>(s, v_full, hv, nullptr, nullptr, st);
+}
+
+// fused Lanczos step (single shard): Q += H*v with the alpha / <Q|Q> partials
+int launch_direct_lanczos(const edigpu_sector* s, const double* v_full, double* q, double* partial, int* np,
+                          hipStream_t st) {
+  return launch_direct_t<true>(s, v_full, q, partial, np, st);
 }
 
 }  // namespace edigpu

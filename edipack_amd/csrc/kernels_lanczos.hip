@@ -186,6 +186,24 @@ int lz_norm_begin(double* vin, int64_t n, double* partial, double* scal, hipStre
   return 0;
 }
 
+__global__ void __launch_bounds__(kLzNT)
+    k_rotate_lazy(double* __restrict__ P, double* __restrict__ Q, int64_t n, const double* __restrict__ scal) {
+  if (scal[SC_STOP] != 0.0) return;
+  const double a = scal[SC_ALPHA], b = scal[SC_BETA], ib = 1.0 / b;
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) {
+    const double p = P[i];
+    P[i] = (Q[i] - a * p) * ib;
+    Q[i] = -b * p;
+  }
+}
+
+int lz_rotate_lazy(double* P, double* Q, int64_t n, const double* scal, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_rotate_lazy, ew_grid(n), dim3(kLzNT), 0, st, P, Q, n, scal);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 int lz_rotate(double* vin, double* vout, int64_t n, const double* scal, hipStream_t st) {
   hipLaunchKernelGGL(k_rotate, ew_grid(n), dim3(kLzNT), 0, st, vin, vout, n, scal);
   EDIGPU_HIP(hipGetLastError());

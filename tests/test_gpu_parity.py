@@ -92,6 +92,28 @@ def test_normal_midsize_lds_paths(gpu):
     hg.destroy()
 
 
+@pytest.mark.parametrize("bath,norb,nbath,sec", [
+    ("normal", 2, 4, (5, 5)),    # all hybridisations equal: a row repeats one amplitude up to 8 times
+    ("hybrid", 3, 4, (3, 4)),    # odd DimUp (35): unvectorised tail path of the row kernel
+    ("normal", 3, 2, (4, 5)),
+])
+def test_normal_symmetric_reference_bath(gpu, bath, norb, nbath, sec):
+    """init_dmft_bath start point (reference ED_BATH/ED_BATH_DMFT.f90): every V equals 1/sqrt(Nbath), so
+    the typed ELL needs one slot per repetition of the amplitude inside a row."""
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("normal", bath, norb, nbath, seed=11, reference_bath=True)
+    ho = O.HNormal(om, *sec)
+    hg = SectorHamiltonian.normal_from_model(pm, *sec)
+    v = np.random.default_rng(77).standard_normal(ho.dim)
+    assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
+    # and through the hand-over boundary (explicit arrays, no factored tables)
+    ha = SectorHamiltonian.normal_from_arrays(ho.dimup, ho.dimdw, ho.hd, ho.up, ho.dw, ho.nd)
+    assert rel_err(ha.apply(v), ho.matvec(v)) < TOL
+    hg.destroy()
+    ha.destroy()
+
+
 def test_normal_two_phase_equals_fused(gpu):
     """edigpu_apply_local_dev + edigpu_apply_remote_dev on two dw-shards reproduce the fused product."""
     import torch
