@@ -549,9 +549,8 @@ std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int
   if (m.ed_mode != 1 && m.ed_mode != 2) return "edigpu_flat_build: model.ed_mode must be superc or nonsu2";
   if (m.ed_mode == 2 && m.nspin != 2) return "edigpu_flat_build: nonsu2 needs nspin=2";
   Idx ix(m);
-  const int ns = model_ns(m), norb = m.norb, nbath = m.nbath;
+  const int ns = model_ns(m), norb = m.norb;
   if (2 * ns > 30) return "edigpu_flat_build: 2*Ns > 30 bits (the reference's integer range)";
-  const int sd = m.nspin - 1;  // spin index used for the down species
   SpinBasis sb;
   sb.init(ns, m.ed_mode, sector);
   out.ns = ns;

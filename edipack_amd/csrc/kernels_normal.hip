@@ -33,7 +33,7 @@
 namespace edigpu {
 
 
-constexpr int kNT = 512;
+
 constexpr int kMaxNbr = 64;  // neighbour-list slots per row kept in LDS
 constexpr int kE = 4;        // adjacent columns owned by one thread per pass (16/32-byte accesses)
 
