@@ -40,6 +40,7 @@ class EdigpuModel(C.Structure):
         ("bv", C.c_double * (2 * MAXORB * MAXBATH)),
         ("bd", C.c_double * (2 * MAXORB * MAXBATH)),
         ("bu", C.c_double * (2 * MAXORB * MAXBATH)),
+        ("hb", C.c_double * (2 * 2 * MAXORB * MAXORB * MAXBATH * 2)),
     ]
 
 

@@ -70,6 +70,13 @@ struct Idx {
   double bath(const double* arr, int is, int a, int k) const {
     return arr[(is * EDIGPU_MAXORB + a) * EDIGPU_MAXBATH + k];
   }
+  // replica/general: hbath_tmp(is,js,a,b,k)
+  cplx hb(int is, int js, int a, int b, int k) const {
+    const double* p =
+        &m.hb[(((((is * 2) + js) * EDIGPU_MAXORB + a) * EDIGPU_MAXORB + b) * EDIGPU_MAXBATH + k) * 2];
+    return cplx(p[0], p[1]);
+  }
+  bool replica() const { return m.bath_type == 2 || m.bath_type == 3; }
   // 0-based level of bath site k of orbital a (getBathStride, ED_SETUP.f90:605-622)
   int bath_pos(int a, int k) const {
     switch (m.bath_type) {
@@ -86,9 +93,6 @@ std::string check_model(const edigpu_model& m) {
   if (m.norb < 1 || m.norb > EDIGPU_MAXORB) return "edigpu: norb out of range";
   if (m.nbath < 0 || m.nbath > EDIGPU_MAXBATH) return "edigpu: nbath out of range";
   if (m.nspin < 1 || m.nspin > 2) return "edigpu: nspin must be 1 or 2";
-  if (m.bath_type == 2 || m.bath_type == 3)
-    return "edigpu: replica/general baths are not built by the library yet; hand the matrices "
-           "over with edigpu_normal_create / edigpu_csr_create_z";
   if (m.bath_type < 0 || m.bath_type > 3) return "edigpu: unknown bath_type";
   int ns = model_ns(m);
   if (ns > 30) return "edigpu: Ns > 30 levels per spin not supported";
@@ -132,6 +136,20 @@ OneBody one_body_normal(const edigpu_model& m, int spin) {
       ob.a[p * ns + a] += v;
       ob.a[a * ns + p] += v;
     }
+  }
+  if (ix.replica()) {
+    // bath levels and inter-orbital bath hops of replica k: hbath_tmp(s,s,a,b,k)
+    // (stored/H_local.f90 bath_diag, stored/H_up.f90:26-50; real part in the real-valued normal mode)
+    for (int k = 0; k < m.nbath; k++)
+      for (int a = 0; a < norb; a++)
+        for (int b = 0; b < norb; b++) {
+          const double h = ix.hb(s, s, a, b, k).real();
+          if (a == b)
+            ob.eps[ix.bath_pos(a, k)] += h;
+          else
+            ob.a[ix.bath_pos(b, k) * ns + ix.bath_pos(a, k)] += h;  // c^+_{a,k} c_{b,k}
+        }
+    return ob;
   }
   for (int a = 0; a < ix.n_ebath_orb(); a++)
     for (int k = 0; k < m.nbath; k++) ob.eps[ix.bath_pos(a, k)] += ix.bath(m.be, s, a, k);
@@ -474,7 +492,7 @@ static void flat_physics(const edigpu_model& m, std::vector<OpTerm>& terms, std:
       hop(a, p, vu);
       hop(p + ns, a + ns, vd);
       hop(a + ns, p + ns, vd);
-      if (m.ed_mode == 2) {  // spin-flip hybridisation (ED_NONSU2/stored/Himp_bath.f90:77-136)
+      if (m.ed_mode == 2 && !ix.replica()) {  // spin-flip hybridisation (ED_NONSU2/stored/Himp_bath.f90:77-136)
         const double uu = ix.bath(m.bu, 0, a, k), ud = ix.bath(m.bu, sd, a, k);
         hop(p + ns, a, uu);
         hop(a, p + ns, uu);
@@ -482,7 +500,39 @@ static void flat_physics(const edigpu_model& m, std::vector<OpTerm>& terms, std:
         hop(a + ns, p, ud);
       }
     }
-  if (m.ed_mode == 1) {
+  if (ix.replica()) {
+    // replica / general bath: matrices hbath_tmp(is,js,a,b,k) (ED_SUPERC/stored/Hbath.f90:40-92,130-186,
+    // ED_NONSU2/stored/Hbath.f90:38-116)
+    const int n1 = m.ed_mode == 1 ? 1 : sd;  // index of the second diagonal block (Nambu hole / spin down)
+    for (int k = 0; k < nbath; k++)
+      for (int a = 0; a < norb; a++)
+        for (int b = 0; b < norb; b++) {
+          const int pa = ix.bath_pos(a, k), pb = ix.bath_pos(b, k);
+          if (a != b) {
+            hop(pa, pb, ix.hb(0, 0, a, b, k));  // up: c^+_{a} c_{b}
+            if (m.ed_mode == 1) {
+              // Nambu hole block: c_{a,dw} c^+_{b,dw} with entry conj(h)
+              const cplx h = ix.hb(n1, n1, a, b, k);
+              if (h != cplx(0.0))
+                terms.push_back({2, {pb + ns, pa + ns, 0, 0}, {true, false, false, false}, std::conj(h)});
+            } else {
+              hop(pa + ns, pb + ns, ix.hb(n1, n1, a, b, k));
+            }
+          }
+          if (m.ed_mode == 1) {
+            // anomalous blocks: c^+_{a,up} c^+_{b,dw} (0,1) and c_{a,dw} c_{b,up} (1,0)
+            const cplx h01 = ix.hb(0, 1, a, b, k), h10 = ix.hb(1, 0, a, b, k);
+            if (h01 != cplx(0.0))
+              terms.push_back({2, {pb + ns, pa, 0, 0}, {true, true, false, false}, std::conj(h01)});
+            if (h10 != cplx(0.0))
+              terms.push_back({2, {pb, pa + ns, 0, 0}, {false, false, false, false}, std::conj(h10)});
+          } else if (m.ed_mode == 2 && m.nspin == 2) {
+            hop(pa, pb + ns, ix.hb(0, 1, a, b, k));       // c^+_{a,up} c_{b,dw}
+            hop(pa + ns, pb, ix.hb(1, 0, a, b, k));       // c^+_{a,dw} c_{b,up}
+          }
+        }
+  }
+  if (m.ed_mode == 1 && !ix.replica()) {
     // bath pairing (ED_SUPERC/stored/Hbath.f90:94-128): d c_{dw} c_{up} and d c^+_{up} c^+_{dw}
     for (int a = 0; a < ix.n_ebath_orb(); a++)
       for (int k = 0; k < nbath; k++) {
@@ -492,6 +542,8 @@ static void flat_physics(const edigpu_model& m, std::vector<OpTerm>& terms, std:
         terms.push_back({2, {p, p + ns, 0, 0}, {false, false, false, false}, cplx(d)});
         terms.push_back({2, {p + ns, p, 0, 0}, {true, true, false, false}, cplx(d)});
       }
+  }
+  if (m.ed_mode == 1) {
     // local pair field (ED_SUPERC/stored/Himp.f90:84-124)
     for (int a = 0; a < norb; a++) {
       const double f = m.pair_field[a];
@@ -527,11 +579,21 @@ static void flat_physics(const edigpu_model& m, std::vector<OpTerm>& terms, std:
     eps[a] = ix.hloc(0, 0, a, a).real() + shift;
     eps[a + ns] = ix.hloc(sd, sd, a, a).real() + shift;
   }
-  for (int a = 0; a < ix.n_ebath_orb(); a++)
-    for (int k = 0; k < nbath; k++) {
-      eps[ix.bath_pos(a, k)] += ix.bath(m.be, 0, a, k);
-      eps[ix.bath_pos(a, k) + ns] += ix.bath(m.be, sd, a, k);
-    }
+  if (ix.replica()) {
+    for (int a = 0; a < norb; a++)
+      for (int k = 0; k < nbath; k++) {
+        eps[ix.bath_pos(a, k)] += ix.hb(0, 0, a, a, k).real();
+        // superc: minus the Nambu hole block (Hbath.f90:44-52); nonsu2: the spin-down block
+        eps[ix.bath_pos(a, k) + ns] +=
+            m.ed_mode == 1 ? -ix.hb(1, 1, a, a, k).real() : ix.hb(sd, sd, a, a, k).real();
+      }
+  } else {
+    for (int a = 0; a < ix.n_ebath_orb(); a++)
+      for (int k = 0; k < nbath; k++) {
+        eps[ix.bath_pos(a, k)] += ix.bath(m.be, 0, a, k);
+        eps[ix.bath_pos(a, k) + ns] += ix.bath(m.be, sd, a, k);
+      }
+  }
   double& cst = cst_out;
   cst = 0.0;
   if (m.hfmode) {

@@ -54,6 +54,10 @@ class ImpurityModel:
     bv: np.ndarray | None = None    # dmft_bath%v [nspin, norb, nbath]
     bd: np.ndarray | None = None    # dmft_bath%d (superc)
     bu: np.ndarray | None = None    # dmft_bath%u (nonsu2)
+    # replica / general baths: hb[is, js, iorb, jorb, k] = build_Hreplica/Hgeneral(lambda_k) (is, js over
+    # Nspin, or the Nambu index in superc); hybridisations in bv (replica: item(k)%v for all is, iorb;
+    # general: item(k)%vg(iorb + Norb*(is-1)))
+    hb: np.ndarray | None = None
 
     @property
     def ns(self) -> int:
@@ -88,6 +92,14 @@ class ImpurityModel:
             v[:k, :k, :no, :no, 1] = h.imag
         if self.pair_field is not None:
             np.ctypeslib.as_array(m.pair_field)[:no] = np.asarray(self.pair_field, dtype=float)
+        if self.bath_type in ("replica", "general"):
+            if self.hb is None or self.bv is None:
+                raise capi.EdigpuError("ImpurityModel: replica/general baths need hb and bv")
+            hb = np.asarray(self.hb, dtype=complex)
+            k = hb.shape[0]
+            v = np.ctypeslib.as_array(m.hb).reshape(2, 2, capi.MAXORB, capi.MAXORB, capi.MAXBATH, 2)
+            v[:k, :k, :no, :no, : self.nbath, 0] = hb.real
+            v[:k, :k, :no, :no, : self.nbath, 1] = hb.imag
         for name in ("be", "bv", "bd", "bu"):
             arr = getattr(self, name)
             if arr is None:

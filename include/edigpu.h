@@ -124,6 +124,13 @@ typedef struct edigpu_model {
   double bv[2 * EDIGPU_MAXORB * EDIGPU_MAXBATH];
   double bd[2 * EDIGPU_MAXORB * EDIGPU_MAXBATH];
   double bu[2 * EDIGPU_MAXORB * EDIGPU_MAXBATH];
+  /* replica / general baths (bath_type 2, 3): the per-replica matrices
+   * hbath_tmp(is,js,iorb,jorb,k) = build_Hreplica / build_Hgeneral(dmft_bath%item(k)%lambda)
+   * (ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:99-122), [is][js][iorb][jorb][k][re,im]; is,js run over
+   * Nspin (normal, nonsu2) or over the Nambu index (superc).  The hybridisations go in bv:
+   * replica bv[is][iorb][k] = item(k)%v for every is,iorb; general bv[is][iorb][k] = item(k)%vg(iorb+Norb*(is-1)).
+   * be, bd, bu are not read for these bath types. */
+  double hb[2 * 2 * EDIGPU_MAXORB * EDIGPU_MAXORB * EDIGPU_MAXBATH * 2];
 } edigpu_model;
 
 /* normal mode sector (N_up, N_dw); the shard owns down-indices [dw_first, dw_first+dw_count)

@@ -108,6 +108,12 @@ class Model:
     bv: np.ndarray | None = None
     bd: np.ndarray | None = None
     bu: np.ndarray | None = None
+    # replica / general baths: hbath_tmp[is, js, iorb, jorb, k] = build_Hreplica/Hgeneral(lambda_k)
+    # (is, js over Nspin, or over the Nambu index in superc), hybridisations item(k)%v (replica, [nbath])
+    # or item(k)%vg (general, [nspin*norb, nbath])
+    hb: np.ndarray | None = None
+    vr: np.ndarray | None = None
+    vg: np.ndarray | None = None
 
     @property
     def ns(self) -> int:
@@ -165,6 +171,18 @@ def to_struct(m: Model) -> OrcModel:
         _np_view(s, "hloc_im")[:nsn, :nsn, :no, :no] = h.imag
     if m.pair_field is not None:
         _np_view(s, "pair_field")[:no] = np.asarray(m.pair_field, dtype=float)
+    if m.bath_type in ("replica", "general"):
+        assert m.hb is not None, "replica/general bath: hb (the per-replica matrices) is required"
+        hb = np.asarray(m.hb, dtype=complex)
+        n1 = hb.shape[0]
+        _np_view(s, "hb_re")[:n1, :n1, :no, :no, : m.nbath] = hb.real
+        _np_view(s, "hb_im")[:n1, :n1, :no, :no, : m.nbath] = hb.imag
+        if m.bath_type == "replica":
+            _np_view(s, "vr")[: m.nbath] = np.asarray(m.vr, dtype=float)
+        else:
+            vg = np.asarray(m.vg, dtype=float)
+            _np_view(s, "vg")[: vg.shape[0], : m.nbath] = vg
+        return s
     if m.be is None:
         init_dmft_bath(m)
     for name, arr in (("be", m.be), ("bv", m.bv), ("bd", m.bd), ("bu", m.bu)):

@@ -35,6 +35,8 @@ def make_models(ed_mode: str, bath_type: str, norb: int, nbath: int, seed: int =
         a = rng.standard_normal((norb, norb))
         a = 0.3 * (a + a.T)
         hl[0, 0] = a
+    if bath_type in ("replica", "general"):
+        return _make_replica_models(rng, ed_mode, bath_type, norb, nbath, nspin, hl, jxp, over)
     par = dict(ed_mode=ed_mode, bath_type=bath_type, norb=norb, nbath=nbath, nspin=nspin, hfmode=True, xmu=0.0,
                uloc=tuple([2.0] * norb), ust=1.5 if norb > 1 else 0.0, jh=0.25 if norb > 1 else 0.0,
                jx=jxp if norb > 1 else 0.0, jp=jxp if norb > 1 else 0.0)
@@ -48,6 +50,96 @@ def make_models(ed_mode: str, bath_type: str, norb: int, nbath: int, seed: int =
     pm = ImpurityModel(hloc=hl, be=be, bv=bv, bd=bd, bu=bu,
                        **{k: (np.asarray(v) if k == "uloc" else v) for k, v in par.items()})
     return om, pm
+
+
+def _replica_pair(ed_mode, bath_type, norb, nbath, nspin, hl, hb, v, par):
+    """oracle.Model + ImpurityModel of one replica/general problem: hb[is,js,a,b,k], v[nspin,norb,nbath]
+    (replica: one value per k)."""
+    om = O.Model(hloc=hl, hb=hb, vr=v[0, 0, :].copy(), vg=v.reshape(nspin * norb, nbath).copy(), **par)
+    pm = ImpurityModel(hloc=hl, hb=hb, bv=v.copy(),
+                       **{k: (np.asarray(x) if k == "uloc" else x) for k, x in par.items()})
+    return om, pm
+
+
+def _make_replica_models(rng, ed_mode, bath_type, norb, nbath, nspin, hl, jxp, over):
+    """Seeded replica/general bath: Hermitian per-replica matrices with inter-orbital (and, nonsu2,
+    spin-flip; superc, anomalous) blocks -- the structure build_Hreplica produces from a symmetric basis."""
+    n1 = 2 if ed_mode in ("superc", "nonsu2") else 1
+    hb = np.zeros((n1, n1, norb, norb, nbath), complex)
+    for k in range(nbath):
+        a = rng.uniform(-0.4, 0.4, (norb, norb))
+        a = 0.5 * (a + a.T) + np.diag(rng.uniform(-2, 2, norb))
+        if ed_mode == "normal":
+            hb[0, 0, :, :, k] = a
+        elif ed_mode == "superc":
+            d = rng.uniform(-0.2, 0.2, (norb, norb))
+            d = 0.5 * (d + d.T)
+            hb[0, 0, :, :, k] = a          # Nambu: [[ h, Delta ], [ Delta^+, -h^T ]]
+            hb[1, 1, :, :, k] = -a.T
+            hb[0, 1, :, :, k] = d
+            hb[1, 0, :, :, k] = d.conj().T
+        else:
+            f = rng.uniform(-0.3, 0.3, (norb, norb)) + 1j * rng.uniform(-0.3, 0.3, (norb, norb))
+            b = a + np.diag(rng.uniform(-0.3, 0.3, norb))
+            hb[0, 0, :, :, k] = a
+            hb[1, 1, :, :, k] = b
+            hb[0, 1, :, :, k] = f
+            hb[1, 0, :, :, k] = f.conj().T
+    if bath_type == "replica":
+        v = np.broadcast_to(rng.uniform(0.1, 0.6, nbath), (nspin, norb, nbath)).copy()
+    else:
+        v = rng.uniform(0.1, 0.6, (nspin, norb, nbath))
+        if nspin == 2 and ed_mode != "nonsu2":
+            v[1] = v[0]
+    par = dict(ed_mode=ed_mode, bath_type=bath_type, norb=norb, nbath=nbath, nspin=nspin, hfmode=True, xmu=0.0,
+               uloc=tuple([2.0] * norb), ust=1.5 if norb > 1 else 0.0, jh=0.25 if norb > 1 else 0.0,
+               jx=jxp if norb > 1 else 0.0, jp=jxp if norb > 1 else 0.0)
+    par.update(over)
+    return _replica_pair(ed_mode, bath_type, norb, nbath, nspin, hl, hb, v, par)
+
+
+def replica_golden_models(inp):
+    """The impurity problems of test/src/{REPLICA,GENERAL}_{NORMAL,SUPERC,NONSU2}: Norb=2, Nbath=2; the
+    symmetry basis and initial lambdas set in ed_replica_*.f90 / ed_general_*.f90 (:47-95), the init_dmft_bath
+    start values (ED_BATH_DMFT.f90:246-290: V=max(0.1,1/sqrt(Nbath)); equal lambdas on a diagonal basis
+    matrix get the +-ed_offset_bath spread) and Hloc = Delta*sigma_z (Mh*Gamma5 in nonsu2)."""
+    mode, bath, norb, nb = inp["ED_MODE"], inp["BATH_TYPE"], 2, 2
+    nspin = 2 if mode == "nonsu2" else 1
+    s0 = np.eye(2, dtype=complex)
+    sx = np.array([[0, 1], [1, 0]], complex)
+    sz = np.diag([1.0, -1.0]).astype(complex)
+
+    def so(m4, n1):  # kron(sigma, tau) -> [is, js, iorb, jorb]
+        out = np.zeros((n1, n1, norb, norb), complex)
+        for i in range(n1):
+            for j in range(n1):
+                out[i, j] = m4[i * norb:(i + 1) * norb, j * norb:(j + 1) * norb]
+        return out
+
+    lam1 = np.array([-1.0 + 2.0 * i / (nb - 1) for i in range(nb)])
+    if mode == "normal":
+        basis, lam, n1 = [so(np.kron(s0, s0)[:2, :2], 1), so(np.kron(s0, sx)[:2, :2], 1)], [lam1, np.full(nb, 0.1)], 1
+        hl = np.zeros((1, 1, 2, 2), complex)
+        hl[0, 0] = inp["DELTA"] * sz
+    elif mode == "superc":
+        basis = [so(np.kron(sz, s0), 2), so(np.kron(sx, s0), 2), so(np.kron(sx, sx), 2)]
+        lam, n1 = [lam1, np.full(nb, 0.1), np.full(nb, 0.2)], 2
+        hl = np.zeros((1, 1, 2, 2), complex)
+        hl[0, 0] = inp["DELTA"] * sz
+    else:
+        sb, mh = 0.01, inp["MH"]          # SB_FIELD of the two NONSU2 inputs
+        off = np.linspace(-0.1, 0.1, nb)  # ED_OFFSET_BATH
+        basis = [so(np.kron(s0, sz), 2), so(np.kron(s0, sx), 2), so(np.kron(sz, sx), 2), so(np.kron(sx, sx), 2)]
+        lam, n1 = [mh + off, np.full(nb, sb), np.full(nb, sb), np.full(nb, -sb)], 2
+        hl = so(mh * np.kron(s0, sz), 2)
+    hb = np.zeros((n1, n1, norb, norb, nb), complex)
+    for b, l in zip(basis, lam):
+        for k in range(nb):
+            hb[..., k] += l[k] * b
+    v = np.full((nspin, norb, nb), max(0.1, 1.0 / np.sqrt(nb)))
+    par = dict(ed_mode=mode, bath_type=bath, norb=norb, nbath=nb, nspin=nspin, hfmode=True, xmu=0.0,
+               uloc=tuple(inp["ULOC"]), ust=inp["UST"], jh=inp["JH"], jx=inp["JX"], jp=inp["JP"])
+    return _replica_pair(mode, bath, norb, nb, nspin, hl, hb, v, par)
 
 
 def rel_err(a, b):

@@ -30,6 +30,9 @@ NORMAL_CASES = [
     ("hybrid", 3, 5, (4, 4)),      # 3 orbitals: non-trivial signs in Hnd
     ("normal", 2, 3, (4, 3)),      # rectangular DimUp != DimDw
     ("normal", 2, 3, (8, 0)),      # edge: DimUp=1
+    ("replica", 2, 2, (3, 3)),     # reference tests REPLICA_NORMAL / GENERAL_NORMAL sizes: inter-orbital bath hops
+    ("general", 2, 3, (4, 3)),
+    ("general", 3, 2, (4, 5)),
 ]
 
 
@@ -188,6 +191,10 @@ FLAT_CASES = [
     ("nonsu2", "hybrid", 2, 4, 5),
     ("nonsu2", "hybrid", 3, 3, 6),   # 3 orbitals: signs across orbitals
     ("nonsu2", "normal", 1, 2, 0),   # 1 x 1
+    ("superc", "replica", 2, 2, 0),  # Nambu-structured replica matrices (anomalous inter-orbital blocks)
+    ("superc", "general", 2, 2, -1),
+    ("nonsu2", "replica", 2, 2, 6),  # spin-flip blocks inside the replicas
+    ("nonsu2", "general", 2, 2, 5),
 ]
 
 
@@ -333,13 +340,8 @@ GOLDEN = [
 ]
 
 
-@pytest.mark.parametrize("mode,bath,norb,nbath,par,e_gold", GOLDEN)
-def test_golden_ground_state_energy_on_gpu(gpu, mode, bath, norb, nbath, par, e_gold):
-    """evals.check of the reference's regression tests (test/src/<BATH>_<MODE>/evals.check, abs tol
-    1e-9, test/src/ASSERTING.f90:74-80), reproduced with GPU-built sectors + GPU Lanczos."""
+def _gpu_ground_state_energy(om, pm, mode):
     from edipack_amd.hamiltonian import SectorHamiltonian
-    from tests.test_oracle_golden import golden_models
-    om, pm = golden_models(mode, bath, norb, nbath, par)
     O = _oracle()
     best = np.inf
     for sec in O.sectors(om):
@@ -360,7 +362,27 @@ def test_golden_ground_state_energy_on_gpu(gpu, mode, bath, norb, nbath, par, e_
             e0, _, _ = hg.lanczos_eigh(nitermax=min(hg.dim, 400), tol=1e-14, check_every=20, want_vector=False)
         best = min(best, e0)
         hg.destroy()
-    assert abs(best - e_gold) < 1e-9
+    return best
+
+
+@pytest.mark.parametrize("mode,bath,norb,nbath,par,e_gold", GOLDEN)
+def test_golden_ground_state_energy_on_gpu(gpu, mode, bath, norb, nbath, par, e_gold):
+    """evals.check of the reference's regression tests (test/src/<BATH>_<MODE>/evals.check, abs tol
+    1e-9, test/src/ASSERTING.f90:74-80), reproduced with GPU-built sectors + GPU Lanczos."""
+    from tests.test_oracle_golden import golden_models
+    om, pm = golden_models(mode, bath, norb, nbath, par)
+    assert abs(_gpu_ground_state_energy(om, pm, mode) - e_gold) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["REPLICA_NORMAL", "GENERAL_NORMAL", "REPLICA_SUPERC", "GENERAL_SUPERC",
+                                  "REPLICA_NONSU2", "GENERAL_NONSU2"])
+def test_golden_replica_general_energy_on_gpu(gpu, name):
+    """The replica / general bath regression tests of the reference through the library's builder."""
+    from tests.common import replica_golden_models
+    from tests.test_oracle_golden import GOLD
+    g = GOLD[name]
+    om, pm = replica_golden_models(g["input"])
+    assert abs(_gpu_ground_state_energy(om, pm, g["input"]["ED_MODE"]) - g["evals"][0]) < 1e-9
 
 
 # --------------------------------------------------------------------------------------------
