@@ -10,7 +10,7 @@
  * /root/reference/src/singlesite unless noted).
  *
  * Parity status: PINNED against the reference's own golden fixtures
- * (test/src/{NORMAL,HYBRID}_{NORMAL,SUPERC,NONSU2}/{evals,dens,docc}.check), see
+ * (test/src/{NORMAL,HYBRID,REPLICA,GENERAL}_{NORMAL,SUPERC,NONSU2}/{evals,dens,docc}.check), see
  * tests/test_oracle_golden.py.  The Lanczos recurrence (SciFortran
  * sp_lanc_tridiag, third party, un-vendored, un-pinned "master") is restated
  * from its published algorithm; it is pinned only end-to-end.
