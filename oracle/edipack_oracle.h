@@ -13,7 +13,8 @@
  * (test/src/{NORMAL,HYBRID,REPLICA,GENERAL}_{NORMAL,SUPERC,NONSU2}/{evals,dens,docc}.check), see
  * tests/test_oracle_golden.py.  The Lanczos recurrence (SciFortran
  * sp_lanc_tridiag, third party, un-vendored, un-pinned "master") is restated
- * from its published algorithm; it is pinned only end-to-end.
+ * from its published algorithm and pinned through Sigma_momenta.check of
+ * NORMAL_NORMAL / HYBRID_NORMAL (functions of the alpha/beta it returns; tests/gf_normal.py).
  */
 #ifndef EDIPACK_ORACLE_H
 #define EDIPACK_ORACLE_H

@@ -374,6 +374,30 @@ def test_golden_ground_state_energy_on_gpu(gpu, mode, bath, norb, nbath, par, e_
     assert abs(_gpu_ground_state_energy(om, pm, mode) - e_gold) < 1e-9
 
 
+@pytest.mark.parametrize("name", ["NORMAL_NORMAL", "HYBRID_NORMAL"])
+def test_golden_sigma_momenta_through_gpu_tridiag(gpu, name):
+    """Sigma_momenta.check with every tridiagonalisation done by edigpu_lanczos_tridiag (GPU-built sector,
+    fused device Lanczos): the reference's own fixture for tridiag_Hv_sector_normal, through the C ABI."""
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from tests.gf_normal import sigma_momenta_normal
+    from tests.test_oracle_golden import GOLD, _from_dir, golden_models
+    O = _oracle()
+    inp, par = _from_dir(name)
+    pm_par = {k: v for k, v in par.items() if k not in ("ed_hw_bath", "deltasc")}
+    om, pm = golden_models(inp["ED_MODE"], inp["BATH_TYPE"], int(inp["NORB"]), int(inp["NBATH"]), pm_par)
+    O.to_struct(om)
+
+    def tridiag(sec, v, nl):
+        hg = SectorHamiltonian.normal_from_model(pm, *sec)
+        a, b, _ = hg.lanczos_tridiag(v, nl)
+        hg.destroy()
+        return a, b
+
+    m = sigma_momenta_normal(om, tridiag, beta=inp["BETA"], ngfiter=int(inp["LANC_NGFITER"]))
+    g = np.array(GOLD[name]["Sigma_momenta"]).reshape(m.shape)
+    assert np.max(np.abs(m - g) / np.abs(g)) < 1e-9
+
+
 @pytest.mark.parametrize("name", ["REPLICA_NORMAL", "GENERAL_NORMAL", "REPLICA_SUPERC", "GENERAL_SUPERC",
                                   "REPLICA_NONSU2", "GENERAL_NONSU2"])
 def test_golden_replica_general_energy_on_gpu(gpu, name):

@@ -64,6 +64,26 @@ def test_oracle_reproduces_reference_fixture(name):
     assert np.max(np.abs(docc - np.array(g["docc"]))) < tol
 
 
+@pytest.mark.parametrize("name", ["NORMAL_NORMAL", "HYBRID_NORMAL"])
+def test_oracle_tridiag_reproduces_sigma_momenta(name):
+    """Sigma_momenta.check: the fixture that goes through tridiag_Hv_sector_normal + sp_lanc_tridiag (one
+    tridiagonalisation of up to lanc_ngfiter=200 steps per orbital, channel and ground state) -- pins the
+    restated three-term recurrence at the level of the alpha/beta it returns.  Measured agreement: 5e-15."""
+    from tests.gf_normal import sigma_momenta_normal
+    inp, par = _from_dir(name)
+    pm_par = {k: v for k, v in par.items() if k not in ("ed_hw_bath", "deltasc")}
+    om, _ = golden_models(inp["ED_MODE"], inp["BATH_TYPE"], int(inp["NORB"]), int(inp["NBATH"]), pm_par)
+    O.to_struct(om)   # fills the init_dmft_bath start bath
+
+    def tridiag(sec, v, nl):
+        a, b, _ = O.HNormal(om, *sec).lanc_tridiag(v.copy(), nl)
+        return a, b
+
+    m = sigma_momenta_normal(om, tridiag, beta=inp["BETA"], ngfiter=int(inp["LANC_NGFITER"]))
+    g = np.array(GOLD[name]["Sigma_momenta"]).reshape(m.shape)
+    assert np.max(np.abs(m - g) / np.abs(g)) < 1e-11
+
+
 @pytest.mark.parametrize("name", REPLICA_DIRS)
 def test_oracle_reproduces_replica_general_fixture(name):
     g = GOLD[name]
