@@ -328,6 +328,10 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
     s->dw_maxrow = std::max<int>(s->dw_maxrow, (int)(dw.rowptr[i + 1] - dw.rowptr[i]));
   s->has_nd = nd_rowptr != nullptr && nd_rowptr[s->nloc] > 0;
   s->nd_nnz = s->has_nd ? nd_rowptr[s->nloc] : 0;
+  if (built && !nd_rowptr) {  // factored-only build: no explicit arrays were made
+    s->has_nd = built->has_nd && built->nd_nnz > 0;
+    s->nd_nnz = s->has_nd ? built->nd_nnz : 0;
+  }
   // library-built sectors keep the diagonal and Hnd in factored form on the device (the explicit
   // arrays stay on the host for export); EDIGPU_NORMAL_EXPLICIT=1 forces the explicit image.
   if (built && built->fac.valid && built->fac.nterms <= 16 && !env_flag("EDIGPU_NORMAL_EXPLICIT")) {
@@ -702,14 +706,24 @@ int edigpu_normal_build(edigpu_handle* h, const edigpu_model* model, int nup, in
   *h = nullptr;
   if (ensure_device()) return 1;
   HostNormal hn;
-  std::string e = build_normal(*model, nup, ndw, dw_first, dw_count, hn);
+  // the O(Dim) explicit images (hd, Hnd CSR) are skipped when the kernels run on the factored tables
+  bool lazy = !env_flag("EDIGPU_NORMAL_EXPLICIT");
+  std::string e = build_normal(*model, nup, ndw, dw_first, dw_count, hn, !lazy);
+  if (e.empty() && lazy && hn.fac.nterms > 16) {
+    lazy = false;
+    e = build_normal(*model, nup, ndw, dw_first, dw_count, hn, true);
+  }
   if (!e.empty()) {
     set_error(e);
     return 1;
   }
   std::unique_ptr<edigpu_sector> s(new edigpu_sector());
-  if (setup_normal(s.get(), hn.dim_up, hn.dim_dw, hn.dw_first, hn.dw_count, hn.hd.data(), hn.up,
-                   hn.dw, hn.has_nd ? hn.nd.rowptr.data() : nullptr, hn.nd.col.data(),
+  s->model = *model;
+  s->sec_a = nup;
+  s->sec_b = ndw;
+  s->lazy_export = lazy;
+  if (setup_normal(s.get(), hn.dim_up, hn.dim_dw, hn.dw_first, hn.dw_count, lazy ? nullptr : hn.hd.data(), hn.up,
+                   hn.dw, (!lazy && hn.has_nd) ? hn.nd.rowptr.data() : nullptr, hn.nd.col.data(),
                    hn.nd.val.data(), &hn)) {
     edigpu_destroy(s.release());
     return 1;
@@ -873,6 +887,18 @@ int edigpu_normal_export(edigpu_handle s, double* hd, int64_t* up_rowptr, int32_
     return 1;
   }
   EDIGPU_HIP(hipSetDevice(s->device));
+  if (s->lazy_export && s->factored) {
+    // first export of a factored sector: materialise the explicit images from the stored model
+    HostNormal hn;
+    std::string e = build_normal(s->model, s->sec_a, s->sec_b, s->dw_first, s->dw_count, hn, true);
+    if (!e.empty()) {
+      set_error(e);
+      return 1;
+    }
+    s->h_hd = std::move(hn.hd);
+    s->h_nd = std::move(hn.nd);
+    s->lazy_export = false;
+  }
   if (hd && s->nloc) {
     if (s->factored)
       std::copy(s->h_hd.begin(), s->h_hd.end(), hd);

@@ -92,8 +92,11 @@ struct edigpu_sector {
   int32_t* d_mx_col = nullptr;
   double* d_mx_val = nullptr;
   int64_t nd_nnz = 0;           // nnz of the (possibly host-only) CSR image of Hnd
-  std::vector<double> h_hd;     // host copies kept for export when the device holds the factored form
-  edigpu::HostCsr h_nd;
+  std::vector<double> h_hd;     // host copies for export when the device holds the factored form;
+  edigpu::HostCsr h_nd;         // built on the first export (lazy_export) from the stored model
+  bool lazy_export = false;
+  edigpu_model model;           // library-built sectors: what edigpu_*_build was given
+  int sec_a = 0, sec_b = 0;
   // ---- flat ----
   edigpu::DevCsr loc, nonloc; // local rows; loc columns are shard-relative, nonloc global
   // ---- direct (on-the-fly) ----

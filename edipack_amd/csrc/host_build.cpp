@@ -211,7 +211,7 @@ std::string sector_dim(const edigpu_model& m, int q1, int q2, int64_t& dim) {
 }
 
 std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_first,
-                         int64_t dw_count, HostNormal& out) {
+                         int64_t dw_count, HostNormal& out, bool explicit_arrays) {
   std::string e = check_model(m);
   if (!e.empty()) return e;
   if (m.ed_mode != 0) return "edigpu_normal_build: model.ed_mode is not normal";
@@ -292,8 +292,9 @@ std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_fir
   fac.ed = ed;
   fac.impd.resize(out.dim_dw);
   for (int64_t idw = 0; idw < out.dim_dw; idw++) fac.impd[idw] = (uint8_t)((uint32_t)out.bdw.states[idw] & impmask);
-  out.hd.resize((size_t)(dw_count * DimUp));
-  for (int64_t r = 0; r < dw_count; r++) {
+  out.hd.clear();
+  if (explicit_arrays) out.hd.resize((size_t)(dw_count * DimUp));
+  for (int64_t r = 0; explicit_arrays && r < dw_count; r++) {
     const int64_t idw = dw_first + r;
     const uint32_t md = (uint32_t)out.bdw.states[idw];
     const double edr = ed[idw];
@@ -363,9 +364,20 @@ std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_fir
               tl.push_back({ba | bb, ba | bb, ix.jp(a, b) * sg});
           }
       }
+    // nnz(Hnd) of the local rows from the impurity-pattern histograms (O(DimUp + DimDw))
+    {
+      std::vector<int64_t> cu((size_t)impmask + 1, 0), cd((size_t)impmask + 1, 0);
+      for (int64_t iup = 0; iup < DimUp; iup++) cu[(uint32_t)out.bup.states[iup] & impmask]++;
+      for (int64_t r = 0; r < dw_count; r++) cd[(uint32_t)out.bdw.states[dw_first + r] & impmask]++;
+      out.nd_nnz = 0;
+      for (uint32_t iu = 0; iu <= impmask; iu++)
+        for (uint32_t id = 0; id <= impmask; id++)
+          out.nd_nnz += cu[iu] * cd[id] * (int64_t)terms[(iu << norb) | id].size();
+    }
     HostCsr& nd = out.nd;
     nd.nrow = dw_count * DimUp;
     nd.ncol = out.dim_up * out.dim_dw;
+    if (!explicit_arrays) return "";
     nd.rowptr.assign(nd.nrow + 1, 0);
     int64_t nnz = 0;
     for (int64_t r = 0; r < dw_count; r++) {

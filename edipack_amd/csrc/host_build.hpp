@@ -61,9 +61,10 @@ struct HostNormal {
   int ns = 0, nup = 0, ndw = 0;
   int64_t dim_up = 0, dim_dw = 0, dw_first = 0, dw_count = 0;
   CombBasis bup, bdw;
-  std::vector<double> hd;  // local rows
-  HostCsr up, dw, nd;      // nd over local rows, global columns
+  std::vector<double> hd;  // local rows (explicit_arrays only)
+  HostCsr up, dw, nd;      // nd over local rows, global columns (explicit_arrays only)
   bool has_nd = false;
+  int64_t nd_nnz = 0;      // entries of Hnd on the local rows (always set)
 };
 
 struct HostFlat {
@@ -101,8 +102,10 @@ int model_ns(const edigpu_model& m);
 int64_t binomial(int n, int k);
 
 // returns "" on success, else an error message
+// explicit_arrays = false skips the O(Dim) images (hd, the Hnd CSR): the factored tables are all the
+// kernels need; the arrays are only materialised for export (edigpu_normal_export).
 std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_first,
-                         int64_t dw_count, HostNormal& out);
+                         int64_t dw_count, HostNormal& out, bool explicit_arrays = true);
 std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
                        HostFlat& out);
 std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
