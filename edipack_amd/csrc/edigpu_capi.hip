@@ -421,6 +421,114 @@ static int setup_flat(edigpu_sector* s, int64_t nrow_local, int64_t ncol_global,
   return finish_handle(s);
 }
 
+// Stored flat image generated on the device from the on-the-fly description (kernels_build.hip).
+// Returns 0 = built, 2 = not applicable (caller falls back to the host CSR builder), 1 = error.
+static int build_flat_on_device(edigpu_sector* s, const HostDirect& hd) {
+  const int nterms = (int)hd.terms.size();
+  const int64_t nrow = hd.row_count;
+  if (nrow == 0 || hd.dim >= ((int64_t)1 << 24)) return 2;  // 24-bit columns in the packed words
+  // ---- value dictionary: ids (2j, 2j+1) = (+v_j, -v_j), j >= 1; ids 0, 1 = 0.0 (padding) ----
+  std::vector<double> dict(4, 0.0);
+  std::vector<uint8_t> vid((size_t)2 * std::max(nterms, 1), 0);
+  auto id_of = [&](double re, double im) -> int {
+    const size_t n = dict.size() / 2;
+    for (size_t k = 2; k < n; k++)
+      if (dict[2 * k] == re && dict[2 * k + 1] == im) return (int)k;
+    if (n + 2 > 256) return -1;
+    dict.push_back(re);
+    dict.push_back(im);
+    dict.push_back(-re);
+    dict.push_back(-im);
+    return (int)n;
+  };
+  for (int t = 0; t < nterms; t++) {
+    const DirectTerm& tm = hd.terms[t];
+    const int f = id_of(tm.cre, tm.cim);
+    const int r = tm.pair ? id_of(tm.c2re, tm.c2im) : f;
+    if (f < 0 || r < 0) return 2;
+    vid[2 * t] = (uint8_t)f;
+    vid[2 * t + 1] = (uint8_t)r;
+  }
+  dict.resize(512, 0.0);
+  // ---- temporaries on the device (the direct image + work arrays) ----
+  struct Tmp {
+    int32_t *states = nullptr, *offdw = nullptr, *rkup = nullptr, *wl = nullptr, *wn = nullptr;
+    DirectTerm* terms = nullptr;
+    uint8_t* vid = nullptr;
+    double *dtab = nullptr, *xtab = nullptr;
+    unsigned long long* totals = nullptr;
+    ~Tmp() {
+      dev_free(states); dev_free(offdw); dev_free(rkup); dev_free(wl); dev_free(wn);
+      dev_free(terms); dev_free(vid); dev_free(dtab); dev_free(xtab); dev_free(totals);
+    }
+  } t;
+  const int64_t nslice = (nrow + 63) / 64;
+  int rc = dev_upload(&t.states, hd.states.data(), hd.states.size());
+  rc |= dev_upload(&t.offdw, hd.off_dw.data(), hd.off_dw.size());
+  rc |= dev_upload(&t.rkup, hd.rk_up.data(), hd.rk_up.size());
+  if (nterms) rc |= dev_upload(&t.terms, hd.terms.data(), hd.terms.size());
+  rc |= dev_upload(&t.vid, vid.data(), vid.size());
+  rc |= dev_upload(&t.dtab, hd.dtab.data(), hd.dtab.size());
+  rc |= dev_upload(&t.xtab, hd.xtab.data(), hd.xtab.size());
+  if (rc) return 1;
+  EDIGPU_HIP(hipMalloc((void**)&t.wl, (size_t)nslice * sizeof(int32_t)));
+  EDIGPU_HIP(hipMalloc((void**)&t.wn, (size_t)nslice * sizeof(int32_t)));
+  EDIGPU_HIP(hipMalloc((void**)&t.totals, 4 * sizeof(unsigned long long)));
+  EDIGPU_HIP(hipMemset(t.totals, 0, 4 * sizeof(unsigned long long)));
+  BuildArgs a;
+  a.nrow = nrow;
+  a.row_first = hd.row_first;
+  a.lo = hd.row_first;
+  a.hi = hd.row_first + nrow;
+  a.ns = hd.ns;
+  a.norb = hd.norb;
+  a.nterms = nterms;
+  a.states = t.states;
+  a.off_dw = t.offdw;
+  a.rk_up = t.rkup;
+  a.terms = t.terms;
+  a.vid = t.vid;
+  a.dtab = t.dtab;
+  a.xtab = t.xtab;
+  if (launch_build_count(a, t.wl, t.wn, t.totals, nullptr)) return 1;
+  std::vector<int32_t> wl((size_t)nslice), wn((size_t)nslice);
+  unsigned long long tot[4];
+  EDIGPU_HIP(hipMemcpy(wl.data(), t.wl, wl.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  EDIGPU_HIP(hipMemcpy(wn.data(), t.wn, wn.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  EDIGPU_HIP(hipMemcpy(tot, t.totals, sizeof(tot), hipMemcpyDeviceToHost));
+  const int maxl = (int)(tot[2] & 0xFFFFFFFFull), maxn = (int)(tot[3] & 0xFFFFFFFFull);
+  if (maxl > 160 || maxn > 160) return 2;  // rows too long for the LDS sort buffers
+  auto finish = [&](DevCsr& d, const std::vector<int32_t>& w, int64_t nent, int maxlen, int which) -> int {
+    d = DevCsr();
+    d.nrow = nrow;
+    d.nnz = nent + (which == 0 ? nrow : 0);  // the loc block also holds the diagonal
+    d.avg_row = (double)d.nnz / (double)nrow;
+    if (nent == 0 && which == 1) return 0;   // no non-local block on a single shard
+    std::vector<int32_t> sp((size_t)nslice + 1, 0);
+    int64_t acc = 0;
+    for (int64_t k = 0; k < nslice; k++) {
+      acc += w[k];
+      if (acc >= ((int64_t)1 << 31) / 64) return 2;
+      sp[k + 1] = (int32_t)acc;
+    }
+    if (nent > 0 && (double)acc * 64.0 > 1.6 * (double)nent) return 2;  // too ragged for SELL
+    d.sell = 1;
+    d.sell_packed = 1;
+    d.nslice = nslice;
+    if (dev_upload(&d.sell_ptr, sp.data(), sp.size())) return 1;
+    if (dev_upload(&d.sell_dict, dict.data(), dict.size())) return 1;
+    EDIGPU_HIP(hipMalloc((void**)&d.sell_pk, (size_t)std::max<int64_t>(acc, 1) * 64 * sizeof(uint32_t)));
+    if (which == 0) EDIGPU_HIP(hipMalloc((void**)&d.sell_diag, (size_t)nrow * 2 * sizeof(double)));
+    return launch_build_fill(a, which, maxlen, d.sell_ptr, d.sell_pk, d.sell_diag, nullptr);
+  };
+  int r0 = finish(s->loc, wl, (int64_t)tot[0], maxl, 0);
+  if (r0) return r0;
+  int r1 = finish(s->nonloc, wn, (int64_t)tot[1], maxn, 1);
+  if (r1) return r1;
+  EDIGPU_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
 static int ensure_workspace(edigpu_sector* s) {
   const int64_t len = s->nloc * (s->is_complex ? 2 : 1);
   if (s->d_vin && s->ws_len == len) return 0;
@@ -740,6 +848,41 @@ int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, i
   }
   *h = nullptr;
   if (ensure_device()) return 1;
+  if (!env_flag("EDIGPU_FLAT_HOSTBUILD")) {
+    // generate the stored image on the device from the on-the-fly description (kernels_build.hip);
+    // the host CSR builder below is the fallback and what edigpu_csr_export materialises
+    HostDirect hd;
+    std::string e = build_direct(*model, sector, row_first, row_count, hd);
+    if (!e.empty()) {
+      set_error(e);
+      return 1;
+    }
+    if (hd.dim == 0) {
+      set_error("edigpu_flat_build: empty sector");
+      return 1;
+    }
+    std::unique_ptr<edigpu_sector> s(new edigpu_sector());
+    s->kind = 1;
+    s->is_complex = 1;
+    s->device = g_device;
+    s->dim = hd.dim;
+    s->nloc = hd.row_count;
+    s->row_first = hd.row_first;
+    s->model = *model;
+    s->sec_a = sector;
+    s->lazy_export = true;
+    const int rc = build_flat_on_device(s.get(), hd);
+    if (rc == 0) {
+      if (finish_handle(s.get())) {
+        edigpu_destroy(s.release());
+        return 1;
+      }
+      *h = s.release();
+      return 0;
+    }
+    edigpu_destroy(s.release());
+    if (rc == 1) return 1;
+  }
   HostFlat hf;
   std::string e = build_flat(*model, sector, row_first, row_count, hf);
   if (!e.empty()) {
@@ -928,6 +1071,19 @@ int edigpu_csr_export(edigpu_handle s, int64_t* rowptr, int32_t* col, double* va
     return 1;
   }
   EDIGPU_HIP(hipSetDevice(s->device));
+  if (s->lazy_export) {
+    // device-built sector: the CSR image only exists if somebody asks for it
+    HostFlat hf;
+    std::string e = build_flat(s->model, s->sec_a, s->row_first, s->nloc, hf);
+    if (!e.empty()) {
+      set_error(e);
+      return 1;
+    }
+    if (rowptr) std::copy(hf.h.rowptr.begin(), hf.h.rowptr.end(), rowptr);
+    if (col) std::copy(hf.h.col.begin(), hf.h.col.end(), col);
+    if (val) std::copy(hf.h.val.begin(), hf.h.val.end(), val);
+    return 0;
+  }
   const int w = s->is_complex ? 2 : 1;
   const int64_t n = s->nloc;
   std::vector<int64_t> rl((size_t)n + 1), rn((size_t)n + 1);

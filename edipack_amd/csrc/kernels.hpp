@@ -56,4 +56,24 @@ int vec_add_dot(int64_t n, const double* vin, double* vout, const double* tmp, d
 int vec_axpy_nrm2(int64_t n, const double* vin, double* vout, const double* alpha, double* out, double* work, hipStream_t st);
 int vec_scale(int64_t n, double* v, const double* nrm2, hipStream_t st);
 
+// ---- on-device construction of the stored flat image (kernels_build.hip) ----
+struct BuildArgs {
+  int64_t nrow, row_first;  // local rows, first global row
+  int64_t lo, hi;           // column window of the loc block (global indices)
+  int ns, norb, nterms;
+  const int32_t* states;
+  const int32_t* off_dw;
+  const int32_t* rk_up;
+  const DirectTerm* terms;
+  const uint8_t* vid;  // [2 * nterms]: dictionary id of +coef for (term, forward / reverse); id ^ 1 = -coef
+  const double* dtab;
+  const double* xtab;
+};
+// widths per 64-row slice of the loc / non-local block; totals = {entries loc, entries non-local,
+// longest row loc, longest row non-local}
+int launch_build_count(const BuildArgs& a, int32_t* width_loc, int32_t* width_non, unsigned long long* totals,
+                       hipStream_t st);
+int launch_build_fill(const BuildArgs& a, int which, int maxlen, const int32_t* sptr, uint32_t* pk, double* diag,
+                      hipStream_t st);
+
 }  // namespace edigpu

@@ -216,6 +216,35 @@ def test_flat_builder_and_apply_match_oracle(gpu, mode, bath, norb, nbath, sec):
     hg.destroy()
 
 
+@pytest.mark.parametrize("mode,bath,norb,nbath,sec", [
+    ("superc", "hybrid", 2, 6, 0),    # Ns=8: 12 870 rows, 202 slices, several workgroups of the builder
+    ("nonsu2", "hybrid", 3, 5, 8),    # Ns=8, N=8: 12 870 rows, spin-flip hybridisation
+    ("nonsu2", "general", 2, 3, 7),   # replica matrices with spin-flip blocks, Ns=8
+])
+def test_flat_device_built_midsize(gpu, mode, bath, norb, nbath, sec, monkeypatch):
+    """The stored image generated on the device (kernels_build.hip) against the oracle's H*v, and against
+    the host-built image of the same sector (EDIGPU_FLAT_HOSTBUILD=1: CSR builder + SELL conversion)."""
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models(mode, bath, norb, nbath, seed=21)
+    ho = O.HFlat(om, sec)
+    rng = np.random.default_rng(8)
+    v = rng.standard_normal(ho.dim) + 1j * rng.standard_normal(ho.dim)
+    ref = ho.matvec(v)
+    hg = SectorHamiltonian.flat_from_model(pm, sec)
+    got_dev = hg.apply(v)
+    rp, col, val = hg.export_csr()          # lazily host-built CSR of a device-built sector
+    assert rp[-1] == len(col) and np.all(np.diff(rp) >= 1)
+    hg.destroy()
+    monkeypatch.setenv("EDIGPU_FLAT_HOSTBUILD", "1")
+    hh = SectorHamiltonian.flat_from_model(pm, sec)
+    got_host = hh.apply(v)
+    hh.destroy()
+    assert rel_err(got_dev, ref) < TOL
+    assert rel_err(got_host, ref) < TOL
+    assert rel_err(got_dev, got_host) < 1e-14
+
+
 def test_flat_two_shards_loc_nonloc(gpu):
     """Row shards with the loc / non-loc column split (spMatVec_mpi_superc_main data flow)."""
     import torch
