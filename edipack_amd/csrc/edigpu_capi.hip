@@ -421,6 +421,76 @@ static int setup_flat(edigpu_sector* s, int64_t nrow_local, int64_t ncol_global,
   return finish_handle(s);
 }
 
+// ed_total_ud = F sector: factor matrices as ELL ([slot][row] per axis, padding col = own row, val = 0),
+// diagonal explicit (hd != null) or as per-axis tables + impurity table
+static int setup_orbs(edigpu_sector* s, const HostOrbs& ho, const double* hd) {
+  s->kind = 3;
+  s->is_complex = 0;
+  s->device = g_device;
+  s->dim = s->nloc = ho.dim;
+  s->row_first = 0;
+  OrbsArgs& a = s->orbs;
+  a = OrbsArgs();
+  a.naxes = ho.naxes;
+  a.dim = ho.dim;
+  std::vector<int32_t> ecol;
+  std::vector<double> eval, eax;
+  std::vector<uint8_t> imp;
+  int64_t stride = 1;
+  for (int k = 0; k < ho.naxes; k++) {
+    const int64_t d = ho.dims[k];
+    a.dims[k] = d;
+    a.stride[k] = stride;
+    stride *= d;
+    const HostCsr& f = ho.fac[k];
+    int w = 0;
+    for (int64_t i = 0; i < d; i++) w = std::max<int>(w, (int)(f.rowptr[i + 1] - f.rowptr[i]));
+    a.width[k] = w;
+    a.elloff[k] = (int64_t)ecol.size();
+    const size_t base = ecol.size();
+    ecol.resize(base + (size_t)w * d);
+    eval.resize(base + (size_t)w * d, 0.0);
+    for (int sl = 0; sl < w; sl++)
+      for (int64_t i = 0; i < d; i++) ecol[base + (size_t)sl * d + i] = (int32_t)i;
+    for (int64_t i = 0; i < d; i++) {
+      int sl = 0;
+      for (int64_t q = f.rowptr[i]; q < f.rowptr[i + 1]; q++, sl++) {
+        ecol[base + (size_t)sl * d + i] = f.col[q];
+        eval[base + (size_t)sl * d + i] = f.val[q];
+      }
+    }
+    a.off[k] = (int)eax.size();
+    if (!hd) {
+      eax.insert(eax.end(), ho.eax[k].begin(), ho.eax[k].end());
+      imp.insert(imp.end(), ho.impbit[k].begin(), ho.impbit[k].end());
+    }
+  }
+  if (ecol.empty()) {  // no off-diagonal element at all: keep valid pointers
+    ecol.push_back(0);
+    eval.push_back(0.0);
+  }
+  int32_t* dcol = nullptr;
+  double *dval = nullptr, *dhd = nullptr, *deax = nullptr, *dx = nullptr;
+  uint8_t* dimp = nullptr;
+  if (dev_upload(&dcol, ecol.data(), ecol.size())) return 1;
+  a.ell_col = dcol;
+  if (dev_upload(&dval, eval.data(), eval.size())) return 1;
+  a.ell_val = dval;
+  if (hd) {
+    if (dev_upload(&dhd, hd, (size_t)ho.dim)) return 1;
+    a.hd = dhd;
+  } else {
+    if (dev_upload(&deax, eax.data(), eax.size())) return 1;
+    a.eax = deax;
+    if (dev_upload(&dimp, imp.data(), imp.size())) return 1;
+    a.impbit = dimp;
+    if (dev_upload(&dx, ho.xtab.data(), ho.xtab.size())) return 1;
+    a.xtab = dx;
+  }
+  s->h_orbs_fac = ho.fac;
+  return finish_handle(s);
+}
+
 // Stored flat image generated on the device from the on-the-fly description (kernels_build.hip).
 // Returns 0 = built, 2 = not applicable (caller falls back to the host CSR builder), 1 = error.
 static int build_flat_on_device(edigpu_sector* s, const HostDirect& hd) {
@@ -549,6 +619,11 @@ static int ensure_workspace(edigpu_sector* s) {
 static int apply_any(edigpu_sector* s, const double* v_local, const double* v_full, double* hv,
                      int phase, hipStream_t st) {
   if (s->kind == 0) return launch_normal(s, v_local, v_full, hv, phase, st);
+  if (s->kind == 3) {
+    // ed_total_ud = F: single shard only (phase 1 = everything, phase 2 = nothing left to add)
+    if (phase == 2) return 0;
+    return launch_orbs(s, v_full, hv, st);
+  }
   if (s->kind == 2) {
     // on-the-fly: like directMatVec_MPI_* the whole product needs the gathered vector
     // (reference ED_NONSU2/ED_HAMILTONIAN_NONSU2_DIRECT_HxV.f90:220-223: gather first, then compute)
@@ -941,6 +1016,92 @@ int edigpu_direct_build(edigpu_handle* h, const edigpu_model* model, int sector,
   return 0;
 }
 
+int edigpu_orbs_build(edigpu_handle* h, const edigpu_model* model, const int32_t* nups, const int32_t* ndws) {
+  if (!h || !model || !nups || !ndws) {
+    set_error("edigpu_orbs_build: NULL argument");
+    return 1;
+  }
+  *h = nullptr;
+  if (ensure_device()) return 1;
+  HostOrbs ho;
+  std::string e = build_orbs(*model, nups, ndws, ho);
+  if (!e.empty()) {
+    set_error(e);
+    return 1;
+  }
+  if (ho.dim == 0) {
+    set_error("edigpu_orbs_build: empty sector");
+    return 1;
+  }
+  std::unique_ptr<edigpu_sector> s(new edigpu_sector());
+  s->model = *model;
+  if (setup_orbs(s.get(), ho, nullptr)) {
+    edigpu_destroy(s.release());
+    return 1;
+  }
+  *h = s.release();
+  return 0;
+}
+
+int edigpu_orbs_create(edigpu_handle* h, int naxes, const int64_t* dims, const double* hd,
+                       const int64_t* fac_rowptr, const int32_t* fac_col, const double* fac_val) {
+  if (!h || !dims || !hd || !fac_rowptr) {
+    set_error("edigpu_orbs_create: NULL argument");
+    return 1;
+  }
+  *h = nullptr;
+  if (ensure_device()) return 1;
+  if (naxes < 2 || naxes > kOrbsMaxAxes || (naxes & 1)) {
+    set_error("edigpu_orbs_create: naxes must be 2*Norb <= 2*EDIGPU_MAXORB");
+    return 1;
+  }
+  HostOrbs ho;
+  ho.naxes = naxes;
+  ho.dims.assign(dims, dims + naxes);
+  ho.fac.resize(naxes);
+  ho.dim = 1;
+  int64_t row0 = 0;
+  for (int k = 0; k < naxes; k++) {
+    const int64_t d = dims[k];
+    if (d < 1 || ho.dim * d >= ((int64_t)1 << 31)) {
+      set_error("edigpu_orbs_create: bad factor dimension / sector dimension >= 2^31");
+      return 1;
+    }
+    ho.dim *= d;
+    HostCsr& f = ho.fac[k];
+    f.nrow = f.ncol = d;
+    f.rowptr.resize(d + 1);
+    const int64_t b0 = fac_rowptr[row0];
+    for (int64_t i = 0; i <= d; i++) {
+      f.rowptr[i] = fac_rowptr[row0 + i] - b0;
+      if (i > 0 && f.rowptr[i] < f.rowptr[i - 1]) {
+        set_error("edigpu_orbs_create: fac_rowptr not monotone");
+        return 1;
+      }
+    }
+    const int64_t nnz = f.rowptr[d];
+    if (nnz > 0 && (!fac_col || !fac_val)) {
+      set_error("edigpu_orbs_create: fac_col/fac_val NULL");
+      return 1;
+    }
+    f.col.assign(fac_col + b0, fac_col + b0 + nnz);
+    f.val.assign(fac_val + b0, fac_val + b0 + nnz);
+    for (int32_t c : f.col)
+      if (c < 0 || c >= d) {
+        set_error("edigpu_orbs_create: column index out of range");
+        return 1;
+      }
+    row0 += d;
+  }
+  std::unique_ptr<edigpu_sector> s(new edigpu_sector());
+  if (setup_orbs(s.get(), ho, hd)) {
+    edigpu_destroy(s.release());
+    return 1;
+  }
+  *h = s.release();
+  return 0;
+}
+
 int edigpu_sector_dim(const edigpu_model* model, int q1, int q2, int64_t* dim) {
   if (!model || !dim) {
     set_error("edigpu_sector_dim: NULL argument");
@@ -972,6 +1133,10 @@ int edigpu_info(edigpu_handle s, int64_t info[10]) {
   } else if (s->kind == 2) {
     info[7] = s->dir_nterms;
     info[8] = 0;
+  } else if (s->kind == 3) {
+    info[7] = 0;
+    for (const HostCsr& f : s->h_orbs_fac) info[7] += f.nnz();
+    info[8] = s->orbs.naxes;
   } else {
     info[7] = s->loc.nnz;
     info[8] = s->nonloc.nnz;
@@ -993,6 +1158,10 @@ int edigpu_algorithmic_bytes(edigpu_handle s, double* bytes_hv, double* bytes_st
     b = 3.0 * sz * n;
     if (s->has_nd) b += (sz + 4.0) * (double)s->nd_nnz + 4.0 * (n + 1.0);
     b += (sz + 4.0) * (double)(s->h_up.nnz() + s->h_dw.nnz()) + 4.0 * (double)(s->dim_up + s->dim_dw + 2);
+  } else if (s->kind == 3) {
+    // orbs: diagonal + 2 vectors + the small factor matrices
+    b = 3.0 * sz * (double)s->nloc;
+    for (const HostCsr& f : s->h_orbs_fac) b += (sz + 4.0) * (double)f.nnz() + 4.0 * (double)(f.nrow + 1);
   } else if (s->kind == 2) {
     // direct: 2 vectors + the sector map (B = 2*s*Dim + 4*DimEl)
     b = 2.0 * sz * (double)s->nloc + 4.0 * (double)s->nloc;
@@ -1443,6 +1612,10 @@ int edigpu_destroy(edigpu_handle s) {
   free_csr(s->nd);
   free_csr(s->loc);
   free_csr(s->nonloc);
+  for (const void* q : {(const void*)s->orbs.ell_col, (const void*)s->orbs.ell_val, (const void*)s->orbs.hd,
+                        (const void*)s->orbs.eax, (const void*)s->orbs.impbit, (const void*)s->orbs.xtab})
+    if (q) (void)hipFree(const_cast<void*>(q));
+  s->orbs = OrbsArgs();
   dev_free(s->d_dir_states);
   dev_free(s->d_dir_offdw);
   dev_free(s->d_dir_rkup);

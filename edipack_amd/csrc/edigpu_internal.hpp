@@ -48,6 +48,24 @@ struct DevCsr {
   double* sell_diag = nullptr;
 };
 
+// ed_total_ud = F ("orbs") sector: kernel argument block (kernels_orbs.hip); all pointers are device memory
+constexpr int kOrbsMaxAxes = 2 * EDIGPU_MAXORB;
+struct OrbsArgs {
+  int naxes = 0;
+  int64_t dim = 0;
+  int64_t dims[kOrbsMaxAxes] = {0};
+  int64_t stride[kOrbsMaxAxes] = {0};
+  int off[kOrbsMaxAxes] = {0};        // offset of axis k inside eax / impbit
+  int width[kOrbsMaxAxes] = {0};      // ELL width of factor k
+  int64_t elloff[kOrbsMaxAxes] = {0};  // offset of factor k inside ell_col / ell_val ([slot][row])
+  const int32_t* ell_col = nullptr;
+  const double* ell_val = nullptr;
+  const double* hd = nullptr;         // explicit diagonal (hand-over) or null: factored tables below
+  const double* eax = nullptr;
+  const uint8_t* impbit = nullptr;
+  const double* xtab = nullptr;
+};
+
 // ELL (column-major [slot][row]) image of a small square factor matrix
 struct DevEll {
   int64_t nrow = 0, pitch = 0;
@@ -64,7 +82,7 @@ struct DevEll {
 }  // namespace edigpu
 
 struct edigpu_sector {
-  int kind = 0;        // 0 normal (Kronecker), 1 flat CSR, 2 direct (on-the-fly superc/nonsu2)
+  int kind = 0;        // 0 normal (Kronecker), 1 flat CSR, 2 direct (on-the-fly superc/nonsu2), 3 orbs (ed_total_ud=F)
   int is_complex = 0;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -99,6 +117,10 @@ struct edigpu_sector {
   int sec_a = 0, sec_b = 0;
   // ---- flat ----
   edigpu::DevCsr loc, nonloc; // local rows; loc columns are shard-relative, nonloc global
+  // ---- orbs (ed_total_ud = F) ----
+  edigpu::OrbsArgs orbs;
+  std::vector<edigpu::HostCsr> h_orbs_fac;  // kept for export (tiny)
+  std::vector<double> h_orbs_hd;            // explicit diagonal when handed over
   // ---- direct (on-the-fly) ----
   int dir_ns = 0, dir_norb = 0, dir_nterms = 0;
   int32_t* d_dir_states = nullptr;

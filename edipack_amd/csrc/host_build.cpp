@@ -703,6 +703,100 @@ std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int
   return "";
 }
 
+std::string build_orbs(const edigpu_model& m, const int* nups, const int* ndws, HostOrbs& out, bool explicit_diag) {
+  std::string e = check_model(m);
+  if (!e.empty()) return e;
+  if (m.ed_mode != 0) return "edigpu_orbs_build: model.ed_mode is not normal";
+  if (m.bath_type != 0) return "edigpu_orbs_build: ed_total_ud=F needs bath_type=normal";
+  Idx ix(m);
+  const int norb = m.norb, nbath = m.nbath, nso = 1 + nbath, sd = m.nspin - 1;
+  out = HostOrbs();
+  out.naxes = 2 * norb;
+  out.dims.resize(out.naxes);
+  out.fac.resize(out.naxes);
+  out.eax.resize(out.naxes);
+  out.impbit.resize(out.naxes);
+  out.factored = true;
+  out.dim = 1;
+  for (int k = 0; k < out.naxes; k++) {
+    const int a = k < norb ? k : k - norb, s = k < norb ? 0 : sd;
+    const int n = k < norb ? nups[a] : ndws[a];
+    if (n < 0 || n > nso) return "edigpu_orbs_build: bad sector";
+    CombBasis b;  // chain of orbital a: level 0 = impurity, level kp = bath site kp
+    b.init(nso, n);
+    const int64_t d = b.size();
+    out.dims[k] = d;
+    if (out.dim * d >= ((int64_t)1 << 31)) return "edigpu_orbs_build: sector dimension >= 2^31";
+    out.dim *= d;
+    // one-body chain: hybridisation hops imp <-> bath, bath energies (stored/Orbs/H_up.f90, H_local.f90)
+    OneBody ob;
+    ob.ns = nso;
+    ob.a.assign((size_t)nso * nso, 0.0);
+    ob.eps.assign(nso, 0.0);
+    for (int kp = 0; kp < nbath; kp++) {
+      const double v = ix.bath(m.bv, s, a, kp);
+      ob.a[0 * nso + (1 + kp)] += v;
+      ob.a[(1 + kp) * nso + 0] += v;
+      ob.eps[1 + kp] = ix.bath(m.be, s, a, kp);
+    }
+    hop_csr(ob, b, out.fac[k]);
+    out.eax[k].resize(d);
+    out.impbit[k].resize(d);
+    for (int64_t i = 0; i < d; i++) {
+      const uint32_t st = (uint32_t)b.states[i];
+      double x = 0.0;
+      for (int p = 1; p < nso; p++)
+        if ((st >> p) & 1u) x += ob.eps[p];
+      out.eax[k][i] = x;
+      out.impbit[k][i] = (uint8_t)(st & 1u);
+    }
+  }
+  // impurity part of the diagonal as a table over the 2*Norb impurity occupations (bit k = axis k)
+  out.xtab.assign((size_t)1 << out.naxes, 0.0);
+  for (uint32_t bits = 0; bits < (1u << out.naxes); bits++) {
+    double x = 0.0;
+    auto nu = [&](int a) { return (double)((bits >> a) & 1u); };
+    auto nd = [&](int a) { return (double)((bits >> (norb + a)) & 1u); };
+    for (int a = 0; a < norb; a++) {
+      x += ix.hloc(0, 0, a, a).real() * nu(a) + ix.hloc(sd, sd, a, a).real() * nd(a) - m.xmu * (nu(a) + nd(a));
+      x += ix.uloc(a) * nu(a) * nd(a);
+      for (int b = a + 1; b < norb; b++) {
+        x += ix.ust(a, b) * (nu(a) * nd(b) + nu(b) * nd(a));
+        x += (ix.ust(a, b) - ix.jh(a, b)) * (nu(a) * nu(b) + nd(a) * nd(b));
+      }
+    }
+    if (m.hfmode) {
+      for (int a = 0; a < norb; a++) x += -0.5 * ix.uloc(a) * (nu(a) + nd(a)) + 0.25 * ix.uloc(a);
+      for (int a = 0; a < norb; a++)
+        for (int b = a + 1; b < norb; b++) {
+          // NB: 0.25 per pair here, 0.5 in the ed_total_ud=T builder -- as in the reference
+          // (stored/Orbs/H_local.f90:61-62 vs stored/H_local.f90:63-64)
+          const double ust = ix.ust(a, b), ujj = ust - ix.jh(a, b), nn = nu(a) + nd(a) + nu(b) + nd(b);
+          x += -0.5 * ust * nn + 0.25 * ust - 0.5 * ujj * nn + 0.25 * ujj;
+        }
+    }
+    out.xtab[bits] = x;
+  }
+  if (explicit_diag) {
+    out.hd.resize((size_t)out.dim);
+    std::vector<int64_t> idx(out.naxes, 0);
+    for (int64_t i = 0; i < out.dim; i++) {
+      double x = 0.0;
+      uint32_t bits = 0;
+      for (int k = 0; k < out.naxes; k++) {
+        x += out.eax[k][idx[k]];
+        bits |= (uint32_t)out.impbit[k][idx[k]] << k;
+      }
+      out.hd[i] = x + out.xtab[bits];
+      for (int k = 0; k < out.naxes; k++) {
+        if (++idx[k] < out.dims[k]) break;
+        idx[k] = 0;
+      }
+    }
+  }
+  return "";
+}
+
 std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
                          HostDirect& out) {
   std::string e = check_model(m);

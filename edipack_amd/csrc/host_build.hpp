@@ -101,7 +101,26 @@ struct HostDirect {
 int model_ns(const edigpu_model& m);
 int64_t binomial(int n, int k);
 
+// ed_total_ud = F ("orbs") image of a normal-mode sector with per-orbital quantum numbers: the vector is the
+// tensor [iup_1..iup_Norb, idw_1..idw_Norb] (first index fastest); H = Hd + one small factor per axis
+// (reference ed_buildh_normal_orbs, ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:273-496).
+struct HostOrbs {
+  int naxes = 0;                      // 2 * Norb: up factors then down factors
+  int64_t dim = 0;
+  std::vector<int64_t> dims;          // [naxes]
+  std::vector<HostCsr> fac;           // [naxes] dims[k] x dims[k], real
+  std::vector<double> hd;             // explicit diagonal (hand-over / export)
+  // factored diagonal (library-built): Hd(i) = sum_k eax[k][idx_k] + xtab[imp bits], imp bit of axis k =
+  // impbit[k][idx_k] at bit position k
+  bool factored = false;
+  std::vector<std::vector<double>> eax;
+  std::vector<std::vector<uint8_t>> impbit;
+  std::vector<double> xtab;           // 2^naxes
+};
+
 // returns "" on success, else an error message
+std::string build_orbs(const edigpu_model& m, const int* nups, const int* ndws, HostOrbs& out,
+                       bool explicit_diag = false);
 // explicit_arrays = false skips the O(Dim) images (hd, the Hnd CSR): the factored tables are all the
 // kernels need; the arrays are only materialised for export (edigpu_normal_export).
 std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_first,

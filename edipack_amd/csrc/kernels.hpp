@@ -56,6 +56,9 @@ int vec_add_dot(int64_t n, const double* vin, double* vout, const double* tmp, d
 int vec_axpy_nrm2(int64_t n, const double* vin, double* vout, const double* alpha, double* out, double* work, hipStream_t st);
 int vec_scale(int64_t n, double* v, const double* nrm2, hipStream_t st);
 
+// ---- ed_total_ud = F sectors (kernels_orbs.hip) ----
+int launch_orbs(const edigpu_sector* s, const double* v, double* hv, hipStream_t st);
+
 // ---- on-device construction of the stored flat image (kernels_build.hip) ----
 struct BuildArgs {
   int64_t nrow, row_first;  // local rows, first global row

@@ -159,6 +159,40 @@ class SectorHamiltonian:
         return cls(h)
 
     @classmethod
+    def orbs_from_model(cls, model: ImpurityModel, nups, ndws) -> "SectorHamiltonian":
+        """ed_total_ud=F: sector with per-orbital (Nup_a, Ndw_a) (build_Hv_sector_normal -> ed_buildh_normal_orbs)."""
+        no = model.norb
+        a = np.ascontiguousarray(nups, dtype=np.int32)
+        b = np.ascontiguousarray(ndws, dtype=np.int32)
+        if a.shape != (no,) or b.shape != (no,):
+            raise capi.EdigpuError("orbs_from_model: nups/ndws need Norb entries each")
+        h = C.c_void_p()
+        cm = model.to_c()
+        capi.check(capi.lib().edigpu_orbs_build(C.byref(h), C.byref(cm), capi.pi32(a), capi.pi32(b)),
+                   "edigpu_orbs_build")
+        return cls(h)
+
+    @classmethod
+    def orbs_from_arrays(cls, dims, hd, factors) -> "SectorHamiltonian":
+        """Hand over spH0d and spH0ups(1:Norb), spH0dws(1:Norb) (each a (rowptr, col, val) triple, in that order)."""
+        dims = np.ascontiguousarray(dims, dtype=np.int64)
+        hd = np.ascontiguousarray(hd, dtype=np.float64)
+        rps, cols, vals, base = [np.zeros(1, np.int64)], [], [], 0
+        for (rp, col, val) in factors:
+            rp = np.asarray(rp, dtype=np.int64)
+            rps.append(rp[1:] + base)
+            base += int(rp[-1])
+            cols.append(np.asarray(col, dtype=np.int32))
+            vals.append(np.asarray(val, dtype=np.float64))
+        rp = np.ascontiguousarray(np.concatenate(rps))
+        col = np.ascontiguousarray(np.concatenate(cols)) if cols else np.zeros(0, np.int32)
+        val = np.ascontiguousarray(np.concatenate(vals)) if vals else np.zeros(0, np.float64)
+        h = C.c_void_p()
+        capi.check(capi.lib().edigpu_orbs_create(C.byref(h), len(dims), capi.pi64(dims), capi.pd(hd), capi.pi64(rp),
+                                                 capi.pi32(col), capi.pd(val)), "edigpu_orbs_create")
+        return cls(h)
+
+    @classmethod
     def normal_from_arrays(cls, dim_up, dim_dw, hd, up, dw, nd=None, dw_first=0, dw_count=None):
         """Hand over spH0d / spH0ups(1) / spH0dws(1) / spH0nd as (rowptr, col, val) triples."""
         if dw_count is None:

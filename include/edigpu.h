@@ -155,6 +155,21 @@ int edigpu_flat_build(edigpu_handle *h, const edigpu_model *model, int sector, i
 int edigpu_direct_build(edigpu_handle *h, const edigpu_model *model, int sector, int64_t row_first,
                         int64_t row_count);
 
+/*
+ * ed_total_ud = F ("orbs") normal-mode sector: quantum numbers (Nup_a, Ndw_a) per orbital, bath_type = normal,
+ * no Jx/Jp.  The vector is the tensor [iup_1..iup_Norb, idw_1..idw_Norb] (first index fastest, state2indices,
+ * ED_AUX_FUNX.f90) and H = Hd + sum over the 2*Norb axes of one (1+Nbath)-level factor each.
+ * Takes the place of build_Hv_sector_normal with ed_total_ud=F -> ed_buildh_normal_orbs
+ * (ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:273-496) and spMatVec_normal_orbs (:652-761).
+ * Single shard only (the MPI variant :932-1082 is not built).  All apply / Lanczos entry points work on it.
+ */
+int edigpu_orbs_build(edigpu_handle *h, const edigpu_model *model, const int32_t *nups, const int32_t *ndws);
+/* hand-over of the reference's own arrays: spH0d (dim values) and spH0ups(1:Norb), spH0dws(1:Norb) as ONE
+ * CSR with the rows of the 2*Norb factors stacked (rowptr of sum(dims)+1 entries, columns local to their
+ * factor, 0-based).  dims[k]: k < Norb = DimUps(k+1), k >= Norb = DimDws(k-Norb+1). */
+int edigpu_orbs_create(edigpu_handle *h, int naxes, const int64_t *dims, const double *hd,
+                       const int64_t *fac_rowptr, const int32_t *fac_col, const double *fac_val);
+
 /* sector dimensions (get_normal/superc/nonsu2_sector_dimension, ED_SETUP.f90:998-1033) */
 int edigpu_sector_dim(const edigpu_model *model, int q1, int q2, int64_t *dim);
 

@@ -730,3 +730,4 @@ int orc_lanc_tridiag_flat(const orc_hflat *h, double *vin, int nitermax, double 
 }
 
 #include "edipack_oracle_flat.inc"
+#include "edipack_oracle_orbs.inc"

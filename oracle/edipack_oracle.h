@@ -140,6 +140,26 @@ int orc_lanc_tridiag_normal(const orc_hnormal *h, double *vin, int nitermax, dou
 int orc_lanc_tridiag_flat(const orc_hflat *h, double *vin, int nitermax, double *alanc,
                           double *blanc, double threshold);
 
+/* ed_total_ud = F ("orbs") variant: per-orbital quantum numbers, H = Hd + sum_a (.. (x) Hup_a (x) ..) +
+ * (.. (x) Hdw_a (x) ..) with (1+Nbath)-level factors.  ed_buildh_normal_orbs / spMatVec_normal_orbs
+ * (ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:273-496, :652-761).  fac[k], maps[k], dims[k]:
+ * k < Norb up-factor of orbital k, k >= Norb down-factor of orbital k - Norb. */
+typedef struct {
+  int norb, nsorb;
+  int nups[ORC_MAXORB], ndws[ORC_MAXORB];
+  int64_t dims[2 * ORC_MAXORB], dim;
+  int32_t *maps[2 * ORC_MAXORB];
+  double *hd;
+  orc_csr fac[2 * ORC_MAXORB];
+} orc_horbs;
+orc_horbs *orc_buildh_normal_orbs(const orc_model *m, const int *nups, const int *ndws);
+void orc_horbs_free(orc_horbs *h);
+void orc_horbs_sizes(const orc_horbs *h, int64_t out[16]);
+void orc_spmatvec_normal_orbs(const orc_horbs *h, const double *v, double *hv);
+void orc_horbs_dense(const orc_horbs *h, double *hmat);
+int orc_lanc_tridiag_orbs(const orc_horbs *h, double *vin, int nitermax, double *alanc, double *blanc,
+                          double threshold);
+
 /* accessors for ctypes */
 void orc_hnormal_sizes(const orc_hnormal *h, int64_t out[8]);
 void orc_hflat_sizes(const orc_hflat *h, int64_t out[4]);

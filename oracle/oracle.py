@@ -35,7 +35,7 @@ BATH_TYPES = {"normal": 0, "hybrid": 1, "replica": 2, "general": 3}
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (idempotent)."""
-    srcs = [os.path.join(HERE, f) for f in ("edipack_oracle.c", "edipack_oracle_flat.inc", "edipack_oracle.h")]
+    srcs = [os.path.join(HERE, f) for f in ("edipack_oracle.c", "edipack_oracle_flat.inc", "edipack_oracle_orbs.inc", "edipack_oracle.h")]
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return LIB_PATH
@@ -220,6 +220,15 @@ def lib() -> C.CDLL:
     L.orc_hnormal_dense.argtypes = [vp, dp]
     L.orc_lanc_tridiag_normal.restype = C.c_int
     L.orc_lanc_tridiag_normal.argtypes = [vp, dp, C.c_int, dp, dp, C.c_double]
+    ip = C.POINTER(C.c_int)
+    L.orc_buildh_normal_orbs.restype = vp
+    L.orc_buildh_normal_orbs.argtypes = [C.POINTER(OrcModel), ip, ip]
+    L.orc_horbs_free.argtypes = [vp]
+    L.orc_horbs_sizes.argtypes = [vp, i64p]
+    L.orc_spmatvec_normal_orbs.argtypes = [vp, dp, dp]
+    L.orc_horbs_dense.argtypes = [vp, dp]
+    L.orc_lanc_tridiag_orbs.restype = C.c_int
+    L.orc_lanc_tridiag_orbs.argtypes = [vp, dp, C.c_int, dp, dp, C.c_double]
     L.orc_buildh_superc_main.restype = vp
     L.orc_buildh_superc_main.argtypes = [C.POINTER(OrcModel), C.c_int]
     L.orc_buildh_nonsu2_main.restype = vp
@@ -316,6 +325,65 @@ class HNormal:
     def close(self):
         if self._h:
             self._L.orc_hnormal_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _HOrbs(C.Structure):
+    _fields_ = [("norb", C.c_int), ("nsorb", C.c_int), ("nups", C.c_int * MAXORB), ("ndws", C.c_int * MAXORB),
+                ("dims", C.c_int64 * (2 * MAXORB)), ("dim", C.c_int64),
+                ("maps", C.POINTER(C.c_int32) * (2 * MAXORB)), ("hd", C.POINTER(C.c_double)),
+                ("fac", _Csr * (2 * MAXORB))]
+
+
+class HOrbs:
+    """Oracle-built ed_total_ud=F sector (per-orbital quantum numbers): diagonal + one small factor per
+    (orbital, spin); index = [iup_1..iup_Norb, idw_1..idw_Norb], first fastest."""
+
+    def __init__(self, model: Model, nups, ndws):
+        self._L = lib()
+        self.model = model
+        self._s = to_struct(model)
+        no = model.norb
+        self.nups, self.ndws = tuple(int(x) for x in nups), tuple(int(x) for x in ndws)
+        a = (C.c_int * no)(*self.nups)
+        b = (C.c_int * no)(*self.ndws)
+        self._h = self._L.orc_buildh_normal_orbs(C.byref(self._s), a, b)
+        if not self._h:
+            raise RuntimeError("oracle: orbs build failed (needs bath_type=normal)")
+        hs = C.cast(self._h, C.POINTER(_HOrbs)).contents
+        self.norb, self.nsorb, self.dim = hs.norb, hs.nsorb, hs.dim
+        self.dims = [int(hs.dims[k]) for k in range(2 * no)]
+        self.maps = [np.ctypeslib.as_array(hs.maps[k], shape=(self.dims[k],)).copy() for k in range(2 * no)]
+        self.hd = np.ctypeslib.as_array(hs.hd, shape=(max(self.dim, 1),)).copy()[: self.dim]
+        self.fac = [_csr_arrays(hs.fac[k]) for k in range(2 * no)]
+
+    def matvec(self, v: np.ndarray) -> np.ndarray:
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        hv = np.empty_like(v)
+        self._L.orc_spmatvec_normal_orbs(self._h, _dp(v), _dp(hv))
+        return hv
+
+    def dense(self) -> np.ndarray:
+        out = np.empty((self.dim, self.dim))
+        self._L.orc_horbs_dense(self._h, _dp(out))
+        return out
+
+    def lanc_tridiag(self, vin: np.ndarray, nitermax: int, threshold: float = 0.0):
+        v = np.array(vin, dtype=np.float64, copy=True)
+        a = np.zeros(nitermax)
+        b = np.zeros(nitermax)
+        n = self._L.orc_lanc_tridiag_orbs(self._h, _dp(v), nitermax, _dp(a), _dp(b), threshold)
+        return a, b, n
+
+    def close(self):
+        if self._h:
+            self._L.orc_horbs_free(self._h)
             self._h = None
 
     def __del__(self):

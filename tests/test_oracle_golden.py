@@ -148,3 +148,33 @@ def test_oracle_lanczos_tridiag_reproduces_spectrum():
         b2 = b[k + 1] ** 2 if k + 1 < n else 0.0
         g = 1.0 / (zz - a[k] - b2 * g)
     assert abs(g - exact) / abs(exact) < 1e-10
+
+
+def test_oracle_orbs_spectrum_equals_total_ud():
+    """ed_total_ud=F restatement (no reference fixture exists for it) pinned through the fixture-pinned
+    ed_total_ud=T oracle: the spectrum of a (Nup,Ndw) sector is the union of the spectra of its
+    orbital-resolved sectors, up to the Hartree constant in which the reference's two builders differ
+    (stored/H_local.f90:63-64 adds 0.5 per orbital pair, stored/Orbs/H_local.f90:61-62 adds 0.25)."""
+    import itertools
+    om, _ = make_models("normal", "normal", 2, 2, seed=5, jxp=0.0)
+    hl = np.zeros_like(om.hloc)
+    for a in range(2):
+        hl[0, 0, a, a] = om.hloc[0, 0, a, a].real
+    om.hloc = hl
+    nso = om.nbath + 1
+    shift = 0.25 * om.ust + 0.25 * (om.ust - om.jh)
+    for nup, ndw in [(3, 3), (2, 4), (1, 1)]:
+        w_t = np.linalg.eigvalsh(O.HNormal(om, nup, ndw).dense())
+        ws = []
+        for nups in itertools.product(range(nso + 1), repeat=2):
+            for ndws in itertools.product(range(nso + 1), repeat=2):
+                if sum(nups) != nup or sum(ndws) != ndw:
+                    continue
+                h = O.HOrbs(om, nups, ndws)
+                d = h.dense()
+                assert np.allclose(d, d.T, atol=1e-14)
+                v = np.random.default_rng(1).standard_normal(h.dim)
+                assert rel_err(h.matvec(v), d @ v) < 1e-13
+                ws.append(np.linalg.eigvalsh(d))
+        ws = np.sort(np.concatenate(ws))
+        assert len(ws) == len(w_t) and np.max(np.abs(ws + shift - w_t)) < 1e-12
