@@ -13,7 +13,8 @@ roofline  : algorithmic bytes of one H*v in the reference's storage format (SURV
             edigpu_algorithmic_bytes) / average H*v launch duration from HIP events recorded
             around every launch of the timed steps.
 cpu_baseline (N=1 only): the CPU oracle (a port of the reference algorithm, NOT the reference
-            binary) timed single-threaded on a bounded sample of the same matrices.
+            binary) timed on a bounded sample of the same matrices: the reference's MPI row
+            decomposition on all host cores (OpenMP threads; the reported value) and the serial loop.
 """
 from __future__ import annotations
 
@@ -41,11 +42,38 @@ def _traffic_from_profiles(workload: str):
         return None
 
 
+def _host_cores() -> int:
+    """CPU cores this process may actually use: the cgroup quota when there is one (a GPU box hands out a
+    share of the host, e.g. 16 of 256 hardware threads), else the affinity mask."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(h, workload, budget_s: float = 15.0):
-    """Time the oracle's spMatVec restatement on the SAME matrices (exported from the handle)."""
+    """Time the oracle's spMatVec restatement on the SAME matrices (exported from the handle): single
+    thread in the reference's serial loop order, and the reference's MPI row decomposition with one OpenMP
+    thread per host core (the reported value; `cores` = threads used)."""
     import numpy as np
     from oracle import oracle as O
     rng = np.random.default_rng(12345)
+    cores = _host_cores()
     if h.kind == 0:
         hd, up, dw, nd = h.export_normal()
         ndarg = nd if nd[0][-1] > 0 else None
@@ -55,24 +83,41 @@ def cpu_baseline(h, workload, budget_s: float = 15.0):
 
         def one():
             O.normal_matvec_arrays(h.dim_up, h.dim_dw, hd, up, dw, ndarg, v, hv)
+
+        def one_mt():
+            O.normal_matvec_arrays_mt(h.dim_up, h.dim_dw, hd, up, dw, ndarg, v, hv, cores)
     else:
         rp, col, val = h.export_csr()
+        rp = np.ascontiguousarray(rp, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.complex128)
         v = (rng.standard_normal(h.dim) + 1j * rng.standard_normal(h.dim)).astype(np.complex128)
         v /= np.linalg.norm(v)
+        y = np.empty_like(v)
 
         def one():
             O.csr_matvec(rp, col, val, v)
-    t0 = time.perf_counter()
-    one()
-    t1 = time.perf_counter() - t0
-    n = int(max(2, min(200, budget_s / max(t1, 1e-6))))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        one()
-    dt = (time.perf_counter() - t0) / n
-    return {"value": 1.0 / dt, "unit": "H*v/s", "cores": 1, "kind": "port",
-            "sample": f"{n} H*v products of workload {workload} (same matrices as the GPU run), "
-                      f"oracle C restatement of spMatVec_*_main, 1 thread, {dt * 1e3:.1f} ms each"}
+
+        def one_mt():
+            O.csr_matvec_z_mt(rp, col, val, v, y, cores)
+
+    def rate(fn, budget):
+        t0 = time.perf_counter()
+        fn()
+        t1 = time.perf_counter() - t0
+        n = int(max(2, min(200, budget / max(t1, 1e-6))))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        return n, (time.perf_counter() - t0) / n
+
+    n1, dt1 = rate(one, 0.4 * budget_s)
+    nm, dtm = rate(one_mt, 0.6 * budget_s)
+    return {"value": 1.0 / dtm, "unit": "H*v/s", "cores": cores, "kind": "port",
+            "single_thread_value": 1.0 / dt1,
+            "sample": f"{nm} H*v products of workload {workload} (same matrices as the GPU run) with the oracle's C "
+                      f"restatement of the reference's MPI row decomposition on {cores} OpenMP threads "
+                      f"({dtm * 1e3:.1f} ms each); serial loop order, 1 thread: {n1} products, {dt1 * 1e3:.1f} ms each"}
 
 
 def run_single(args):

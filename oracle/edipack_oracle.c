@@ -596,6 +596,52 @@ void orc_spmatvec_normal_arrays(int64_t dimup, int64_t dimdw, const double *hd,
   orc_spmatvec_normal_main(&h, v, hv);
 }
 
+/* The same product with the reference's MPI decomposition (spMatVec_mpi_normal_main, :765-929: every rank
+ * owns a block of down indices) mapped on OpenMP threads of one host: thread t = rank t.  Shared memory
+ * replaces the two MPI_Alltoallv transposes and the MPI_Allgatherv (all threads read the same v).
+ * Used only as the multi-core CPU baseline of bench.py. */
+void orc_spmatvec_normal_arrays_mt(int64_t dimup, int64_t dimdw, const double *hd,
+                                   const int64_t *up_rowptr, const int32_t *up_col, const double *up_val,
+                                   const int64_t *dw_rowptr, const int32_t *dw_col, const double *dw_val,
+                                   const int64_t *nd_rowptr, const int32_t *nd_col, const double *nd_val,
+                                   const double *v, double *hv, int nthreads) {
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+  for (int64_t idw = 0; idw < dimdw; idw++) {
+    for (int64_t iup = 0; iup < dimup; iup++) {
+      int64_t i = iup + idw * dimup;
+      double acc = hd[i] * v[i];
+      for (int64_t jj = up_rowptr[iup]; jj < up_rowptr[iup + 1]; jj++)
+        acc += up_val[jj] * v[(int64_t)up_col[jj] + idw * dimup];
+      hv[i] = acc;
+    }
+    for (int64_t jj = dw_rowptr[idw]; jj < dw_rowptr[idw + 1]; jj++) {
+      const double w = dw_val[jj];
+      const double *src = v + (int64_t)dw_col[jj] * dimup;
+      double *dst = hv + idw * dimup;
+      for (int64_t iup = 0; iup < dimup; iup++) dst[iup] += w * src[iup];
+    }
+    if (nd_rowptr)
+      for (int64_t i = idw * dimup; i < (idw + 1) * dimup; i++)
+        for (int64_t jj = nd_rowptr[i]; jj < nd_rowptr[i + 1]; jj++) hv[i] += nd_val[jj] * v[nd_col[jj]];
+  }
+}
+
+/* row-partitioned CSR product (spMatVec_mpi_superc_main / _nonsu2_main data flow) on OpenMP threads */
+void orc_csr_matvec_z_mt(const orc_csr *a, const double *x, double *y, int nthreads) {
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+  for (int64_t i = 0; i < a->nrow; i++) {
+    double sr = 0.0, si = 0.0;
+    for (int64_t k = a->rowptr[i]; k < a->rowptr[i + 1]; k++) {
+      const double ar = a->val[2 * k], ai = a->val[2 * k + 1];
+      const double xr = x[2 * (int64_t)a->col[k]], xi = x[2 * (int64_t)a->col[k] + 1];
+      sr += ar * xr - ai * xi;
+      si += ar * xi + ai * xr;
+    }
+    y[2 * i] = sr;
+    y[2 * i + 1] = si;
+  }
+}
+
 /* ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:209-262 (Hmat dump), row-major. */
 void orc_hnormal_dense(const orc_hnormal *h, double *hmat) {
   int64_t N = h->dim, DimUp = h->dimup, DimDw = h->dimdw;

@@ -114,6 +114,14 @@ void orc_spmatvec_normal_arrays(int64_t dimup, int64_t dimdw, const double *hd,
                                 const int64_t *nd_rowptr, const int32_t *nd_col, const double *nd_val,
                                 const double *v, double *hv);
 
+/* multi-core CPU baseline of bench.py: the reference's MPI row decompositions (spMatVec_mpi_normal_main
+ * :765-929, spMatVec_mpi_superc_main :366-432) with one OpenMP thread per "rank" */
+void orc_spmatvec_normal_arrays_mt(int64_t dimup, int64_t dimdw, const double *hd,
+                                   const int64_t *up_rowptr, const int32_t *up_col, const double *up_val,
+                                   const int64_t *dw_rowptr, const int32_t *dw_col, const double *dw_val,
+                                   const int64_t *nd_rowptr, const int32_t *nd_col, const double *nd_val,
+                                   const double *v, double *hv, int nthreads);
+
 /* flat CSR modes: ED_SUPERC/ED_HAMILTONIAN_SUPERC_STORED_HxV.f90:29-293, ED_NONSU2/..._STORED_HxV.f90:29-175 */
 typedef struct {
   int ns;
@@ -131,6 +139,7 @@ void orc_hflat_dense(const orc_hflat *h, double *hmat_re_im);
 /* generic CSR y = A x in the reference's loop order (ED_SPARSE_MATRIX.f90:778-793) */
 void orc_csr_matvec_d(const orc_csr *a, const double *x, double *y);
 void orc_csr_matvec_z(const orc_csr *a, const double *x, double *y);
+void orc_csr_matvec_z_mt(const orc_csr *a, const double *x, double *y, int nthreads);
 
 /* SciFortran SF_SP_LINALG sp_lanc_tridiag restated (three-term recurrence);
  * call sites ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:360-365 etc.  vin is

@@ -456,6 +456,26 @@ def normal_matvec_arrays(dimup, dimdw, hd, up, dw, nd, v, hv=None):
     return hv
 
 
+def normal_matvec_arrays_mt(dimup, dimdw, hd, up, dw, nd, v, hv, nthreads):
+    """spMatVec_mpi_normal_main's decomposition (blocks of down indices) on `nthreads` OpenMP threads."""
+    L = lib()
+    i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))  # noqa: E731
+    i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
+    ndargs = (i64(nd[0]), i32(nd[1]), _dp(nd[2])) if nd is not None else (None, None, None)
+    L.orc_spmatvec_normal_arrays_mt(C.c_int64(dimup), C.c_int64(dimdw), _dp(hd), i64(up[0]), i32(up[1]), _dp(up[2]),
+                                    i64(dw[0]), i32(dw[1]), _dp(dw[2]), *ndargs, _dp(v), _dp(hv), C.c_int(nthreads))
+    return hv
+
+
+def csr_matvec_z_mt(rowptr, col, val, x, y, nthreads):
+    """row-partitioned complex CSR product on `nthreads` OpenMP threads (arrays must be contiguous)."""
+    L = lib()
+    c = _Csr(rowptr.shape[0] - 1, x.shape[0], col.shape[0], 1, rowptr.ctypes.data_as(C.POINTER(C.c_int64)),
+             col.ctypes.data_as(C.POINTER(C.c_int32)), val.view(np.float64).ctypes.data_as(C.POINTER(C.c_double)))
+    L.orc_csr_matvec_z_mt(C.byref(c), _dp(x.view(np.float64)), _dp(y.view(np.float64)), C.c_int(nthreads))
+    return y
+
+
 # ----------------------------------------------------------------------------
 # generic CSR products in the reference loop order (checker for the flat kernels)
 # ----------------------------------------------------------------------------

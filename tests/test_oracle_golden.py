@@ -178,3 +178,21 @@ def test_oracle_orbs_spectrum_equals_total_ud():
                 ws.append(np.linalg.eigvalsh(d))
         ws = np.sort(np.concatenate(ws))
         assert len(ws) == len(w_t) and np.max(np.abs(ws + shift - w_t)) < 1e-12
+
+
+def test_oracle_threaded_baselines_equal_serial():
+    """bench.py's multi-core CPU baseline (the reference's MPI row decomposition on OpenMP threads) computes
+    the same product as the serial restatement."""
+    om, _ = make_models("normal", "normal", 2, 3, seed=1)
+    h = O.HNormal(om, 4, 4)
+    v = np.random.default_rng(0).standard_normal(h.dim)
+    hv = np.empty_like(v)
+    O.normal_matvec_arrays_mt(h.dimup, h.dimdw, h.hd, h.up, h.dw, h.nd, v, hv, 3)
+    assert rel_err(hv, h.matvec(v)) < 1e-14
+    om, _ = make_models("superc", "normal", 2, 2, seed=1)
+    f = O.HFlat(om, 0)
+    rp, col, val = (np.ascontiguousarray(a) for a in f.csr)
+    x = np.random.default_rng(1).standard_normal(f.dim) + 1j * np.random.default_rng(2).standard_normal(f.dim)
+    y = np.empty_like(x)
+    O.csr_matvec_z_mt(rp, col, val, x, y, 3)
+    assert rel_err(y, f.matvec(x)) < 1e-14
