@@ -904,6 +904,7 @@ int edigpu_normal_build(edigpu_handle* h, const edigpu_model* model, int nup, in
   s->model = *model;
   s->sec_a = nup;
   s->sec_b = ndw;
+  s->built_by_library = true;
   s->lazy_export = lazy;
   if (setup_normal(s.get(), hn.dim_up, hn.dim_dw, hn.dw_first, hn.dw_count, lazy ? nullptr : hn.hd.data(), hn.up,
                    hn.dw, (!lazy && hn.has_nd) ? hn.nd.rowptr.data() : nullptr, hn.nd.col.data(),
@@ -1339,9 +1340,10 @@ int edigpu_apply_remote_dev(edigpu_handle s, const void* v_full_dev, void* hv_de
   return apply_any(s, nullptr, (const double*)v_full_dev, (double*)hv_dev, 2, st);
 }
 
-int edigpu_lanczos_tridiag(edigpu_handle s, const double* vin_host, int nlanc, double* alanc,
-                           double* blanc, double threshold, int* niter_done) {
-  if (!s || !vin_host || !alanc || !blanc || nlanc <= 0) {
+// seed from host or device memory (hipMemcpyDefault); norm2 = <vin|vin> as tridiag_Hv_sector_* returns it
+static int tridiag_impl(edigpu_handle s, const double* vin, int nlanc, double* alanc, double* blanc,
+                        double threshold, int* niter_done, double* norm2) {
+  if (!s || !vin || !alanc || !blanc || nlanc <= 0) {
     set_error("edigpu_lanczos_tridiag: bad argument");
     return 1;
   }
@@ -1350,7 +1352,7 @@ int edigpu_lanczos_tridiag(edigpu_handle s, const double* vin_host, int nlanc, d
   if (ensure_workspace(s)) return 1;
   hipStream_t st = s->stream;
   if (lanczos_prepare(s, nlanc, threshold, st)) return 1;
-  EDIGPU_HIP(hipMemcpyAsync(s->d_vin, vin_host, (size_t)s->ws_len * sizeof(double), hipMemcpyHostToDevice, st));
+  EDIGPU_HIP(hipMemcpyAsync(s->d_vin, vin, (size_t)s->ws_len * sizeof(double), hipMemcpyDefault, st));
   if (lz_norm_begin(s->d_vin, s->ws_len, s->d_partial, s->d_scal, st)) return 1;
   for (int it = 0; it < nlanc; it++)
     if (lanczos_step(s, it, nlanc, st)) return 1;
@@ -1362,7 +1364,67 @@ int edigpu_lanczos_tridiag(edigpu_handle s, const double* vin_host, int nlanc, d
     blanc[k] = sc[SC_AB + nlanc + k];
   }
   if (niter_done) *niter_done = (int)sc[SC_NDONE];
+  if (norm2) *norm2 = sc[SC_NORM] * sc[SC_NORM];
   return 0;
+}
+
+int edigpu_lanczos_tridiag(edigpu_handle s, const double* vin_host, int nlanc, double* alanc,
+                           double* blanc, double threshold, int* niter_done) {
+  return tridiag_impl(s, vin_host, nlanc, alanc, blanc, threshold, niter_done, nullptr);
+}
+
+int edigpu_lanczos_tridiag_dev(edigpu_handle s, const double* vin_dev, int nlanc, double* alanc,
+                               double* blanc, double threshold, int* niter_done, double* norm2) {
+  return tridiag_impl(s, vin_dev, nlanc, alanc, blanc, threshold, niter_done, norm2);
+}
+
+int edigpu_apply_op_normal(edigpu_handle src, edigpu_handle dst, const double* v_src_dev, double* v_dst_dev,
+                           int iorb, int ispin, int create, void* stream) {
+  if (!src || !dst || !v_src_dev || !v_dst_dev) {
+    set_error("edigpu_apply_op_normal: NULL argument");
+    return 1;
+  }
+  if (src->kind != 0 || dst->kind != 0 || !src->lazy_and_model_ok() || !dst->lazy_and_model_ok()) {
+    set_error("edigpu_apply_op_normal: both handles must be normal-mode sectors built by edigpu_normal_build");
+    return 1;
+  }
+  if (src->nloc != src->dim || dst->nloc != dst->dim) {
+    set_error("edigpu_apply_op_normal: handles must hold whole sectors (single shard)");
+    return 1;
+  }
+  const int ns = model_ns(src->model);
+  if (iorb < 0 || iorb >= src->model.norb || ispin < 0 || ispin > 1) {
+    set_error("edigpu_apply_op_normal: orbital / spin out of range");
+    return 1;
+  }
+  const int d = create ? 1 : -1;
+  const int nup_s = src->sec_a, ndw_s = src->sec_b;
+  if (dst->sec_a != nup_s + (ispin == 0 ? d : 0) || dst->sec_b != ndw_s + (ispin == 1 ? d : 0) ||
+      model_ns(dst->model) != ns) {
+    set_error("edigpu_apply_op_normal: destination sector is not (source sector +- one particle of that spin)");
+    return 1;
+  }
+  EDIGPU_HIP(hipSetDevice(src->device));
+  // signed partial permutation of the changed species: for every destination state its preimage
+  CombBasis bs, bd;
+  bs.init(ns, ispin == 0 ? nup_s : ndw_s);
+  bd.init(ns, ispin == 0 ? dst->sec_a : dst->sec_b);
+  const uint32_t bit = 1u << iorb;
+  std::vector<uint32_t> part((size_t)std::max<int64_t>(bd.size(), 1), 0xFFFFFFFFu);
+  for (int64_t j = 0; j < bd.size(); j++) {
+    const uint32_t t = (uint32_t)bd.states[j];
+    if (create ? !(t & bit) : (t & bit) != 0u) continue;  // c^+ leaves the level occupied, c leaves it empty
+    const uint32_t sst = t ^ bit;                         // source state
+    const uint32_t sg = (__builtin_popcount(sst & (bit - 1u)) & 1) ? 0x80000000u : 0u;
+    part[j] = (uint32_t)bs.rank(sst) | sg;
+  }
+  uint32_t* d_part = nullptr;
+  if (dev_upload(&d_part, part.data(), part.size())) return 1;
+  const int rc = launch_apply_op_normal(dst->dim_up, dst->dim_dw, src->dim_up, ispin, d_part, v_src_dev, v_dst_dev,
+                                        (hipStream_t)stream);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(d_part);
+  return rc;
 }
 
 int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_every,
@@ -1388,7 +1450,7 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
   };
   if (lanczos_prepare(s, nitermax, 0.0, st)) return fail();
   if (v0_host) {
-    if (hipMemcpyAsync(s->d_vin, v0_host, vbytes, hipMemcpyHostToDevice, st) != hipSuccess) return fail();
+    if (hipMemcpyAsync(s->d_vin, v0_host, vbytes, hipMemcpyDefault, st) != hipSuccess) return fail();
   } else if (lz_fill_random(s->d_vin, len, 0x5eed1234ull, st)) {
     return fail();
   }
@@ -1450,7 +1512,7 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
     }
     // normalise
     if (!rc) rc |= lz_norm_begin(d_acc, len, s->d_partial, s->d_scal, st);
-    if (!rc && hipMemcpyAsync(evec_host, d_acc, vbytes, hipMemcpyDeviceToHost, st) != hipSuccess) rc = 1;
+    if (!rc && hipMemcpyAsync(evec_host, d_acc, vbytes, hipMemcpyDefault, st) != hipSuccess) rc = 1;
     if (hipStreamSynchronize(st) != hipSuccess) rc = 1;
     (void)hipFree(d_acc);
     if (rc) {

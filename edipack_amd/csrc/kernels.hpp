@@ -56,6 +56,10 @@ int vec_add_dot(int64_t n, const double* vin, double* vout, const double* tmp, d
 int vec_axpy_nrm2(int64_t n, const double* vin, double* vout, const double* alpha, double* out, double* work, hipStream_t st);
 int vec_scale(int64_t n, double* v, const double* nrm2, hipStream_t st);
 
+// ---- c / c^+ between normal-mode sectors (kernels_ops.hip) ----
+int launch_apply_op_normal(int64_t dst_dimup, int64_t dst_dimdw, int64_t src_dimup, int spin_down,
+                           const uint32_t* part, const double* src, double* dst, hipStream_t st);
+
 // ---- ed_total_ud = F sectors (kernels_orbs.hip) ----
 int launch_orbs(const edigpu_sector* s, const double* v, double* hv, hipStream_t st);
 

@@ -1,0 +1,46 @@
+// kernels_ops.hip -- c / c^+ on a normal-mode sector vector, device to device.
+//
+// Takes the place of apply_op_C / apply_op_CDG (reference ED_SECTOR.f90:465-536, 654-839) for the
+// ed_total_ud=T normal mode: the step between the diagonalisation and the Green's-function
+// tridiagonalisation (ED_NORMAL/ED_GF_NORMAL.f90:141-175).  In the reference it runs on the master rank and is
+// followed by a scatter; here the eigenvector stays on the device and the result is the seed of
+// edigpu_lanczos_tridiag_dev.  The operator changes one spin species only, so it is a signed partial
+// permutation of the columns (up) or of the rows (down) of V[idw][iup]:
+//     up  : dst[jdw][jup] = sgn(jup) * src[jdw][part(jup)]
+//     down: dst[jdw][jup] = sgn(jdw) * src[part(jdw)][jup]
+// part = index in the source sector | sign << 31, 0xFFFFFFFF = no preimage (host table, O(DimUp|DimDw)).
+#include "kernels.hpp"
+
+namespace edigpu {
+
+__global__ void __launch_bounds__(256)
+    apply_op_normal_kernel(int64_t dst_dimup, int64_t dst_dimdw, int64_t src_dimup, int spin_down,
+                           const uint32_t* __restrict__ part, const double* __restrict__ src,
+                           double* __restrict__ dst) {
+  const int64_t n = dst_dimup * dst_dimdw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t jdw = i / dst_dimup, jup = i - jdw * dst_dimup;
+    const uint32_t p = part[spin_down ? jdw : jup];
+    double x = 0.0;
+    if (p != 0xFFFFFFFFu) {
+      const int64_t k = (int64_t)(p & 0x7FFFFFFFu);
+      x = spin_down ? src[k * src_dimup + jup] : src[jdw * src_dimup + k];
+      if (p >> 31) x = -x;
+    }
+    dst[i] = x;
+  }
+}
+
+int launch_apply_op_normal(int64_t dst_dimup, int64_t dst_dimdw, int64_t src_dimup, int spin_down,
+                           const uint32_t* part, const double* src, double* dst, hipStream_t st) {
+  const int64_t n = dst_dimup * dst_dimdw;
+  if (n == 0) return 0;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 256 * 16) nb = 256 * 16;
+  hipLaunchKernelGGL(apply_op_normal_kernel, dim3((unsigned)nb), dim3(256), 0, st, dst_dimup, dst_dimdw, src_dimup,
+                     spin_down, part, src, dst);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace edigpu

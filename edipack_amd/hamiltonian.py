@@ -296,6 +296,22 @@ class SectorHamiltonian:
                                                      capi.pd(b), threshold, C.byref(nd)), "edigpu_lanczos_tridiag")
         return a, b, nd.value
 
+    def lanczos_tridiag_dev(self, vin_ptr: int, nlanc: int, threshold: float = 0.0):
+        """tridiag_Hv_sector_* with the seed already on the device: -> (alanc, blanc, niter, norm2)."""
+        a = np.zeros(nlanc)
+        b = np.zeros(nlanc)
+        nd = C.c_int(0)
+        n2 = C.c_double(0.0)
+        capi.check(capi.lib().edigpu_lanczos_tridiag_dev(self._h, vin_ptr, nlanc, capi.pd(a), capi.pd(b), threshold,
+                                                         C.byref(nd), C.byref(n2)), "edigpu_lanczos_tridiag_dev")
+        return a, b, nd.value, n2.value
+
+    def apply_op_to(self, dst: "SectorHamiltonian", v_src_ptr: int, v_dst_ptr: int, iorb: int, ispin: int,
+                    create: bool, stream: int = 0) -> None:
+        """apply_op_C / apply_op_CDG on device vectors: |dst> = c^(+)_{iorb,ispin} |src> (self = source sector)."""
+        capi.check(capi.lib().edigpu_apply_op_normal(self._h, dst._h, v_src_ptr, v_dst_ptr, iorb, ispin, int(create),
+                                                     stream if stream else None), "edigpu_apply_op_normal")
+
     def lanczos_eigh(self, nitermax: int = 512, tol: float = 1e-12, check_every: int = 10,
                      v0: np.ndarray | None = None, want_vector: bool = True):
         """sp_lanc_eigh semantics (lowest eigenpair)."""

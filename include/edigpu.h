@@ -240,6 +240,22 @@ int edigpu_apply_remote_dev(edigpu_handle h, const void *v_full_dev, void *hv_de
 int edigpu_lanczos_tridiag(edigpu_handle h, const double *vin_host, int nlanc, double *alanc,
                            double *blanc, double threshold, int *niter_done);
 /*
+ * Device-resident neighbours of the tridiagonalisation: the seed of a Green's-function
+ * tridiagonalisation is c / c^+ applied to an eigenvector (apply_op_C / apply_op_CDG, ED_SECTOR.f90:465-536,
+ * called from ED_NORMAL/ED_GF_NORMAL.f90:141-175 on the master rank, then scattered).  Here it maps a
+ * device vector of one normal-mode sector to a device vector of the neighbouring sector; both handles
+ * must come from edigpu_normal_build (whole sectors).  iorb 0-based, ispin 0 = up / 1 = down, create != 0 = c^+.
+ * The down-spin sign counts down electrons only, as the reference does.  Returns after the stream finished.
+ */
+int edigpu_apply_op_normal(edigpu_handle src, edigpu_handle dst, const double *v_src_dev, double *v_dst_dev,
+                           int iorb, int ispin, int create, void *stream);
+/* edigpu_lanczos_tridiag with the seed in device memory (e.g. the output of edigpu_apply_op_normal; it must be
+ * complete when the call is made) and norm2 = <vin|vin> returned as tridiag_Hv_sector_* does.
+ * edigpu_lanczos_eigh likewise accepts device pointers for v0 and for the eigenvector. */
+int edigpu_lanczos_tridiag_dev(edigpu_handle h, const double *vin_dev, int nlanc, double *alanc, double *blanc,
+                               double threshold, int *niter_done, double *norm2);
+
+/*
  * Lowest eigenpair by plain Lanczos (lanc_method="lanczos": sp_lanc_eigh call
  * sites ED_NORMAL/ED_DIAG_NORMAL.f90:206-214): iterate until the lowest Ritz value
  * moves by less than tol (checked every `check_every` steps) or nitermax, then

@@ -427,6 +427,60 @@ def test_golden_sigma_momenta_through_gpu_tridiag(gpu, name):
     assert np.max(np.abs(m - g) / np.abs(g)) < 1e-10   # north_star: Green's functions within 1e-10 relative
 
 
+def test_apply_op_and_device_seeded_tridiag(gpu):
+    """edigpu_apply_op_normal (c / c^+ device to device, both spins) against the test-side restatement of
+    apply_op_C/CDG, and edigpu_lanczos_tridiag_dev (seed and norm2 on the device side) against the
+    host-seeded entry point -- the device-resident form of the GF inner loop."""
+    import torch
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from tests.gf_normal import apply_c_up
+    om, pm = make_models("normal", "hybrid", 3, 3, seed=41)
+    ns = om.ns
+    nup, ndw = 3, 2
+    hs_o = O.HNormal(om, nup, ndw)
+    hs = SectorHamiltonian.normal_from_model(pm, nup, ndw)
+    v = np.random.default_rng(9).standard_normal(hs.dim)
+    vd = torch.from_numpy(v).cuda()
+    for iorb in range(3):
+        for create in (True, False):
+            # spin up against the restatement used for the Sigma fixtures
+            n2 = nup + (1 if create else -1)
+            ht_o = O.HNormal(om, n2, ndw)
+            ht = SectorHamiltonian.normal_from_model(pm, n2, ndw)
+            out = torch.full((ht.dim,), 7.0, dtype=torch.float64, device="cuda")
+            hs.apply_op_to(ht, vd.data_ptr(), out.data_ptr(), iorb, 0, create)
+            ref = apply_c_up(hs_o, ht_o, v, iorb, create)
+            assert np.max(np.abs(out.cpu().numpy() - ref)) < 1e-15
+            # device-seeded tridiagonalisation == host-seeded one, norm2 = <seed|seed>
+            if np.linalg.norm(ref) > 0:
+                a1, b1, n1, nrm2 = ht.lanczos_tridiag_dev(out.data_ptr(), 30)
+                a0, b0, n0 = ht.lanczos_tridiag(ref, 30)
+                assert n0 == n1 and np.array_equal(a0, a1) and np.array_equal(b0, b1)
+                assert abs(nrm2 - ref @ ref) < 1e-12 * max(1.0, ref @ ref)
+            ht.destroy()
+            # spin down: rows move instead of columns; sign from the down string only
+            m2 = ndw + (1 if create else -1)
+            hd_o = O.HNormal(om, nup, m2)
+            hd = SectorHamiltonian.normal_from_model(pm, nup, m2)
+            outd = torch.empty(hd.dim, dtype=torch.float64, device="cuda")
+            hs.apply_op_to(hd, vd.data_ptr(), outd.data_ptr(), iorb, 1, create)
+            refd = np.zeros((hd_o.dimdw, hd_o.dimup))
+            v2 = v.reshape(hs_o.dimdw, hs_o.dimup)
+            rank = {int(s): i for i, s in enumerate(hd_o.mapdw)}
+            bit = 1 << iorb
+            for i, st in enumerate(hs_o.mapdw):
+                st = int(st)
+                if bool(st & bit) == create:
+                    continue
+                sg = -1.0 if bin(st & (bit - 1)).count("1") & 1 else 1.0
+                refd[rank[st ^ bit], :] = sg * v2[i, :]
+            assert np.max(np.abs(outd.cpu().numpy() - refd.reshape(-1))) < 1e-15
+            hd.destroy()
+    hs.destroy()
+    assert ns == 6
+
+
 @pytest.mark.parametrize("name", ["REPLICA_NORMAL", "GENERAL_NORMAL", "REPLICA_SUPERC", "GENERAL_SUPERC",
                                   "REPLICA_NONSU2", "GENERAL_NONSU2"])
 def test_golden_replica_general_energy_on_gpu(gpu, name):
