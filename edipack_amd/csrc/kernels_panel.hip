@@ -70,6 +70,12 @@ __global__ void __launch_bounds__(kPanelNT)
     const int64_t g = a.dw_first + r;
     double acc0 = hv[r * DimUp + cc];
     double acc1 = two ? hv[r2 * DimUp + cc] : 0.0;
+    // ALPHA: the lane's own elements of v, issued with the result loads instead of after the gather chain
+    double own0 = 0.0, own1 = 0.0;
+    if (ALPHA) {
+      own0 = v_full[(a.dw_first + r) * DimUp + cc];
+      own1 = two ? v_full[(a.dw_first + r2) * DimUp + cc] : 0.0;
+    }
     if (DO_DW && !DO_ND) {
       const int32_t b0 = a.dw_rowptr[g], e0 = a.dw_rowptr[g + 1];
       int32_t b1 = 0, e1 = 0;
@@ -130,10 +136,10 @@ __global__ void __launch_bounds__(kPanelNT)
       hv[r * DimUp + c] = acc0;
       if (two) hv[r2 * DimUp + c] = acc1;
       if (ALPHA) {
-        asum += v_full[(a.dw_first + r) * DimUp + c] * acc0;
+        asum += own0 * acc0;
         qsum += acc0 * acc0;
         if (two) {
-          asum += v_full[(a.dw_first + r2) * DimUp + c] * acc1;
+          asum += own1 * acc1;
           qsum += acc1 * acc1;
         }
       }

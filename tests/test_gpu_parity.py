@@ -117,6 +117,30 @@ def test_normal_symmetric_reference_bath(gpu, bath, norb, nbath, sec):
     ha.destroy()
 
 
+@pytest.mark.parametrize("bath,norb,nbath,sec,explicit", [
+    ("hybrid", 4, 2, (3, 3), False),   # 24 spin-exchange / pair-hopping terms > 16: explicit Hd + CSR Hnd image
+    ("hybrid", 5, 1, (3, 2), False),   # EDIGPU_MAXORB orbitals
+    ("normal", 2, 3, (4, 4), True),    # EDIGPU_NORMAL_EXPLICIT=1 on a sector that would be factored
+])
+def test_normal_explicit_image_paths(gpu, bath, norb, nbath, sec, explicit, monkeypatch):
+    """The non-factored device image (explicit diagonal, Hnd as CSR inside the row kernel) and its Lanczos."""
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    if explicit:
+        monkeypatch.setenv("EDIGPU_NORMAL_EXPLICIT", "1")
+    om, pm = make_models("normal", bath, norb, nbath, seed=17)
+    ho = O.HNormal(om, *sec)
+    hg = SectorHamiltonian.normal_from_model(pm, *sec)
+    v = np.random.default_rng(3).standard_normal(ho.dim)
+    assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
+    hd, up, dw, nd = hg.export_normal()
+    assert rel_err(hd, ho.hd) < 1e-13
+    ao, bo, _ = ho.lanc_tridiag(v, 20)
+    ag, bg, _ = hg.lanczos_tridiag(v, 20)
+    assert rel_err(ag[:15], ao[:15]) < 1e-9 and rel_err(bg[:15], bo[:15]) < 1e-9
+    hg.destroy()
+
+
 def test_normal_two_phase_equals_fused(gpu):
     """edigpu_apply_local_dev + edigpu_apply_remote_dev on two dw-shards reproduce the fused product."""
     import torch
