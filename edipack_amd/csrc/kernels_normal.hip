@@ -34,7 +34,6 @@ namespace edigpu {
 
 
 
-constexpr int kMaxNbr = 64;  // neighbour-list slots per row kept in LDS
 constexpr int kE = 4;        // adjacent columns owned by one thread per pass (16/32-byte accesses)
 
 // VEC: DimUp even => every (row, 2-column pair) is 16-byte aligned and never straddles a row end
@@ -65,16 +64,13 @@ __device__ inline double lds_abs_read(uint32_t byte_addr) { return *reinterpret_
 //   2: x = Q/beta (the new Lanczos vector), P <- x, Q <- (Hd+Hup) x - beta*P_old.
 //   3: as 2 with the pending axpy folded in: x = (Q - alpha*P)/beta  (no separate beta kernel).
 // NT: threads per workgroup (512; 1024 when the staged rows leave room for one workgroup per CU only)
-template <int NT, int TD, bool USE_LDS, bool LOCAL, bool DW, bool ND, bool PACKED, bool VEC, bool HDF, int FUSE>
+template <int NT, int TD, bool USE_LDS, bool LOCAL, bool ND, bool PACKED, bool VEC, bool HDF, int FUSE>
 __global__ void __launch_bounds__(NT)
     normal_rows_kernel(NormalArgs a, const double* v_local, const double* __restrict__ v_full,
                        double* hv) {
   // dynamic LDS: TD staged rows (LOCAL && USE_LDS) at offset 0 -- the packed ELL holds byte offsets
   // into them, so no base has to be added per gather -- followed by the 128 hop amplitudes
   extern __shared__ double vs[];
-  __shared__ int32_t nb_col[TD][kMaxNbr];
-  __shared__ double nb_val[TD][kMaxNbr];
-  __shared__ int nb_cnt[TD];
 
   const int64_t DimUp = a.dim_up;
   // staged row stride: DimUp columns + a zero slot at index DimUp (target of the dead ELL slots), even
@@ -98,24 +94,8 @@ __global__ void __launch_bounds__(NT)
   const double* __restrict__ v_src = (FUSE >= 2) ? hv : v_local;
 
   if (LOCAL && PACKED && tid < 128) coef_s[tid] = a.ell_coef[tid];
-  if (DW) {
-    // neighbour lists of the TD rows -> LDS (rows longer than kMaxNbr keep cnt = -1: slow path)
-    for (int r = 0; r < nr; r++) {
-      const int64_t g = a.dw_first + r0 + r;
-      const int32_t b = a.dw_rowptr[g], n = a.dw_rowptr[g + 1] - b;
-      if (n <= kMaxNbr) {
-        if (tid < n) {
-          nb_col[r][tid] = a.dw_col[b + tid];
-          nb_val[r][tid] = a.dw_val[b + tid];
-        }
-        if (tid == 0) nb_cnt[r] = n;
-      } else if (tid == 0) {
-        nb_cnt[r] = -1;
-      }
-    }
-  }
   if (LOCAL && USE_LDS) {
-    if (!DW && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)vs != 0u) __builtin_trap();
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)vs != 0u) __builtin_trap();
     if (tid < TD) vs[tid * S + DimUp] = 0.0;
     // stage the TD rows: 4 independent loads in flight per thread and row
     if (VEC) {
@@ -215,7 +195,7 @@ __global__ void __launch_bounds__(NT)
       // Typed ELL of an LDS sector (the normal case): slot k = one hop type with a wave-uniform
       // amplitude; an entry is (byte offset in the staged row) | sign << 31, dead entries name the
       // row's zero slot.  Per gather: v_and, ds_read_b64, v_bitop3 (sign), v_fma_f64.
-      const bool fast = PACKED && USE_LDS && !DW && a.ell_typed != 0;
+      const bool fast = PACKED && USE_LDS && a.ell_typed != 0;
       if (fast) {
         const uint32_t* __restrict__ epk = a.ell_pk + col0;
         const int epitch = (int)a.ell_pitch;
@@ -316,33 +296,6 @@ __global__ void __launch_bounds__(NT)
         }
       }
     }
-    if (DW) {
-      // ---- (Hdw (x) 1): whole neighbour rows, contiguous in iup ----
-#pragma unroll
-      for (int r = 0; r < TD; r++)
-        if (r < nr) {
-          const int n = nb_cnt[r];
-          if (n >= 0) {
-#pragma unroll 4
-            for (int jj = 0; jj < n; jj++) {
-              const double w = nb_val[r][jj];
-              double x[kE];
-              load4<VEC>(v_full, (int64_t)nb_col[r][jj] * DimUp + col0, ok, x);
-#pragma unroll
-              for (int e = 0; e < kE; e++) acc[r][e] += w * x[e];
-            }
-          } else {
-            const int64_t g = a.dw_first + r0 + r;
-            for (int32_t jj = a.dw_rowptr[g]; jj < a.dw_rowptr[g + 1]; jj++) {
-              const double w = a.dw_val[jj];
-              double x[kE];
-              load4<VEC>(v_full, (int64_t)a.dw_col[jj] * DimUp + col0, ok, x);
-#pragma unroll
-              for (int e = 0; e < kE; e++) acc[r][e] += w * x[e];
-            }
-          }
-        }
-    }
     if (ND) {
       // ---- Hnd: short CSR rows with global columns ----
       if (a.has_nd) {
@@ -427,50 +380,46 @@ int normal_pick_rows_per_block(int64_t dim_up, int64_t dw_count) {
   return td;
 }
 
-// what: bit0 = diagonal+up (overwrite), bit1 = down term inside the row kernel, bit2 = CSR Hnd
+// what: 1 = diagonal + up (overwrite), 5 = the same + CSR Hnd, 4 = CSR Hnd only (accumulate), 101-103 = fused Lanczos
 template <int NT, int TD, bool USE_LDS, bool PACKED, bool VEC, bool HDF>
 static int launch_te(const NormalArgs& a, const double* vl, const double* vf, double* hv,
                      int what, hipStream_t st) {
   const int64_t nblk = (a.dw_count + TD - 1) / TD;
   const size_t lds = (USE_LDS ? (size_t)TD * ((a.dim_up + 2) & ~(int64_t)1) * sizeof(double) : 0) + 128 * sizeof(double);
   dim3 grid((unsigned)nblk), block(NT);
-#define EDIGPU_LAUNCH_ROWS(LOC, DWF, NDF, LDSB, UL, PK, HF)                                      \
+#define EDIGPU_LAUNCH_ROWS(LOC, NDF, LDSB, UL, PK, HF)                                           \
   do {                                                                                           \
-    auto kern = normal_rows_kernel<NT, TD, UL, LOC, DWF, NDF, PK, VEC, HF, 0>;                       \
+    auto kern = normal_rows_kernel<NT, TD, UL, LOC, NDF, PK, VEC, HF, 0>;                            \
     if ((LDSB) > 48 * 1024)                                                                      \
       EDIGPU_HIP(hipFuncSetAttribute((const void*)kern,                                          \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB)));  \
     hipLaunchKernelGGL(kern, grid, block, (LDSB), st, a, vl, vf, hv);                            \
   } while (0)
   switch (what) {
-    case 1: EDIGPU_LAUNCH_ROWS(true, false, false, lds, USE_LDS, PACKED, HDF); break;
-    case 5: EDIGPU_LAUNCH_ROWS(true, false, true, lds, USE_LDS, PACKED, HDF); break;
-    case 7: EDIGPU_LAUNCH_ROWS(true, true, true, lds, USE_LDS, PACKED, HDF); break;
-    case 3: EDIGPU_LAUNCH_ROWS(true, true, false, lds, USE_LDS, PACKED, HDF); break;
+    case 1: EDIGPU_LAUNCH_ROWS(true, false, lds, USE_LDS, PACKED, HDF); break;
+    case 5: EDIGPU_LAUNCH_ROWS(true, true, lds, USE_LDS, PACKED, HDF); break;
     case 101: {  // fused Lanczos, first step
-      auto kern = normal_rows_kernel<NT, TD, USE_LDS, true, false, false, PACKED, VEC, HDF, 1>;
+      auto kern = normal_rows_kernel<NT, TD, USE_LDS, true, false, PACKED, VEC, HDF, 1>;
       if (lds > 48 * 1024)
         EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid, block, lds, st, a, vl, vf, hv);
       break;
     }
     case 102: {  // fused Lanczos, rotate + H*v
-      auto kern = normal_rows_kernel<NT, TD, USE_LDS, true, false, false, PACKED, VEC, HDF, 2>;
+      auto kern = normal_rows_kernel<NT, TD, USE_LDS, true, false, PACKED, VEC, HDF, 2>;
       if (lds > 48 * 1024)
         EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid, block, lds, st, a, vl, vf, hv);
       break;
     }
     case 103: {  // fused Lanczos, pending axpy + rotate + H*v
-      auto kern = normal_rows_kernel<NT, TD, USE_LDS, true, false, false, PACKED, VEC, HDF, 3>;
+      auto kern = normal_rows_kernel<NT, TD, USE_LDS, true, false, PACKED, VEC, HDF, 3>;
       if (lds > 48 * 1024)
         EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, grid, block, lds, st, a, vl, vf, hv);
       break;
     }
-    case 4: EDIGPU_LAUNCH_ROWS(false, false, true, (size_t)0, false, false, false); break;
-    case 6: EDIGPU_LAUNCH_ROWS(false, true, true, (size_t)0, false, false, false); break;
-    case 2: EDIGPU_LAUNCH_ROWS(false, true, false, (size_t)0, false, false, false); break;
+    case 4: EDIGPU_LAUNCH_ROWS(false, true, (size_t)0, false, false, false); break;
     default: set_error("launch_normal: bad term mask"); return 1;
   }
 #undef EDIGPU_LAUNCH_ROWS
@@ -507,17 +456,6 @@ static int launch_rows(const edigpu_sector* s, const NormalArgs& a, const double
     case 8: return launch_td<8, true>(a, packed, hdf, vl, vf, hv, what, st);
     default: set_error("launch_normal: bad rows_per_block"); return 1;
   }
-}
-
-// EDIGPU_NORMAL_DW=rows keeps the down term inside the row kernel (single pass, neighbour rows
-// through L2/Infinity Cache); the default "panels" runs it as the L2-blocked column-panel sweep.
-static bool dw_in_rows() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("EDIGPU_NORMAL_DW");
-    mode = (e && std::string(e) == "rows") ? 1 : 0;
-  }
-  return mode == 1;
 }
 
 static void fill_args(const edigpu_sector* s, NormalArgs& a) {
@@ -564,26 +502,14 @@ int launch_normal(const edigpu_sector* s, const double* v_local, const double* v
   const bool fac = s->factored != 0;
   const bool csr_nd = !fac && s->has_nd;       // Hnd applied by the row kernel from CSR
   const bool fac_nd = fac && a.nterms > 0 && s->d_mx_rowptr != nullptr;     // Hnd applied by the panel kernel from the factored terms
-  // timing-only ablations (results are wrong on purpose)
-  if (const char* ab = getenv("EDIGPU_ABLATE_ELL")) {
-    if (ab[0] == '1') a.ell_w = 0;
-  }
-  if (const char* ab = getenv("EDIGPU_ABLATE_TERMS")) {
-    if (std::string(ab) == "panels") return launch_dw_panels(a, true, fac_nd, v_full, hv, st);
-    if (std::string(ab) == "panels_dw") return launch_dw_panels(a, true, false, v_full, hv, st);
-    return launch_rows(s, a, v_local, v_full, hv, atoi(ab), st);
-  }
-  const bool rows = dw_in_rows();
   if (phase == 1) return launch_rows(s, a, v_local, v_full, hv, 1, st);
   if (phase == 3) {
-    const int what = 1 | (rows ? 2 : 0) | (csr_nd ? 4 : 0);
-    if (launch_rows(s, a, v_local, v_full, hv, what, st)) return 1;
-    return launch_dw_panels(a, !rows, fac_nd, v_full, hv, st);
+    if (launch_rows(s, a, v_local, v_full, hv, csr_nd ? 5 : 1, st)) return 1;
+    return launch_dw_panels(a, true, fac_nd, v_full, hv, st);
   }
   // phase 2: the terms that need the gathered vector, accumulated into hv
-  const int what = (rows ? 2 : 0) | (csr_nd ? 4 : 0);
-  if (what && launch_rows(s, a, v_local, v_full, hv, what, st)) return 1;
-  return launch_dw_panels(a, !rows, fac_nd, v_full, hv, st);
+  if (csr_nd && launch_rows(s, a, v_local, v_full, hv, 4, st)) return 1;
+  return launch_dw_panels(a, true, fac_nd, v_full, hv, st);
 }
 
 // One fused Lanczos step on a single-shard normal handle (see normal_rows_kernel FUSE):
