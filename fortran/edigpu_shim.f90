@@ -21,6 +21,31 @@ module EDIGPU_SHIM
 
   type(c_ptr), save :: gpu_sector = c_null_ptr   !< the live edigpu_handle
 
+  integer, parameter, public :: EDIGPU_MAXORB = 5, EDIGPU_MAXBATH = 16
+
+  !> struct edigpu_model (include/edigpu.h): the module globals the reference's builders read.  C arrays
+  !! are row-major, so the Fortran index order is reversed: uloc(iorb), ust(jorb,iorb) ... ,
+  !! hloc(re/im, jorb, iorb, jspin, ispin), be(k, iorb, ispin), hb(re/im, k, jorb, iorb, js, is).
+  type, bind(C), public :: edigpu_model_t
+     integer(c_int32_t) :: ed_mode = 0      !< 0 normal, 1 superc, 2 nonsu2
+     integer(c_int32_t) :: bath_type = 0    !< 0 normal, 1 hybrid, 2 replica, 3 general
+     integer(c_int32_t) :: norb = 1, nbath = 1, nspin = 1
+     integer(c_int32_t) :: hfmode = 1
+     real(c_double) :: xmu = 0d0
+     real(c_double) :: uloc(EDIGPU_MAXORB) = 0d0
+     real(c_double) :: ust(EDIGPU_MAXORB, EDIGPU_MAXORB) = 0d0
+     real(c_double) :: jh(EDIGPU_MAXORB, EDIGPU_MAXORB) = 0d0
+     real(c_double) :: jx(EDIGPU_MAXORB, EDIGPU_MAXORB) = 0d0
+     real(c_double) :: jp(EDIGPU_MAXORB, EDIGPU_MAXORB) = 0d0
+     real(c_double) :: hloc(2, EDIGPU_MAXORB, EDIGPU_MAXORB, 2, 2) = 0d0
+     real(c_double) :: pair_field(EDIGPU_MAXORB) = 0d0
+     real(c_double) :: be(EDIGPU_MAXBATH, EDIGPU_MAXORB, 2) = 0d0
+     real(c_double) :: bv(EDIGPU_MAXBATH, EDIGPU_MAXORB, 2) = 0d0
+     real(c_double) :: bd(EDIGPU_MAXBATH, EDIGPU_MAXORB, 2) = 0d0
+     real(c_double) :: bu(EDIGPU_MAXBATH, EDIGPU_MAXORB, 2) = 0d0
+     real(c_double) :: hb(2, EDIGPU_MAXBATH, EDIGPU_MAXORB, EDIGPU_MAXORB, 2, 2) = 0d0
+  end type edigpu_model_t
+
   interface
      function edigpu_last_error() bind(C, name="edigpu_last_error") result(msg)
        import :: c_ptr
@@ -41,6 +66,40 @@ module EDIGPU_SHIM
        type(c_ptr), value :: nd_rowptr, nd_col, nd_val
        integer(c_int) :: ierr
      end function edigpu_normal_create
+     function edigpu_normal_build(h, model, nup, ndw, dw_first, dw_count) &
+          bind(C, name="edigpu_normal_build") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, edigpu_model_t
+       type(c_ptr) :: h
+       type(edigpu_model_t), intent(in) :: model
+       integer(c_int), value :: nup, ndw
+       integer(c_int64_t), value :: dw_first, dw_count
+       integer(c_int) :: ierr
+     end function edigpu_normal_build
+     function edigpu_flat_build(h, model, sector, row_first, row_count) &
+          bind(C, name="edigpu_flat_build") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, edigpu_model_t
+       type(c_ptr) :: h
+       type(edigpu_model_t), intent(in) :: model
+       integer(c_int), value :: sector
+       integer(c_int64_t), value :: row_first, row_count
+       integer(c_int) :: ierr
+     end function edigpu_flat_build
+     function edigpu_direct_build(h, model, sector, row_first, row_count) &
+          bind(C, name="edigpu_direct_build") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, edigpu_model_t
+       type(c_ptr) :: h
+       type(edigpu_model_t), intent(in) :: model
+       integer(c_int), value :: sector
+       integer(c_int64_t), value :: row_first, row_count
+       integer(c_int) :: ierr
+     end function edigpu_direct_build
+     function edigpu_orbs_build(h, model, nups, ndws) bind(C, name="edigpu_orbs_build") result(ierr)
+       import :: c_ptr, c_int, c_int32_t, edigpu_model_t
+       type(c_ptr) :: h
+       type(edigpu_model_t), intent(in) :: model
+       integer(c_int32_t), intent(in) :: nups(*), ndws(*)
+       integer(c_int) :: ierr
+     end function edigpu_orbs_build
      function edigpu_csr_create_d(h, nrow_local, ncol_global, row_first, rowptr, col, val) &
           bind(C, name="edigpu_csr_create_d") result(ierr)
        import :: c_ptr, c_int, c_int64_t
@@ -97,6 +156,8 @@ module EDIGPU_SHIM
 
   public :: gpu_init, gpu_delete_sector
   public :: gpu_set_normal, gpu_set_csr_d, gpu_set_csr_c
+  public :: gpu_model_set_kanamori, gpu_model_set_hloc, gpu_model_set_bath
+  public :: gpu_build_normal, gpu_build_flat, gpu_build_orbs
   public :: spMatVec_gpu_d, spMatVec_gpu_c
   public :: gpu_lanc_tridiag_d, gpu_lanc_tridiag_c
   public :: flatten_rows_count
@@ -165,6 +226,99 @@ contains
          c_loc(up_rowptr), c_loc(up_col), c_loc(up_val), &
          c_loc(dw_rowptr), c_loc(dw_col), c_loc(dw_val), pr, pc, pv), "gpu_set_normal")
   end subroutine gpu_set_normal
+
+  !> ---- library-built sectors: skip ed_buildh_* altogether (factored normal image, device-built
+  !! superc / nonsu2 image, on-the-fly kernel).  Fill edigpu_model_t from the module globals: ----
+
+  !> Uloc_internal, Ust/Jh/Jx/Jp_internal (ED_VARS_GLOBAL.f90:216-220)
+  subroutine gpu_model_set_kanamori(m, uloc, ust, jh, jx, jp)
+    type(edigpu_model_t), intent(inout) :: m
+    real(8), intent(in) :: uloc(:), ust(:,:), jh(:,:), jx(:,:), jp(:,:)
+    integer :: a, b, no
+    no = size(uloc)
+    m%uloc(1:no) = uloc
+    do a = 1, no
+       do b = 1, no     ! C [a][b] = Fortran (b,a)
+          m%ust(b,a) = ust(a,b); m%jh(b,a) = jh(a,b); m%jx(b,a) = jx(a,b); m%jp(b,a) = jp(a,b)
+       end do
+    end do
+  end subroutine gpu_model_set_kanamori
+
+  !> impHloc + mfHloc, Fortran shape (Nspin,Nspin,Norb,Norb) as in ED_VARS_GLOBAL
+  subroutine gpu_model_set_hloc(m, hloc)
+    type(edigpu_model_t), intent(inout) :: m
+    complex(8), intent(in) :: hloc(:,:,:,:)
+    integer :: is, js, a, b
+    do is = 1, size(hloc,1)
+       do js = 1, size(hloc,2)
+          do a = 1, size(hloc,3)
+             do b = 1, size(hloc,4)
+                m%hloc(1, b, a, js, is) = dble(hloc(is,js,a,b))
+                m%hloc(2, b, a, js, is) = aimag(hloc(is,js,a,b))
+             end do
+          end do
+       end do
+    end do
+  end subroutine gpu_model_set_hloc
+
+  !> dmft_bath%e, %v (and %d for superc, %u for nonsu2), Fortran shape (Nspin, Norb|1, Nbath)
+  subroutine gpu_model_set_bath(m, e, v, d, u)
+    type(edigpu_model_t), intent(inout) :: m
+    real(8), intent(in) :: e(:,:,:), v(:,:,:)
+    real(8), intent(in), optional :: d(:,:,:), u(:,:,:)
+    integer :: is, a, k
+    do is = 1, size(e,1)
+       do a = 1, size(e,2)
+          do k = 1, size(e,3)
+             m%be(k, a, is) = e(is,a,k)
+             if (present(d)) m%bd(k, a, is) = d(is,a,k)
+          end do
+       end do
+    end do
+    do is = 1, size(v,1)
+       do a = 1, size(v,2)
+          do k = 1, size(v,3)
+             m%bv(k, a, is) = v(is,a,k)
+             if (present(u)) m%bu(k, a, is) = u(is,a,k)
+          end do
+       end do
+    end do
+  end subroutine gpu_model_set_bath
+
+  !> build_Hv_sector_normal(isector) with ed_total_ud=T: the (Nup,Ndw) sector; dw_first/dw_count as in
+  !! gpu_set_normal (dw_count < 0: the whole sector)
+  subroutine gpu_build_normal(m, nup, ndw, dw_first, dw_count)
+    type(edigpu_model_t), intent(in) :: m
+    integer, intent(in) :: nup, ndw, dw_first, dw_count
+    if (c_associated(gpu_sector)) stop "gpu_build_normal: a sector is already allocated"
+    call gpu_check(edigpu_normal_build(gpu_sector, m, int(nup, c_int), int(ndw, c_int), &
+         int(dw_first, c_int64_t), int(dw_count, c_int64_t)), "gpu_build_normal")
+  end subroutine gpu_build_normal
+
+  !> build_Hv_sector_superc / _nonsu2: sector = Sz / Ntot; direct=.true. selects ed_sparse_H=F
+  subroutine gpu_build_flat(m, sector, row_first, row_count, direct)
+    type(edigpu_model_t), intent(in) :: m
+    integer, intent(in) :: sector, row_first, row_count
+    logical, intent(in) :: direct
+    if (c_associated(gpu_sector)) stop "gpu_build_flat: a sector is already allocated"
+    if (direct) then
+       call gpu_check(edigpu_direct_build(gpu_sector, m, int(sector, c_int), int(row_first, c_int64_t), &
+            int(row_count, c_int64_t)), "gpu_build_flat(direct)")
+    else
+       call gpu_check(edigpu_flat_build(gpu_sector, m, int(sector, c_int), int(row_first, c_int64_t), &
+            int(row_count, c_int64_t)), "gpu_build_flat")
+    end if
+  end subroutine gpu_build_flat
+
+  !> build_Hv_sector_normal with ed_total_ud=F: per-orbital (Nups, Ndws)
+  subroutine gpu_build_orbs(m, nups, ndws)
+    type(edigpu_model_t), intent(in) :: m
+    integer, intent(in) :: nups(:), ndws(:)
+    integer(c_int32_t) :: a(size(nups)), b(size(ndws))
+    if (c_associated(gpu_sector)) stop "gpu_build_orbs: a sector is already allocated"
+    a = int(nups, c_int32_t); b = int(ndws, c_int32_t)
+    call gpu_check(edigpu_orbs_build(gpu_sector, m, a, b), "gpu_build_orbs")
+  end subroutine gpu_build_orbs
 
   !> hand over a flat real CSR (sp_matvec-type use, e.g. a real spH0)
   subroutine gpu_set_csr_d(nrow_local, ncol_global, row_first, rowptr, col, val)

@@ -78,6 +78,9 @@ program test_shim
   ! ---- a small Hermitian complex CSR through spHtimesV_cc ----
   call test_complex(nfail)
 
+  ! ---- library-built sector from the model globals (no ed_buildh_* on the host) ----
+  call test_model_build(nfail)
+
   if (nfail == 0) then
      write(*,"(A)") "FORTRAN SHIM OK"
   else
@@ -149,5 +152,40 @@ contains
     if (e > 1d-13) nfail = nfail + 1
     call gpu_delete_sector()
   end subroutine test_complex
+
+  !> single-orbital Anderson impurity with one bath level, sector (Nup,Ndw) = (1,1): 4 x 4, known in
+  !! closed form.  Basis index i = iup + (idw-1)*2 with iup/idw = 1: electron on the impurity,
+  !! 2: electron on the bath level (ascending integers, ED_SECTOR.f90:217-242).
+  subroutine test_model_build(nfail)
+    integer, intent(inout) :: nfail
+    type(edigpu_model_t) :: m
+    real(8), parameter :: ed = -0.4d0, eb = 0.7d0, vhyb = 0.35d0, u = 2.0d0
+    real(8) :: h(4,4), x(4), y(4), yref(4), e
+    real(8) :: ebath(1,1,1), vbath(1,1,1), zero2(1,1)
+    complex(8) :: hloc(1,1,1,1)
+    integer :: ii
+    m%ed_mode = 0; m%bath_type = 0; m%norb = 1; m%nbath = 1; m%nspin = 1; m%hfmode = 0; m%xmu = 0d0
+    zero2 = 0d0
+    call gpu_model_set_kanamori(m, [u], zero2, zero2, zero2, zero2)
+    hloc = cmplx(ed, 0d0, 8)
+    call gpu_model_set_hloc(m, hloc)
+    ebath = eb; vbath = vhyb
+    call gpu_model_set_bath(m, ebath, vbath)
+    call gpu_build_normal(m, 1, 1, 0, -1)
+    h = 0d0
+    h(1,1) = 2d0*ed + u; h(2,2) = eb + ed; h(3,3) = ed + eb; h(4,4) = 2d0*eb
+    h(1,2) = vhyb; h(2,1) = vhyb; h(3,4) = vhyb; h(4,3) = vhyb      ! up hop, idw fixed
+    h(1,3) = vhyb; h(3,1) = vhyb; h(2,4) = vhyb; h(4,2) = vhyb      ! down hop, iup fixed
+    do ii = 1, 4
+       x(ii) = 0.3d0*ii - 0.5d0
+    end do
+    spHtimesV_p => spMatVec_gpu_d
+    call spHtimesV_p(4, x, y)
+    yref = matmul(h, x)
+    e = maxval(abs(y-yref))/maxval(abs(yref))
+    write(*,"(A,ES10.2)") "model-built Anderson sector (1,1) H*v: max rel err =", e
+    if (e > 1d-13) nfail = nfail + 1
+    call gpu_delete_sector()
+  end subroutine test_model_build
 
 end program test_shim
