@@ -1524,6 +1524,181 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
   return 0;
 }
 
+// cyclic Jacobi for a small dense symmetric matrix (row-major n x n, destroyed); eigenvalues ascending in
+// w, eigenvectors in the COLUMNS of z (row-major n x n)
+static void jacobi_eigh(int n, std::vector<double>& a, std::vector<double>& w, std::vector<double>& z) {
+  z.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; i++) z[(size_t)i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 60; sweep++) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < n; i++) {
+      diag += a[(size_t)i * n + i] * a[(size_t)i * n + i];
+      for (int j = i + 1; j < n; j++) off += a[(size_t)i * n + j] * a[(size_t)i * n + j];
+    }
+    if (off <= 1e-32 * (diag + off) || off == 0.0) break;
+    for (int p = 0; p < n - 1; p++)
+      for (int q = p + 1; q < n; q++) {
+        const double apq = a[(size_t)p * n + q];
+        if (apq == 0.0) continue;
+        const double theta = (a[(size_t)q * n + q] - a[(size_t)p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < n; k++) {
+          const double akp = a[(size_t)k * n + p], akq = a[(size_t)k * n + q];
+          a[(size_t)k * n + p] = c * akp - sn * akq;
+          a[(size_t)k * n + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < n; k++) {
+          const double apk = a[(size_t)p * n + k], aqk = a[(size_t)q * n + k];
+          a[(size_t)p * n + k] = c * apk - sn * aqk;
+          a[(size_t)q * n + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < n; k++) {
+          const double zkp = z[(size_t)k * n + p], zkq = z[(size_t)k * n + q];
+          z[(size_t)k * n + p] = c * zkp - sn * zkq;
+          z[(size_t)k * n + q] = sn * zkp + c * zkq;
+        }
+      }
+  }
+  std::vector<int> ord(n);
+  for (int i = 0; i < n; i++) ord[i] = i;
+  std::sort(ord.begin(), ord.end(), [&](int i, int j) { return a[(size_t)i * n + i] < a[(size_t)j * n + j]; });
+  w.resize(n);
+  std::vector<double> zs((size_t)n * n);
+  for (int c = 0; c < n; c++) {
+    w[c] = a[(size_t)ord[c] * n + ord[c]];
+    for (int k = 0; k < n; k++) zs[(size_t)k * n + c] = z[(size_t)k * n + ord[c]];
+  }
+  z.swap(zs);
+}
+
+// Thick-restart Lanczos with full re-orthogonalisation: the lowest `neigen` eigenpairs from an
+// ncv-dimensional basis -- the job the reference gives to ARPACK (sp_eigh, ED_NORMAL/ED_DIAG_NORMAL.f90:179-196).
+int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, int maxrestart, const double* v0,
+                              double* evals, double* evecs, int* nconv_out, int* nmatvec_out) {
+  if (!s || !evals || neigen <= 0) {
+    set_error("edigpu_lanczos_eigh_multi: bad argument");
+    return 1;
+  }
+  if (single_shard(s, "edigpu_lanczos_eigh_multi")) return 1;
+  EDIGPU_HIP(hipSetDevice(s->device));
+  if (ensure_workspace(s)) return 1;
+  hipStream_t st = s->stream;
+  const int cplx = s->is_complex;
+  const int64_t n = s->nloc, len = s->ws_len;
+  if ((int64_t)neigen > n) neigen = (int)n;
+  int m = ncv > 0 ? ncv : std::max(2 * neigen + 10, 20);
+  if (m < neigen + 2) m = neigen + 2;
+  if (m > 128) m = 128;
+  if ((int64_t)m > n) m = (int)n;
+  if (tol <= 0.0) tol = 1e-12;
+  if (maxrestart <= 0) maxrestart = 300;
+  const size_t vbytes = (size_t)len * sizeof(double);
+  struct Bufs {
+    double *Q = nullptr, *Qt = nullptr, *h = nullptr, *part = nullptr, *Y = nullptr;
+    ~Bufs() { (void)hipFree(Q); (void)hipFree(Qt); (void)hipFree(h); (void)hipFree(part); (void)hipFree(Y); }
+  } b;
+  EDIGPU_HIP(hipMalloc((void**)&b.Q, vbytes * (size_t)(m + 1)));
+  EDIGPU_HIP(hipMalloc((void**)&b.h, sizeof(double) * 2 * (size_t)(m + 16)));
+  EDIGPU_HIP(hipMalloc((void**)&b.part, sizeof(double) * (size_t)trl_partial_doubles()));
+  EDIGPU_HIP(hipMalloc((void**)&b.Y, sizeof(double) * (size_t)m * m));
+  auto q = [&](int j) { return b.Q + (size_t)j * len; };
+  std::vector<double> hh(2 * (size_t)(m + 16));
+  auto norm_of = [&](double* w, double& out) -> int {
+    if (trl_norm2(cplx, n, w, b.h, b.part, st)) return 1;
+    EDIGPU_HIP(hipMemcpyAsync(hh.data(), b.h, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    EDIGPU_HIP(hipStreamSynchronize(st));
+    out = sqrt(std::max(hh[0], 0.0));
+    return 0;
+  };
+  // start vector
+  if (v0) {
+    EDIGPU_HIP(hipMemcpyAsync(q(0), v0, vbytes, hipMemcpyDefault, st));
+  } else if (lz_fill_random(q(0), len, 0x7e57ab1eull, st)) {
+    return 1;
+  }
+  double nrm = 0.0;
+  if (norm_of(q(0), nrm)) return 1;
+  if (nrm == 0.0) {
+    set_error("edigpu_lanczos_eigh_multi: zero start vector");
+    return 1;
+  }
+  if (trl_scale(len, q(0), 1.0 / nrm, st)) return 1;
+
+  std::vector<double> T((size_t)m * m, 0.0), Tw, theta, Y;
+  int k = 0, meff = m, nmv = 0, nconv = 0;
+  double beta_last = 0.0;
+  bool invariant = false;
+  for (int restart = 0; restart <= maxrestart; restart++) {
+    invariant = false;
+    meff = m;
+    for (int j = k; j < m; j++) {
+      double* w = q(j + 1);
+      if (apply_any(s, q(j), q(j), w, 3, st)) return 1;
+      nmv++;
+      // classical Gram-Schmidt against q_0..q_j, twice; the coefficients are column j of Q^H H Q
+      if (trl_orthogonalize(cplx, n, j + 1, b.Q, len, w, b.h, b.part, st)) return 1;
+      EDIGPU_HIP(hipMemcpyAsync(hh.data(), b.h, 2 * sizeof(double) * (size_t)(j + 1), hipMemcpyDeviceToHost, st));
+      EDIGPU_HIP(hipStreamSynchronize(st));
+      for (int i = 0; i <= j; i++) T[(size_t)i * m + j] = hh[2 * i];
+      if (trl_orthogonalize(cplx, n, j + 1, b.Q, len, w, b.h, b.part, st)) return 1;
+      EDIGPU_HIP(hipMemcpyAsync(hh.data(), b.h, 2 * sizeof(double) * (size_t)(j + 1), hipMemcpyDeviceToHost, st));
+      EDIGPU_HIP(hipStreamSynchronize(st));
+      for (int i = 0; i <= j; i++) {
+        T[(size_t)i * m + j] += hh[2 * i];
+        T[(size_t)j * m + i] = T[(size_t)i * m + j];
+      }
+      double beta = 0.0;
+      if (norm_of(w, beta)) return 1;
+      beta_last = beta;
+      const double scale = fabs(T[(size_t)j * m + j]) + 1.0;
+      if (beta <= 1e-13 * scale) {  // invariant subspace: the basis q_0..q_j is closed under H
+        meff = j + 1;
+        invariant = true;
+        break;
+      }
+      if (trl_scale(len, w, 1.0 / beta, st)) return 1;
+    }
+    // Rayleigh-Ritz on the meff x meff projection
+    Tw.assign((size_t)meff * meff, 0.0);
+    for (int i = 0; i < meff; i++)
+      for (int j = 0; j < meff; j++) Tw[(size_t)i * meff + j] = T[(size_t)i * m + j];
+    jacobi_eigh(meff, Tw, theta, Y);
+    const int want = std::min(neigen, meff);
+    nconv = 0;
+    for (int i = 0; i < want; i++) {
+      const double res = invariant ? 0.0 : fabs(beta_last * Y[(size_t)(meff - 1) * meff + i]);
+      if (res <= tol * std::max(fabs(theta[i]), 1.0)) nconv++;
+      else break;
+    }
+    if (nconv >= want || invariant || restart == maxrestart) break;
+    // thick restart: keep the wanted Ritz vectors plus half of the rest, then the residual vector
+    int kk = want + (meff - want) / 2;
+    if (kk > meff - 1) kk = meff - 1;
+    if (kk < 1) kk = 1;
+    if (!b.Qt) EDIGPU_HIP(hipMalloc((void**)&b.Qt, vbytes * (size_t)m));
+    EDIGPU_HIP(hipMemcpyAsync(b.Y, Y.data(), sizeof(double) * (size_t)meff * meff, hipMemcpyHostToDevice, st));
+    if (trl_rotate_basis(len, meff, kk, b.Q, len, b.Y, meff, b.Qt, len, st)) return 1;
+    EDIGPU_HIP(hipMemcpyAsync(b.Q, b.Qt, vbytes * (size_t)kk, hipMemcpyDeviceToDevice, st));
+    EDIGPU_HIP(hipMemcpyAsync(q(kk), q(meff), vbytes, hipMemcpyDeviceToDevice, st));
+    std::fill(T.begin(), T.end(), 0.0);
+    for (int i = 0; i < kk; i++) T[(size_t)i * m + i] = theta[i];
+    k = kk;
+  }
+  const int want = std::min(neigen, meff);
+  for (int i = 0; i < neigen; i++) evals[i] = i < want ? theta[i] : 0.0;
+  if (nconv_out) *nconv_out = nconv;
+  if (nmatvec_out) *nmatvec_out = nmv;
+  if (evecs) {
+    if (!b.Qt) EDIGPU_HIP(hipMalloc((void**)&b.Qt, vbytes * (size_t)m));
+    EDIGPU_HIP(hipMemcpyAsync(b.Y, Y.data(), sizeof(double) * (size_t)meff * meff, hipMemcpyHostToDevice, st));
+    if (trl_rotate_basis(len, meff, want, b.Q, len, b.Y, meff, b.Qt, len, st)) return 1;
+    EDIGPU_HIP(hipMemcpyAsync(evecs, b.Qt, vbytes * (size_t)want, hipMemcpyDefault, st));
+  }
+  EDIGPU_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
 int edigpu_vec_work_doubles(void) { return kRedBlocks; }
 
 int edigpu_vec_rotate(int64_t n, double* vin_dev, double* vout_dev, const double* beta2_dev, void* stream) {

@@ -56,6 +56,16 @@ int vec_add_dot(int64_t n, const double* vin, double* vout, const double* tmp, d
 int vec_axpy_nrm2(int64_t n, const double* vin, double* vout, const double* alpha, double* out, double* work, hipStream_t st);
 int vec_scale(int64_t n, double* v, const double* nrm2, hipStream_t st);
 
+// ---- thick-restart Lanczos multi-vector kernels (kernels_trl.hip) ----
+// h_dev (2 doubles per basis vector: re, im) = Q^H w, then w -= Q h; n counts complex or real elements
+int trl_orthogonalize(int cplx, int64_t n, int nvec, const double* Q, int64_t ldq, double* w, double* h_dev,
+                      double* partial, hipStream_t st);
+int trl_norm2(int cplx, int64_t n, const double* w, double* h_dev, double* partial, hipStream_t st);
+int trl_partial_doubles(void);
+int trl_rotate_basis(int64_t len, int m, int k, const double* Q, int64_t ldq, const double* Y_dev, int ldy,
+                     double* out, int64_t ldo, hipStream_t st);
+int trl_scale(int64_t len, double* v, double f, hipStream_t st);
+
 // ---- c / c^+ between normal-mode sectors (kernels_ops.hip) ----
 int launch_apply_op_normal(int64_t dst_dimup, int64_t dst_dimdw, int64_t src_dimup, int spin_down,
                            const uint32_t* part, const double* src, double* dst, hipStream_t st);

@@ -1,0 +1,201 @@
+// kernels_trl.hip -- multi-vector kernels of the thick-restart Lanczos eigensolver (edigpu_lanczos_eigh_multi).
+//
+// The reference's default spectrum path is ARPACK through SciFortran's sp_eigh (LANC_METHOD=arpack,
+// ED_NORMAL/ED_DIAG_NORMAL.f90:179-196, ncv = lanc_ncv_factor*Neigen + lanc_ncv_add): an ncv-dimensional
+// Krylov basis, full re-orthogonalisation, restarts that keep the wanted Ritz vectors.  The basis lives on
+// the device as ncv+1 contiguous vectors; what ARPACK does with BLAS-2 on the host (classical Gram-Schmidt
+// against the basis, basis rotation at a restart) are the three streaming kernels below, NC basis vectors
+// per pass so that w is read once per NC instead of once per vector.
+// Complex sectors use the complex inner product (the real view of a Hermitian matrix has every eigenvalue
+// twice: v and i*v).
+#include "kernels.hpp"
+
+namespace edigpu {
+
+constexpr int kTrlNT = 256;
+constexpr int kTrlNC = 8;
+
+// partial[(c*2+q) * gridDim + block] = sum over the block's elements of conj(Q_c) * w  (q: re, im)
+template <bool CPLX>
+__global__ void __launch_bounds__(kTrlNT)
+    trl_mdot_kernel(int64_t n, int nc, const double* __restrict__ Q, int64_t ldq, const double* __restrict__ w,
+                    double* __restrict__ partial) {
+  __shared__ double red[kTrlNT / 64][2 * kTrlNC];
+  double sr[kTrlNC], si[kTrlNC];
+#pragma unroll
+  for (int c = 0; c < kTrlNC; c++) sr[c] = si[c] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kTrlNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTrlNT) {
+    if (CPLX) {
+      const double2 x = reinterpret_cast<const double2*>(w)[i];
+#pragma unroll
+      for (int c = 0; c < kTrlNC; c++)
+        if (c < nc) {
+          const double2 q = reinterpret_cast<const double2*>(Q + c * ldq)[i];
+          sr[c] += q.x * x.x + q.y * x.y;
+          si[c] += q.x * x.y - q.y * x.x;
+        }
+    } else {
+      const double x = w[i];
+#pragma unroll
+      for (int c = 0; c < kTrlNC; c++)
+        if (c < nc) sr[c] += Q[c * ldq + i] * x;
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < kTrlNC; c++) {
+    double a = sr[c], b = si[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a += __shfl_down(a, off, 64);
+      b += __shfl_down(b, off, 64);
+    }
+    if (lane == 0) {
+      red[wv][2 * c] = a;
+      red[wv][2 * c + 1] = b;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * kTrlNC) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < kTrlNT / 64; k++) t += red[k][threadIdx.x];
+    partial[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = t;
+  }
+}
+
+// h[2*c+q] = sum_b partial[(2*c+q) * nb + b]
+__global__ void __launch_bounds__(256) trl_msum_kernel(const double* __restrict__ partial, int nb, double* __restrict__ h) {
+  __shared__ double sh[256];
+  const int k = blockIdx.x;  // 0 .. 2*NC-1
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nb; b += 256) s += partial[(int64_t)k * nb + b];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) h[k] = sh[0];
+}
+
+// w -= sum_c h_c * Q_c
+template <bool CPLX>
+__global__ void __launch_bounds__(kTrlNT)
+    trl_maxpy_kernel(int64_t n, int nc, const double* __restrict__ Q, int64_t ldq, const double* __restrict__ h,
+                     double* __restrict__ w) {
+  double hr[kTrlNC], hi[kTrlNC];
+#pragma unroll
+  for (int c = 0; c < kTrlNC; c++) {
+    hr[c] = c < nc ? h[2 * c] : 0.0;
+    hi[c] = c < nc ? h[2 * c + 1] : 0.0;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * kTrlNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTrlNT) {
+    if (CPLX) {
+      double2 x = reinterpret_cast<double2*>(w)[i];
+#pragma unroll
+      for (int c = 0; c < kTrlNC; c++)
+        if (c < nc) {
+          const double2 q = reinterpret_cast<const double2*>(Q + c * ldq)[i];
+          x.x -= hr[c] * q.x - hi[c] * q.y;
+          x.y -= hr[c] * q.y + hi[c] * q.x;
+        }
+      reinterpret_cast<double2*>(w)[i] = x;
+    } else {
+      double x = w[i];
+#pragma unroll
+      for (int c = 0; c < kTrlNC; c++)
+        if (c < nc) x -= hr[c] * Q[c * ldq + i];
+      w[i] = x;
+    }
+  }
+}
+
+// out_c = sum_j Y[j][c] * Q_j  for c < nc (Y real, row-major m x ldy): basis rotation at a restart
+__global__ void __launch_bounds__(kTrlNT)
+    trl_rotate_kernel(int64_t len, int m, int nc, const double* __restrict__ Q, int64_t ldq,
+                      const double* __restrict__ Y, int ldy, int c0, double* __restrict__ out, int64_t ldo) {
+  for (int64_t i = (int64_t)blockIdx.x * kTrlNT + threadIdx.x; i < len; i += (int64_t)gridDim.x * kTrlNT) {
+    double acc[kTrlNC];
+#pragma unroll
+    for (int c = 0; c < kTrlNC; c++) acc[c] = 0.0;
+    for (int j = 0; j < m; j++) {
+      const double q = Q[j * ldq + i];
+#pragma unroll
+      for (int c = 0; c < kTrlNC; c++)
+        if (c < nc) acc[c] = fma(Y[j * ldy + c0 + c], q, acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < kTrlNC; c++)
+      if (c < nc) out[c * ldo + i] = acc[c];
+  }
+}
+
+__global__ void __launch_bounds__(kTrlNT) trl_scale_kernel(int64_t len, double* __restrict__ v, double f) {
+  for (int64_t i = (int64_t)blockIdx.x * kTrlNT + threadIdx.x; i < len; i += (int64_t)gridDim.x * kTrlNT) v[i] *= f;
+}
+
+static inline int trl_grid(int64_t n) {
+  int64_t nb = (n + kTrlNT - 1) / kTrlNT;
+  return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+}
+
+// h (device, 2*nvec doubles: re, im) = Q[0..nvec)^H w ; then w -= Q h.  n = complex or real element count.
+int trl_orthogonalize(int cplx, int64_t n, int nvec, const double* Q, int64_t ldq, double* w, double* h_dev,
+                      double* partial, hipStream_t st) {
+  const int nb = trl_grid(n);
+  for (int c0 = 0; c0 < nvec; c0 += kTrlNC) {
+    const int nc = nvec - c0 < kTrlNC ? nvec - c0 : kTrlNC;
+    const double* q0 = Q + (int64_t)c0 * ldq;
+    if (cplx)
+      hipLaunchKernelGGL((trl_mdot_kernel<true>), dim3(nb), dim3(kTrlNT), 0, st, n, nc, q0, ldq, w, partial);
+    else
+      hipLaunchKernelGGL((trl_mdot_kernel<false>), dim3(nb), dim3(kTrlNT), 0, st, n, nc, q0, ldq, w, partial);
+    hipLaunchKernelGGL(trl_msum_kernel, dim3(2 * kTrlNC), dim3(256), 0, st, partial, nb, h_dev + 2 * c0);
+  }
+  for (int c0 = 0; c0 < nvec; c0 += kTrlNC) {
+    const int nc = nvec - c0 < kTrlNC ? nvec - c0 : kTrlNC;
+    const double* q0 = Q + (int64_t)c0 * ldq;
+    if (cplx)
+      hipLaunchKernelGGL((trl_maxpy_kernel<true>), dim3(nb), dim3(kTrlNT), 0, st, n, nc, q0, ldq, h_dev + 2 * c0, w);
+    else
+      hipLaunchKernelGGL((trl_maxpy_kernel<false>), dim3(nb), dim3(kTrlNT), 0, st, n, nc, q0, ldq, h_dev + 2 * c0, w);
+  }
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+// h_dev[0] = <w|w>
+int trl_norm2(int cplx, int64_t n, const double* w, double* h_dev, double* partial, hipStream_t st) {
+  const int nb = trl_grid(n);
+  if (cplx)
+    hipLaunchKernelGGL((trl_mdot_kernel<true>), dim3(nb), dim3(kTrlNT), 0, st, n, 1, w, (int64_t)0, w, partial);
+  else
+    hipLaunchKernelGGL((trl_mdot_kernel<false>), dim3(nb), dim3(kTrlNT), 0, st, n, 1, w, (int64_t)0, w, partial);
+  hipLaunchKernelGGL(trl_msum_kernel, dim3(2 * kTrlNC), dim3(256), 0, st, partial, nb, h_dev);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int trl_partial_doubles(void) { return 2 * kTrlNC * 1024; }
+
+// out[0..k) = Q[0..m) * Y[:, 0..k)   (len = doubles per vector)
+int trl_rotate_basis(int64_t len, int m, int k, const double* Q, int64_t ldq, const double* Y_dev, int ldy,
+                     double* out, int64_t ldo, hipStream_t st) {
+  const int nb = trl_grid(len);
+  for (int c0 = 0; c0 < k; c0 += kTrlNC) {
+    const int nc = k - c0 < kTrlNC ? k - c0 : kTrlNC;
+    hipLaunchKernelGGL(trl_rotate_kernel, dim3(nb), dim3(kTrlNT), 0, st, len, m, nc, Q, ldq, Y_dev, ldy, c0,
+                       out + (int64_t)c0 * ldo, ldo);
+  }
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int trl_scale(int64_t len, double* v, double f, hipStream_t st) {
+  hipLaunchKernelGGL(trl_scale_kernel, dim3(trl_grid(len)), dim3(kTrlNT), 0, st, len, v, f);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace edigpu

@@ -296,6 +296,24 @@ class SectorHamiltonian:
                                                      capi.pd(b), threshold, C.byref(nd)), "edigpu_lanczos_tridiag")
         return a, b, nd.value
 
+    def lanczos_eigh_multi(self, neigen: int, ncv: int = 0, tol: float = 1e-12, maxrestart: int = 300,
+                           v0: np.ndarray | None = None, want_vectors: bool = True):
+        """sp_eigh (ARPACK) semantics: the lowest `neigen` eigenpairs -> (evals, evecs[neigen, nloc] | None,
+        nconv, nmatvec)."""
+        neigen = min(int(neigen), self.nloc)
+        ev = np.zeros(neigen)
+        vec = np.zeros((neigen, self.nloc), dtype=self.dtype) if want_vectors else None
+        nc, nmv = C.c_int(0), C.c_int(0)
+        v0p = None
+        if v0 is not None:
+            v0 = np.ascontiguousarray(v0, dtype=self.dtype)
+            v0p = v0.ctypes.data_as(C.c_void_p)
+        capi.check(capi.lib().edigpu_lanczos_eigh_multi(
+            self._h, neigen, ncv, tol, maxrestart, v0p, capi.pd(ev),
+            vec.ctypes.data_as(C.c_void_p) if want_vectors else None, C.byref(nc), C.byref(nmv)),
+            "edigpu_lanczos_eigh_multi")
+        return ev, vec, nc.value, nmv.value
+
     def lanczos_tridiag_dev(self, vin_ptr: int, nlanc: int, threshold: float = 0.0):
         """tridiag_Hv_sector_* with the seed already on the device: -> (alanc, blanc, niter, norm2)."""
         a = np.zeros(nlanc)

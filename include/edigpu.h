@@ -240,6 +240,19 @@ int edigpu_apply_remote_dev(edigpu_handle h, const void *v_full_dev, void *hv_de
 int edigpu_lanczos_tridiag(edigpu_handle h, const double *vin_host, int nlanc, double *alanc,
                            double *blanc, double threshold, int *niter_done);
 /*
+ * Lowest `neigen` eigenpairs by thick-restart Lanczos with full re-orthogonalisation on an ncv-dimensional,
+ * device-resident Krylov basis: the role ARPACK plays behind sp_eigh in the reference's
+ * default LANC_METHOD=arpack path (ED_NORMAL/ED_DIAG_NORMAL.f90:179-196, ncv = lanc_ncv_factor*Neigen +
+ * lanc_ncv_add; ED_SUPERC / ED_NONSU2 likewise).  ncv <= 0 picks max(2*neigen+10, 20); ncv is capped at 128 and
+ * at the sector dimension.  v0 (host or device, may be NULL = seeded random), evecs (host or device, may be
+ * NULL): neigen vectors of the sector's length, consecutive.  nconv = number of leading eigenpairs whose
+ * residual |H x - theta x| <= tol * max(|theta|, 1).  As with ARPACK, a degenerate eigenvalue is found with
+ * the multiplicity the start vector (and rounding) exposes.
+ */
+int edigpu_lanczos_eigh_multi(edigpu_handle h, int neigen, int ncv, double tol, int maxrestart, const double *v0,
+                              double *evals, double *evecs, int *nconv, int *nmatvec);
+
+/*
  * Device-resident neighbours of the tridiagonalisation: the seed of a Green's-function
  * tridiagonalisation is c / c^+ applied to an eigenvector (apply_op_C / apply_op_CDG, ED_SECTOR.f90:465-536,
  * called from ED_NORMAL/ED_GF_NORMAL.f90:141-175 on the master rank, then scattered).  Here it maps a
