@@ -182,8 +182,10 @@ static int upload_ell(DevEll& e, const HostCsr& a, bool lds) {
 
 // SELL-64 image of a CSR block (kernels_csr.hip, sell_rows_kernel): rows sorted by column, 64 rows per
 // slice, column-major inside the slice.  Built when the padding stays below 60 % of the entries.
+// max_pad: padded slots allowed per stored entry (1.6 for the dense-ish flat Hamiltonians; the sparse Hnd
+// block -- most rows empty -- is cheap in absolute terms and takes more)
 static int upload_sell(DevCsr& d, int64_t nrow, int64_t ncol, const int64_t* rowptr, const int32_t* col,
-                       const double* val, int cplx, bool is_loc) {
+                       const double* val, int cplx, bool is_loc, double max_pad = 1.6) {
   if (nrow == 0 || rowptr[nrow] == 0 || getenv("EDIGPU_CSR_NOSELL")) return 0;
   const int w = cplx ? 2 : 1;
   // ---- value dictionary (off-diagonal entries; the loc block's diagonal goes to its own array) ----
@@ -232,7 +234,7 @@ static int upload_sell(DevCsr& d, int64_t nrow, int64_t ncol, const int64_t* row
     if (tot >= ((int64_t)1 << 31) / 64) return 0;
     sp[s + 1] = (int32_t)tot;
   }
-  if (nent > 0 && (double)tot * 64.0 > 1.6 * (double)nent) return 0;  // too ragged: keep the CSR kernel
+  if (nent > 0 && (double)tot * 64.0 > max_pad * (double)nent) return 0;  // too ragged: keep the CSR kernel
   std::vector<int32_t> sc;
   std::vector<uint32_t> spk;
   std::vector<double> sv;
@@ -375,6 +377,11 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
   } else {
     if (dev_upload(&s->d_hd, hd, (size_t)s->nloc)) return 1;
     if (s->has_nd && upload_csr(s->nd, s->nloc, nd_rowptr, nd_col, nd_val, 0)) return 1;
+    // Hnd as its own SELL pass after the panel sweep (global columns): keeps the row kernel free of the CSR
+    // row pointers and lets the Lanczos step stay fused (the dot partials move to this last pass)
+    if (s->has_nd && !env_flag("EDIGPU_ND_IN_ROWS") &&
+        upload_sell(s->nd, s->nloc, dim_up * dim_dw, nd_rowptr, nd_col, nd_val, 0, false, 16.0))
+      return 1;
   }
   return finish_handle(s);
 }
@@ -611,7 +618,9 @@ static int ensure_workspace(edigpu_sector* s) {
   EDIGPU_HIP(hipMalloc((void**)&s->d_vin, n * sizeof(double)));
   EDIGPU_HIP(hipMalloc((void**)&s->d_vout, n * sizeof(double)));
   EDIGPU_HIP(hipMalloc((void**)&s->d_tmp, n * sizeof(double)));
-  EDIGPU_HIP(hipMalloc((void**)&s->d_partial, kMaxPartials * sizeof(double)));
+  // per-workgroup partials: two per 256-row workgroup of the SELL dot epilogue is the largest user
+  s->partial_cap = std::max<int64_t>(kMaxPartials, 2 * ((s->nloc + 255) / 256) + 64);
+  EDIGPU_HIP(hipMalloc((void**)&s->d_partial, (size_t)s->partial_cap * sizeof(double)));
   s->ws_len = len;
   return 0;
 }
@@ -716,7 +725,7 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
     int np = 0;
     if (launch_normal_lanczos(s, s->d_vin, s->d_vout, s->d_scal, s->d_partial, iter == 0, !exactbeta, st, &np))
       return 1;
-    if (2 * np > kMaxPartials) {
+    if (2 * (int64_t)np > s->partial_cap) {
       set_error("lanczos_step: partial buffer too small");
       return 1;
     }
@@ -736,7 +745,7 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
     } else if (launch_csr_lanczos(s->loc, s->is_complex, s->d_vin, s->d_vout, s->d_partial, &np, st)) {
       return 1;
     }
-    if (2 * np > kMaxPartials) {
+    if (2 * (int64_t)np > s->partial_cap) {
       set_error("lanczos_step: partial buffer too small");
       return 1;
     }

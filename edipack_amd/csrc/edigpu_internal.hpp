@@ -132,6 +132,7 @@ struct edigpu_sector {
   double* d_dir_dtab = nullptr;
   double* d_dir_xtab = nullptr;
   // ---- Lanczos workspace (lazily allocated) ----
+  int64_t partial_cap = 0;      // doubles in d_partial
   double* d_vin = nullptr;
   double* d_vout = nullptr;
   double* d_tmp = nullptr;

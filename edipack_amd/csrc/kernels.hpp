@@ -7,7 +7,7 @@ namespace edigpu {
 // device-resident Lanczos scalars (kernels_lanczos.hip)
 enum { SC_ALPHA = 0, SC_BETA = 1, SC_STOP = 2, SC_NDONE = 3, SC_NORM = 4, SC_THR = 5, SC_EXACT = 6, SC_AB = 8 };
 constexpr int kRedBlocks = 1024;
-constexpr int kMaxPartials = 1 << 16;  // capacity of the per-workgroup partial buffer
+constexpr int kMaxPartials = 1 << 16;  // minimum capacity of the per-workgroup partial buffer (edigpu_sector::partial_cap)
 
 // ---- normal mode (kernels_normal.hip) ----
 // phase: 3 = fused (local+remote, overwrite), 1 = local only (overwrite), 2 = remote only (accumulate)

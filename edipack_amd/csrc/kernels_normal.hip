@@ -500,16 +500,19 @@ int launch_normal(const edigpu_sector* s, const double* v_local, const double* v
   fill_args(s, a);
   if (s->dw_count == 0) return 0;
   const bool fac = s->factored != 0;
-  const bool csr_nd = !fac && s->has_nd;       // Hnd applied by the row kernel from CSR
+  const bool sell_nd = !fac && s->has_nd && s->nd.sell;   // Hnd as a separate SELL pass (after the panels)
+  const bool csr_nd = !fac && s->has_nd && !sell_nd;      // Hnd applied by the row kernel from CSR
   const bool fac_nd = fac && a.nterms > 0 && s->d_mx_rowptr != nullptr;     // Hnd applied by the panel kernel from the factored terms
   if (phase == 1) return launch_rows(s, a, v_local, v_full, hv, 1, st);
   if (phase == 3) {
     if (launch_rows(s, a, v_local, v_full, hv, csr_nd ? 5 : 1, st)) return 1;
-    return launch_dw_panels(a, true, fac_nd, v_full, hv, st);
+    if (launch_dw_panels(a, true, fac_nd, v_full, hv, st)) return 1;
+    return sell_nd ? launch_csr(s->nd, 0, v_full, hv, 1, st) : 0;
   }
   // phase 2: the terms that need the gathered vector, accumulated into hv
   if (csr_nd && launch_rows(s, a, v_local, v_full, hv, 4, st)) return 1;
-  return launch_dw_panels(a, true, fac_nd, v_full, hv, st);
+  if (launch_dw_panels(a, true, fac_nd, v_full, hv, st)) return 1;
+  return sell_nd ? launch_csr(s->nd, 0, v_full, hv, 1, st) : 0;
 }
 
 // One fused Lanczos step on a single-shard normal handle (see normal_rows_kernel FUSE):
@@ -519,7 +522,7 @@ int launch_normal(const edigpu_sector* s, const double* v_local, const double* v
 bool normal_lanczos_fusable(const edigpu_sector* s) {
   if (s->kind != 0 || s->nloc != s->dim || s->dw_count == 0) return false;
   if (s->rows_per_block == 0) return false;               // needs the LDS row kernel
-  if (!s->factored && s->has_nd) return false;             // CSR Hnd needs the complete new vector
+  if (!s->factored && s->has_nd && !s->nd.sell) return false;  // CSR Hnd inside the row kernel needs the complete new vector
   if (getenv("EDIGPU_LANCZOS_UNFUSED")) return false;
   return true;
 }
@@ -532,6 +535,12 @@ int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const do
   a.partial = partial;
   if (launch_rows(s, a, P, P, Q, first ? 101 : (lazy_axpy ? 103 : 102), st)) return 1;
   const bool fac_nd = s->factored && a.nterms > 0 && s->d_mx_rowptr != nullptr;
+  if (!s->factored && s->has_nd && s->nd.sell) {
+    // explicit image (hand-over arrays): panels without the dot, then Q += Hnd v as a SELL pass whose
+    // epilogue carries the <v|Q>, <Q|Q> partials
+    if (launch_dw_panels(a, true, false, P, Q, st)) return 1;
+    return launch_csr_lanczos(s->nd, 0, P, Q, partial, npartial, st);
+  }
   return launch_dw_panels(a, true, fac_nd, P, Q, st, true, npartial);
 }
 
