@@ -725,3 +725,64 @@ def test_eigh_multi_matches_dense(gpu, mode, bath, norb, nbath, sec, neigen, ncv
     g = vec.conj() @ vec.T
     assert np.max(np.abs(g - np.eye(k))) < 1e-10
     hg.destroy()
+
+
+def test_sigma_momenta_fully_device_resident(gpu):
+    """The whole zero-temperature GF inner loop on the device, against the reference's Sigma_momenta fixture:
+    ground state by edigpu_lanczos_eigh_multi (eigenvector stays on the GPU), c / c^+ by
+    edigpu_apply_op_normal, tridiagonalisation by edigpu_lanczos_tridiag_dev -- only alpha/beta/norm2 reach
+    the host (rows a12, f1, f3 of SURVEY.md 8 together)."""
+    import torch
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from tests.test_oracle_golden import GOLD, _from_dir, golden_models
+    O = _oracle()
+    name = "NORMAL_NORMAL"
+    inp, par = _from_dir(name)
+    pm_par = {k: v for k, v in par.items() if k not in ("ed_hw_bath", "deltasc")}
+    om, pm = golden_models(inp["ED_MODE"], inp["BATH_TYPE"], int(inp["NORB"]), int(inp["NBATH"]), pm_par)
+    O.to_struct(om)
+    ns, norb = om.ns, om.norb
+    # lowest two levels of every sector -> ground-state manifold
+    found = []
+    for nup in range(ns + 1):
+        for ndw in range(ns + 1):
+            h = SectorHamiltonian.normal_from_model(pm, nup, ndw)
+            ev, vec, nconv, _ = h.lanczos_eigh_multi(min(2, h.dim), tol=1e-13)
+            for k in range(len(ev)):
+                found.append((ev[k], (nup, ndw), vec[k].copy()))
+            h.destroy()
+    e0 = min(f[0] for f in found)
+    states = [f for f in found if f[0] - e0 <= 1e-9]
+    zeta = float(len(states))
+    beta, lmats = inp["BETA"], 4096
+    wm = np.pi / beta * (2.0 * np.arange(1, lmats + 1) - 1.0)
+    z = 1j * wm
+    out = np.zeros((norb, 4))
+    for a in range(norb):
+        g = np.zeros(lmats, complex)
+        for ei, (nup, ndw), vec in states:
+            hs = SectorHamiltonian.normal_from_model(pm, nup, ndw)
+            vd = torch.from_numpy(vec).cuda()
+            for create, isign in ((True, 1), (False, -1)):
+                n2 = nup + (1 if create else -1)
+                if n2 < 0 or n2 > ns:
+                    continue
+                ht = SectorHamiltonian.normal_from_model(pm, n2, ndw)
+                seed = torch.empty(ht.dim, dtype=torch.float64, device="cuda")
+                hs.apply_op_to(ht, vd.data_ptr(), seed.data_ptr(), a, 0, create)
+                nl = min(ht.dim, int(inp["LANC_NGFITER"]))
+                al, bl, _, norm2 = ht.lanczos_tridiag_dev(seed.data_ptr(), nl)
+                ht.destroy()
+                if norm2 == 0.0:
+                    continue
+                t = np.diag(al[:nl]) + np.diag(bl[1:nl], 1) + np.diag(bl[1:nl], -1)
+                evs, zz = np.linalg.eigh(t)
+                g += np.sum((norm2 / zeta * zz[0, :] ** 2)[None, :] / (z[:, None] - (isign * (evs - ei))[None, :]), axis=1)
+            hs.destroy()
+        delta = np.sum(om.bv[0, a, :][None, :] ** 2 / (z[:, None] - om.be[0, a, :][None, :]), axis=1)
+        sig = z + om.xmu - om.hloc[0, 0, a, a].real - delta - 1.0 / g
+        for n in range(1, 5):
+            out[a, n - 1] = np.sum(np.abs(sig) * wm ** n) / np.sum(np.abs(sig))
+    gold = np.array(GOLD[name]["Sigma_momenta"]).reshape(out.shape)
+    assert abs(e0 - GOLD[name]["evals"][0]) < 1e-9
+    assert np.max(np.abs(out - gold) / np.abs(gold)) < 1e-9
