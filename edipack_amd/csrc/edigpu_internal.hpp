@@ -129,6 +129,7 @@ struct edigpu_sector {
   int32_t* d_dir_offdw = nullptr;
   int32_t* d_dir_rkup = nullptr;
   edigpu::DirectTerm* d_dir_terms = nullptr;
+  uint2* d_dir_tests = nullptr;   // (need_set, need_set | need_clear) per term, padded to a multiple of 4
   double* d_dir_dtab = nullptr;
   double* d_dir_xtab = nullptr;
   // ---- Lanczos workspace (lazily allocated) ----

@@ -847,33 +847,8 @@ std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, i
     d.cim = t.coef.imag();
     out.terms.push_back(d);
   }
-  // merge every hop c^+_p c_q with its reverse c^+_q c_p (same flip mask, swapped conditions): one term
-  // that applies whenever exactly one of the two levels is occupied -- half the terms, twice the hit rate
-  {
-    std::vector<DirectTerm> merged;
-    std::vector<char> used(out.terms.size(), 0);
-    for (size_t i = 0; i < out.terms.size(); i++) {
-      if (used[i]) continue;
-      DirectTerm a = out.terms[i];
-      const bool hop = popc(a.need_set) == 1 && popc(a.need_clear) == 1 && a.flip == (a.need_set | a.need_clear);
-      if (hop) {
-        for (size_t j = i + 1; j < out.terms.size(); j++) {
-          const DirectTerm& b = out.terms[j];
-          if (!used[j] && b.flip == a.flip && b.need_set == a.need_clear && b.need_clear == a.need_set &&
-              b.sign_mask == a.sign_mask) {
-            a.pair = 1;
-            a.c2re = b.cre;
-            a.c2im = b.cim;
-            a.csign = (a.csign & 1) | ((b.csign & 1) << 16);
-            used[j] = 1;
-            break;
-          }
-        }
-      }
-      merged.push_back(a);
-    }
-    out.terms.swap(merged);
-  }
+  // (an earlier version merged every hop with its reverse into one "pair" term; with the two-instruction
+  // applicability test of the kernels a plain term list is faster -- see kernels_direct.hip)
   // diagonal: byte-wise sums of the one-body energies + impurity interaction table
   out.dtab.assign(4 * 256, 0.0);
   for (int byte = 0; byte < 4; byte++)

@@ -7,7 +7,7 @@
 //
 // What the reference does per element -- bdecomp into an int array, O(pos) btest loops for the
 // fermionic sign, a recursive binary search for the column -- becomes bit arithmetic in registers:
-//   applicability : (s & need_set) == need_set && (s & need_clear) == 0
+//   applicability : (s & (need_set | need_clear)) == need_set      (two VALU instructions)
 //   sign          : parity of popcount(s & sign_mask) (+ a per-term constant)
 //   column        : off_dw[w >> Ns] + rk_up[w & (2^Ns-1)]   (two table lookups, w = s ^ flip)
 // One lane owns one row; the term list is wave-uniform (scalar loads).  The gathers of v go through
@@ -26,9 +26,9 @@ __global__ void __launch_bounds__(kDirNT)
     direct_rows_kernel(int64_t nrow, int64_t row_first, int ns, int norb, int nterms,
                        const int32_t* __restrict__ states, const int32_t* __restrict__ off_dw,
                        const int32_t* __restrict__ rk_up, const DirectTerm* __restrict__ terms,
-                       const double* __restrict__ dtab, const double* __restrict__ xtab,
-                       const double2* __restrict__ v_full, double2* __restrict__ hv,
-                       double* __restrict__ partial) {
+                       const uint2* __restrict__ tests, const double* __restrict__ dtab,
+                       const double* __restrict__ xtab, const double2* __restrict__ v_full,
+                       double2* __restrict__ hv, double* __restrict__ partial) {
   extern __shared__ int32_t tabs[];  // [off_dw | rk_up] when LDS_TABLES
   __shared__ double red_a[kDirNT / 64], red_q[kDirNT / 64];
   double da = 0.0, dq = 0.0;
@@ -50,34 +50,28 @@ __global__ void __launch_bounds__(kDirNT)
                       dtab[768 + (s >> 24)] + xtab[(((s >> ns) & impmask) << norb) | (s & impmask)];
     const double2 x0 = v_full[row_first + r];
     double ar = dg * x0.x, ai = dg * x0.y;
-    for (int t = 0; t < nterms; t++) {
-      const DirectTerm tm = terms[t];  // wave-uniform
-      bool on;
-      double cr, ci;
-      int cs;
-      if (tm.pair) {
-        // hop merged with its reverse: exactly one of the two levels occupied
-        const bool fwd = (s & tm.need_set) != 0u;
-        on = fwd != ((s & tm.need_clear) != 0u);
-        cr = fwd ? tm.cre : tm.c2re;
-        ci = fwd ? tm.cim : tm.c2im;
-        cs = fwd ? (tm.csign & 1) : ((tm.csign >> 16) & 1);
-      } else {
-        on = (s & tm.need_set) == tm.need_set && (s & tm.need_clear) == 0u;
-        cr = tm.cre;
-        ci = tm.cim;
-        cs = tm.csign & 1;
-      }
-      if (on) {
-        const uint32_t w = s ^ tm.flip;
-        const int64_t j = (int64_t)t_off[w >> ns] + t_rk[w & lomask];
-        if ((__popc(s & tm.sign_mask) + cs) & 1) {
-          cr = -cr;
-          ci = -ci;
+    // tests[t] = (need_set, need_set | need_clear), padded to a multiple of 4 with never-matching entries:
+    // four applicability tests per batch of scalar loads; the rest of a term is fetched only where it applies
+    for (int t0 = 0; t0 < nterms; t0 += 4) {
+      uint2 tq[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) tq[u] = tests[t0 + u];      // wave-uniform: scalar loads
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if ((s & tq[u].y) == tq[u].x) {                       // v_and + v_cmp: the whole applicability test
+          const DirectTerm tm = terms[t0 + u];
+          const uint32_t w = s ^ tm.flip;
+          const int64_t j = (int64_t)t_off[w >> ns] + t_rk[w & lomask];
+          // sign = parity of the occupied levels the operators cross (+ a per-term constant), folded into x
+          const int sg = (int)((uint32_t)((__popc(s & tm.sign_mask) + tm.csign) & 1) << 31);
+          double2 x = v_full[j];
+          x.x = __hiloint2double(__double2hiint(x.x) ^ sg, __double2loint(x.x));
+          x.y = __hiloint2double(__double2hiint(x.y) ^ sg, __double2loint(x.y));
+          ar = fma(tm.cre, x.x, ar);
+          ar = fma(-tm.cim, x.y, ar);
+          ai = fma(tm.cre, x.y, ai);
+          ai = fma(tm.cim, x.x, ai);
         }
-        const double2 x = v_full[j];
-        ar += cr * x.x - ci * x.y;
-        ai += cr * x.y + ci * x.x;
       }
     }
     if (LZ) {
@@ -128,11 +122,11 @@ static int launch_direct_t(const edigpu_sector* s, const double* v_full, double*
       EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kDirNT), tab_bytes, st, s->nloc, s->row_first, s->dir_ns,
                        s->dir_norb, s->dir_nterms, s->d_dir_states, s->d_dir_offdw, s->d_dir_rkup, s->d_dir_terms,
-                       s->d_dir_dtab, s->d_dir_xtab, v2, h2, partial);
+                       s->d_dir_tests, s->d_dir_dtab, s->d_dir_xtab, v2, h2, partial);
   } else {
     hipLaunchKernelGGL((direct_rows_kernel<false, LZ>), dim3((unsigned)nb), dim3(kDirNT), 0, st, s->nloc,
                        s->row_first, s->dir_ns, s->dir_norb, s->dir_nterms, s->d_dir_states, s->d_dir_offdw,
-                       s->d_dir_rkup, s->d_dir_terms, s->d_dir_dtab, s->d_dir_xtab, v2, h2, partial);
+                       s->d_dir_rkup, s->d_dir_terms, s->d_dir_tests, s->d_dir_dtab, s->d_dir_xtab, v2, h2, partial);
   }
   EDIGPU_HIP(hipGetLastError());
   return 0;
