@@ -1017,10 +1017,10 @@ int edigpu_direct_build(edigpu_handle* h, const edigpu_model* model, int sector,
   rc |= dev_upload(&s->d_dir_rkup, hd.rk_up.data(), hd.rk_up.size());
   rc |= dev_upload(&s->d_dir_terms, hd.terms.data(), hd.terms.size());
   {
-    std::vector<uint2> tests((hd.terms.size() + 3) / 4 * 4, make_uint2(0xFFFFFFFFu, 0u));  // padding never matches
+    std::vector<uint2> tests((hd.terms.size() + 31) / 32 * 32, make_uint2(0xFFFFFFFFu, 0u));  // padding never matches
     for (size_t t = 0; t < hd.terms.size(); t++)
       tests[t] = make_uint2(hd.terms[t].need_set, hd.terms[t].need_set | hd.terms[t].need_clear);
-    if (tests.empty()) tests.assign(4, make_uint2(0xFFFFFFFFu, 0u));
+    if (tests.empty()) tests.assign(32, make_uint2(0xFFFFFFFFu, 0u));
     rc |= dev_upload(&s->d_dir_tests, tests.data(), tests.size());
   }
   rc |= dev_upload(&s->d_dir_dtab, hd.dtab.data(), hd.dtab.size());

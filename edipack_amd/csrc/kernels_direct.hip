@@ -13,15 +13,22 @@
 // One lane owns one row; the term list is wave-uniform (scalar loads).  The gathers of v go through
 // L2 / Infinity Cache (consecutive rows map to nearby columns: the rank maps are monotone).
 // Integer/latency bound, not a bandwidth kernel: judged by iterations/s.
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace edigpu {
 
+constexpr int kDirMaxTerms = 512;  // COMPACT variant: term table kept in LDS (14 KiB)
 constexpr int kDirNT = 1024;  // 2 workgroups/CU with the 2 x 2^Ns-entry rank tables staged in LDS (Ns <= 13)
 
 // LZ (fused Lanczos step): hv = Q accumulates H*v on top of -beta*v_prev, and the workgroup writes its
 // partials of <v|Q_new> and <Q_new|Q_new> (real view) to partial[blockIdx], partial[gridDim + blockIdx].
-template <bool LDS_TABLES, bool LZ>
+// COMPACT: instead of visiting the terms in order with a quarter of the lanes active per gather, a lane first
+// collects the applicability of 32 terms in a bit mask and then pops its own set bits, two per round: every
+// gather instruction has all lanes active and two are in flight per lane -- about 4x fewer dependent gather
+// rounds per row.  The per-term data then differ from lane to lane and come from an LDS copy of the term list.
+template <bool LDS_TABLES, bool LZ, bool COMPACT>
 __global__ void __launch_bounds__(kDirNT)
     direct_rows_kernel(int64_t nrow, int64_t row_first, int ns, int norb, int nterms,
                        const int32_t* __restrict__ states, const int32_t* __restrict__ off_dw,
@@ -43,6 +50,21 @@ __global__ void __launch_bounds__(kDirNT)
   }
   const int32_t* __restrict__ t_off = LDS_TABLES ? tabs : off_dw;
   const int32_t* __restrict__ t_rk = LDS_TABLES ? tabs + (1 << ns) : rk_up;
+  // COMPACT: term table in LDS behind the rank tables: flip | sign_mask | csign (256 words each) | coef (256 x 16 B)
+  uint32_t* t_flip = reinterpret_cast<uint32_t*>(tabs + (LDS_TABLES ? (2 << ns) : 0));
+  uint32_t* t_smask = t_flip + kDirMaxTerms;
+  uint32_t* t_csign = t_smask + kDirMaxTerms;
+  double2* t_coef = reinterpret_cast<double2*>(t_csign + kDirMaxTerms);
+  if (COMPACT) {
+    for (int t = threadIdx.x; t < nterms; t += kDirNT) {
+      const DirectTerm tm = terms[t];
+      t_flip[t] = tm.flip;
+      t_smask[t] = tm.sign_mask;
+      t_csign[t] = (uint32_t)tm.csign;
+      t_coef[t] = make_double2(tm.cre, tm.cim);
+    }
+    __syncthreads();
+  }
   for (int64_t r = (int64_t)blockIdx.x * kDirNT + threadIdx.x; r < nrow; r += (int64_t)gridDim.x * kDirNT) {
     const uint32_t s = (uint32_t)states[r];
     // diagonal: one-body energies byte by byte + impurity interaction table
@@ -50,9 +72,54 @@ __global__ void __launch_bounds__(kDirNT)
                       dtab[768 + (s >> 24)] + xtab[(((s >> ns) & impmask) << norb) | (s & impmask)];
     const double2 x0 = v_full[row_first + r];
     double ar = dg * x0.x, ai = dg * x0.y;
-    // tests[t] = (need_set, need_set | need_clear), padded to a multiple of 4 with never-matching entries:
+    if (COMPACT) {
+      for (int g0 = 0; g0 < nterms; g0 += 32) {
+        uint32_t mw = 0;
+#pragma unroll
+        for (int b4 = 0; b4 < 32; b4 += 4) {
+          uint2 tq[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) tq[u] = tests[g0 + b4 + u];  // padded to a multiple of 32
+#pragma unroll
+          for (int u = 0; u < 4; u++) mw |= ((s & tq[u].y) == tq[u].x) ? (1u << (b4 + u)) : 0u;
+        }
+        while (__any(mw != 0u)) {
+          // two applicable terms of this lane (the second may be missing: weight 0, own row)
+          const bool h1 = mw != 0u;
+          const int b1 = h1 ? __ffs(mw) - 1 : 0;
+          mw &= mw - 1u;
+          const bool h2 = mw != 0u;
+          const int b2 = h2 ? __ffs(mw) - 1 : 0;
+          mw &= mw - 1u;
+          const int t1 = g0 + b1, t2 = g0 + b2;
+          const uint32_t w1 = s ^ t_flip[t1], w2 = s ^ t_flip[t2];
+          const int64_t j1 = h1 ? (int64_t)t_off[w1 >> ns] + t_rk[w1 & lomask] : row_first + r;
+          const int64_t j2 = h2 ? (int64_t)t_off[w2 >> ns] + t_rk[w2 & lomask] : row_first + r;
+          double2 x1 = v_full[j1];
+          double2 x2 = v_full[j2];
+          const int sg1 = (int)((uint32_t)((__popc(s & t_smask[t1]) + (int)t_csign[t1]) & 1) << 31);
+          const int sg2 = (int)((uint32_t)((__popc(s & t_smask[t2]) + (int)t_csign[t2]) & 1) << 31);
+          double2 c1 = t_coef[t1], c2 = t_coef[t2];
+          if (!h1) c1 = make_double2(0.0, 0.0);
+          if (!h2) c2 = make_double2(0.0, 0.0);
+          x1.x = __hiloint2double(__double2hiint(x1.x) ^ sg1, __double2loint(x1.x));
+          x1.y = __hiloint2double(__double2hiint(x1.y) ^ sg1, __double2loint(x1.y));
+          x2.x = __hiloint2double(__double2hiint(x2.x) ^ sg2, __double2loint(x2.x));
+          x2.y = __hiloint2double(__double2hiint(x2.y) ^ sg2, __double2loint(x2.y));
+          ar = fma(c1.x, x1.x, ar);
+          ar = fma(-c1.y, x1.y, ar);
+          ai = fma(c1.x, x1.y, ai);
+          ai = fma(c1.y, x1.x, ai);
+          ar = fma(c2.x, x2.x, ar);
+          ar = fma(-c2.y, x2.y, ar);
+          ai = fma(c2.x, x2.y, ai);
+          ai = fma(c2.y, x2.x, ai);
+        }
+      }
+    }
+    // tests[t] = (need_set, need_set | need_clear), padded with never-matching entries:
     // four applicability tests per batch of scalar loads; the rest of a term is fetched only where it applies
-    for (int t0 = 0; t0 < nterms; t0 += 4) {
+    for (int t0 = COMPACT ? nterms : 0; t0 < nterms; t0 += 4) {
       uint2 tq[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) tq[u] = tests[t0 + u];      // wave-uniform: scalar loads
@@ -111,23 +178,36 @@ template <bool LZ>
 static int launch_direct_t(const edigpu_sector* s, const double* v_full, double* hv, double* partial, int* np,
                            hipStream_t st) {
   int64_t nb = (s->nloc + kDirNT - 1) / kDirNT;
-  if (nb > 256 * 2) nb = 256 * 2;  // persistent: two workgroups per CU sweep the rows
+  static const int wgs_per_cu = getenv("EDIGPU_DIRECT_WGS") ? atoi(getenv("EDIGPU_DIRECT_WGS")) : 2;
+  if (nb > 256 * wgs_per_cu) nb = 256 * wgs_per_cu;  // persistent workgroups sweep the rows
   if (np) *np = (int)nb;
   const size_t tab_bytes = (size_t)2 * sizeof(int32_t) << s->dir_ns;
+  const size_t term_bytes = (size_t)kDirMaxTerms * (3 * sizeof(uint32_t) + sizeof(double2));
+  static const bool no_compact = getenv("EDIGPU_DIRECT_TERMORDER") != nullptr;
+  const bool compact = !no_compact && s->dir_nterms <= kDirMaxTerms;
   const double2* v2 = reinterpret_cast<const double2*>(v_full);
   double2* h2 = reinterpret_cast<double2*>(hv);
+#define EDIGPU_LAUNCH_DIRECT(LT, CP, LDSB)                                                                       \
+  do {                                                                                                           \
+    auto kern = direct_rows_kernel<LT, LZ, CP>;                                                                  \
+    if ((LDSB) > 48 * 1024)                                                                                      \
+      EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB))); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kDirNT), (LDSB), st, s->nloc, s->row_first, s->dir_ns,     \
+                       s->dir_norb, s->dir_nterms, s->d_dir_states, s->d_dir_offdw, s->d_dir_rkup,              \
+                       s->d_dir_terms, s->d_dir_tests, s->d_dir_dtab, s->d_dir_xtab, v2, h2, partial);          \
+  } while (0)
   if (tab_bytes <= 64 * 1024) {
-    auto kern = direct_rows_kernel<true, LZ>;
-    if (tab_bytes > 48 * 1024)
-      EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes));
-    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kDirNT), tab_bytes, st, s->nloc, s->row_first, s->dir_ns,
-                       s->dir_norb, s->dir_nterms, s->d_dir_states, s->d_dir_offdw, s->d_dir_rkup, s->d_dir_terms,
-                       s->d_dir_tests, s->d_dir_dtab, s->d_dir_xtab, v2, h2, partial);
+    if (compact)
+      EDIGPU_LAUNCH_DIRECT(true, true, tab_bytes + term_bytes);
+    else
+      EDIGPU_LAUNCH_DIRECT(true, false, tab_bytes);
   } else {
-    hipLaunchKernelGGL((direct_rows_kernel<false, LZ>), dim3((unsigned)nb), dim3(kDirNT), 0, st, s->nloc,
-                       s->row_first, s->dir_ns, s->dir_norb, s->dir_nterms, s->d_dir_states, s->d_dir_offdw,
-                       s->d_dir_rkup, s->d_dir_terms, s->d_dir_tests, s->d_dir_dtab, s->d_dir_xtab, v2, h2, partial);
+    if (compact)
+      EDIGPU_LAUNCH_DIRECT(false, true, term_bytes);
+    else
+      EDIGPU_LAUNCH_DIRECT(false, false, (size_t)0);
   }
+#undef EDIGPU_LAUNCH_DIRECT
   EDIGPU_HIP(hipGetLastError());
   return 0;
 }
