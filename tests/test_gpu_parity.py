@@ -786,3 +786,43 @@ def test_sigma_momenta_fully_device_resident(gpu):
     gold = np.array(GOLD[name]["Sigma_momenta"]).reshape(out.shape)
     assert abs(e0 - GOLD[name]["evals"][0]) < 1e-9
     assert np.max(np.abs(out - gold) / np.abs(gold)) < 1e-9
+
+
+# --------------------------------------------------------------------------------------------
+# error behaviour of the boundary (the reference `stop`s with a message; here: non-zero + edigpu_last_error)
+# --------------------------------------------------------------------------------------------
+def test_error_paths(gpu):
+    import torch
+    from edipack_amd import capi
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    _, pm = make_models("normal", "normal", 2, 2, seed=1)
+    with pytest.raises(capi.EdigpuError, match="bad sector"):
+        SectorHamiltonian.normal_from_model(pm, 7, 0)                 # Nup > Ns
+    with pytest.raises(capi.EdigpuError, match="not normal"):
+        _, ps = make_models("superc", "normal", 2, 2, seed=1)
+        SectorHamiltonian.normal_from_model(ps, 1, 1)
+    with pytest.raises(capi.EdigpuError, match="bath_type=normal"):
+        _, ph = make_models("normal", "hybrid", 2, 2, seed=1, jxp=0.0)
+        SectorHamiltonian.orbs_from_model(ph, (1, 1), (1, 1))
+    with pytest.raises(capi.EdigpuError, match="bad sector"):
+        SectorHamiltonian.orbs_from_model(pm, (9, 1), (1, 1))
+    # apply_op between sectors that are not neighbours
+    a = SectorHamiltonian.normal_from_model(pm, 3, 3)
+    b = SectorHamiltonian.normal_from_model(pm, 2, 2)
+    va = torch.zeros(a.dim, dtype=torch.float64, device="cuda")
+    vb = torch.zeros(b.dim, dtype=torch.float64, device="cuda")
+    with pytest.raises(capi.EdigpuError, match="destination sector"):
+        a.apply_op_to(b, va.data_ptr(), vb.data_ptr(), 0, 0, True)
+    with pytest.raises(capi.EdigpuError, match="out of range"):
+        a.apply_op_to(b, va.data_ptr(), vb.data_ptr(), 5, 0, False)
+    # a shard refuses the single-shard entry points
+    sh = SectorHamiltonian.normal_from_model(pm, 3, 3, dw_first=0, dw_count=5)
+    with pytest.raises(capi.EdigpuError, match="shard"):
+        sh.lanczos_tridiag(np.zeros(sh.nloc), 4)
+    with pytest.raises(capi.EdigpuError, match="zero start vector"):
+        a.lanczos_eigh_multi(2, v0=np.zeros(a.dim))
+    # wrong vector length through the host-callback boundary
+    with pytest.raises(capi.EdigpuError):
+        a.apply(np.zeros(a.dim + 1))
+    for h in (a, b, sh):
+        h.destroy()
