@@ -955,6 +955,7 @@ int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, i
     s->row_first = hd.row_first;
     s->model = *model;
     s->sec_a = sector;
+    s->built_by_library = true;
     s->lazy_export = true;
     const int rc = build_flat_on_device(s.get(), hd);
     if (rc == 0) {
@@ -979,6 +980,9 @@ int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, i
     return 1;
   }
   std::unique_ptr<edigpu_sector> s(new edigpu_sector());
+  s->model = *model;
+  s->sec_a = sector;
+  s->built_by_library = true;
   if (setup_flat(s.get(), hf.row_count, hf.dim, hf.row_first, hf.h.rowptr.data(), hf.h.col.data(),
                  hf.h.val.data(), 1)) {
     edigpu_destroy(s.release());
@@ -1004,6 +1008,9 @@ int edigpu_direct_build(edigpu_handle* h, const edigpu_model* model, int sector,
   }
   std::unique_ptr<edigpu_sector> s(new edigpu_sector());
   s->kind = 2;
+  s->model = *model;
+  s->sec_a = sector;
+  s->built_by_library = true;
   s->is_complex = 1;
   s->device = g_device;
   s->dim = hd.dim;
@@ -1440,6 +1447,58 @@ int edigpu_apply_op_normal(edigpu_handle src, edigpu_handle dst, const double* v
                                         (hipStream_t)stream);
   (void)hipStreamSynchronize((hipStream_t)stream);
   (void)hipFree(d_part);
+  return rc;
+}
+
+int edigpu_apply_op_flat(edigpu_handle src, edigpu_handle dst, const double* v_src_dev, double* v_dst_dev,
+                         int iorb, int ispin, int create, void* stream) {
+  if (!src || !dst || !v_src_dev || !v_dst_dev) {
+    set_error("edigpu_apply_op_flat: NULL argument");
+    return 1;
+  }
+  if ((src->kind != 1 && src->kind != 2) || (dst->kind != 1 && dst->kind != 2) || !src->built_by_library ||
+      !dst->built_by_library) {
+    set_error("edigpu_apply_op_flat: both handles must be superc / nonsu2 sectors built by edigpu_flat_build or "
+              "edigpu_direct_build");
+    return 1;
+  }
+  if (src->nloc != src->dim || dst->nloc != dst->dim) {
+    set_error("edigpu_apply_op_flat: handles must hold whole sectors (single shard)");
+    return 1;
+  }
+  const edigpu_model& m = src->model;
+  const int ns = model_ns(m);
+  if (iorb < 0 || iorb >= m.norb || ispin < 0 || ispin > 1 || dst->model.ed_mode != m.ed_mode ||
+      model_ns(dst->model) != ns) {
+    set_error("edigpu_apply_op_flat: orbital / spin out of range or sectors of different models");
+    return 1;
+  }
+  // superc: sector = Sz = Nup - Ndw; nonsu2: sector = Ntot
+  const int d = create ? 1 : -1;
+  const int want = m.ed_mode == 1 ? src->sec_a + (ispin == 0 ? d : -d) : src->sec_a + d;
+  if (dst->sec_a != want) {
+    set_error("edigpu_apply_op_flat: destination sector is not the one the operator leads to");
+    return 1;
+  }
+  EDIGPU_HIP(hipSetDevice(src->device));
+  HostDirect hs, hd;
+  std::string e = build_direct(src->model, src->sec_a, 0, -1, hs);
+  if (e.empty()) e = build_direct(dst->model, dst->sec_a, 0, -1, hd);
+  if (!e.empty()) {
+    set_error(e);
+    return 1;
+  }
+  int32_t *d_states = nullptr, *d_off = nullptr, *d_rk = nullptr;
+  int rc = dev_upload(&d_states, hd.states.data(), hd.states.size());
+  rc |= dev_upload(&d_off, hs.off_dw.data(), hs.off_dw.size());
+  rc |= dev_upload(&d_rk, hs.rk_up.data(), hs.rk_up.size());
+  if (!rc)
+    rc = launch_apply_op_flat(hd.dim, ns, 1u << (iorb + ispin * ns), create, d_states, d_off, d_rk, v_src_dev,
+                              v_dst_dev, (hipStream_t)stream);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  dev_free(d_states);
+  dev_free(d_off);
+  dev_free(d_rk);
   return rc;
 }
 

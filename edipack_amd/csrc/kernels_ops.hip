@@ -31,6 +31,41 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// flat (superc / nonsu2) sectors: one map over the 2*Ns-bit states; the sign counts every occupied level
+// below the operator's level (ED_AUX_FUNX.f90:334-384), complex vectors
+__global__ void __launch_bounds__(256)
+    apply_op_flat_kernel(int64_t ndst, int ns, uint32_t bit, int create, const int32_t* __restrict__ dst_states,
+                         const int32_t* __restrict__ src_offdw, const int32_t* __restrict__ src_rkup,
+                         const double2* __restrict__ src, double2* __restrict__ dst) {
+  const uint32_t lomask = (1u << ns) - 1u;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < ndst; j += (int64_t)gridDim.x * 256) {
+    const uint32_t t = (uint32_t)dst_states[j];
+    double2 x = make_double2(0.0, 0.0);
+    if (create ? (t & bit) != 0u : (t & bit) == 0u) {
+      const uint32_t sst = t ^ bit;
+      const int64_t i = (int64_t)src_offdw[sst >> ns] + src_rkup[sst & lomask];
+      x = src[i];
+      if (__popc(sst & (bit - 1u)) & 1) {
+        x.x = -x.x;
+        x.y = -x.y;
+      }
+    }
+    dst[j] = x;
+  }
+}
+
+int launch_apply_op_flat(int64_t ndst, int ns, uint32_t bit, int create, const int32_t* dst_states,
+                         const int32_t* src_offdw, const int32_t* src_rkup, const double* src, double* dst,
+                         hipStream_t st) {
+  if (ndst == 0) return 0;
+  int64_t nb = (ndst + 255) / 256;
+  if (nb > 256 * 16) nb = 256 * 16;
+  hipLaunchKernelGGL(apply_op_flat_kernel, dim3((unsigned)nb), dim3(256), 0, st, ndst, ns, bit, create, dst_states,
+                     src_offdw, src_rkup, reinterpret_cast<const double2*>(src), reinterpret_cast<double2*>(dst));
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_apply_op_normal(int64_t dst_dimup, int64_t dst_dimdw, int64_t src_dimup, int spin_down,
                            const uint32_t* part, const double* src, double* dst, hipStream_t st) {
   const int64_t n = dst_dimup * dst_dimdw;

@@ -327,8 +327,9 @@ class SectorHamiltonian:
     def apply_op_to(self, dst: "SectorHamiltonian", v_src_ptr: int, v_dst_ptr: int, iorb: int, ispin: int,
                     create: bool, stream: int = 0) -> None:
         """apply_op_C / apply_op_CDG on device vectors: |dst> = c^(+)_{iorb,ispin} |src> (self = source sector)."""
-        capi.check(capi.lib().edigpu_apply_op_normal(self._h, dst._h, v_src_ptr, v_dst_ptr, iorb, ispin, int(create),
-                                                     stream if stream else None), "edigpu_apply_op_normal")
+        fn = capi.lib().edigpu_apply_op_normal if self.kind == 0 else capi.lib().edigpu_apply_op_flat
+        capi.check(fn(self._h, dst._h, v_src_ptr, v_dst_ptr, iorb, ispin, int(create),
+                      stream if stream else None), "edigpu_apply_op")
 
     def lanczos_eigh(self, nitermax: int = 512, tol: float = 1e-12, check_every: int = 10,
                      v0: np.ndarray | None = None, want_vector: bool = True):

@@ -262,6 +262,11 @@ int edigpu_lanczos_eigh_multi(edigpu_handle h, int neigen, int ncv, double tol, 
  */
 int edigpu_apply_op_normal(edigpu_handle src, edigpu_handle dst, const double *v_src_dev, double *v_dst_dev,
                            int iorb, int ispin, int create, void *stream);
+/* the same for superc / nonsu2 sectors (handles from edigpu_flat_build / edigpu_direct_build, complex vectors):
+ * superc sectors are labelled by Sz, so c^+_up / c_dw lead to Sz+1 and c^+_dw / c_up to Sz-1; nonsu2 by Ntot.
+ * The sign counts every occupied level below the operator's level in the 2*Ns-bit state (up levels first). */
+int edigpu_apply_op_flat(edigpu_handle src, edigpu_handle dst, const double *v_src_dev, double *v_dst_dev,
+                         int iorb, int ispin, int create, void *stream);
 /* edigpu_lanczos_tridiag with the seed in device memory (e.g. the output of edigpu_apply_op_normal; it must be
  * complete when the call is made) and norm2 = <vin|vin> returned as tridiag_Hv_sector_* does.
  * edigpu_lanczos_eigh likewise accepts device pointers for v0 and for the eigenvector. */

@@ -727,6 +727,47 @@ def test_eigh_multi_matches_dense(gpu, mode, bath, norb, nbath, sec, neigen, ncv
     hg.destroy()
 
 
+@pytest.mark.parametrize("mode,sec", [("superc", 0), ("nonsu2", 5)])
+def test_apply_op_flat_sectors(gpu, mode, sec):
+    """edigpu_apply_op_flat against a direct evaluation with the oracle's c / cdg on the sector maps."""
+    import torch
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models(mode, "hybrid", 2, 3, seed=61)
+    ns = om.ns
+    hs_o = O.HFlat(om, sec)
+    hs = SectorHamiltonian.flat_from_model(pm, sec)
+    rng = np.random.default_rng(4)
+    v = rng.standard_normal(hs.dim) + 1j * rng.standard_normal(hs.dim)
+    vd = torch.from_numpy(v).cuda()
+    for iorb in range(2):
+        for ispin in range(2):
+            for create in (True, False):
+                d = 1 if create else -1
+                sec2 = sec + (d if ispin == 0 else -d) if mode == "superc" else sec + d
+                try:
+                    ht_o = O.HFlat(om, sec2)
+                except Exception:
+                    continue
+                if ht_o.dim == 0:
+                    continue
+                ht = (SectorHamiltonian.direct_from_model if create else SectorHamiltonian.flat_from_model)(pm, sec2)
+                out = torch.full((ht.dim,), 3.0 + 0j, dtype=torch.complex128, device="cuda")
+                hs.apply_op_to(ht, vd.data_ptr(), out.data_ptr(), iorb, ispin, create)
+                ref = np.zeros(ht_o.dim, complex)
+                rank = {int(s): i for i, s in enumerate(ht_o.map)}
+                bit = 1 << (iorb + ispin * ns)
+                for i, st in enumerate(hs_o.map):
+                    st = int(st)
+                    if bool(st & bit) == create:
+                        continue
+                    sg = -1.0 if bin(st & (bit - 1)).count("1") & 1 else 1.0
+                    ref[rank[st ^ bit]] = sg * v[i]
+                assert np.max(np.abs(out.cpu().numpy() - ref)) < 1e-15
+                ht.destroy()
+    hs.destroy()
+
+
 def test_sigma_momenta_fully_device_resident(gpu):
     """The whole zero-temperature GF inner loop on the device, against the reference's Sigma_momenta fixture:
     ground state by edigpu_lanczos_eigh_multi (eigenvector stays on the GPU), c / c^+ by
