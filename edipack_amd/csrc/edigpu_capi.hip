@@ -1407,7 +1407,7 @@ int edigpu_apply_op_normal(edigpu_handle src, edigpu_handle dst, const double* v
     set_error("edigpu_apply_op_normal: NULL argument");
     return 1;
   }
-  if (src->kind != 0 || dst->kind != 0 || !src->lazy_and_model_ok() || !dst->lazy_and_model_ok()) {
+  if (src->kind != 0 || dst->kind != 0 || !src->from_model() || !dst->from_model()) {
     set_error("edigpu_apply_op_normal: both handles must be normal-mode sectors built by edigpu_normal_build");
     return 1;
   }

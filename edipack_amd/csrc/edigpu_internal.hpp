@@ -115,8 +115,8 @@ struct edigpu_sector {
   bool lazy_export = false;
   edigpu_model model;           // library-built sectors: what edigpu_*_build was given
   int sec_a = 0, sec_b = 0;
-  bool built_by_library = false;
-  bool lazy_and_model_ok() const { return built_by_library; }
+  bool built_by_library = false;   // made by edigpu_*_build: model, sec_a, sec_b are valid
+  bool from_model() const { return built_by_library; }
   // ---- flat ----
   edigpu::DevCsr loc, nonloc; // local rows; loc columns are shard-relative, nonloc global
   // ---- orbs (ed_total_ud = F) ----
