@@ -169,6 +169,35 @@ def test_normal_two_phase_equals_fused(gpu):
     assert rel_err(np.concatenate(out), ref) < TOL
 
 
+def test_normal_two_phase_handover_shards(gpu):
+    """The same two-phase product on the hand-over image (explicit spH0d, spH0nd rows of the shard with global
+    columns as spMatVec_mpi_normal_main holds them): local rows only for Hd / Hnd, H up / H dw replicated."""
+    import torch
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, _ = make_models("normal", "hybrid", 3, 3, seed=9)
+    ho = O.HNormal(om, 3, 3)
+    v = np.random.default_rng(5).standard_normal(ho.dim)
+    ref = ho.matvec(v)
+    vd = torch.from_numpy(v).cuda()
+    out = []
+    cut = ho.dimdw // 3
+    ndr, ndc, ndv = ho.nd
+    for first, cnt in ((0, cut), (cut, ho.dimdw - cut)):
+        r0, r1 = first * ho.dimup, (first + cnt) * ho.dimup
+        nd_loc = (ndr[r0:r1 + 1] - ndr[r0], ndc[ndr[r0]:ndr[r1]], ndv[ndr[r0]:ndr[r1]])
+        hs = SectorHamiltonian.normal_from_arrays(ho.dimup, ho.dimdw, ho.hd[r0:r1], ho.up, ho.dw, nd_loc,
+                                                  dw_first=first, dw_count=cnt)
+        hv = torch.empty(hs.nloc, dtype=torch.float64, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        hs.apply_local_dev(vd[hs.row_first:].data_ptr(), hv.data_ptr(), st)
+        hs.apply_remote_dev(vd.data_ptr(), hv.data_ptr(), st)
+        torch.cuda.synchronize()
+        out.append(hv.cpu().numpy())
+        hs.destroy()
+    assert rel_err(np.concatenate(out), ref) < TOL
+
+
 # --------------------------------------------------------------------------------------------
 # flat CSR (real / complex), loc + non-loc split
 # --------------------------------------------------------------------------------------------
