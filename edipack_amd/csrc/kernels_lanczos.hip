@@ -219,12 +219,15 @@ int lz_alpha(const double* vin, double* vout, const double* tmp, int64_t n, doub
   return 0;
 }
 
-// alpha and beta from the panel-sweep partials: beta^2 = <Q|Q> - alpha^2 (|v| = 1).  When that
-// difference loses more than ~3 digits to cancellation SC_EXACT is raised and the (otherwise idle)
-// exact pass recomputes beta^2 = |Q - alpha v|^2 directly.
+// alpha and beta from the sweep's partials: beta^2 = <Q|Q> - alpha^2 (|v| = 1).  When that difference loses
+// more than ~3 digits to cancellation (near-invariant subspace, rare) the same single workgroup recomputes
+// beta^2 = |Q - alpha v|^2 directly by sweeping the two vectors (Q is left untouched: the axpy stays pending).
+// One launch per step: the former separate fallback kernel cost ~4.7 us per step while idle.
 __global__ void __launch_bounds__(1024)
-    k_finalize_ab(const double* __restrict__ partial, int np, double* __restrict__ scal, int iter, int nlanc) {
+    k_finalize_ab(const double* __restrict__ partial, int np, const double* __restrict__ P,
+                  const double* __restrict__ Q, int64_t n, double* __restrict__ scal, int iter, int nlanc) {
   __shared__ double sa[1024], sq[1024];
+  __shared__ int exact;
   if (scal[SC_STOP] != 0.0) return;
   double a = 0.0, q = 0.0;
   for (int i = threadIdx.x; i < np; i += 1024) {
@@ -241,50 +244,32 @@ __global__ void __launch_bounds__(1024)
     }
     __syncthreads();
   }
+  const double alpha = sa[0], qq = sq[0];
+  double b2 = qq - alpha * alpha;
+  if (threadIdx.x == 0) exact = b2 < 1e-3 * qq;
+  __syncthreads();
+  if (exact) {  // uniform
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+      const double w = Q[i] - alpha * P[i];
+      s += w * w;
+    }
+    __syncthreads();
+    sa[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+      if (threadIdx.x < off) sa[threadIdx.x] += sa[threadIdx.x + off];
+      __syncthreads();
+    }
+    b2 = sa[0];
+  }
   if (threadIdx.x == 0) {
-    const double alpha = sa[0], qq = sq[0];
-    double b2 = qq - alpha * alpha;
     scal[SC_ALPHA] = alpha;
     scal[SC_AB + iter] = alpha;
     scal[SC_NDONE] = (double)(iter + 1);
-    if (b2 < 1e-3 * qq) {
-      scal[SC_EXACT] = 1.0;  // beta written by the exact pass
-    } else {
-      scal[SC_EXACT] = 0.0;
-      const double b = sqrt(b2);
-      scal[SC_BETA] = b;
-      if (fabs(b) < scal[SC_THR])
-        scal[SC_STOP] = 1.0;
-      else if (iter + 1 < nlanc)
-        scal[SC_AB + nlanc + iter + 1] = b;
-    }
-  }
-}
-
-// exact |Q - alpha*P|^2 (only when SC_EXACT is raised; Q is left untouched: the axpy stays pending).
-// One workgroup: the launch costs ~2 us when idle; when it does run (near-invariant subspace, rare) it
-// sweeps the vectors alone.
-__global__ void __launch_bounds__(1024)
-    k_beta_exact_single(const double* __restrict__ P, const double* __restrict__ Q, int64_t n,
-                        double* __restrict__ scal, int iter, int nlanc) {
-  __shared__ double sh[1024];
-  if (scal[SC_STOP] != 0.0 || scal[SC_EXACT] == 0.0) return;
-  const double a = scal[SC_ALPHA];
-  double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) {
-    const double w = Q[i] - a * P[i];
-    s += w * w;
-  }
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int off = 512; off > 0; off >>= 1) {
-    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const double b = sqrt(sh[0]);
-    scal[SC_BETA] = b;
     scal[SC_EXACT] = 0.0;
+    const double b = sqrt(b2 > 0.0 ? b2 : 0.0);
+    scal[SC_BETA] = b;
     if (fabs(b) < scal[SC_THR])
       scal[SC_STOP] = 1.0;
     else if (iter + 1 < nlanc)
@@ -294,9 +279,7 @@ __global__ void __launch_bounds__(1024)
 
 int lz_finalize_alpha_beta(const double* P, const double* Q, int64_t n, double* partial, int np,
                            double* scal, int iter, int nlanc, hipStream_t st) {
-  hipLaunchKernelGGL(k_finalize_ab, dim3(1), dim3(1024), 0, st, partial, np, scal, iter, nlanc);
-  // exact fallback: returns immediately unless SC_EXACT was raised
-  hipLaunchKernelGGL(k_beta_exact_single, dim3(1), dim3(1024), 0, st, P, Q, n, scal, iter, nlanc);
+  hipLaunchKernelGGL(k_finalize_ab, dim3(1), dim3(1024), 0, st, partial, np, P, Q, n, scal, iter, nlanc);
   EDIGPU_HIP(hipGetLastError());
   return 0;
 }
