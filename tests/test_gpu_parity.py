@@ -896,3 +896,75 @@ def test_error_paths(gpu):
         a.apply(np.zeros(a.dim + 1))
     for h in (a, b, sh):
         h.destroy()
+
+
+# --------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties (the oracle cannot reach these dimensions in
+# seconds; two independent device images of the same Hamiltonian must agree, H must be Hermitian and linear)
+# --------------------------------------------------------------------------------------------
+def _dev_apply(h, x):
+    import torch
+    y = torch.empty_like(x)
+    h.apply_dev(x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return y
+
+
+def test_fullsize_config2_properties(gpu, monkeypatch):
+    """config 2 (Dim = 11 778 624): factored image vs explicit image (different kernels: factored diagonal /
+    Hnd in the panel sweep vs streamed diagonal / Hnd as SELL pass), Hermiticity, linearity, and the fused
+    Lanczos recurrence vs the unfused one."""
+    import torch
+    from edipack_amd.synthetic import WORKLOADS, build_workload
+    w = WORKLOADS["cfg2"]
+    hf = build_workload(w)
+    monkeypatch.setenv("EDIGPU_NORMAL_EXPLICIT", "1")
+    he = build_workload(w)
+    monkeypatch.delenv("EDIGPU_NORMAL_EXPLICIT")
+    assert hf.dim == he.dim == 11778624
+    g = torch.Generator(device="cuda").manual_seed(7)
+    u = torch.randn(hf.dim, dtype=torch.float64, device="cuda", generator=g)
+    v = torch.randn(hf.dim, dtype=torch.float64, device="cuda", generator=g)
+    hu, hv = _dev_apply(hf, u), _dev_apply(hf, v)
+    scale = float(torch.linalg.norm(hv))
+    assert float(torch.linalg.norm(hv - _dev_apply(he, v))) < 1e-13 * scale        # two images, one operator
+    assert abs(float(torch.dot(u, hv) - torch.dot(hu, v))) < 1e-11 * scale * float(torch.linalg.norm(u))
+    lin = _dev_apply(hf, 2.0 * u - 3.0 * v) - (2.0 * hu - 3.0 * hv)
+    assert float(torch.linalg.norm(lin)) < 1e-13 * scale
+    # Lanczos: fused (factored) vs fused (explicit image): same alpha/beta
+    v0 = v.cpu().numpy()
+    a1, b1, _ = hf.lanczos_tridiag(v0, 30)
+    a2, b2, _ = he.lanczos_tridiag(v0, 30)
+    assert rel_err(a1, a2) < 1e-10 and rel_err(b1, b2) < 1e-10
+    # alpha_1 = <v|H|v>/<v|v> from the plain product
+    assert abs(a1[0] - float(torch.dot(v, hv) / torch.dot(v, v))) < 1e-10 * abs(a1[0])
+    hf.destroy()
+    he.destroy()
+
+
+def test_fullsize_flat_properties(gpu, monkeypatch):
+    """cfg4 ladder (Ns=12, 2.7 M rows, complex): device-built SELL image vs the on-the-fly kernel (no matrix at
+    all) -- two independent evaluations of the same operator -- plus Hermiticity."""
+    import torch
+    from edipack_amd.synthetic import WORKLOADS, synthetic_model
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    w = WORKLOADS["cfg4_ns12"]
+    m = synthetic_model(w)
+    hs = SectorHamiltonian.flat_from_model(m, w.sector)
+    hd = SectorHamiltonian.direct_from_model(m, w.sector)
+    assert hs.dim == hd.dim == 2704156
+    g = torch.Generator(device="cuda").manual_seed(3)
+    def rnd():
+        return torch.complex(torch.randn(hs.dim, dtype=torch.float64, device="cuda", generator=g),
+                             torch.randn(hs.dim, dtype=torch.float64, device="cuda", generator=g))
+    u, v = rnd(), rnd()
+    hv_s, hv_d = _dev_apply(hs, v), _dev_apply(hd, v)
+    scale = float(torch.linalg.norm(hv_s))
+    assert float(torch.linalg.norm(hv_s - hv_d)) < 1e-13 * scale
+    hu = _dev_apply(hs, u)
+    assert abs(complex(torch.vdot(u, hv_s) - torch.vdot(hu, v))) < 1e-11 * scale * float(torch.linalg.norm(u))
+    a1, b1, _ = hs.lanczos_tridiag(v.cpu().numpy(), 25)
+    a2, b2, _ = hd.lanczos_tridiag(v.cpu().numpy(), 25)
+    assert rel_err(a1, a2) < 1e-10 and rel_err(b1, b2) < 1e-10
+    hs.destroy()
+    hd.destroy()
