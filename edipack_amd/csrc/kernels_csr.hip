@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(kCsrNT)
   const bool in = slice < nslice;
   const int32_t b = in ? sptr[slice] : 0, e = in ? sptr[slice + 1] : 0;
   double sr = 0.0, si = 0.0, da = 0.0, dq = 0.0;
-#pragma unroll 4
+#pragma unroll 8
   for (int32_t k = b; k < e; k++) {
     const int64_t o = (int64_t)k * 64 + lane;
     const int64_t c = col[o];
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(kCsrNT)
   const bool in = slice < nslice;
   const int32_t b = in ? sptr[slice] : 0, e = in ? sptr[slice + 1] : 0;
   double sr = 0.0, si = 0.0, da = 0.0, dq = 0.0;
-#pragma unroll 4
+#pragma unroll 8
   for (int32_t k = b; k < e; k++) {
     const uint32_t p = pk[(int64_t)k * 64 + lane];
     const int64_t c = p & 0xFFFFFFu;
