@@ -14,7 +14,11 @@
 // Measured (round 1, cfg2): issuing the whole list of two rows as one batch of independent loads
 // (6..8 in flight per row) is 10-20 % SLOWER than this two-entries-at-a-time loop: the kernel is
 // bound by the fabric/L2 traffic of the sweep, not by load latency, and a deeper queue only spreads
-// the workgroups of a panel further apart.
+// the workgroups of a panel further apart.  Ablation of this kernel on config 2 (99 us under rocprofv3): no
+// result store 94, no result load 94, neither 82, no neighbour gathers 40, nothing but the list handling 18
+// -- i.e. ~60 us are the L2 gathers.  A variant with two columns per lane (16-byte gathers, a half-wave per
+// row, lists staged in LDS: half as many gather instructions) measured 1.8x SLOWER (175 us), so the gather
+// cost does not go with the instruction count either.
 #include <cstdlib>
 
 #include "normal_args.hpp"
