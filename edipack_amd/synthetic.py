@@ -42,6 +42,7 @@ WORKLOADS = {
     # BASELINE.json configs[4]: 3 orbitals, Nbath=10 (hybrid), nonsu2, on-the-fly kernel
     "cfg5": Workload("cfg5", 5, "nonsu2", "hybrid", 3, 10, 13, "Ns=13, N=13, Dim=10 400 600, complex, direct", True),
     "cfg5_ns11": Workload("cfg5_ns11", 5, "nonsu2", "hybrid", 3, 8, 11, "Ns=11, N=11, Dim=705 432, direct", True),
+    "cfg5_stored": Workload("cfg5_stored", 5, "nonsu2", "hybrid", 3, 10, 13, "Ns=13, N=13, Dim=10 400 600, complex, stored"),
     "cfg5_stored_ns11": Workload("cfg5_stored_ns11", 5, "nonsu2", "hybrid", 3, 8, 11, "Ns=11, N=11, Dim=705 432"),
 }
 
