@@ -1704,6 +1704,17 @@ int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, 
   int k = 0, meff = m, nmv = 0, nconv = 0;
   double beta_last = 0.0;
   bool invariant = false;
+  // per cycle the Gram-Schmidt coefficients (two passes) and the squared norms stay on the device and are
+  // fetched once: no host synchronisation inside the Lanczos steps
+  const size_t hstride = 2 * (size_t)(m + 16);
+  double *d_coef = nullptr, *d_nrm = nullptr;
+  EDIGPU_HIP(hipMalloc((void**)&d_coef, sizeof(double) * 2 * hstride * (size_t)m));
+  EDIGPU_HIP(hipMalloc((void**)&d_nrm, sizeof(double) * (2 * (size_t)m + 32)));  // the reduction writes 16 slots
+  struct Free2 {
+    double *&a, *&b;
+    ~Free2() { (void)hipFree(a); (void)hipFree(b); }
+  } free2{d_coef, d_nrm};
+  std::vector<double> hcoef(2 * hstride * (size_t)m), hnrm(2 * (size_t)m + 32);
   for (int restart = 0; restart <= maxrestart; restart++) {
     invariant = false;
     meff = m;
@@ -1712,27 +1723,31 @@ int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, 
       if (apply_any(s, q(j), q(j), w, 3, st)) return 1;
       nmv++;
       // classical Gram-Schmidt against q_0..q_j, twice; the coefficients are column j of Q^H H Q
-      if (trl_orthogonalize(cplx, n, j + 1, b.Q, len, w, b.h, b.part, st)) return 1;
-      EDIGPU_HIP(hipMemcpyAsync(hh.data(), b.h, 2 * sizeof(double) * (size_t)(j + 1), hipMemcpyDeviceToHost, st));
-      EDIGPU_HIP(hipStreamSynchronize(st));
-      for (int i = 0; i <= j; i++) T[(size_t)i * m + j] = hh[2 * i];
-      if (trl_orthogonalize(cplx, n, j + 1, b.Q, len, w, b.h, b.part, st)) return 1;
-      EDIGPU_HIP(hipMemcpyAsync(hh.data(), b.h, 2 * sizeof(double) * (size_t)(j + 1), hipMemcpyDeviceToHost, st));
-      EDIGPU_HIP(hipStreamSynchronize(st));
+      double* c1 = d_coef + (size_t)(2 * j) * hstride;
+      double* c2 = d_coef + (size_t)(2 * j + 1) * hstride;
+      if (trl_orthogonalize(cplx, n, j + 1, b.Q, len, w, c1, b.part, st)) return 1;
+      if (trl_orthogonalize(cplx, n, j + 1, b.Q, len, w, c2, b.part, st)) return 1;
+      if (trl_norm2(cplx, n, w, d_nrm + 2 * j, b.part, st)) return 1;
+      if (vec_scale(len, w, d_nrm + 2 * j, st)) return 1;  // w / sqrt(<w|w>) with the norm read on the device
+    }
+    EDIGPU_HIP(hipMemcpyAsync(hcoef.data(), d_coef, sizeof(double) * hcoef.size(), hipMemcpyDeviceToHost, st));
+    EDIGPU_HIP(hipMemcpyAsync(hnrm.data(), d_nrm, sizeof(double) * hnrm.size(), hipMemcpyDeviceToHost, st));
+    EDIGPU_HIP(hipStreamSynchronize(st));
+    for (int j = k; j < m; j++) {
+      const double* c1 = &hcoef[(size_t)(2 * j) * hstride];
+      const double* c2 = &hcoef[(size_t)(2 * j + 1) * hstride];
       for (int i = 0; i <= j; i++) {
-        T[(size_t)i * m + j] += hh[2 * i];
+        T[(size_t)i * m + j] = c1[2 * i] + c2[2 * i];
         T[(size_t)j * m + i] = T[(size_t)i * m + j];
       }
-      double beta = 0.0;
-      if (norm_of(w, beta)) return 1;
+      const double beta = sqrt(std::max(hnrm[2 * j], 0.0));
       beta_last = beta;
       const double scale = fabs(T[(size_t)j * m + j]) + 1.0;
-      if (beta <= 1e-13 * scale) {  // invariant subspace: the basis q_0..q_j is closed under H
+      if (!(beta > 1e-13 * scale)) {  // invariant subspace: q_0..q_j is closed under H (later steps are discarded)
         meff = j + 1;
         invariant = true;
         break;
       }
-      if (trl_scale(len, w, 1.0 / beta, st)) return 1;
     }
     // Rayleigh-Ritz on the meff x meff projection
     Tw.assign((size_t)meff * meff, 0.0);
