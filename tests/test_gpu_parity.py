@@ -970,3 +970,43 @@ def test_fullsize_flat_properties(gpu, monkeypatch):
     assert rel_err(a1, a2) < 1e-10 and rel_err(b1, b2) < 1e-10
     hs.destroy()
     hd.destroy()
+
+
+# --------------------------------------------------------------------------------------------
+# randomized sweep: small random models over every mode / bath type / sector, stored and on-the-fly
+# --------------------------------------------------------------------------------------------
+def test_randomized_model_sweep(gpu):
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    rng = np.random.default_rng(20260630)
+    ncase = 0
+    for trial in range(60):
+        mode = ["normal", "superc", "nonsu2"][trial % 3]
+        bath = ["normal", "hybrid", "replica", "general"][int(rng.integers(0, 4))]
+        norb = int(rng.integers(1, 4))
+        nbath = int(rng.integers(1, 4))
+        if mode != "normal" and (norb + (nbath if bath == "hybrid" else nbath * norb)) > 7:
+            nbath = 1                      # keep 2*Ns <= 14 bits for the flat modes
+        if bath in ("replica", "general") and norb == 1 and mode == "nonsu2":
+            bath = "normal"
+        om, pm = make_models(mode, bath, norb, nbath, seed=100 + trial)
+        ns = om.ns
+        if mode == "normal":
+            sec = (int(rng.integers(0, ns + 1)), int(rng.integers(0, ns + 1)))
+            ho = O.HNormal(om, *sec)
+            hs = [SectorHamiltonian.normal_from_model(pm, *sec)]
+            v = rng.standard_normal(ho.dim)
+        else:
+            sec = int(rng.integers(-ns, ns + 1)) if mode == "superc" else int(rng.integers(0, 2 * ns + 1))
+            ho = O.HFlat(om, sec)
+            if ho.dim == 0:
+                continue
+            hs = [SectorHamiltonian.flat_from_model(pm, sec), SectorHamiltonian.direct_from_model(pm, sec)]
+            v = rng.standard_normal(ho.dim) + 1j * rng.standard_normal(ho.dim)
+        ref = ho.matvec(v)
+        for h in hs:
+            assert h.dim == ho.dim
+            assert rel_err(h.apply(v), ref) < TOL, (trial, mode, bath, norb, nbath, sec)
+            h.destroy()
+        ncase += 1
+    assert ncase >= 50
