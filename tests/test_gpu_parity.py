@@ -1010,3 +1010,40 @@ def test_randomized_model_sweep(gpu):
             h.destroy()
         ncase += 1
     assert ncase >= 50
+
+
+def test_randomized_orbs_and_tridiag_sweep(gpu):
+    """random ed_total_ud=F sectors, and the device tridiagonalisation on random sectors of every mode."""
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    rng = np.random.default_rng(424242)
+    for trial in range(20):
+        norb, nbath = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        om, pm = _orbs_models(norb, nbath, seed=200 + trial)
+        nups = tuple(int(x) for x in rng.integers(0, nbath + 2, norb))
+        ndws = tuple(int(x) for x in rng.integers(0, nbath + 2, norb))
+        ho = O.HOrbs(om, nups, ndws)
+        hg = SectorHamiltonian.orbs_from_model(pm, nups, ndws)
+        v = rng.standard_normal(ho.dim)
+        assert rel_err(hg.apply(v), ho.matvec(v)) < TOL, (trial, norb, nbath, nups, ndws)
+        hg.destroy()
+    for trial in range(18):
+        mode = ["normal", "superc", "nonsu2"][trial % 3]
+        bath = ["normal", "hybrid", "general"][int(rng.integers(0, 3))]
+        om, pm = make_models(mode, bath, 2, 2, seed=300 + trial)
+        ns = om.ns
+        if mode == "normal":
+            sec = (int(rng.integers(1, ns)), int(rng.integers(1, ns)))
+            ho, hg = O.HNormal(om, *sec), SectorHamiltonian.normal_from_model(pm, *sec)
+            v = rng.standard_normal(ho.dim)
+        else:
+            sec = int(rng.integers(-1, 2)) if mode == "superc" else int(rng.integers(ns - 1, ns + 2))
+            ho = O.HFlat(om, sec)
+            hg = (SectorHamiltonian.direct_from_model if trial % 2 else SectorHamiltonian.flat_from_model)(pm, sec)
+            v = rng.standard_normal(ho.dim) + 1j * rng.standard_normal(ho.dim)
+        nl = min(ho.dim, 12)
+        ao, bo, _ = ho.lanc_tridiag(v, nl)
+        ag, bg, _ = hg.lanczos_tridiag(v, nl)
+        # early coefficients only: in tiny sectors the recurrence amplifies rounding differences within a few steps
+        assert rel_err(ag[:5], ao[:5]) < 1e-9 and rel_err(bg[:5], bo[:5]) < 1e-9, (trial, mode, bath, sec)
+        hg.destroy()
