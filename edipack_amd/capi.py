@@ -41,6 +41,9 @@ class EdigpuModel(C.Structure):
         ("bd", C.c_double * (2 * MAXORB * MAXBATH)),
         ("bu", C.c_double * (2 * MAXORB * MAXBATH)),
         ("hb", C.c_double * (2 * 2 * MAXORB * MAXORB * MAXBATH * 2)),
+        ("nph", C.c_int32), ("pad_", C.c_int32),
+        ("w0_ph", C.c_double), ("a_ph", C.c_double),
+        ("g_ph", C.c_double * (MAXORB * MAXORB)),
     ]
 
 

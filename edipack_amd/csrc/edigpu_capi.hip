@@ -627,6 +627,18 @@ static int ensure_workspace(edigpu_sector* s) {
 
 static int apply_any(edigpu_sector* s, const double* v_local, const double* v_full, double* hv,
                      int phase, hipStream_t st) {
+  if (s->kind == 0 && s->nph > 0) {
+    // phonon branches: the electronic product on every phonon block, then the phonon / electron-phonon pass
+    if (phase != 3) {
+      set_error("phonon sectors are single-shard: use the fused product");
+      return 1;
+    }
+    for (int iph = 0; iph <= s->nph; iph++) {
+      const int64_t o = (int64_t)iph * s->dim_el;
+      if (launch_normal(s, v_local + o, v_full + o, hv + o, 3, st)) return 1;
+    }
+    return launch_phonon(s, v_full, hv, st);
+  }
   if (s->kind == 0) return launch_normal(s, v_local, v_full, hv, phase, st);
   if (s->kind == 3) {
     // ed_total_ud = F: single shard only (phase 1 = everything, phase 2 = nothing left to add)
@@ -920,6 +932,44 @@ int edigpu_normal_build(edigpu_handle* h, const edigpu_model* model, int nup, in
                    hn.nd.val.data(), &hn)) {
     edigpu_destroy(s.release());
     return 1;
+  }
+  if (model->nph > 0) {
+    // phonon branches: (Nph + 1) electronic blocks per vector; density couplings only
+    if (s->dw_count != s->dim_dw) {
+      set_error("edigpu_normal_build: phonons (nph > 0) need the whole sector on one shard");
+      edigpu_destroy(s.release());
+      return 1;
+    }
+    for (int a = 0; a < model->norb; a++)
+      for (int b = 0; b < model->norb; b++)
+        if (a != b && model->g_ph[a * EDIGPU_MAXORB + b] != 0.0) {
+          set_error("edigpu_normal_build: only the density couplings g_ph(a,a) are built (off-diagonal g_ph: hand "
+                    "the matrices over)");
+          edigpu_destroy(s.release());
+          return 1;
+        }
+    std::vector<double> gu((size_t)hn.dim_up, 0.0), gd((size_t)hn.dim_dw, 0.0);
+    for (int64_t i = 0; i < hn.dim_up; i++)
+      for (int a = 0; a < model->norb; a++)
+        if ((hn.bup.states[i] >> a) & 1) gu[i] += model->g_ph[a * EDIGPU_MAXORB + a];
+    for (int64_t i = 0; i < hn.dim_dw; i++)
+      for (int a = 0; a < model->norb; a++)
+        if ((hn.bdw.states[i] >> a) & 1) gd[i] += model->g_ph[a * EDIGPU_MAXORB + a];
+    if (dev_upload(&s->d_gu, gu.data(), gu.size()) || dev_upload(&s->d_gd, gd.data(), gd.size())) {
+      edigpu_destroy(s.release());
+      return 1;
+    }
+    if (s->dim * (model->nph + 1) >= ((int64_t)1 << 31)) {
+      set_error("edigpu_normal_build: sector dimension x (Nph+1) >= 2^31");
+      edigpu_destroy(s.release());
+      return 1;
+    }
+    s->nph = model->nph;
+    s->w0_ph = model->w0_ph;
+    s->a_ph = model->a_ph;
+    s->dim_el = s->dim;
+    s->dim *= (model->nph + 1);
+    s->nloc = s->dim;
   }
   *h = s.release();
   return 0;
@@ -1239,7 +1289,8 @@ int edigpu_normal_export(edigpu_handle s, double* hd, int64_t* up_rowptr, int32_
     if (s->factored)
       std::copy(s->h_hd.begin(), s->h_hd.end(), hd);
     else
-      EDIGPU_HIP(hipMemcpy(hd, s->d_hd, (size_t)s->nloc * sizeof(double), hipMemcpyDeviceToHost));
+      EDIGPU_HIP(hipMemcpy(hd, s->d_hd, (size_t)(s->nph > 0 ? s->dim_el : s->nloc) * sizeof(double),
+                           hipMemcpyDeviceToHost));  // the electronic diagonal (one phonon block)
   }
   auto cp = [](const HostCsr& a, int64_t* rp, int32_t* c, double* v) {
     if (rp) std::copy(a.rowptr.begin(), a.rowptr.end(), rp);
@@ -1407,7 +1458,7 @@ int edigpu_apply_op_normal(edigpu_handle src, edigpu_handle dst, const double* v
     set_error("edigpu_apply_op_normal: NULL argument");
     return 1;
   }
-  if (src->kind != 0 || dst->kind != 0 || !src->from_model() || !dst->from_model()) {
+  if (src->kind != 0 || dst->kind != 0 || !src->from_model() || !dst->from_model() || src->nph > 0 || dst->nph > 0) {
     set_error("edigpu_apply_op_normal: both handles must be normal-mode sectors built by edigpu_normal_build");
     return 1;
   }
@@ -1922,6 +1973,8 @@ int edigpu_destroy(edigpu_handle s) {
     (void)hipStreamDestroy(s->stream);
   }
   dev_free(s->d_hd);
+  dev_free(s->d_gu);
+  dev_free(s->d_gd);
   dev_free(s->d_mx_rowptr);
   dev_free(s->d_mx_col);
   dev_free(s->d_mx_val);

@@ -109,6 +109,12 @@ struct edigpu_sector {
   int32_t* d_mx_rowptr = nullptr;  // per local row: Hdw entries + applicable Hnd terms
   int32_t* d_mx_col = nullptr;
   double* d_mx_val = nullptr;
+  // phonon branches (normal mode, whole sectors): vectors hold (nph + 1) electronic blocks of dim_el elements
+  int nph = 0;
+  int64_t dim_el = 0;
+  double w0_ph = 0.0, a_ph = 0.0;
+  double* d_gu = nullptr;       // [dim_up]  sum_a g_aa n_a,up
+  double* d_gd = nullptr;       // [dim_dw]
   int64_t nd_nnz = 0;           // nnz of the (possibly host-only) CSR image of Hnd
   std::vector<double> h_hd;     // host copies for export when the device holds the factored form;
   edigpu::HostCsr h_nd;         // built on the first export (lazy_export) from the stored model

@@ -520,7 +520,7 @@ int launch_normal(const edigpu_sector* s, const double* v_local, const double* v
 //   panel sweep: Q += (Hdw + Hnd) v ; per-workgroup partials of alpha = <v|Q>
 // Returns the number of partials written.  The caller finalises alpha and runs the beta kernel.
 bool normal_lanczos_fusable(const edigpu_sector* s) {
-  if (s->kind != 0 || s->nloc != s->dim || s->dw_count == 0) return false;
+  if (s->kind != 0 || s->nloc != s->dim || s->dw_count == 0 || s->nph > 0) return false;
   if (s->rows_per_block == 0) return false;               // needs the LDS row kernel
   if (!s->factored && s->has_nd && !s->nd.sell) return false;  // CSR Hnd inside the row kernel needs the complete new vector
   if (getenv("EDIGPU_LANCZOS_UNFUSED")) return false;

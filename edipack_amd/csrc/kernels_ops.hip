@@ -66,6 +66,35 @@ int launch_apply_op_flat(int64_t ndst, int ns, uint32_t bit, int create, const i
   return 0;
 }
 
+// Phonon branches of spMatVec_normal_main (reference ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:597-629):
+//   hv(i_el, n) += w0 n v(i_el, n) + (A + g_el(i_el)) (sqrt(n) v(i_el, n-1) + sqrt(n+1) v(i_el, n+1)),
+// g_el = sum_a g_aa (n_a,up + n_a,dw) = gu[iup] + gd[idw] (density couplings; stored/H_ph.f90, H_e_ph.f90).
+// The electronic part has already been applied to every phonon block; this is one streaming pass.
+__global__ void __launch_bounds__(256)
+    phonon_kernel(int64_t dim_el, int dimph, int64_t dim_up, double w0, double a_ph, const double* __restrict__ gu,
+                  const double* __restrict__ gd, const double* __restrict__ v, double* __restrict__ hv) {
+  const int64_t n = dim_el * dimph;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t iph = i / dim_el, iel = i - iph * dim_el;
+    const int64_t idw = iel / dim_up, iup = iel - idw * dim_up;
+    const double g = a_ph + gu[iup] + gd[idw];
+    double acc = hv[i] + w0 * (double)iph * v[i];
+    if (iph > 0) acc = fma(g * sqrt((double)iph), v[i - dim_el], acc);
+    if (iph + 1 < dimph) acc = fma(g * sqrt((double)(iph + 1)), v[i + dim_el], acc);
+    hv[i] = acc;
+  }
+}
+
+int launch_phonon(const edigpu_sector* s, const double* v, double* hv, hipStream_t st) {
+  const int64_t n = s->dim_el * (s->nph + 1);
+  int64_t nb = (n + 255) / 256;
+  if (nb > 256 * 16) nb = 256 * 16;
+  hipLaunchKernelGGL(phonon_kernel, dim3((unsigned)nb), dim3(256), 0, st, s->dim_el, s->nph + 1, s->dim_up, s->w0_ph,
+                     s->a_ph, s->d_gu, s->d_gd, v, hv);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_apply_op_normal(int64_t dst_dimup, int64_t dst_dimdw, int64_t src_dimup, int spin_down,
                            const uint32_t* part, const double* src, double* dst, hipStream_t st) {
   const int64_t n = dst_dimup * dst_dimdw;

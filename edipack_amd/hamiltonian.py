@@ -58,6 +58,12 @@ class ImpurityModel:
     # Nspin, or the Nambu index in superc); hybridisations in bv (replica: item(k)%v for all is, iorb;
     # general: item(k)%vg(iorb + Norb*(is-1)))
     hb: np.ndarray | None = None
+    # phonons (normal mode): cut-off Nph, frequency, displacement field, coupling matrix g_ph[a, b] (density
+    # couplings g_aa only)
+    nph: int = 0
+    w0_ph: float = 0.0
+    a_ph: float = 0.0
+    g_ph: np.ndarray | None = None
 
     @property
     def ns(self) -> int:
@@ -92,6 +98,10 @@ class ImpurityModel:
             v[:k, :k, :no, :no, 1] = h.imag
         if self.pair_field is not None:
             np.ctypeslib.as_array(m.pair_field)[:no] = np.asarray(self.pair_field, dtype=float)
+        m.nph, m.w0_ph, m.a_ph = int(self.nph), float(self.w0_ph), float(self.a_ph)
+        if self.g_ph is not None:
+            np.ctypeslib.as_array(m.g_ph).reshape(capi.MAXORB, capi.MAXORB)[:no, :no] = \
+                np.asarray(self.g_ph, dtype=float).reshape(no, no)
         if self.bath_type in ("replica", "general"):
             if self.hb is None or self.bv is None:
                 raise capi.EdigpuError("ImpurityModel: replica/general baths need hb and bv")

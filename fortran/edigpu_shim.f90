@@ -44,6 +44,10 @@ module EDIGPU_SHIM
      real(c_double) :: bd(EDIGPU_MAXBATH, EDIGPU_MAXORB, 2) = 0d0
      real(c_double) :: bu(EDIGPU_MAXBATH, EDIGPU_MAXORB, 2) = 0d0
      real(c_double) :: hb(2, EDIGPU_MAXBATH, EDIGPU_MAXORB, EDIGPU_MAXORB, 2, 2) = 0d0
+     integer(c_int32_t) :: nph = 0          !< phonon cut-off Nph (0: none); DimPh = Nph+1
+     integer(c_int32_t) :: pad_ = 0
+     real(c_double) :: w0_ph = 0d0, a_ph = 0d0
+     real(c_double) :: g_ph(EDIGPU_MAXORB, EDIGPU_MAXORB) = 0d0   !< g_ph(jorb,iorb) = C [iorb][jorb]
   end type edigpu_model_t
 
   interface

@@ -569,6 +569,56 @@ void orc_spmatvec_normal_main(const orc_hnormal *h, const double *v, double *hv)
         hv[i] = hv[i] + h->nd.val[jj] * v[h->nd.col[jj]];
 }
 
+/* spMatVec_normal_main with DimPh > 1 (:517-650 incl. :597-629) */
+void orc_spmatvec_normal_ph(const orc_hnormal *h, const orc_model *m, const double *v, double *hv) {
+  const int64_t N = h->dim, DimUp = h->dimup;
+  const int dimph = m->nph + 1, norb = m->norb;
+  /* electronic part, the same for every phonon number */
+  for (int iph = 0; iph < dimph; iph++) orc_spmatvec_normal_main(h, v + iph * N, hv + iph * N);
+  for (int iph = 1; iph <= dimph; iph++)
+    for (int64_t i_el = 1; i_el <= N; i_el++) {
+      int64_t i = (i_el - 1) + (int64_t)(iph - 1) * N;
+      /* PHONON: stored/H_ph.f90 -- diagonal w0*(iph-1); A*sqrt(iph) at (iph+1,iph), A*sqrt(iph-1) at (iph-1,iph) */
+      hv[i] += m->w0_ph * (double)(iph - 1) * v[i];
+      if (m->a_ph != 0.0) {
+        if (iph > 1) hv[i] += m->a_ph * sqrt((double)(iph - 1)) * v[i - N]; /* row iph, col iph-1 */
+        if (iph < dimph) hv[i] += m->a_ph * sqrt((double)iph) * v[i + N];   /* row iph, col iph+1 */
+      }
+      /* ELECTRON-PHONON: (rows of spH0e_eph) x (b + b^+): stored/H_e_ph.f90 */
+      int64_t iup = (i_el - 1) % DimUp, idw = (i_el - 1) / DimUp;
+      int32_t mup = h->mapup[iup], mdw = h->mapdw[idw];
+      for (int side = 0; side < 2; side++) { /* phonon neighbour: iph-1, iph+1 */
+        int jph = side == 0 ? iph - 1 : iph + 1;
+        if (jph < 1 || jph > dimph) continue;
+        double bval = side == 0 ? sqrt((double)(iph - 1)) : sqrt((double)iph);
+        int64_t joff = (int64_t)(jph - 1) * N;
+        double gdiag = 0.0;
+        for (int io = 0; io < norb; io++) gdiag += m->g_ph[io][io] * (double)(((mup >> io) & 1) + ((mdw >> io) & 1));
+        hv[i] += gdiag * bval * v[(i_el - 1) + joff];
+        /* off-diagonal g: the stored entry (row j, col i) = g(io,jo) c^+_io c_jo |i>; the matrix is symmetric
+         * (g Hermitian, real here), so row i holds the same values at the columns its hops reach */
+        for (int io = 1; io <= norb; io++)
+          for (int jo = 1; jo <= norb; jo++) {
+            if (io == jo || m->g_ph[io - 1][jo - 1] == 0.0) continue;
+            int32_t k1, k2;
+            double sg1, sg2;
+            if (((mup >> (jo - 1)) & 1) == 1 && ((mup >> (io - 1)) & 1) == 0) {
+              orc_c(jo, mup, &k1, &sg1);
+              orc_cdg(io, k1, &k2, &sg2);
+              int64_t jup = orc_binary_search(h->mapup, h->dimup, k2) - 1;
+              hv[i] += m->g_ph[io - 1][jo - 1] * sg1 * sg2 * bval * v[jup + idw * DimUp + joff];
+            }
+            if (((mdw >> (jo - 1)) & 1) == 1 && ((mdw >> (io - 1)) & 1) == 0) {
+              orc_c(jo, mdw, &k1, &sg1);
+              orc_cdg(io, k1, &k2, &sg2);
+              int64_t jdw = orc_binary_search(h->mapdw, h->dimdw, k2) - 1;
+              hv[i] += m->g_ph[io - 1][jo - 1] * sg1 * sg2 * bval * v[iup + jdw * DimUp + joff];
+            }
+          }
+      }
+    }
+}
+
 void orc_spmatvec_normal_arrays(int64_t dimup, int64_t dimdw, const double *hd,
                                 const int64_t *up_rowptr, const int32_t *up_col, const double *up_val,
                                 const int64_t *dw_rowptr, const int32_t *dw_col, const double *dw_val,
@@ -721,6 +771,22 @@ static void mv_normal(const void *ctx, const double *v, double *hv) {
 int orc_lanc_tridiag_normal(const orc_hnormal *h, double *vin, int nitermax, double *alanc,
                             double *blanc, double threshold) {
   return lanc_tridiag(mv_normal, h, h->dim, 1, vin, nitermax, alanc, blanc, threshold);
+}
+
+typedef struct {
+  const orc_hnormal *h;
+  const orc_model *m;
+} ph_ctx;
+
+static void mv_normal_ph(const void *ctx, const double *v, double *hv) {
+  const ph_ctx *c = (const ph_ctx *)ctx;
+  orc_spmatvec_normal_ph(c->h, c->m, v, hv);
+}
+
+int orc_lanc_tridiag_normal_ph(const orc_hnormal *h, const orc_model *m, double *vin, int nitermax, double *alanc,
+                               double *blanc, double threshold) {
+  ph_ctx c = {h, m};
+  return lanc_tridiag(mv_normal_ph, &c, h->dim * (m->nph + 1), 1, vin, nitermax, alanc, blanc, threshold);
 }
 
 /* ------------------------------------------------------------------ */

@@ -61,6 +61,10 @@ typedef struct {
   double hb_im[2][2][ORC_MAXORB][ORC_MAXORB][ORC_MAXBATH];
   double vr[ORC_MAXBATH];                 /* replica: item(k)%v            */
   double vg[2 * ORC_MAXORB][ORC_MAXBATH]; /* general: item(k)%vg(io+Norb*(is-1)) */
+  /* phonons (ED_INPUT_VARS.f90:184-198): Nph = cut-off (DimPh = Nph+1), W0_PH, A_PH, g_ph(iorb,jorb) */
+  int nph;
+  double w0_ph, a_ph;
+  double g_ph[ORC_MAXORB][ORC_MAXORB];
 } orc_model;
 
 /* CSR matrix in the reference's row order (insertion order inside a row,
@@ -103,6 +107,12 @@ orc_hnormal *orc_buildh_normal_main(const orc_model *m, int nup, int ndw);
 void orc_hnormal_free(orc_hnormal *h);
 /* ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:517-650 */
 void orc_spmatvec_normal_main(const orc_hnormal *h, const double *v, double *hv);
+/* the same with the phonon branches (DimPh = Nph+1 > 1, :597-629): H = 1 (x) H_el + H_ph (x) 1 + (b + b^+) (x) G_el with
+ * H_ph = w0 b^+ b + A (b + b^+) (stored/H_ph.f90) and G_el = sum_ab g_ab c^+_a c_b over both spins
+ * (stored/H_e_ph.f90); vectors of length dim * (Nph+1), index i_el + iph * dim.  PARITY UNPINNED against
+ * fixtures (the reference ships none with phonons): checked through the g = A = 0 limit and the Lang-Firsov
+ * atomic limit in tests/test_oracle_golden.py. */
+void orc_spmatvec_normal_ph(const orc_hnormal *h, const orc_model *m, const double *v, double *hv);
 /* dense dump: ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:209-262 (column-major nothing: symmetric, row-major out) */
 void orc_hnormal_dense(const orc_hnormal *h, double *hmat);
 
@@ -146,6 +156,8 @@ void orc_csr_matvec_z_mt(const orc_csr *a, const double *x, double *y, int nthre
  * overwritten (as in the reference).  Returns the number of iterations done. */
 int orc_lanc_tridiag_normal(const orc_hnormal *h, double *vin, int nitermax, double *alanc,
                             double *blanc, double threshold);
+int orc_lanc_tridiag_normal_ph(const orc_hnormal *h, const orc_model *m, double *vin, int nitermax, double *alanc,
+                               double *blanc, double threshold);
 int orc_lanc_tridiag_flat(const orc_hflat *h, double *vin, int nitermax, double *alanc,
                           double *blanc, double threshold);
 

@@ -74,6 +74,9 @@ class OrcModel(C.Structure):
         ("hb_im", ((((_D * MAXBATH) * MAXORB) * MAXORB) * 2) * 2),
         ("vr", _D * MAXBATH),
         ("vg", (_D * MAXBATH) * (2 * MAXORB)),
+        ("nph", C.c_int),
+        ("w0_ph", _D), ("a_ph", _D),
+        ("g_ph", (_D * MAXORB) * MAXORB),
     ]
 
 
@@ -114,6 +117,11 @@ class Model:
     hb: np.ndarray | None = None
     vr: np.ndarray | None = None
     vg: np.ndarray | None = None
+    # phonons: cut-off Nph (DimPh = Nph + 1), frequency, displacement field, coupling matrix g_ph[a, b]
+    nph: int = 0
+    w0_ph: float = 0.0
+    a_ph: float = 0.0
+    g_ph: np.ndarray | None = None
 
     @property
     def ns(self) -> int:
@@ -156,6 +164,9 @@ def to_struct(m: Model) -> OrcModel:
     s.hfmode = int(m.hfmode)
     s.xmu = m.xmu
     no = m.norb
+    s.nph, s.w0_ph, s.a_ph = int(m.nph), float(m.w0_ph), float(m.a_ph)
+    if m.g_ph is not None:
+        _np_view(s, "g_ph")[:no, :no] = np.asarray(m.g_ph, dtype=float).reshape(no, no)
     assert no <= MAXORB and m.nbath <= MAXBATH
     _np_view(s, "uloc")[:no] = np.asarray(m.uloc, dtype=float)[:no]
     # ED_PARSE_UMATRIX.f90:136-142 (ed_use_kanamori): off-diagonal constants
@@ -217,7 +228,10 @@ def lib() -> C.CDLL:
     L.orc_hnormal_free.argtypes = [vp]
     L.orc_hnormal_sizes.argtypes = [vp, i64p]
     L.orc_spmatvec_normal_main.argtypes = [vp, dp, dp]
+    L.orc_spmatvec_normal_ph.argtypes = [vp, C.POINTER(OrcModel), dp, dp]
     L.orc_hnormal_dense.argtypes = [vp, dp]
+    L.orc_lanc_tridiag_normal_ph.restype = C.c_int
+    L.orc_lanc_tridiag_normal_ph.argtypes = [vp, C.POINTER(OrcModel), dp, C.c_int, dp, dp, C.c_double]
     L.orc_lanc_tridiag_normal.restype = C.c_int
     L.orc_lanc_tridiag_normal.argtypes = [vp, dp, C.c_int, dp, dp, C.c_double]
     ip = C.POINTER(C.c_int)
@@ -303,14 +317,28 @@ class HNormal:
         self.dw = _csr_arrays(hs.dw)
         self.has_nd = bool(hs.has_nd)
         self.nd = _csr_arrays(hs.nd) if self.has_nd else None
+        self.dim_el = self.dim
+        if model.nph > 0:           # phonon branches: vectors of length dim_el * (Nph + 1)
+            self.dim = self.dim_el * (model.nph + 1)
 
     def matvec(self, v: np.ndarray) -> np.ndarray:
         v = np.ascontiguousarray(v, dtype=np.float64)
         hv = np.empty_like(v)
-        self._L.orc_spmatvec_normal_main(self._h, _dp(v), _dp(hv))
+        if self.model.nph > 0:
+            self._L.orc_spmatvec_normal_ph(self._h, C.byref(self._s), _dp(v), _dp(hv))
+        else:
+            self._L.orc_spmatvec_normal_main(self._h, _dp(v), _dp(hv))
         return hv
 
     def dense(self) -> np.ndarray:
+        if self.model.nph > 0:
+            out = np.empty((self.dim, self.dim))
+            e = np.zeros(self.dim)
+            for j in range(self.dim):
+                e[j] = 1.0
+                out[:, j] = self.matvec(e)
+                e[j] = 0.0
+            return out
         out = np.empty((self.dim, self.dim))
         self._L.orc_hnormal_dense(self._h, _dp(out))
         return out
@@ -319,7 +347,10 @@ class HNormal:
         v = np.array(vin, dtype=np.float64, copy=True)
         a = np.zeros(nitermax)
         b = np.zeros(nitermax)
-        n = self._L.orc_lanc_tridiag_normal(self._h, _dp(v), nitermax, _dp(a), _dp(b), threshold)
+        if self.model.nph > 0:
+            n = self._L.orc_lanc_tridiag_normal_ph(self._h, C.byref(self._s), _dp(v), nitermax, _dp(a), _dp(b), threshold)
+        else:
+            n = self._L.orc_lanc_tridiag_normal(self._h, _dp(v), nitermax, _dp(a), _dp(b), threshold)
         return a, b, n
 
     def close(self):

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_model_struct_layout_matches_header(built):
     """sizeof(edigpu_model) computed from the header's array extents == ctypes layout."""
     mo, mb = capi.MAXORB, capi.MAXBATH
-    n_int, n_dbl = 6, 1 + mo + 4 * mo * mo + 2 * 2 * mo * mo * 2 + mo + 4 * 2 * mo * mb + 2 * 2 * mo * mo * mb * 2
+    n_int, n_dbl = 6, 1 + mo + 4 * mo * mo + 2 * 2 * mo * mo * 2 + mo + 4 * 2 * mo * mb + 2 * 2 * mo * mo * mb * 2 + 1 + 2 + mo * mo
     assert C.sizeof(capi.EdigpuModel) == n_int * 4 + n_dbl * 8
 
 

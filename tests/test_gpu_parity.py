@@ -1047,3 +1047,61 @@ def test_randomized_orbs_and_tridiag_sweep(gpu):
         # early coefficients only: in tiny sectors the recurrence amplifies rounding differences within a few steps
         assert rel_err(ag[:5], ao[:5]) < 1e-9 and rel_err(bg[:5], bo[:5]) < 1e-9, (trial, mode, bath, sec)
         hg.destroy()
+
+
+# --------------------------------------------------------------------------------------------
+# phonon branches of the normal-mode product (DimPh = Nph + 1 > 1).  No reference fixture exists (untested
+# upstream): the oracle restatement is checked through exact limits, the GPU against the oracle.
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bath,norb,nbath,sec,nph,g,aph", [
+    ("normal", 1, 3, (2, 2), 4, (0.4,), 0.0),
+    ("normal", 2, 2, (3, 2), 3, (0.3, 0.5), 0.15),       # two orbitals, displacement field
+    ("hybrid", 3, 3, (3, 3), 2, (0.2, 0.1, 0.4), 0.0),   # Hnd + phonons
+])
+def test_phonon_branches_match_oracle(gpu, bath, norb, nbath, sec, nph, g, aph):
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("normal", bath, norb, nbath, seed=81)
+    for m in (om, pm):
+        m.nph, m.w0_ph, m.a_ph, m.g_ph = nph, 0.8, aph, np.diag(g)
+    ho = O.HNormal(om, *sec)
+    hg = SectorHamiltonian.normal_from_model(pm, *sec)
+    assert hg.dim == ho.dim == ho.dim_el * (nph + 1)
+    v = np.random.default_rng(2).standard_normal(ho.dim)
+    assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
+    ao, bo, _ = ho.lanc_tridiag(v, 15)
+    ag, bg, _ = hg.lanczos_tridiag(v, 15)
+    assert rel_err(ag[:10], ao[:10]) < 1e-9 and rel_err(bg[:10], bo[:10]) < 1e-9
+    hg.destroy()
+
+
+def test_phonon_exact_limits(gpu):
+    """(i) g = A = 0: the spectrum is E_el + w0 n.  (ii) Lang-Firsov atomic limit of the Holstein coupling: a
+    decoupled impurity (V = 0) with N electrons and H_ph = w0 b^+ b + g N (b + b^+) has the ground-state energy
+    E_el - g^2 N^2 / w0 (phonon cut-off large enough)."""
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("normal", "normal", 2, 2, seed=82)
+    for m in (om, pm):
+        m.nph, m.w0_ph = 3, 0.7
+    hg = SectorHamiltonian.normal_from_model(pm, 3, 3)
+    om0, _ = make_models("normal", "normal", 2, 2, seed=82)
+    w_el = np.linalg.eigvalsh(O.HNormal(om0, 3, 3).dense())
+    ev, _, nconv, _ = hg.lanczos_eigh_multi(3, ncv=40, tol=1e-12, want_vectors=False)
+    expect = np.sort(np.concatenate([w_el + 0.7 * n for n in range(4)]))
+    assert nconv == 3 and abs(ev[0] - expect[0]) < 1e-9
+    hg.destroy()
+    om1, pm1 = make_models("normal", "normal", 1, 1, seed=83)
+    for m in (om1, pm1):
+        m.bv = np.zeros_like(m.bv)
+        m.be = np.full_like(m.be, 5.0)
+        m.hfmode = False
+        m.hloc = np.zeros((1, 1, 1, 1), complex)
+        m.nph, m.w0_ph, m.g_ph = 40, 1.0, np.array([[0.5]])
+    om1.uloc = (0.0,)
+    pm1.uloc = np.array([0.0])
+    h1 = SectorHamiltonian.normal_from_model(pm1, 1, 1)
+    e_gpu, _, _ = h1.lanczos_eigh(nitermax=160, tol=1e-13, want_vector=False)
+    e_orc = np.linalg.eigvalsh(O.HNormal(om1, 1, 1).dense())[0]
+    assert abs(e_orc - (-0.25 * 4)) < 1e-10 and abs(e_gpu - (-1.0)) < 1e-9
+    h1.destroy()

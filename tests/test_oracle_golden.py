@@ -196,3 +196,26 @@ def test_oracle_threaded_baselines_equal_serial():
     y = np.empty_like(x)
     O.csr_matvec_z_mt(rp, col, val, x, y, 3)
     assert rel_err(y, f.matvec(x)) < 1e-14
+
+
+def test_oracle_phonon_limits():
+    """The phonon branches of the restatement have no reference fixture (PARITY UNPINNED against fixtures): exact
+    limits instead -- Hermiticity, E = E_el + w0 n at g = A = 0, and the Lang-Firsov atomic limit."""
+    om, _ = make_models("normal", "normal", 2, 2, seed=3)
+    om.nph, om.w0_ph = 3, 0.7
+    h = O.HNormal(om, 3, 2)
+    d = h.dense()
+    assert h.dim == 4 * h.dim_el and np.max(np.abs(d - d.T)) < 1e-14
+    om0, _ = make_models("normal", "normal", 2, 2, seed=3)
+    w0 = np.linalg.eigvalsh(O.HNormal(om0, 3, 2).dense())
+    ref = np.sort(np.concatenate([w0 + 0.7 * n for n in range(4)]))
+    assert np.max(np.abs(np.linalg.eigvalsh(d) - ref)) < 1e-12
+    om.g_ph, om.a_ph = np.array([[0.3, 0.1], [0.1, 0.5]]), 0.2    # off-diagonal coupling + displacement field
+    d2 = O.HNormal(om, 3, 2).dense()
+    assert np.max(np.abs(d2 - d2.T)) < 1e-14
+    om1, _ = make_models("normal", "normal", 1, 1, seed=1)
+    om1.bv = np.zeros_like(om1.bv)
+    om1.be = np.full_like(om1.be, 5.0)
+    om1.hfmode, om1.uloc, om1.hloc = False, (0.0,), np.zeros((1, 1, 1, 1), complex)
+    om1.nph, om1.w0_ph, om1.g_ph = 40, 1.0, np.array([[0.5]])
+    assert abs(np.linalg.eigvalsh(O.HNormal(om1, 1, 1).dense())[0] + 1.0) < 1e-10
