@@ -640,6 +640,22 @@ static int apply_any(edigpu_sector* s, const double* v_local, const double* v_fu
     return launch_phonon(s, v_full, hv, st);
   }
   if (s->kind == 0) return launch_normal(s, v_local, v_full, hv, phase, st);
+  if ((s->kind == 1 || s->kind == 2) && s->nph > 0) {
+    // phonon branches of the superc / nonsu2 products: electronic product per phonon block, then the phonon pass
+    if (phase != 3) {
+      set_error("phonon sectors are single-shard: use the fused product");
+      return 1;
+    }
+    for (int iph = 0; iph <= s->nph; iph++) {
+      const int64_t o = 2 * (int64_t)iph * s->dim_el;
+      if (s->kind == 2) {
+        if (launch_direct(s, v_full + o, hv + o, st)) return 1;
+      } else if (launch_csr(s->loc, 1, v_full + o, hv + o, 0, st)) {
+        return 1;
+      }
+    }
+    return launch_phonon(s, v_full, hv, st);
+  }
   if (s->kind == 3) {
     // ed_total_ud = F: single shard only (phase 1 = everything, phase 2 = nothing left to add)
     if (phase == 2) return 0;
@@ -723,7 +739,7 @@ static int tql2(int n, std::vector<double>& d, std::vector<double>& e, std::vect
 // enqueue one Lanczos step (iter is 0-based); vin/vout/tmp live in the workspace
 static bool flat_lanczos_fusable(const edigpu_sector* s) {
   static const bool off = getenv("EDIGPU_LANCZOS_UNFUSED") != nullptr;
-  if (off || s->nloc != s->dim || s->nloc == 0) return false;
+  if (off || s->nloc != s->dim || s->nloc == 0 || s->nph > 0) return false;
   if (s->kind == 2) return true;
   return s->kind == 1 && csr_lanczos_fusable(s->loc) && s->nonloc.nnz == 0;
 }
@@ -975,6 +991,37 @@ int edigpu_normal_build(edigpu_handle* h, const edigpu_model* model, int nup, in
   return 0;
 }
 
+// phonon branches for a library-built superc / nonsu2 handle holding a whole sector: g_el per row from the map
+static int attach_phonons_flat(edigpu_sector* s, const edigpu_model& m, const std::vector<int32_t>& states, int ns) {
+  if (m.nph <= 0) return 0;
+  if (s->nloc != s->dim) {
+    set_error("phonons (nph > 0) need the whole sector on one shard");
+    return 1;
+  }
+  for (int a = 0; a < m.norb; a++)
+    for (int b = 0; b < m.norb; b++)
+      if (a != b && m.g_ph[a * EDIGPU_MAXORB + b] != 0.0) {
+        set_error("only the density couplings g_ph(a,a) are built (off-diagonal g_ph: hand the matrices over)");
+        return 1;
+      }
+  if (s->dim * (m.nph + 1) >= ((int64_t)1 << 31)) {
+    set_error("sector dimension x (Nph+1) >= 2^31");
+    return 1;
+  }
+  std::vector<double> gel(states.size(), 0.0);
+  for (size_t i = 0; i < states.size(); i++)
+    for (int a = 0; a < m.norb; a++)
+      gel[i] += m.g_ph[a * EDIGPU_MAXORB + a] * (double)(((states[i] >> a) & 1) + ((states[i] >> (a + ns)) & 1));
+  if (dev_upload(&s->d_gu, gel.data(), gel.size())) return 1;
+  s->nph = m.nph;
+  s->w0_ph = m.w0_ph;
+  s->a_ph = m.a_ph;
+  s->dim_el = s->dim;
+  s->dim *= (m.nph + 1);
+  s->nloc = s->dim;
+  return 0;
+}
+
 int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, int64_t row_first,
                       int64_t row_count) {
   if (!h || !model) {
@@ -1009,6 +1056,10 @@ int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, i
     s->lazy_export = true;
     const int rc = build_flat_on_device(s.get(), hd);
     if (rc == 0) {
+      if (attach_phonons_flat(s.get(), *model, hd.states, hd.ns)) {
+        edigpu_destroy(s.release());
+        return 1;
+      }
       if (finish_handle(s.get())) {
         edigpu_destroy(s.release());
         return 1;
@@ -1037,6 +1088,15 @@ int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, i
                  hf.h.val.data(), 1)) {
     edigpu_destroy(s.release());
     return 1;
+  }
+  if (model->nph > 0) {
+    HostDirect hd;  // for the sector map
+    e = build_direct(*model, sector, row_first, row_count, hd);
+    if (!e.empty()) set_error(e);
+    if (!e.empty() || attach_phonons_flat(s.get(), *model, hd.states, hd.ns)) {
+      edigpu_destroy(s.release());
+      return 1;
+    }
   }
   *h = s.release();
   return 0;
@@ -1082,7 +1142,7 @@ int edigpu_direct_build(edigpu_handle* h, const edigpu_model* model, int sector,
   }
   rc |= dev_upload(&s->d_dir_dtab, hd.dtab.data(), hd.dtab.size());
   rc |= dev_upload(&s->d_dir_xtab, hd.xtab.data(), hd.xtab.size());
-  if (rc || finish_handle(s.get())) {
+  if (rc || attach_phonons_flat(s.get(), *model, hd.states, hd.ns) || finish_handle(s.get())) {
     edigpu_destroy(s.release());
     return 1;
   }
@@ -1318,7 +1378,8 @@ int edigpu_csr_export(edigpu_handle s, int64_t* rowptr, int32_t* col, double* va
   if (s->lazy_export) {
     // device-built sector: the CSR image only exists if somebody asks for it
     HostFlat hf;
-    std::string e = build_flat(s->model, s->sec_a, s->row_first, s->nloc, hf);
+    // (phonon sectors: the electronic block, as edigpu_normal_export hands back the electronic factors)
+    std::string e = build_flat(s->model, s->sec_a, s->row_first, s->nph > 0 ? s->dim_el : s->nloc, hf);
     if (!e.empty()) {
       set_error(e);
       return 1;
@@ -1515,6 +1576,10 @@ int edigpu_apply_op_flat(edigpu_handle src, edigpu_handle dst, const double* v_s
   }
   if (src->nloc != src->dim || dst->nloc != dst->dim) {
     set_error("edigpu_apply_op_flat: handles must hold whole sectors (single shard)");
+    return 1;
+  }
+  if (src->nph > 0 || dst->nph > 0) {
+    set_error("edigpu_apply_op_flat: phonon sectors are not supported");
     return 1;
   }
   const edigpu_model& m = src->model;

@@ -177,7 +177,8 @@ __global__ void __launch_bounds__(kDirNT)
 template <bool LZ>
 static int launch_direct_t(const edigpu_sector* s, const double* v_full, double* hv, double* partial, int* np,
                            hipStream_t st) {
-  int64_t nb = (s->nloc + kDirNT - 1) / kDirNT;
+  const int64_t nrow = s->nph > 0 ? s->dim_el : s->nloc;  // phonon sectors: one electronic block per launch
+  int64_t nb = (nrow + kDirNT - 1) / kDirNT;
   static const int wgs_per_cu = getenv("EDIGPU_DIRECT_WGS") ? atoi(getenv("EDIGPU_DIRECT_WGS")) : 2;
   if (nb > 256 * wgs_per_cu) nb = 256 * wgs_per_cu;  // persistent workgroups sweep the rows
   if (np) *np = (int)nb;
@@ -192,7 +193,7 @@ static int launch_direct_t(const edigpu_sector* s, const double* v_full, double*
     auto kern = direct_rows_kernel<LT, LZ, CP>;                                                                  \
     if ((LDSB) > 48 * 1024)                                                                                      \
       EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB))); \
-    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kDirNT), (LDSB), st, s->nloc, s->row_first, s->dir_ns,     \
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kDirNT), (LDSB), st, nrow, s->row_first, s->dir_ns,        \
                        s->dir_norb, s->dir_nterms, s->d_dir_states, s->d_dir_offdw, s->d_dir_rkup,              \
                        s->d_dir_terms, s->d_dir_tests, s->d_dir_dtab, s->d_dir_xtab, v2, h2, partial);          \
   } while (0)

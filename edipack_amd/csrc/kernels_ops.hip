@@ -85,7 +85,44 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// the same pass for the complex (superc / nonsu2) sectors: g_el(i_el) comes as one table over the sector rows
+__global__ void __launch_bounds__(256)
+    phonon_flat_kernel(int64_t dim_el, int dimph, double w0, double a_ph, const double* __restrict__ gel,
+                       const double2* __restrict__ v, double2* __restrict__ hv) {
+  const int64_t n = dim_el * dimph;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t iph = i / dim_el, iel = i - iph * dim_el;
+    const double g = a_ph + gel[iel];
+    double2 acc = hv[i];
+    const double2 x = v[i];
+    acc.x = fma(w0 * (double)iph, x.x, acc.x);
+    acc.y = fma(w0 * (double)iph, x.y, acc.y);
+    if (iph > 0) {
+      const double2 y = v[i - dim_el];
+      const double c = g * sqrt((double)iph);
+      acc.x = fma(c, y.x, acc.x);
+      acc.y = fma(c, y.y, acc.y);
+    }
+    if (iph + 1 < dimph) {
+      const double2 y = v[i + dim_el];
+      const double c = g * sqrt((double)(iph + 1));
+      acc.x = fma(c, y.x, acc.x);
+      acc.y = fma(c, y.y, acc.y);
+    }
+    hv[i] = acc;
+  }
+}
+
 int launch_phonon(const edigpu_sector* s, const double* v, double* hv, hipStream_t st) {
+  if (s->is_complex) {
+    const int64_t n = s->dim_el * (s->nph + 1);
+    int64_t nb = (n + 255) / 256;
+    if (nb > 256 * 16) nb = 256 * 16;
+    hipLaunchKernelGGL(phonon_flat_kernel, dim3((unsigned)nb), dim3(256), 0, st, s->dim_el, s->nph + 1, s->w0_ph,
+                       s->a_ph, s->d_gu, reinterpret_cast<const double2*>(v), reinterpret_cast<double2*>(hv));
+    EDIGPU_HIP(hipGetLastError());
+    return 0;
+  }
   const int64_t n = s->dim_el * (s->nph + 1);
   int64_t nb = (n + 255) / 256;
   if (nb > 256 * 16) nb = 256 * 16;

@@ -841,5 +841,63 @@ int orc_lanc_tridiag_flat(const orc_hflat *h, double *vin, int nitermax, double 
   return lanc_tridiag(mv_flat, h, h->dim, 2, vin, nitermax, alanc, blanc, threshold);
 }
 
+/* spMatVec_superc_main / spMatVec_nonsu2_main with DimPh > 1 */
+void orc_spmatvec_flat_ph(const orc_hflat *h, const orc_model *m, const double *v, double *hv) {
+  const int64_t N = h->dim;
+  const int dimph = m->nph + 1, norb = m->norb, ns = h->ns;
+  for (int iph = 0; iph < dimph; iph++) orc_spmatvec_flat_z(h, v + 2 * iph * N, hv + 2 * iph * N);
+  for (int iph = 1; iph <= dimph; iph++)
+    for (int64_t i_el = 0; i_el < N; i_el++) {
+      const int64_t i = i_el + (int64_t)(iph - 1) * N;
+      const int32_t st = h->map[i_el];
+      double ar = m->w0_ph * (double)(iph - 1) * v[2 * i], ai = m->w0_ph * (double)(iph - 1) * v[2 * i + 1];
+      for (int side = 0; side < 2; side++) {
+        const int jph = side == 0 ? iph - 1 : iph + 1;
+        if (jph < 1 || jph > dimph) continue;
+        const double bval = side == 0 ? sqrt((double)(iph - 1)) : sqrt((double)iph);
+        const int64_t joff = (int64_t)(jph - 1) * N;
+        double gd = m->a_ph; /* A (b + b^+) has the same phonon structure */
+        for (int io = 0; io < norb; io++) gd += m->g_ph[io][io] * (double)(((st >> io) & 1) + ((st >> (io + ns)) & 1));
+        ar += gd * bval * v[2 * (i_el + joff)];
+        ai += gd * bval * v[2 * (i_el + joff) + 1];
+        for (int io = 1; io <= norb; io++)
+          for (int jo = 1; jo <= norb; jo++) {
+            if (io == jo || m->g_ph[io - 1][jo - 1] == 0.0) continue;
+            for (int sp = 0; sp < 2; sp++) {
+              const int pi = io + sp * ns, pj = jo + sp * ns;
+              if (((st >> (pj - 1)) & 1) == 1 && ((st >> (pi - 1)) & 1) == 0) {
+                int32_t k1, k2;
+                double sg1, sg2;
+                orc_c(pj, st, &k1, &sg1);
+                orc_cdg(pi, k1, &k2, &sg2);
+                const int64_t j = orc_binary_search(h->map, N, k2) - 1;
+                const double w = m->g_ph[io - 1][jo - 1] * sg1 * sg2 * bval;
+                ar += w * v[2 * (j + joff)];
+                ai += w * v[2 * (j + joff) + 1];
+              }
+            }
+          }
+      }
+      hv[2 * i] += ar;
+      hv[2 * i + 1] += ai;
+    }
+}
+
+typedef struct {
+  const orc_hflat *h;
+  const orc_model *m;
+} phf_ctx;
+
+static void mv_flat_ph(const void *ctx, const double *v, double *hv) {
+  const phf_ctx *c = (const phf_ctx *)ctx;
+  orc_spmatvec_flat_ph(c->h, c->m, v, hv);
+}
+
+int orc_lanc_tridiag_flat_ph(const orc_hflat *h, const orc_model *m, double *vin, int nitermax, double *alanc,
+                             double *blanc, double threshold) {
+  phf_ctx c = {h, m};
+  return lanc_tridiag(mv_flat_ph, &c, h->dim * (m->nph + 1), 2, vin, nitermax, alanc, blanc, threshold);
+}
+
 #include "edipack_oracle_flat.inc"
 #include "edipack_oracle_orbs.inc"

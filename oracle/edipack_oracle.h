@@ -145,6 +145,11 @@ void orc_hflat_free(orc_hflat *h);
 /* ED_SUPERC/..._STORED_HxV.f90:312-362, ED_NONSU2/..._STORED_HxV.f90:194-209 */
 void orc_spmatvec_flat_z(const orc_hflat *h, const double *v, double *hv);
 void orc_hflat_dense(const orc_hflat *h, double *hmat_re_im);
+/* phonon branches of spMatVec_superc_main / _nonsu2_main (ED_SUPERC/..._STORED_HxV.f90:336-360, stored/H_ph.f90,
+ * H_e_ph.f90): vectors of dim * (Nph+1) complex elements.  PARITY UNPINNED against fixtures (none exist). */
+void orc_spmatvec_flat_ph(const orc_hflat *h, const orc_model *m, const double *v, double *hv);
+int orc_lanc_tridiag_flat_ph(const orc_hflat *h, const orc_model *m, double *vin, int nitermax, double *alanc,
+                             double *blanc, double threshold);
 
 /* generic CSR y = A x in the reference's loop order (ED_SPARSE_MATRIX.f90:778-793) */
 void orc_csr_matvec_d(const orc_csr *a, const double *x, double *y);

@@ -230,6 +230,9 @@ def lib() -> C.CDLL:
     L.orc_spmatvec_normal_main.argtypes = [vp, dp, dp]
     L.orc_spmatvec_normal_ph.argtypes = [vp, C.POINTER(OrcModel), dp, dp]
     L.orc_hnormal_dense.argtypes = [vp, dp]
+    L.orc_spmatvec_flat_ph.argtypes = [vp, C.POINTER(OrcModel), dp, dp]
+    L.orc_lanc_tridiag_flat_ph.restype = C.c_int
+    L.orc_lanc_tridiag_flat_ph.argtypes = [vp, C.POINTER(OrcModel), dp, C.c_int, dp, dp, C.c_double]
     L.orc_lanc_tridiag_normal_ph.restype = C.c_int
     L.orc_lanc_tridiag_normal_ph.argtypes = [vp, C.POINTER(OrcModel), dp, C.c_int, dp, dp, C.c_double]
     L.orc_lanc_tridiag_normal.restype = C.c_int
@@ -443,14 +446,28 @@ class HFlat:
         self.ns, self.dim = hs.ns, hs.dim
         self.map = np.ctypeslib.as_array(hs.map, shape=(hs.dim,)).copy() if hs.dim else np.zeros(0, np.int32)
         self.csr = _csr_arrays(hs.h)
+        self.dim_el = self.dim
+        if model.nph > 0:           # phonon branches: vectors of dim_el * (Nph + 1) elements
+            self.dim = self.dim_el * (model.nph + 1)
 
     def matvec(self, v: np.ndarray) -> np.ndarray:
         v = np.ascontiguousarray(v, dtype=np.complex128)
         hv = np.empty_like(v)
-        self._L.orc_spmatvec_flat_z(self._h, _dp(v.view(np.float64)), _dp(hv.view(np.float64)))
+        if self.model.nph > 0:
+            self._L.orc_spmatvec_flat_ph(self._h, C.byref(self._s), _dp(v.view(np.float64)), _dp(hv.view(np.float64)))
+        else:
+            self._L.orc_spmatvec_flat_z(self._h, _dp(v.view(np.float64)), _dp(hv.view(np.float64)))
         return hv
 
     def dense(self) -> np.ndarray:
+        if self.model.nph > 0:
+            out = np.empty((self.dim, self.dim), dtype=np.complex128)
+            e = np.zeros(self.dim, dtype=np.complex128)
+            for j in range(self.dim):
+                e[j] = 1.0
+                out[:, j] = self.matvec(e)
+                e[j] = 0.0
+            return out
         out = np.empty((self.dim, self.dim), dtype=np.complex128)
         self._L.orc_hflat_dense(self._h, _dp(out.view(np.float64)))
         return out
@@ -459,7 +476,11 @@ class HFlat:
         v = np.array(vin, dtype=np.complex128, copy=True)
         a = np.zeros(nitermax)
         b = np.zeros(nitermax)
-        n = self._L.orc_lanc_tridiag_flat(self._h, _dp(v.view(np.float64)), nitermax, _dp(a), _dp(b), threshold)
+        if self.model.nph > 0:
+            n = self._L.orc_lanc_tridiag_flat_ph(self._h, C.byref(self._s), _dp(v.view(np.float64)), nitermax, _dp(a),
+                                                 _dp(b), threshold)
+        else:
+            n = self._L.orc_lanc_tridiag_flat(self._h, _dp(v.view(np.float64)), nitermax, _dp(a), _dp(b), threshold)
         return a, b, n
 
     def close(self):

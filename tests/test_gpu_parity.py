@@ -1105,3 +1105,45 @@ def test_phonon_exact_limits(gpu):
     e_orc = np.linalg.eigvalsh(O.HNormal(om1, 1, 1).dense())[0]
     assert abs(e_orc - (-0.25 * 4)) < 1e-10 and abs(e_gpu - (-1.0)) < 1e-9
     h1.destroy()
+
+
+@pytest.mark.parametrize("mode,bath,norb,nbath,sec,nph,g,aph", [
+    ("superc", "normal", 2, 2, 0, 3, (0.3, 0.5), 0.0),
+    ("superc", "hybrid", 2, 3, 1, 2, (0.2, 0.4), 0.15),
+    ("nonsu2", "normal", 2, 2, 6, 2, (0.3, 0.1), 0.1),
+    ("nonsu2", "hybrid", 3, 2, 5, 2, (0.2, 0.1, 0.4), 0.0),
+])
+@pytest.mark.parametrize("form", ["stored", "direct", "hostbuild"])
+def test_phonon_branches_flat_match_oracle(gpu, monkeypatch, form, mode, bath, norb, nbath, sec, nph, g, aph):
+    """Phonon branches of the superc / nonsu2 products (spMatVec_superc_main / spMatVec_nonsu2_main with
+    DimPh > 1): stored image built on the device, on the host, and the on-the-fly form, against the oracle."""
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models(mode, bath, norb, nbath, seed=91)
+    for m in (om, pm):
+        m.nph, m.w0_ph, m.a_ph, m.g_ph = nph, 0.8, aph, np.diag(g)
+    ho = O.HFlat(om, sec)
+    if form == "hostbuild":
+        monkeypatch.setenv("EDIGPU_FLAT_HOSTBUILD", "1")
+    hg = (SectorHamiltonian.direct_from_model if form == "direct" else SectorHamiltonian.flat_from_model)(pm, sec)
+    assert hg.dim == ho.dim == ho.dim_el * (nph + 1)
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(ho.dim) + 1j * rng.standard_normal(ho.dim)
+    assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
+    ao, bo, _ = ho.lanc_tridiag(v, 15)
+    ag, bg, _ = hg.lanczos_tridiag(v, 15)
+    assert rel_err(ag[:10], ao[:10]) < 1e-9 and rel_err(bg[:10], bo[:10]) < 1e-9
+    e_gpu, _, _ = hg.lanczos_eigh(nitermax=min(300, ho.dim), tol=1e-13, want_vector=False)
+    assert abs(e_gpu - np.linalg.eigvalsh(ho.dense())[0]) < 1e-9
+    hg.destroy()
+
+
+def test_phonon_flat_error_paths(gpu):
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    _, pm = make_models("superc", "normal", 2, 2, seed=92)
+    pm.nph, pm.w0_ph, pm.g_ph = 2, 0.8, np.array([[0.3, 0.1], [0.1, 0.5]])
+    with pytest.raises(RuntimeError, match="density couplings"):
+        SectorHamiltonian.flat_from_model(pm, 0)
+    pm.g_ph = np.diag([0.3, 0.5])
+    with pytest.raises(RuntimeError, match="one shard"):
+        SectorHamiltonian.direct_from_model(pm, 0, row_first=0, row_count=8)

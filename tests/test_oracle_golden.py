@@ -219,3 +219,39 @@ def test_oracle_phonon_limits():
     om1.hfmode, om1.uloc, om1.hloc = False, (0.0,), np.zeros((1, 1, 1, 1), complex)
     om1.nph, om1.w0_ph, om1.g_ph = 40, 1.0, np.array([[0.5]])
     assert abs(np.linalg.eigvalsh(O.HNormal(om1, 1, 1).dense())[0] + 1.0) < 1e-10
+
+
+def test_oracle_flat_phonon_limits():
+    """Phonon branches of the superc / nonsu2 restatement (orc_spmatvec_flat_ph; PARITY UNPINNED against
+    fixtures, untested upstream): Hermiticity, E = E_el + w0 n at g = A = 0, and -- with the spin-flip terms
+    switched off -- the nonsu2 N sector reproduces the union of the normal-mode (nup, ndw) sectors, phonons
+    and density couplings included (two independent restatements of the same physics)."""
+    for mode, sec in (("superc", 0), ("nonsu2", 4)):
+        om, _ = make_models(mode, "hybrid", 2, 2, seed=5)
+        om.nph, om.w0_ph = 2, 0.7
+        h = O.HFlat(om, sec)
+        d = h.dense()
+        assert h.dim == 3 * h.dim_el and np.max(np.abs(d - d.conj().T)) < 1e-14
+        om0, _ = make_models(mode, "hybrid", 2, 2, seed=5)
+        w0 = np.linalg.eigvalsh(O.HFlat(om0, sec).dense())
+        ref = np.sort(np.concatenate([w0 + 0.7 * n for n in range(3)]))
+        assert np.max(np.abs(np.linalg.eigvalsh(d) - ref)) < 1e-12
+        om.g_ph, om.a_ph = np.diag([0.3, 0.5]), 0.2
+        d2 = h.__class__(om, sec).dense()
+        assert np.max(np.abs(d2 - d2.conj().T)) < 1e-14 and np.max(np.abs(d2 - d)) > 0.1
+        x = np.random.default_rng(4).standard_normal(h.dim) + 1j * np.random.default_rng(5).standard_normal(h.dim)
+        assert rel_err(O.HFlat(om, sec).matvec(x), d2 @ x) < 1e-13
+    # nonsu2 without spin mixing == union of normal sectors
+    on, _ = make_models("normal", "normal", 2, 2, seed=6)
+    on.nph, on.w0_ph, on.a_ph, on.g_ph = 2, 0.9, 0.1, np.diag([0.4, 0.2])
+    o2, _ = make_models("nonsu2", "normal", 2, 2, seed=6)
+    hl = np.zeros((2, 2, 2, 2), complex)
+    hl[0, 0] = hl[1, 1] = on.hloc[0, 0]
+    o2.hloc, o2.bu = hl, np.zeros_like(o2.bu)
+    o2.be, o2.bv = np.stack([on.be[0]] * 2), np.stack([on.bv[0]] * 2)
+    o2.nph, o2.w0_ph, o2.a_ph, o2.g_ph = on.nph, on.w0_ph, on.a_ph, on.g_ph
+    ntot, ns = 5, 6
+    w_flat = np.linalg.eigvalsh(O.HFlat(o2, ntot).dense())
+    w_norm = np.sort(np.concatenate([np.linalg.eigvalsh(O.HNormal(on, nu, ntot - nu).dense())
+                                     for nu in range(ntot + 1) if nu <= ns and ntot - nu <= ns]))
+    assert w_flat.shape == w_norm.shape and np.max(np.abs(w_flat - w_norm)) < 1e-11
