@@ -5,9 +5,10 @@
 
 One "step" = one Lanczos iteration (H*v + three-term recurrence) on the largest sector of the
 workload, vectors resident in HBM.  N=1: single-shard device-resident loop inside libedigpu.so.
-N>1 (launched by torch.distributed.run, one rank per GPU): the vector is row-sharded, the exchange
-is an RCCL all-gather overlapped with the shard-local part of H*v; total work is fixed (strong
-scaling).  Rank 0 prints ONE JSON line.
+N>1 (launched by torch.distributed.run, one rank per GPU): the vector is row-sharded; normal mode uses the
+transposed exchange (two RCCL all-to-alls per product, the first overlapped with the row half of H*v;
+EDIGPU_EXCHANGE=allgather selects the all-gather form), the flat modes an all-gather overlapped with the
+shard-local block; total work is fixed (strong scaling).  Rank 0 prints ONE JSON line.
 
 roofline  : algorithmic bytes of one H*v in the reference's storage format (SURVEY.md 8d,
             edigpu_algorithmic_bytes) / average H*v launch duration from HIP events recorded
@@ -160,7 +161,7 @@ def run_multi(args):
     import torch
     import torch.distributed as dist
     from edipack_amd import capi
-    from edipack_amd.sharding import gpu_sharded_hamiltonian
+    from edipack_amd.sharding import gpu_sharded_hamiltonian, gpu_transposed_hamiltonian
     from edipack_amd.synthetic import WORKLOADS, synthetic_model
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -177,8 +178,19 @@ def run_multi(args):
     capi.init(dev)
     w = WORKLOADS[args.workload]
     model = synthetic_model(w)
-    plan, h, lz = gpu_sharded_hamiltonian(model, w.sector, world, rank, direct=w.direct)
+    exchange = "allgather"
+    if w.ed_mode == "normal" and os.environ.get("EDIGPU_EXCHANGE", "transpose") != "allgather":
+        try:
+            plan, h, lz = gpu_transposed_hamiltonian(model, w.sector, world, rank, stage_host=backend != "nccl")
+            exchange = "transpose"
+        except RuntimeError:      # sector not servable this way (explicit spH0nd, phonons)
+            pass
+    if exchange == "allgather":
+        plan, h, lz = gpu_sharded_hamiltonian(model, w.sector, world, rank, direct=w.direct)
     bytes_hv, _ = h.algorithmic_bytes()   # this shard's share of the algorithmic bytes
+    if exchange == "transpose":
+        bytes_hv /= world                 # every rank holds the whole sector's (small) tables
+    sent = lz.exchange_bytes if exchange == "transpose" else 8 * plan.chunk * (world - 1) * (2 if lz.dtype.is_complex else 1)
     gen = torch.Generator(device="cuda").manual_seed(12345 + rank)
     v0 = torch.randn(plan.nloc, dtype=torch.float64, device="cuda", generator=gen)
     if lz.dtype.is_complex:
@@ -186,17 +198,19 @@ def run_multi(args):
     lz.tridiag(v0, max(1, args.warmup))
     # timed region: K Lanczos steps, barrier + synchronize on both sides
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    hv_orig = lz.hv
+    # transposed exchange: the product comes fused with the vector updates and the one all-reduce of the step
+    hook = "fused_step" if getattr(lz, "fused", False) else "hv"
+    hv_orig = getattr(lz, hook)
     counter = {"k": 0}
 
-    def hv_timed():
+    def hv_timed(*a):
         k = counter["k"]
         ev[k][0].record()
-        hv_orig()
+        hv_orig(*a)
         ev[k][1].record()
         counter["k"] = k + 1
 
-    lz.hv = hv_timed
+    setattr(lz, hook, hv_timed)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -221,8 +235,12 @@ def run_multi(args):
             "dtype": "c128" if lz.dtype.is_complex else "f64", "data": "synthetic",
             "config": {"workload": f"{w.name}: {w.ed_mode} mode, bath={w.bath_type}, Norb={w.norb}, "
                                    f"Nbath={w.nbath}, sector={w.sector}, Dim={h.dim} ({w.note})",
-                       "parallelism": f"row-sharded over {world} GPUs, RCCL all-gather of v overlapped with the "
-                                      f"shard-local part of H*v"},
+                       "parallelism": (f"row-sharded over {world} GPUs, transposed exchange: two RCCL all-to-alls per "
+                                       f"H*v, the first overlapped with the row half (Hd + Hup)"
+                                       if exchange == "transpose" else
+                                       f"row-sharded over {world} GPUs, RCCL all-gather of v overlapped with the "
+                                       f"shard-local part of H*v"),
+                       "exchange_bytes_per_rank_per_hv": int(sent)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
                          "note": "whole-job: sum of shard algorithmic bytes / slowest rank's H*v time "

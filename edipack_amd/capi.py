@@ -79,6 +79,15 @@ SIGNATURES = {
     "edigpu_apply_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
     "edigpu_apply_local_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
     "edigpu_apply_remote_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "edigpu_normal_transpose_info": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    "edigpu_normal_apply_rows_dev": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "edigpu_normal_apply_cols_dev": (C.c_int, [_vp, _i64, _i64, _i64, C.c_int32, _vp, _vp, _vp]),
+    "edigpu_transpose_pack": (C.c_int, [_i64, _i64, _i64, C.c_int32, _i64, C.c_int32, _vp, _vp, _vp]),
+    "edigpu_transpose_unpack_add": (C.c_int, [_i64, _i64, _i64, C.c_int32, _i64, C.c_int32, _vp, _vp, _vp]),
+    "edigpu_transpose_rotate_pack": (C.c_int, [C.c_int32, _i64, _i64, _i64, C.c_int32, _i64, C.c_int32, _vp, _vp, _vp,
+                                               _vp, _vp]),
+    "edigpu_transpose_unpack_add_dot2": (C.c_int, [_i64, _i64, _i64, C.c_int32, _i64, C.c_int32, _vp, _vp, _vp, _vp,
+                                                   _vp, _vp, _vp]),
     "edigpu_lanczos_tridiag": (C.c_int, [_vp, _pd, C.c_int, _pd, _pd, C.c_double, _pint]),
     "edigpu_lanczos_eigh": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int, _pd, _pd, _pd, _pint]),
     "edigpu_orbs_build": (C.c_int, [C.POINTER(_vp), C.POINTER(EdigpuModel), _pi32, _pi32]),

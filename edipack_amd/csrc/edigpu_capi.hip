@@ -347,6 +347,12 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
     if (f.nterms > 0) {
       if (dev_upload(&s->d_ndcoef, f.coef.data(), f.coef.size())) return 1;
       if (dev_upload(&s->d_jup, f.jup.data(), f.jup.size())) return 1;
+      for (int t = 0; t < f.nterms; t++)
+        for (int64_t c = 0; c < dim_up; c++) {
+          const uint32_t jt = f.jup[(size_t)t * dim_up + c];
+          if (jt != 0xFFFFFFFFu)
+            s->col_halo = std::max<int>(s->col_halo, (int)std::llabs((int64_t)(jt & 0x7FFFFFFFu) - c));
+        }
       if (dev_upload(&s->d_jdw, f.jdw.data(), f.jdw.size())) return 1;
       // merged per-local-row list for the panel kernel: Hdw entries (tag 0) + applicable Hnd terms
       if (dim_dw < ((int64_t)1 << 24) && f.nterms < 127) {
@@ -1473,6 +1479,112 @@ int edigpu_apply_remote_dev(edigpu_handle s, const void* v_full_dev, void* hv_de
   }
   hipStream_t st = (hipStream_t)stream;  // NULL = the HIP default (null) stream
   return apply_any(s, nullptr, (const double*)v_full_dev, (double*)hv_dev, 2, st);
+}
+
+// ---- transposed exchange (normal mode, N > 1): see include/edigpu.h ----
+int edigpu_normal_transpose_info(edigpu_handle s, int32_t* halo) {
+  if (!s || !halo) {
+    set_error("edigpu_normal_transpose_info: NULL argument");
+    return 1;
+  }
+  if (!normal_transposable(s)) {
+    set_error("edigpu_normal_transpose_info: needs a whole normal-mode sector built by edigpu_normal_build "
+              "(factored Hnd, no phonons); use the all-gather entry points otherwise");
+    return 1;
+  }
+  *halo = s->col_halo;
+  return 0;
+}
+
+int edigpu_normal_apply_rows_dev(edigpu_handle s, int64_t dw_first, int64_t dw_count, const void* v_rows_dev,
+                                 void* hv_rows_dev, void* stream) {
+  if (!s || !v_rows_dev || !hv_rows_dev) {
+    set_error("edigpu_normal_apply_rows_dev: NULL argument");
+    return 1;
+  }
+  if (!normal_transposable(s)) {
+    set_error("edigpu_normal_apply_rows_dev: not a transposable handle (see edigpu_normal_transpose_info)");
+    return 1;
+  }
+  if (dw_first < 0 || dw_count < 0 || dw_first + dw_count > s->dim_dw) {
+    set_error("edigpu_normal_apply_rows_dev: row range outside [0, DimDw)");
+    return 1;
+  }
+  EDIGPU_HIP(hipSetDevice(s->device));
+  return launch_normal_rows(s, dw_first, dw_count, (const double*)v_rows_dev, (double*)hv_rows_dev,
+                            (hipStream_t)stream);
+}
+
+int edigpu_normal_apply_cols_dev(edigpu_handle s, int64_t col_first, int64_t col_count, int64_t row_stride,
+                                 int32_t halo, const void* w_cols_dev, void* hv_cols_dev, void* stream) {
+  if (!s || !w_cols_dev || !hv_cols_dev) {
+    set_error("edigpu_normal_apply_cols_dev: NULL argument");
+    return 1;
+  }
+  if (!normal_transposable(s)) {
+    set_error("edigpu_normal_apply_cols_dev: not a transposable handle (see edigpu_normal_transpose_info)");
+    return 1;
+  }
+  if (col_first < 0 || col_count < 0 || col_first + col_count > s->dim_up || halo < s->col_halo ||
+      row_stride < col_count + 2 * (int64_t)halo) {
+    set_error("edigpu_normal_apply_cols_dev: column range outside [0, DimUp), halo smaller than the sector needs, "
+              "or row stride < col_count + 2 halo");
+    return 1;
+  }
+  EDIGPU_HIP(hipSetDevice(s->device));
+  return launch_normal_cols(s, col_first, col_count, row_stride, halo, (const double*)w_cols_dev, (double*)hv_cols_dev,
+                            (hipStream_t)stream);
+}
+
+int edigpu_transpose_pack(int64_t dim_up, int64_t nrows, int64_t q, int32_t world, int64_t pcol, int32_t halo,
+                          const void* v_rows_dev, void* send_dev, void* stream) {
+  if (!v_rows_dev || !send_dev || dim_up <= 0 || nrows < 0 || nrows > q || world <= 0 || pcol <= 0 || halo < 0 ||
+      pcol * world < dim_up) {
+    set_error("edigpu_transpose_pack: bad argument");
+    return 1;
+  }
+  if (ensure_device()) return 1;
+  return launch_transpose_pack(dim_up, nrows, q, world, pcol, halo, (const double*)v_rows_dev, (double*)send_dev,
+                               (hipStream_t)stream);
+}
+
+int edigpu_transpose_unpack_add(int64_t dim_up, int64_t nrows, int64_t q, int32_t world, int64_t pcol,
+                                int32_t halo, const void* recv_dev, void* hv_rows_dev, void* stream) {
+  if (!recv_dev || !hv_rows_dev || dim_up <= 0 || nrows < 0 || nrows > q || world <= 0 || pcol <= 0 || halo < 0 ||
+      pcol * world < dim_up) {
+    set_error("edigpu_transpose_unpack_add: bad argument");
+    return 1;
+  }
+  if (ensure_device()) return 1;
+  return launch_transpose_unpack_add(dim_up, nrows, q, world, pcol, halo, (const double*)recv_dev,
+                                     (double*)hv_rows_dev, (hipStream_t)stream);
+}
+
+int edigpu_transpose_rotate_pack(int32_t first, int64_t dim_up, int64_t nrows, int64_t q, int32_t world,
+                                 int64_t pcol, int32_t halo, void* vin_dev, void* vout_dev, const void* ab_dev,
+                                 void* send_dev, void* stream) {
+  if (!vin_dev || !vout_dev || !send_dev || (!first && !ab_dev) || dim_up <= 0 || nrows < 0 || nrows > q ||
+      world <= 0 || pcol <= 0 || halo < 0 || pcol * world < dim_up) {
+    set_error("edigpu_transpose_rotate_pack: bad argument");
+    return 1;
+  }
+  if (ensure_device()) return 1;
+  return vec_rotate_pack(first, dim_up, nrows, q, world, pcol, halo, (double*)vin_dev, (double*)vout_dev,
+                         (const double*)ab_dev, (double*)send_dev, (hipStream_t)stream);
+}
+
+int edigpu_transpose_unpack_add_dot2(int64_t dim_up, int64_t nrows, int64_t q, int32_t world, int64_t pcol,
+                                     int32_t halo, const void* vin_dev, void* vout_dev, const void* tmp_dev,
+                                     const void* back_dev, void* out2_dev, void* work_dev, void* stream) {
+  if (!vin_dev || !vout_dev || !tmp_dev || !back_dev || !out2_dev || !work_dev || dim_up <= 0 || nrows < 0 ||
+      nrows > q || world <= 0 || pcol <= 0 || halo < 0 || pcol * world < dim_up) {
+    set_error("edigpu_transpose_unpack_add_dot2: bad argument");
+    return 1;
+  }
+  if (ensure_device()) return 1;
+  return vec_unpack_add_dot2(dim_up, nrows, q, pcol, halo, (const double*)vin_dev, (double*)vout_dev,
+                             (const double*)tmp_dev, (const double*)back_dev, (double*)out2_dev, (double*)work_dev,
+                             (hipStream_t)stream);
 }
 
 // seed from host or device memory (hipMemcpyDefault); norm2 = <vin|vin> as tridiag_Hv_sector_* returns it

@@ -105,6 +105,7 @@ struct edigpu_sector {
   uint8_t* d_impd = nullptr;    // dim_dw
   double* d_ndcoef = nullptr;   // nterms
   uint32_t* d_jup = nullptr;    // nterms * dim_up
+  int col_halo = 0;             // max |partner column - column| over the factored Hnd terms (transposed exchange)
   uint32_t* d_jdw = nullptr;    // nterms * dim_dw
   int32_t* d_mx_rowptr = nullptr;  // per local row: Hdw entries + applicable Hnd terms
   int32_t* d_mx_col = nullptr;

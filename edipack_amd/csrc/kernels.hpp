@@ -15,6 +15,17 @@ constexpr int kMaxPartials = 1 << 16;  // minimum capacity of the per-workgroup 
 int launch_normal(const edigpu_sector* s, const double* v_local, const double* v_full, double* hv,
                   int phase, hipStream_t st);
 int normal_pick_rows_per_block(int64_t dim_up, int64_t dw_count);
+// transposed exchange: the row half and the column half of the product on a whole-sector handle
+bool normal_transposable(const edigpu_sector* s);
+int launch_normal_rows(const edigpu_sector* s, int64_t dw_first, int64_t dw_count, const double* v_rows,
+                       double* hv_rows, hipStream_t st);
+int launch_normal_cols(const edigpu_sector* s, int64_t col_first, int64_t ncol, int64_t stride, int halo,
+                       const double* w, double* hv, hipStream_t st);
+// row shard <-> all-to-all buffers (kernels_ops.hip)
+int launch_transpose_pack(int64_t dim_up, int64_t nrows, int64_t q, int world, int64_t pcol, int halo,
+                          const double* v_rows, double* send, hipStream_t st);
+int launch_transpose_unpack_add(int64_t dim_up, int64_t nrows, int64_t q, int world, int64_t pcol, int halo,
+                                const double* recv, double* hv_rows, hipStream_t st);
 // fused Lanczos step (normal, single shard): P = Lanczos vector, Q = work vector, see kernels_normal.hip
 bool normal_lanczos_fusable(const edigpu_sector* s);
 int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const double* scal,
@@ -55,6 +66,12 @@ int vec_rotate(int64_t n, double* vin, double* vout, const double* beta2, hipStr
 int vec_add_dot(int64_t n, const double* vin, double* vout, const double* tmp, double* out, double* work, hipStream_t st);
 int vec_axpy_nrm2(int64_t n, const double* vin, double* vout, const double* alpha, double* out, double* work, hipStream_t st);
 int vec_scale(int64_t n, double* v, const double* nrm2, hipStream_t st);
+// fused vector updates of the transposed-exchange Lanczos step (work: kRedBlocks doubles)
+int vec_rotate_pack(int first, int64_t dim_up, int64_t nrows, int64_t q, int world, int64_t pcol, int halo,
+                    double* vin, double* vout, const double* ab, double* send, hipStream_t st);
+int vec_unpack_add_dot2(int64_t dim_up, int64_t nrows, int64_t q, int64_t pcol, int halo, const double* vin,
+                        double* vout, const double* tmp, const double* back, double* out2, double* work,
+                        hipStream_t st);
 
 // ---- thick-restart Lanczos multi-vector kernels (kernels_trl.hip) ----
 // h_dev (2 doubles per basis vector: re, im) = Q^H w, then w -= Q h; n counts complex or real elements

@@ -368,6 +368,106 @@ __global__ void __launch_bounds__(kLzNT) kv_scale(int64_t n, double* __restrict_
   for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) v[i] *= inv;
 }
 
+// ---- fused vector updates of the transposed-exchange Lanczos step (normal mode, N > 1) ----
+// ab = (<v|w>, <w|w>) of the previous step, already summed over the ranks: alpha = ab[0], beta^2 = ab[1] - alpha^2.
+// One pass: the pending axpy w - alpha v, the rotate (v, w) <- (w/beta, -beta v), and the new v written straight
+// into the all-to-all send buffer (layout of transpose_pack_kernel, kernels_ops.hip; halo columns are written
+// into every block that holds them; positions never written stay zero from the allocation).
+__global__ void __launch_bounds__(kLzNT)
+    kv_rotate_pack(int first, int64_t dim_up, int64_t nrows, int64_t q, int world, int64_t pcol, int halo,
+                   double* __restrict__ vin, double* __restrict__ vout, const double* __restrict__ ab,
+                   double* __restrict__ send) {
+  double a = 0.0, b = 1.0, ib = 1.0;
+  if (!first) {
+    a = ab[0];
+    b = sqrt(ab[1] - a * a);
+    ib = 1.0 / b;
+  }
+  const int64_t pw = pcol + 2 * halo, n = nrows * dim_up;
+  for (int64_t e = (int64_t)blockIdx.x * kLzNT + threadIdx.x; e < n; e += (int64_t)gridDim.x * kLzNT) {
+    const int64_t i = e / dim_up, col = e - i * dim_up;
+    double x = vin[e];
+    if (!first) {
+      const double t = x;
+      x = (vout[e] - a * t) * ib;
+      vin[e] = x;
+      vout[e] = -b * t;
+    }
+    int64_t clo = col >= halo ? (col - halo) / pcol : 0, chi = (col + halo) / pcol;
+    if (chi > world - 1) chi = world - 1;
+    for (int64_t c = clo; c <= chi; c++) send[(c * q + i) * pw + (col - c * pcol + halo)] = x;
+  }
+}
+
+// w += tmp + (the down half received from the column shards); partials of <v|w> and <w|w>
+__global__ void __launch_bounds__(kLzNT)
+    kv_unpack_add_dot2(int64_t dim_up, int64_t nrows, int64_t q, int64_t pcol, int halo,
+                       const double* __restrict__ vin, double* __restrict__ vout, const double* __restrict__ tmp,
+                       const double* __restrict__ back, double* __restrict__ partial) {
+  const int64_t pw = pcol + 2 * halo, n = nrows * dim_up;
+  double s = 0.0, qq = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * kLzNT + threadIdx.x; e < n; e += (int64_t)gridDim.x * kLzNT) {
+    const int64_t i = e / dim_up, col = e - i * dim_up;
+    const int64_t c = col / pcol, j = col - c * pcol;
+    const double w = vout[e] + tmp[e] + back[(c * q + i) * pw + halo + j];
+    vout[e] = w;
+    s += vin[e] * w;
+    qq += w * w;
+  }
+  s = block_sum(s);
+  qq = block_sum(qq);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = s;
+    partial[kRedBlocks / 2 + blockIdx.x] = qq;
+  }
+}
+
+__global__ void __launch_bounds__(1024) kv_sum2(const double* __restrict__ partial, int np, double* __restrict__ out) {
+  __shared__ double sh[2][1024];
+  double s = 0.0, t = 0.0;
+  for (int i = threadIdx.x; i < np; i += 1024) {
+    s += partial[i];
+    t += partial[kRedBlocks / 2 + i];
+  }
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = t;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + off];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = sh[0][0];
+    out[1] = sh[1][0];
+  }
+}
+
+int vec_rotate_pack(int first, int64_t dim_up, int64_t nrows, int64_t q, int world, int64_t pcol, int halo,
+                    double* vin, double* vout, const double* ab, double* send, hipStream_t st) {
+  if (nrows * dim_up <= 0) return 0;
+  hipLaunchKernelGGL(kv_rotate_pack, ew_grid(nrows * dim_up), dim3(kLzNT), 0, st, first, dim_up, nrows, q, world, pcol,
+                     halo, vin, vout, ab, send);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int vec_unpack_add_dot2(int64_t dim_up, int64_t nrows, int64_t q, int64_t pcol, int halo, const double* vin,
+                        double* vout, const double* tmp, const double* back, double* out2, double* work,
+                        hipStream_t st) {
+  const int64_t n = nrows * dim_up;
+  int64_t nb = (n + kLzNT - 1) / kLzNT;
+  if (nb > kRedBlocks / 2) nb = kRedBlocks / 2;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(kv_unpack_add_dot2, dim3((unsigned)nb), dim3(kLzNT), 0, st, dim_up, nrows, q, pcol, halo, vin,
+                     vout, tmp, back, work);
+  hipLaunchKernelGGL(kv_sum2, dim3(1), dim3(1024), 0, st, work, (int)nb, out2);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 int vec_rotate(int64_t n, double* vin, double* vout, const double* beta2, hipStream_t st) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(kv_rotate, ew_grid(n), dim3(kLzNT), 0, st, n, vin, vout, beta2);

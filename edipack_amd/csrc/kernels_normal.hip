@@ -515,6 +515,37 @@ int launch_normal(const edigpu_sector* s, const double* v_local, const double* v
   return sell_nd ? launch_csr(s->nd, 0, v_full, hv, 1, st) : 0;
 }
 
+// Transposed exchange (reference spMatVec_mpi_normal_main :765-866): the two halves of the
+// product on a whole-sector handle, each on the part of the vector a rank owns in that phase.
+//   rows: hv_rows = (Hd + 1 (x) Hup) v for the down rows [dw_first, dw_first + dw_count), v_rows / hv_rows
+//         hold those rows (row stride DimUp)
+//   cols: hv_cols = (Hdw (x) 1 + Hnd) v for the up columns [col_first, col_first + ncol) of all rows, buffers
+//         with halo columns on both sides (launch_dw_panel_cols)
+bool normal_transposable(const edigpu_sector* s) {
+  if (s->kind != 0 || s->nloc != s->dim || s->dw_count == 0 || s->nph > 0) return false;
+  if (!s->factored && s->has_nd) return false;  // explicit spH0nd couples arbitrary columns: all-gather form only
+  if (s->factored && s->fac_nterms > 0 && s->d_mx_rowptr == nullptr) return false;
+  return true;
+}
+
+int launch_normal_rows(const edigpu_sector* s, int64_t dw_first, int64_t dw_count, const double* v_rows,
+                       double* hv_rows, hipStream_t st) {
+  if (dw_count <= 0) return 0;
+  NormalArgs a;
+  fill_args(s, a);
+  a.dw_first = dw_first;
+  a.dw_count = dw_count;
+  return launch_rows(s, a, v_rows, nullptr, hv_rows, 1, st);
+}
+
+int launch_normal_cols(const edigpu_sector* s, int64_t col_first, int64_t ncol, int64_t stride, int halo,
+                       const double* w, double* hv, hipStream_t st) {
+  NormalArgs a;
+  fill_args(s, a);
+  const bool fac_nd = s->factored && a.nterms > 0;
+  return launch_dw_panel_cols(a, fac_nd, col_first, ncol, stride, halo, w, hv, st);
+}
+
 // One fused Lanczos step on a single-shard normal handle (see normal_rows_kernel FUSE):
 //   row kernel : [rotate] + Q <- (Hd+Hup) v [- beta*P_old]
 //   panel sweep: Q += (Hdw + Hnd) v ; per-workgroup partials of alpha = <v|Q>

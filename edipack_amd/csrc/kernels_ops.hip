@@ -85,6 +85,62 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- transposed exchange (reference vector_transpose_MPI, ED_NORMAL/ED_HAMILTONIAN_NORMAL_COMMON.f90:66-167) ----
+// A rank owns q down rows of V[idw][iup] (row shard).  For the down half of the product every rank needs ALL rows of
+// a block of pcol up columns (+ halo columns on both sides for Hnd): block (r -> c) = rows of rank r, columns
+// [c*pcol - halo, (c+1)*pcol + halo).  send[c][i][j] is laid out so that one equal-split all-to-all delivers
+// recv[r][i][j] = rows r*q + i in order, i.e. the column shard with row stride pcol + 2*halo and no unpacking.
+// Rows >= nrows (the tail rank's padding) and columns outside [0, DimUp) are sent as zeros.
+__global__ void __launch_bounds__(256)
+    transpose_pack_kernel(int64_t dim_up, int64_t nrows, int64_t q, int world, int64_t pcol, int halo,
+                          const double* __restrict__ v, double* __restrict__ send) {
+  const int64_t pw = pcol + 2 * halo;
+  const int64_t n = (int64_t)world * q * pw;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int64_t j = e % pw, i = (e / pw) % q, c = e / (pw * q);
+    const int64_t col = c * pcol - halo + j;
+    send[e] = (i < nrows && col >= 0 && col < dim_up) ? v[i * dim_up + col] : 0.0;
+  }
+}
+
+// the way back: recv[c][i][halo + j] = the down half of H*v for (row i of this rank, column c*pcol + j)
+__global__ void __launch_bounds__(256)
+    transpose_unpack_add_kernel(int64_t dim_up, int64_t nrows, int64_t q, int64_t pcol, int halo,
+                                const double* __restrict__ recv, double* __restrict__ hv) {
+  const int64_t pw = pcol + 2 * halo;
+  const int64_t n = nrows * dim_up;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int64_t i = e / dim_up, col = e - i * dim_up;
+    const int64_t c = col / pcol, j = col - c * pcol;
+    hv[e] += recv[(c * q + i) * pw + halo + j];
+  }
+}
+
+int launch_transpose_pack(int64_t dim_up, int64_t nrows, int64_t q, int world, int64_t pcol, int halo,
+                          const double* v_rows, double* send, hipStream_t st) {
+  const int64_t n = (int64_t)world * q * (pcol + 2 * halo);
+  if (n == 0) return 0;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 256 * 32) nb = 256 * 32;
+  hipLaunchKernelGGL(transpose_pack_kernel, dim3((unsigned)nb), dim3(256), 0, st, dim_up, nrows, q, world, pcol, halo,
+                     v_rows, send);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_transpose_unpack_add(int64_t dim_up, int64_t nrows, int64_t q, int world, int64_t pcol, int halo,
+                                const double* recv, double* hv_rows, hipStream_t st) {
+  (void)world;
+  const int64_t n = nrows * dim_up;
+  if (n == 0) return 0;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 256 * 32) nb = 256 * 32;
+  hipLaunchKernelGGL(transpose_unpack_add_kernel, dim3((unsigned)nb), dim3(256), 0, st, dim_up, nrows, q, pcol, halo,
+                     recv, hv_rows);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 // the same pass for the complex (superc / nonsu2) sectors: g_el(i_el) comes as one table over the sector rows
 __global__ void __launch_bounds__(256)
     phonon_flat_kernel(int64_t dim_el, int dimph, double w0, double a_ph, const double* __restrict__ gel,

@@ -27,6 +27,10 @@ namespace edigpu {
 
 struct PanelArgs {
   int npanels, width, blocks_per_panel, rows_per_block;
+  // COLS (column shard of the transposed exchange, see launch_dw_panel_cols): the buffers hold the columns
+  // [col_first - halo, col_first + ncol + halo) of every row at the given row stride (>= ncol + 2 * halo)
+  int64_t col_first, ncol, stride;
+  int halo;
 };
 
 constexpr int kPanelNT = 512;
@@ -34,7 +38,8 @@ constexpr int kMaxNdTerms = 16;
 
 // ALPHA: also accumulate <v|hv_new> over the local rows (v = v_full rows of this shard) and write
 // one partial per workgroup (deterministic two-stage reduction, see kernels_lanczos.hip)
-template <bool DO_DW, bool DO_ND, bool ALPHA>
+// COLS: column-shard form -- hv is written (not accumulated), columns are shard-local (see PanelArgs)
+template <bool DO_DW, bool DO_ND, bool ALPHA, bool COLS = false>
 __global__ void __launch_bounds__(kPanelNT)
     normal_dw_panel_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full,
                            double* __restrict__ hv) {
@@ -55,10 +60,13 @@ __global__ void __launch_bounds__(kPanelNT)
   const int chunk = k % p.blocks_per_panel;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t DimUp = a.dim_up;
-  const int64_t c = (int64_t)panel * p.width + lane;
-  const bool ok = lane < p.width && c < DimUp;
-  const int64_t cc = ok ? c : DimUp - 1;
+  // DimUp doubles as the row stride of v_full / hv; c, cc index into a row
+  const int64_t NCol = COLS ? p.ncol : a.dim_up;
+  const int64_t DimUp = COLS ? p.stride : a.dim_up;
+  const int64_t c0 = (int64_t)panel * p.width + lane;
+  const bool ok = lane < p.width && c0 < NCol;
+  const int64_t c = c0 + (COLS ? p.halo : 0);
+  const int64_t cc = ok ? c : NCol - 1 + (COLS ? p.halo : 0);
   int64_t rend = (int64_t)(chunk + 1) * p.rows_per_block;
   if (rend > a.dw_count) rend = a.dw_count;
   constexpr int NW = kPanelNT / 64;
@@ -66,14 +74,24 @@ __global__ void __launch_bounds__(kPanelNT)
   // back its own words only, so no barrier is needed
   __shared__ uint32_t ju_s[(DO_ND ? kMaxNdTerms : 1) * kPanelNT];
   if (DO_ND)
-    for (int t = 0; t < a.nterms; t++) ju_s[t * kPanelNT + threadIdx.x] = a.jup[(int64_t)t * DimUp + cc];
+    for (int t = 0; t < a.nterms; t++) {
+      if (COLS) {
+        // global partner column -> position in the shard's rows (inside the halo by construction)
+        const uint32_t jt = a.jup[(int64_t)t * a.dim_up + (p.col_first + cc - p.halo)];
+        ju_s[t * kPanelNT + threadIdx.x] =
+            jt == 0xFFFFFFFFu ? jt
+                              : ((jt & 0x80000000u) | (uint32_t)((int64_t)(jt & 0x7FFFFFFFu) - p.col_first + p.halo));
+      } else {
+        ju_s[t * kPanelNT + threadIdx.x] = a.jup[(int64_t)t * DimUp + cc];
+      }
+    }
   for (int64_t r = (int64_t)chunk * p.rows_per_block + wave; r < rend; r += 2 * NW) {
     // two rows per iteration: independent load streams in flight
     const int64_t r2 = r + NW;
     const bool two = r2 < rend;
     const int64_t g = a.dw_first + r;
-    double acc0 = hv[r * DimUp + cc];
-    double acc1 = two ? hv[r2 * DimUp + cc] : 0.0;
+    double acc0 = COLS ? 0.0 : hv[r * DimUp + cc];
+    double acc1 = (!COLS && two) ? hv[r2 * DimUp + cc] : 0.0;
     // ALPHA: the lane's own elements of v, issued with the result loads instead of after the gather chain
     double own0 = 0.0, own1 = 0.0;
     if (ALPHA) {
@@ -185,6 +203,52 @@ static int panel_resident_blocks() {
   return v;
 }
 
+// panels over ncol columns: a multiple of 8 (one stream of panels per XCD), at most 64 columns wide
+static void plan_panels(PanelArgs& p, int64_t ncol) {
+  int wmax = 64;
+  if (const char* e = getenv("EDIGPU_PANEL_W")) {
+    wmax = atoi(e);
+    if (wmax < 1 || wmax > 64) wmax = 64;
+  }
+  int np = (int)((ncol + 8 * wmax - 1) / (8 * wmax)) * 8;
+  if (np < 8) np = 8;
+  p.width = (int)((ncol + np - 1) / np);
+  if (p.width < 1) p.width = 1;
+  p.npanels = (int)((ncol + p.width - 1) / p.width);
+}
+
+// Column-shard form (transposed exchange, reference spMatVec_mpi_normal_main :834-866 +
+// vector_transpose_MPI): w holds the columns [col_first - halo, col_first + ncol + halo) of ALL DimDw rows
+// (row stride `stride`: the full column block of the exchange, which the last rank only partly owns); hv (same layout) receives (Hdw (x) 1 + Hnd) v for the ncol owned columns.
+// a must describe the whole sector (dw_first = 0, dw_count = DimDw).
+int launch_dw_panel_cols(const NormalArgs& a, bool do_nd, int64_t col_first, int64_t ncol, int64_t stride, int halo,
+                         const double* w, double* hv, hipStream_t st) {
+  if (ncol <= 0) return 0;
+  if (do_nd && a.nterms > kMaxNdTerms) {
+    set_error("launch_dw_panel_cols: too many factored Hnd terms");
+    return 1;
+  }
+  PanelArgs p;
+  plan_panels(p, ncol);
+  p.col_first = col_first;
+  p.ncol = ncol;
+  p.stride = stride;
+  p.halo = halo;
+  int bpp = panel_resident_blocks();
+  p.rows_per_block = (int)((a.dw_count + bpp - 1) / bpp);
+  if (p.rows_per_block < 16) p.rows_per_block = 16;
+  bpp = (int)((a.dw_count + p.rows_per_block - 1) / p.rows_per_block);
+  p.blocks_per_panel = bpp;
+  const int panel_groups = (p.npanels + 7) / 8;
+  const dim3 grid((unsigned)((int64_t)panel_groups * bpp * 8)), block(kPanelNT);
+  if (do_nd)
+    hipLaunchKernelGGL((normal_dw_panel_kernel<true, true, false, true>), grid, block, 0, st, a, p, w, hv);
+  else
+    hipLaunchKernelGGL((normal_dw_panel_kernel<true, false, false, true>), grid, block, 0, st, a, p, w, hv);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* v_full, double* hv,
                      hipStream_t st, bool alpha, int* nblocks) {
   if (!do_dw && !do_nd && !alpha) return 0;
@@ -193,17 +257,11 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
     return 1;
   }
   PanelArgs p;
-  // panels: a multiple of 8 (one stream of panels per XCD), at most 64 columns wide
-  int wmax = 64;
-  if (const char* e = getenv("EDIGPU_PANEL_W")) {
-    wmax = atoi(e);
-    if (wmax < 1 || wmax > 64) wmax = 64;
-  }
-  int np = (int)((a.dim_up + 8 * wmax - 1) / (8 * wmax)) * 8;
-  if (np < 8) np = 8;
-  p.width = (int)((a.dim_up + np - 1) / np);
-  if (p.width < 1) p.width = 1;
-  p.npanels = (int)((a.dim_up + p.width - 1) / p.width);
+  plan_panels(p, a.dim_up);
+  p.col_first = 0;
+  p.ncol = a.dim_up;
+  p.stride = a.dim_up;
+  p.halo = 0;
   int bpp = panel_resident_blocks();
   p.rows_per_block = (int)((a.dw_count + bpp - 1) / bpp);
   if (p.rows_per_block < 16) p.rows_per_block = 16;

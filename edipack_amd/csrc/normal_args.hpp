@@ -50,4 +50,7 @@ struct NormalArgs {
 int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* v_full, double* hv,
                      hipStream_t st, bool alpha = false, int* nblocks = nullptr);
 
+int launch_dw_panel_cols(const NormalArgs& a, bool do_nd, int64_t col_first, int64_t ncol, int64_t stride, int halo,
+                         const double* w, double* hv, hipStream_t st);
+
 }  // namespace edigpu

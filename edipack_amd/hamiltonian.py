@@ -295,6 +295,23 @@ class SectorHamiltonian:
         capi.check(capi.lib().edigpu_apply_remote_dev(self._h, v_full_ptr, hv_ptr, stream if stream else None),
                    "edigpu_apply_remote_dev")
 
+    # ---- transposed exchange (normal mode, N > 1; include/edigpu.h) ---------------------------
+    def transpose_halo(self) -> int:
+        h = C.c_int32(0)
+        capi.check(capi.lib().edigpu_normal_transpose_info(self._h, C.byref(h)), "edigpu_normal_transpose_info")
+        return h.value
+
+    def apply_rows_dev(self, dw_first: int, dw_count: int, v_rows_ptr: int, hv_rows_ptr: int, stream: int = 0):
+        capi.check(capi.lib().edigpu_normal_apply_rows_dev(self._h, dw_first, dw_count, v_rows_ptr, hv_rows_ptr,
+                                                           stream if stream else None),
+                   "edigpu_normal_apply_rows_dev")
+
+    def apply_cols_dev(self, col_first: int, col_count: int, row_stride: int, halo: int, w_ptr: int, hv_ptr: int,
+                       stream: int = 0):
+        capi.check(capi.lib().edigpu_normal_apply_cols_dev(self._h, col_first, col_count, row_stride, halo, w_ptr, hv_ptr,
+                                                           stream if stream else None),
+                   "edigpu_normal_apply_cols_dev")
+
     # ---- Lanczos ------------------------------------------------------------------------------
     def lanczos_tridiag(self, vin: np.ndarray, nlanc: int, threshold: float = 0.0):
         """sp_lanc_tridiag semantics, vector resident on the device."""

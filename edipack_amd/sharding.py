@@ -20,6 +20,7 @@ is not observable in the results).
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Callable
 
@@ -147,7 +148,7 @@ class ShardedLanczos:
     """
 
     def __init__(self, plan: ShardPlan, apply_local: Callable, apply_remote: Callable,
-                 dtype=torch.float64, device="cpu", group=None, vec_ops=None):
+                 dtype=torch.float64, device="cpu", group=None, vec_ops=None, gathered: bool = True):
         self.plan, self.apply_local, self.apply_remote = plan, apply_local, apply_remote
         self.dtype, self.device, self.group = dtype, device, group
         self.ops = vec_ops if vec_ops is not None else TorchVecOps()
@@ -155,7 +156,7 @@ class ShardedLanczos:
         self.vin = torch.zeros(n, dtype=dtype, device=device)     # padded chunk; tail stays zero
         self.vout = torch.zeros(n, dtype=dtype, device=device)
         self.tmp = torch.zeros(n, dtype=dtype, device=device)
-        self.vfull = torch.zeros(n * plan.world, dtype=dtype, device=device)
+        self.vfull = torch.zeros(n * plan.world, dtype=dtype, device=device) if gathered else None
 
     # -- collectives --------------------------------------------------------------------------
     def _allreduce(self, t: torch.Tensor) -> torch.Tensor:
@@ -220,6 +221,186 @@ class ShardedLanczos:
         alanc[ndone:] = 0.0
         blanc[ndone:] = 0.0
         return alanc, blanc, ndone
+
+
+class TransposedKernels:
+    """The four device steps of the transposed exchange through libedigpu.so (include/edigpu.h)."""
+
+    def __init__(self, h, plan: ShardPlan):
+        from . import capi
+        self.h, self.L, self.check, self.plan = h, capi.lib(), capi.check, plan
+        self.halo = h.transpose_halo()
+        self.dim_up, self.dim_dw = h.dim_up, h.dim_dw
+        self.work = None
+
+    @staticmethod
+    def _st():
+        return torch.cuda.current_stream().cuda_stream
+
+    def pack(self, lz, vin, send):
+        pl = self.plan
+        self.check(self.L.edigpu_transpose_pack(self.dim_up, pl.count, pl.q, pl.world, lz.pcol, lz.halo,
+                                                vin.data_ptr(), send.data_ptr(), self._st()))
+
+    def rows(self, lz, vin, out):
+        self.h.apply_rows_dev(self.plan.first, self.plan.count, vin.data_ptr(), out.data_ptr(), self._st())
+
+    def cols(self, lz, recv, hvc):
+        self.h.apply_cols_dev(lz.col_first, lz.col_count, lz.pw, lz.halo, recv.data_ptr(), hvc.data_ptr(), self._st())
+
+    def unpack_add(self, lz, back, out):
+        pl = self.plan
+        self.check(self.L.edigpu_transpose_unpack_add(self.dim_up, pl.count, pl.q, pl.world, lz.pcol, lz.halo,
+                                                      back.data_ptr(), out.data_ptr(), self._st()))
+
+    # fused with the vector updates of the recurrence (one all-reduce per step)
+    def rotate_pack(self, lz, first, vin, vout, ab_prev, send):
+        pl = self.plan
+        self.check(self.L.edigpu_transpose_rotate_pack(1 if first else 0, self.dim_up, pl.count, pl.q, pl.world,
+                                                       lz.pcol, lz.halo, vin.data_ptr(), vout.data_ptr(),
+                                                       None if first else ab_prev.data_ptr(), send.data_ptr(),
+                                                       self._st()))
+
+    def unpack_add_dot2(self, lz, vin, vout, tmp, back, out2):
+        pl = self.plan
+        if self.work is None:
+            self.work = torch.zeros(self.L.edigpu_vec_work_doubles(), dtype=torch.float64, device=vin.device)
+        self.check(self.L.edigpu_transpose_unpack_add_dot2(self.dim_up, pl.count, pl.q, pl.world, lz.pcol, lz.halo,
+                                                           vin.data_ptr(), vout.data_ptr(), tmp.data_ptr(),
+                                                           back.data_ptr(), out2.data_ptr(), self.work.data_ptr(),
+                                                           self._st()))
+
+
+class TransposedLanczos(ShardedLanczos):
+    """Normal mode with the transposed exchange (reference spMatVec_mpi_normal_main,
+    ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:834-866, with vector_transpose_MPI,
+    ED_NORMAL/ED_HAMILTONIAN_NORMAL_COMMON.f90:66-167).
+
+    The vector stays row-sharded (rank r owns down rows [r q, (r+1) q)).  Per product two equal-split
+    all-to-alls move (N-1)/N of the shard each way instead of an all-gather of the whole vector: pack ->
+    all-to-all (in flight while the row half (Hd + Hup) runs) -> column half (Hdw + Hnd) on this rank's
+    up columns of all rows -> all-to-all back -> unpack-add.  No physical transpose: the column-panel
+    kernel works on the received blocks as they arrive (they are already in row order), and Hnd is served
+    by a few halo columns instead of the reference's all-gather (:906-927).
+
+    ``kernels`` supplies pack / rows / cols / unpack_add (TransposedKernels on the GPU; the CPU tests pass
+    stand-ins built on the oracle's matrices) and the attributes halo, dim_up, dim_dw.
+    """
+
+    def __init__(self, plan: ShardPlan, kernels, device="cuda", group=None, vec_ops=None, stage_host: bool = False):
+        self.k = kernels
+        self.halo, self.dim_up, self.dim_dw = kernels.halo, kernels.dim_up, kernels.dim_dw
+        self.pcol = -(-self.dim_up // plan.world)
+        self.col_first = min(plan.rank * self.pcol, self.dim_up)
+        self.col_count = max(0, min(self.pcol, self.dim_up - self.col_first))
+        self.pw = self.pcol + 2 * self.halo
+        self.stage_host = stage_host          # gloo rehearsal on a GPU: all_to_all through host memory
+        self.exact = bool(os.environ.get("EDIGPU_LANCZOS_EXACTBETA"))   # two all-reduces per step, beta from ||w - alpha v||
+        ShardedLanczos.__init__(self, plan, None, None, dtype=torch.float64, device=device, group=group,
+                                vec_ops=vec_ops, gathered=False)
+        n = plan.world * plan.q * self.pw
+        self.send = torch.zeros(n, dtype=torch.float64, device=device)
+        self.recv = torch.zeros(n, dtype=torch.float64, device=device)   # column shard of v
+        self.hvc = torch.zeros(n, dtype=torch.float64, device=device)    # column shard of the down half; padding rows stay 0
+        self.back = torch.zeros(n, dtype=torch.float64, device=device)
+
+    @property
+    def exchange_bytes(self) -> int:
+        """bytes this rank sends per product (both all-to-alls, own block excluded)"""
+        return 2 * 8 * (self.plan.world - 1) * self.plan.q * self.pw
+
+    def _a2a(self, dst, src, async_op=False):
+        if self.plan.world == 1:
+            dst.copy_(src)
+            return None
+        if self.stage_host:
+            s, d = src.cpu(), torch.empty(src.numel(), dtype=src.dtype)
+            dist.all_to_all_single(d, s, group=self.group)
+            dst.copy_(d)
+            return None
+        return dist.all_to_all_single(dst, src, group=self.group, async_op=async_op)
+
+    def _exchange_and_apply(self) -> None:
+        work = self._a2a(self.recv, self.send, async_op=True)
+        self.k.rows(self, self.vin, self.tmp)
+        if work is not None:
+            work.wait()
+        self.k.cols(self, self.recv, self.hvc)
+        self._a2a(self.back, self.hvc)
+
+    def hv(self) -> None:
+        self.k.pack(self, self.vin, self.send)
+        self._exchange_and_apply()
+        self.k.unpack_add(self, self.back, self.tmp)
+
+    # -- fused recurrence: one all-reduce per step ------------------------------------------------
+    @property
+    def fused(self) -> bool:
+        return hasattr(self.k, "rotate_pack") and not self.exact
+
+    def fused_step(self, it: int, ab: torch.Tensor) -> None:
+        """ab[2 it : 2 it + 2] <- (<v|w>, <w|w>) of step `it`, summed over the ranks.  The axpy w - alpha v
+        and the rotate of step it-1 are applied lazily at the start (rotate_pack)."""
+        self.k.rotate_pack(self, it == 0, self.vin, self.vout, None if it == 0 else ab[2 * it - 2:2 * it], self.send)
+        self._exchange_and_apply()
+        self.k.unpack_add_dot2(self, self.vin, self.vout, self.tmp, self.back, ab[2 * it:2 * it + 2])
+        self._allreduce(ab[2 * it:2 * it + 2])
+
+    def tridiag(self, v_local: torch.Tensor, nlanc: int, threshold: float = 0.0):
+        if not self.fused:
+            return super().tridiag(v_local, nlanc, threshold)
+        import numpy as np
+        nl = self.plan.nloc
+        self.vin.zero_()
+        self.vin[:nl].copy_(v_local)
+        self.vout.zero_()
+        nrm2 = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.ops.nrm2(self.vin, nrm2)
+        self._allreduce(nrm2)
+        self.ops.scale(self.vin, nrm2)
+        ab = torch.zeros(2 * nlanc, dtype=torch.float64, device=self.device)
+        for it in range(nlanc):
+            self.fused_step(it, ab)
+        abh = ab.cpu().numpy()
+        al, qq = abh[0::2], abh[1::2]
+        b2 = qq - al * al
+        alanc, blanc, ndone = np.zeros(nlanc), np.zeros(nlanc), nlanc
+        for k in range(nlanc):
+            if not (b2[k] > 1e-3 * qq[k]):
+                # beta^2 = <w|w> - alpha^2 lost more than three digits (or the recurrence broke down): the same
+                # values on every rank, so every rank repeats the run with the exact two-reduction recurrence
+                self.exact = True
+                try:
+                    return super().tridiag(v_local, nlanc, threshold)
+                finally:
+                    self.exact = False
+            alanc[k] = al[k]
+            be = np.sqrt(b2[k])
+            if abs(be) < threshold:
+                ndone = k + 1
+                break
+            if k + 1 < nlanc:
+                blanc[k + 1] = be
+        alanc[ndone:] = 0.0
+        blanc[ndone:] = 0.0
+        return alanc, blanc, ndone
+
+
+def gpu_transposed_hamiltonian(model, sector, world: int, rank: int, group=None, stage_host: bool = False):
+    """Normal mode, transposed exchange: every rank builds the whole sector (factored tables only) and runs
+    TransposedLanczos on its row shard.  Raises RuntimeError when the sector cannot be served this way
+    (explicit spH0nd, phonons): fall back to gpu_sharded_hamiltonian (all-gather form)."""
+    from .hamiltonian import SectorHamiltonian
+    nup, ndw = sector
+    h = SectorHamiltonian.normal_from_model(model, nup, ndw)
+    try:
+        plan = ShardPlan(units=h.dim_dw, unit_len=h.dim_up, world=world, rank=rank)
+        lz = TransposedLanczos(plan, TransposedKernels(h, plan), group=group, vec_ops=NativeVecOps(),
+                               stage_host=stage_host)
+    except Exception:
+        h.destroy()
+        raise
+    return plan, h, lz
 
 
 def gpu_sharded_hamiltonian(model, workload_sector, world: int, rank: int, direct: bool = False):

@@ -231,6 +231,54 @@ int edigpu_apply_dev(edigpu_handle h, const void *v_full_dev, void *hv_dev, void
 int edigpu_apply_local_dev(edigpu_handle h, const void *v_local_dev, void *hv_dev, void *stream);
 int edigpu_apply_remote_dev(edigpu_handle h, const void *v_full_dev, void *hv_dev, void *stream);
 
+/*
+ * Transposed exchange for normal mode on N > 1 GPUs.  Replaces the two vector_transpose_MPI calls per product
+ * of spMatVec_mpi_normal_main (ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:834-866; the transpose itself
+ * ED_NORMAL/ED_HAMILTONIAN_NORMAL_COMMON.f90:66-167) AND its allgather_vector_MPI for spH0nd (:906-927).
+ * Every rank builds the WHOLE sector (edigpu_normal_build with dw_count < 0: only O(DimUp + DimDw) tables) and
+ * owns, of the vector, q = ceil(DimDw / N) down rows in the row phase and pcol = ceil(DimUp / N) up columns of
+ * ALL rows in the column phase:
+ *   edigpu_transpose_pack          row shard v_rows[nrows][DimUp] -> send[N][q][pcol + 2 halo]
+ *   (equal-split all-to-all, e.g. torch.distributed.all_to_all_single over RCCL)
+ *                                  -> recv[N*q][pcol + 2 halo] = the column shard, already in row order
+ *   edigpu_normal_apply_rows_dev   hv_rows  = (Hd + 1 (x) Hup) v on the row shard (runs during the exchange)
+ *   edigpu_normal_apply_cols_dev   hv_cols  = (Hdw (x) 1 + Hnd) v on the column shard (same layout as recv;
+ *                                  only the col_count owned columns of the DimDw real rows are written;
+ *                                  row_stride = pcol + 2 halo, also on the last rank, which owns fewer columns)
+ *   (equal-split all-to-all back: block r of hv_cols goes to rank r, no packing)
+ *   edigpu_transpose_unpack_add    hv_rows += the received blocks
+ * halo (edigpu_normal_transpose_info): the spin-exchange / pair-hopping terms of Hnd move one electron between
+ * impurity levels of the up configuration, i.e. reach a column at most `halo` away -- a few columns travel
+ * twice instead of the whole vector being gathered.  All calls are enqueued on `stream` without host
+ * synchronisation.  Handles holding explicit spH0nd arrays or phonons are refused (use the all-gather form).
+ */
+int edigpu_normal_transpose_info(edigpu_handle h, int32_t *halo);
+int edigpu_normal_apply_rows_dev(edigpu_handle h, int64_t dw_first, int64_t dw_count, const void *v_rows_dev,
+                                 void *hv_rows_dev, void *stream);
+int edigpu_normal_apply_cols_dev(edigpu_handle h, int64_t col_first, int64_t col_count, int64_t row_stride,
+                                 int32_t halo, const void *w_cols_dev, void *hv_cols_dev, void *stream);
+int edigpu_transpose_pack(int64_t dim_up, int64_t nrows, int64_t q, int32_t world, int64_t pcol, int32_t halo,
+                          const void *v_rows_dev, void *send_dev, void *stream);
+int edigpu_transpose_unpack_add(int64_t dim_up, int64_t nrows, int64_t q, int32_t world, int64_t pcol,
+                                int32_t halo, const void *recv_dev, void *hv_rows_dev, void *stream);
+/*
+ * The same two steps fused with the vector updates of lanczos_iteration (one all-reduce per step instead of
+ * two, three passes over the shard less):
+ *   _rotate_pack      first = 0: alpha = ab[0], beta^2 = ab[1] - alpha^2 (the all-reduced <v|w>, <w|w> of the
+ *                     previous step); w -= alpha v, (v, w) <- (w / beta, -beta v), new v -> send buffer.
+ *                     first = 1: only packs v.
+ *   _unpack_add_dot2  w += hv_rows + received blocks; out2 = this rank's (<v|w>, <w|w>);
+ *                     work: edigpu_vec_work_doubles() doubles.
+ * beta^2 = <w|w> - alpha^2 loses digits when beta << |alpha|; the caller checks the history and repeats the
+ * run with the exact two-reduction recurrence in that case (edipack_amd/sharding.py).
+ */
+int edigpu_transpose_rotate_pack(int32_t first, int64_t dim_up, int64_t nrows, int64_t q, int32_t world,
+                                 int64_t pcol, int32_t halo, void *vin_dev, void *vout_dev, const void *ab_dev,
+                                 void *send_dev, void *stream);
+int edigpu_transpose_unpack_add_dot2(int64_t dim_up, int64_t nrows, int64_t q, int32_t world, int64_t pcol,
+                                     int32_t halo, const void *vin_dev, void *vout_dev, const void *tmp_dev,
+                                     const void *back_dev, void *out2_dev, void *work_dev, void *stream);
+
 /* ----------------------------------------------------------------------- */
 /* device-resident Lanczos                                                    */
 /* ----------------------------------------------------------------------- */

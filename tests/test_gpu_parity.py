@@ -1147,3 +1147,182 @@ def test_phonon_flat_error_paths(gpu):
     pm.g_ph = np.diag([0.3, 0.5])
     with pytest.raises(RuntimeError, match="one shard"):
         SectorHamiltonian.direct_from_model(pm, 0, row_first=0, row_count=8)
+
+
+# --------------------------------------------------------------------------------------------
+# transposed exchange: the row half / column half of the product with the
+# all-to-all emulated in one process (block (r -> c) of rank r's send buffer = block r of rank c's
+# receive buffer), for several rank counts including ragged tails
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bath,norb,nbath,sec,jxp", [
+    ("normal", 1, 4, (2, 3), 0.0),
+    ("normal", 2, 3, (4, 3), 0.0),       # no Hnd: halo 0
+    ("normal", 2, 3, (4, 4), 0.25),      # spin-exchange / pair-hopping: halo columns
+    ("hybrid", 3, 2, (4, 5), 0.25),
+    ("replica", 2, 2, (3, 3), 0.25),
+])
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+def test_transposed_exchange_emulated(gpu, bath, norb, nbath, sec, jxp, world):
+    import torch
+    from edipack_amd import capi
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from edipack_amd.sharding import ShardPlan
+    O = _oracle()
+    om, pm = make_models("normal", bath, norb, nbath, seed=61, jxp=jxp)
+    ho = O.HNormal(om, *sec)
+    h = SectorHamiltonian.normal_from_model(pm, *sec)
+    L, st = capi.lib(), torch.cuda.current_stream().cuda_stream
+    halo = h.transpose_halo()
+    assert (halo > 0) == (jxp != 0.0 and norb > 1)
+    du, dd = h.dim_up, h.dim_dw
+    v = np.random.default_rng(6).standard_normal(ho.dim)
+    ref = ho.matvec(v)
+    plans = [ShardPlan(units=dd, unit_len=du, world=world, rank=r) for r in range(world)]
+    q, pcol = plans[0].q, -(-du // world)
+    pw = pcol + 2 * halo
+    n = world * q * pw
+    vin, tmp, send = [], [], []
+    for pl in plans:
+        x = torch.zeros(pl.chunk, dtype=torch.float64, device="cuda")
+        x[:pl.nloc] = torch.from_numpy(v[pl.row_first:pl.row_first + pl.nloc]).cuda()
+        sb = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        capi.check(L.edigpu_transpose_pack(du, pl.count, q, world, pcol, halo, x.data_ptr(), sb.data_ptr(), st))
+        t = torch.zeros(pl.chunk, dtype=torch.float64, device="cuda")
+        h.apply_rows_dev(pl.first, pl.count, x.data_ptr(), t.data_ptr(), st)
+        vin.append(x), tmp.append(t), send.append(sb.view(world, q * pw))
+    hvc = []
+    for c in range(world):
+        recv = torch.cat([send[r][c] for r in range(world)]).contiguous()
+        assert not torch.isnan(recv).any()
+        out = torch.zeros(n, dtype=torch.float64, device="cuda")
+        cf = min(c * pcol, du)
+        cc = max(0, min(pcol, du - cf))
+        h.apply_cols_dev(cf, cc, pw, halo, recv.data_ptr(), out.data_ptr(), st)
+        hvc.append(out.view(world, q * pw))
+    res = []
+    for r, pl in enumerate(plans):
+        back = torch.cat([hvc[c][r] for c in range(world)]).contiguous()
+        capi.check(L.edigpu_transpose_unpack_add(du, pl.count, q, world, pcol, halo, back.data_ptr(),
+                                                 tmp[r].data_ptr(), st))
+        res.append(tmp[r][:pl.nloc].cpu().numpy())
+    torch.cuda.synchronize()
+    assert rel_err(np.concatenate(res), ref) < TOL
+    h.destroy()
+
+
+def test_transposed_exchange_refusals(gpu):
+    """Hand-over images with explicit spH0nd and phonon sectors are refused (all-gather form instead)."""
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    O = _oracle()
+    om, pm = make_models("normal", "hybrid", 2, 2, seed=62)
+    ho = O.HNormal(om, 3, 3)
+    hh = SectorHamiltonian.normal_from_arrays(ho.dimup, ho.dimdw, ho.hd, ho.up, ho.dw, ho.nd)
+    with pytest.raises(RuntimeError, match="all-gather"):
+        hh.transpose_halo()
+    hh.destroy()
+    pm.nph, pm.w0_ph = 2, 0.5
+    hp = SectorHamiltonian.normal_from_model(pm, 3, 3)
+    with pytest.raises(RuntimeError, match="all-gather"):
+        hp.transpose_halo()
+    hp.destroy()
+
+
+def _transposed_rank(rank, world, port, q, exact):
+    import os
+    if exact:
+        os.environ["EDIGPU_LANCZOS_EXACTBETA"] = "1"
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from edipack_amd import capi
+        from edipack_amd.sharding import gpu_transposed_hamiltonian
+        from oracle import oracle as O
+        capi.init(0)
+        torch.cuda.set_device(0)
+        om, pm = make_models("normal", "hybrid", 3, 3, seed=64)      # Ns = 6: 20 x 15 states
+        ho = O.HNormal(om, 3, 4)
+        plan, h, lz = gpu_transposed_hamiltonian(pm, (3, 4), world, rank, stage_host=True)
+        v0 = np.random.default_rng(778).standard_normal(ho.dim)
+        a, b, n = lz.tridiag(torch.from_numpy(v0[plan.row_first:plan.row_first + plan.nloc].copy()).cuda(), 30)
+        a_ref, b_ref, _ = ho.lanc_tridiag(v0, 30)
+        err = max(np.max(np.abs(a[:12] - a_ref[:12])) / np.max(np.abs(a_ref)),
+                  np.max(np.abs(b[:12] - b_ref[:12])) / np.max(np.abs(b_ref)))
+        assert lz.fused == (not exact)
+        q.put((rank, float(err), int(lz.halo)))
+        h.destroy()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,exact", [(2, False), (3, False), (2, True)])
+def test_transposed_lanczos_ranks_share_one_gpu(gpu, world, exact):
+    """The N > 1 loop with the real kernels: the ranks share the GPU, the all-to-alls travel over gloo
+    through host memory (RCCL needs one GPU per rank); alpha / beta against the serial oracle.  Fused
+    recurrence (one all-reduce per step) and the exact two-reduction form."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_transposed_rank, args=(r, world, port, q, exact)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, halo in res:
+        assert halo > 0 and err < 1e-10, (rank, err)
+
+
+@pytest.mark.parametrize("world,du,nrows,q,halo", [(1, 10, 4, 4, 0), (2, 11, 3, 5, 2), (3, 20, 7, 7, 3),
+                                                   (5, 9, 2, 2, 1), (7, 10, 3, 3, 3), (4, 924, 231, 231, 2)])
+def test_transposed_fused_vector_kernels(gpu, world, du, nrows, q, halo):
+    """edigpu_transpose_rotate_pack == lazy axpy + rotate (torch) + edigpu_transpose_pack, also when a block is
+    narrower than the halo (a column then sits in more than two blocks); edigpu_transpose_unpack_add_dot2 ==
+    edigpu_transpose_unpack_add + torch dots."""
+    import torch
+    from edipack_amd import capi
+    L, st = capi.lib(), torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pcol = -(-du // world)
+    pw = pcol + 2 * halo
+    n, nb = nrows * du, world * q * pw
+    vin = torch.randn(q * du, dtype=torch.float64, device="cuda", generator=g)
+    vout = torch.randn(q * du, dtype=torch.float64, device="cuda", generator=g)
+    ab = torch.tensor([0.7, 0.7 * 0.7 + 2.25], dtype=torch.float64, device="cuda")     # alpha = 0.7, beta = 1.5
+    v_ref = (vout[:n] - 0.7 * vin[:n]) / 1.5
+    w_ref = -1.5 * vin[:n]
+    for first in (1, 0):
+        a, b = vin.clone(), vout.clone()
+        send = torch.zeros(nb, dtype=torch.float64, device="cuda")
+        capi.check(L.edigpu_transpose_rotate_pack(first, du, nrows, q, world, pcol, halo, a.data_ptr(), b.data_ptr(),
+                                                  ab.data_ptr(), send.data_ptr(), st))
+        x = vin.clone()
+        if not first:
+            x[:n] = v_ref
+            assert torch.allclose(b[:n], w_ref, rtol=1e-15, atol=0) and torch.allclose(a[:n], v_ref, rtol=1e-15, atol=1e-16)
+        else:
+            assert torch.equal(a, vin) and torch.equal(b, vout)
+        ref = torch.full((nb,), float("nan"), dtype=torch.float64, device="cuda")
+        capi.check(L.edigpu_transpose_pack(du, nrows, q, world, pcol, halo, (a if not first else x).data_ptr(),
+                                           ref.data_ptr(), st))
+        assert torch.equal(send, ref)
+    tmp = torch.randn(q * du, dtype=torch.float64, device="cuda", generator=g)
+    back = torch.randn(nb, dtype=torch.float64, device="cuda", generator=g)
+    work = torch.zeros(L.edigpu_vec_work_doubles(), dtype=torch.float64, device="cuda")
+    out2 = torch.zeros(2, dtype=torch.float64, device="cuda")
+    w = vout.clone()
+    capi.check(L.edigpu_transpose_unpack_add_dot2(du, nrows, q, world, pcol, halo, vin.data_ptr(), w.data_ptr(),
+                                                  tmp.data_ptr(), back.data_ptr(), out2.data_ptr(), work.data_ptr(), st))
+    t2 = tmp.clone()
+    capi.check(L.edigpu_transpose_unpack_add(du, nrows, q, world, pcol, halo, back.data_ptr(), t2.data_ptr(), st))
+    w_ref2 = vout[:n] + t2[:n]
+    torch.cuda.synchronize()
+    assert torch.allclose(w[:n], w_ref2, rtol=1e-14, atol=1e-15) and torch.equal(w[n:], vout[n:])
+    assert abs(float(out2[0]) - float(torch.dot(vin[:n], w_ref2))) < 1e-10 * max(1.0, n ** 0.5)
+    assert abs(float(out2[1]) - float(torch.dot(w_ref2, w_ref2))) < 1e-12 * float(torch.dot(w_ref2, w_ref2))
