@@ -147,7 +147,7 @@ def run_single(args):
                    "hv_only_ms": ms_hv_only, "lanczos_step_GBs": bytes_step / (ms_step * 1e-3) / 1e9},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profiles(w.name),
-                     "kernel": {0: "normal_rows_kernel + normal_dw_panel_kernel", 1: "sell_rows_packed_kernel (SELL-64 + value dictionary; csr_rows_kernel fallback)",
+                     "kernel": {0: "normal_rows_kernel + normal_dw_panel2_kernel (normal_dw_panel_kernel for odd DimUp / small sectors)", 1: "sell_rows_packed_kernel (SELL-64 + value dictionary; csr_rows_kernel fallback)",
                                 2: "direct_rows_kernel"}[h.kind],
                      "algorithmic_bytes_per_launch": bytes_hv, "ms_per_launch": ms_hv},
     }

@@ -17,8 +17,9 @@
 // the workgroups of a panel further apart.  Ablation of this kernel on config 2 (99 us under rocprofv3): no
 // result store 94, no result load 94, neither 82, no neighbour gathers 40, nothing but the list handling 18
 // -- i.e. ~60 us are the L2 gathers.  A variant with two columns per lane (16-byte gathers, a half-wave per
-// row, lists staged in LDS: half as many gather instructions) measured 1.8x SLOWER (175 us), so the gather
-// cost does not go with the instruction count either.
+// row, lists staged in LDS: half as many gather instructions) measured 1.8x SLOWER (175 us).  What does pay is
+// two columns per lane with a FULL wave per row (normal_dw_panel2_kernel below: 1024-byte segments, 16-byte
+// gathers, panels twice as wide): 95 -> 81 us.
 #include <cstdlib>
 
 #include "normal_args.hpp"
@@ -192,6 +193,128 @@ __global__ void __launch_bounds__(kPanelNT)
   }
 }
 
+// Two adjacent columns per lane (default for large sectors with an even DimUp; EDIGPU_PANEL_VEC2=0 switches it
+// off): a wave still owns one output row, now as a
+// 1024-byte segment of up to 128 columns, and the down-hop gathers are 16-byte loads -- the L2 serves 16-byte
+// accesses at ~1.5-1.8x the rate of 8-byte ones (MI355X_MICROARCH.md, scope/cache-policy table).  The panel is
+// twice as wide, i.e. twice the L2 footprint.  Needs an even DimUp (16-byte aligned rows).
+template <bool DO_ND, bool ALPHA>
+__global__ void __launch_bounds__(kPanelNT)
+    normal_dw_panel2_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full, double* __restrict__ hv) {
+  __shared__ double red[2 * (kPanelNT / 64)];
+  extern __shared__ uint32_t ju2[];  // [2 * nterms][kPanelNT]: partner columns of the lane's two columns
+  const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const int panel = (k / p.blocks_per_panel) * 8 + x;
+  if (ALPHA) {
+    if (panel >= p.npanels || a.scal[SC_STOP] != 0.0) {
+      if (threadIdx.x == 0) {
+        a.partial[blockIdx.x] = 0.0;
+        a.partial[gridDim.x + blockIdx.x] = 0.0;
+      }
+      return;
+    }
+  }
+  if (panel >= p.npanels) return;
+  double asum = 0.0, qsum = 0.0;
+  const int chunk = k % p.blocks_per_panel;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t DimUp = a.dim_up;
+  const int64_t c = (int64_t)panel * p.width + 2 * lane;  // even (width and DimUp are even)
+  const bool ok = 2 * lane < p.width && c < DimUp;
+  const int64_t cc = ok ? c : DimUp - 2;
+  int64_t rend = (int64_t)(chunk + 1) * p.rows_per_block;
+  if (rend > a.dw_count) rend = a.dw_count;
+  constexpr int NW = kPanelNT / 64;
+  if (DO_ND)
+    for (int t = 0; t < a.nterms; t++) {
+      ju2[(2 * t) * kPanelNT + threadIdx.x] = a.jup[(int64_t)t * DimUp + cc];
+      ju2[(2 * t + 1) * kPanelNT + threadIdx.x] = a.jup[(int64_t)t * DimUp + cc + 1];
+    }
+  auto row_sum = [&](int64_t r, double2 acc) -> double2 {
+    if (!DO_ND) {
+      const int64_t g = a.dw_first + r;
+      const int32_t b0 = a.dw_rowptr[g], e0 = a.dw_rowptr[g + 1];
+#pragma unroll 4
+      for (int32_t jj = b0; jj < e0; jj++) {
+        const double w = a.dw_val[jj];
+        const double2 y = *reinterpret_cast<const double2*>(&v_full[(int64_t)a.dw_col[jj] * DimUp + cc]);
+        acc.x += w * y.x;
+        acc.y += w * y.y;
+      }
+    } else {
+      const int32_t b0 = a.mx_rowptr[r], e0 = a.mx_rowptr[r + 1];
+#pragma unroll 2
+      for (int32_t jj = b0; jj < e0; jj++) {
+        const uint32_t cw = (uint32_t)a.mx_col[jj];
+        const int tag = (int)(cw >> 24);  // wave-uniform
+        const double w = a.mx_val[jj];
+        const int64_t base = (int64_t)(cw & 0xFFFFFFu) * DimUp;
+        if (tag == 0) {
+          const double2 y = *reinterpret_cast<const double2*>(&v_full[base + cc]);
+          acc.x += w * y.x;
+          acc.y += w * y.y;
+        } else {
+          const uint32_t j0 = ju2[(2 * (tag - 1)) * kPanelNT + threadIdx.x];
+          const uint32_t j1 = ju2[(2 * (tag - 1) + 1) * kPanelNT + threadIdx.x];
+          const bool v0 = j0 != 0xFFFFFFFFu, v1 = j1 != 0xFFFFFFFFu;
+          const double w0 = v0 ? ((j0 >> 31) ? -w : w) : 0.0, w1 = v1 ? ((j1 >> 31) ? -w : w) : 0.0;
+          acc.x += w0 * v_full[base + (v0 ? (int64_t)(j0 & 0x7FFFFFFFu) : cc)];
+          acc.y += w1 * v_full[base + (v1 ? (int64_t)(j1 & 0x7FFFFFFFu) : cc)];
+        }
+      }
+    }
+    return acc;
+  };
+  for (int64_t r = (int64_t)chunk * p.rows_per_block + wave; r < rend; r += 2 * NW) {
+    const int64_t r2 = r + NW;
+    const bool two = r2 < rend;
+    double2 acc0 = *reinterpret_cast<const double2*>(&hv[r * DimUp + cc]);
+    double2 acc1 = two ? *reinterpret_cast<const double2*>(&hv[r2 * DimUp + cc]) : make_double2(0.0, 0.0);
+    double2 own0 = make_double2(0.0, 0.0), own1 = own0;
+    if (ALPHA) {
+      own0 = *reinterpret_cast<const double2*>(&v_full[(a.dw_first + r) * DimUp + cc]);
+      if (two) own1 = *reinterpret_cast<const double2*>(&v_full[(a.dw_first + r2) * DimUp + cc]);
+    }
+    acc0 = row_sum(r, acc0);
+    if (two) acc1 = row_sum(r2, acc1);
+    if (ok) {
+      *reinterpret_cast<double2*>(&hv[r * DimUp + c]) = acc0;
+      if (two) *reinterpret_cast<double2*>(&hv[r2 * DimUp + c]) = acc1;
+      if (ALPHA) {
+        asum += own0.x * acc0.x + own0.y * acc0.y;
+        qsum += acc0.x * acc0.x + acc0.y * acc0.y;
+        if (two) {
+          asum += own1.x * acc1.x + own1.y * acc1.y;
+          qsum += acc1.x * acc1.x + acc1.y * acc1.y;
+        }
+      }
+    }
+  }
+  if (ALPHA) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      asum += __shfl_down(asum, off, 64);
+      qsum += __shfl_down(qsum, off, 64);
+    }
+    if (lane == 0) {
+      red[wave] = asum;
+      red[kPanelNT / 64 + wave] = qsum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0, q = 0.0;
+#pragma unroll
+      for (int i = 0; i < kPanelNT / 64; i++) {
+        t += red[i];
+        q += red[kPanelNT / 64 + i];
+      }
+      a.partial[blockIdx.x] = t;
+      a.partial[gridDim.x + blockIdx.x] = q;
+    }
+  }
+}
+
 static int panel_resident_blocks() {
   // EDIGPU_PANEL_BPP: workgroups per panel (tuning knob); default = what one XCD keeps resident
   static int v = -1;
@@ -256,13 +379,32 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
     set_error("launch_dw_panels: too many factored Hnd terms");
     return 1;
   }
+  static const bool vec2_env = !getenv("EDIGPU_PANEL_VEC2") || atoi(getenv("EDIGPU_PANEL_VEC2")) != 0;
+  // measured: config 2 H*v 0.145 -> 0.132 ms, Ns=16 ladder 5.07 -> 4.87 ms; cache-resident sectors (cfg3, 213 k rows)
+  // are 13 % SLOWER with the wider panels (fewer, fatter waves), hence the size gate
+  const bool vec2 = vec2_env && do_dw && (a.dim_up % 2) == 0 && a.dim_up * a.dw_count >= ((int64_t)1 << 21) &&
+                    (((uintptr_t)v_full | (uintptr_t)hv) & 15) == 0;
   PanelArgs p;
-  plan_panels(p, a.dim_up);
+  if (vec2) {
+    int wmax = 128;
+    if (const char* e = getenv("EDIGPU_PANEL_W")) {
+      wmax = atoi(e) & ~1;
+      if (wmax < 2 || wmax > 128) wmax = 128;
+    }
+    int np = (int)((a.dim_up + 8 * wmax - 1) / (8 * wmax)) * 8;
+    if (np < 8) np = 8;
+    p.width = (int)((a.dim_up + np - 1) / np);
+    p.width += p.width & 1;
+    p.npanels = (int)((a.dim_up + p.width - 1) / p.width);
+  } else {
+    plan_panels(p, a.dim_up);
+  }
   p.col_first = 0;
   p.ncol = a.dim_up;
   p.stride = a.dim_up;
   p.halo = 0;
   int bpp = panel_resident_blocks();
+  if (vec2 && !getenv("EDIGPU_PANEL_BPP")) bpp = 256;  // half as many panels: twice the workgroups on each (measured)
   p.rows_per_block = (int)((a.dw_count + bpp - 1) / bpp);
   if (p.rows_per_block < 16) p.rows_per_block = 16;
   bpp = (int)((a.dw_count + p.rows_per_block - 1) / p.rows_per_block);
@@ -270,6 +412,27 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
   const int panel_groups = (p.npanels + 7) / 8;
   const dim3 grid((unsigned)((int64_t)panel_groups * bpp * 8)), block(kPanelNT);
   if (nblocks) *nblocks = (int)grid.x;
+  if (vec2) {
+    const size_t lds = do_nd ? (size_t)2 * a.nterms * kPanelNT * sizeof(uint32_t) : 0;
+#define EDIGPU_LAUNCH_P2(ND, AL)                                                                               \
+  do {                                                                                                         \
+    auto kern = normal_dw_panel2_kernel<ND, AL>;                                                               \
+    if (lds > 48 * 1024)                                                                                       \
+      EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a, p, v_full, hv);                                          \
+  } while (0)
+    if (do_nd && alpha)
+      EDIGPU_LAUNCH_P2(true, true);
+    else if (do_nd)
+      EDIGPU_LAUNCH_P2(true, false);
+    else if (alpha)
+      EDIGPU_LAUNCH_P2(false, true);
+    else
+      EDIGPU_LAUNCH_P2(false, false);
+#undef EDIGPU_LAUNCH_P2
+    EDIGPU_HIP(hipGetLastError());
+    return 0;
+  }
   if (alpha) {
     if (do_nd)
       hipLaunchKernelGGL((normal_dw_panel_kernel<true, true, true>), grid, block, 0, st, a, p, v_full, hv);

@@ -23,7 +23,7 @@ def main():
     for f in glob.glob(os.path.join(out, "pmc_*", "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
-            key = ("panel" if "panel" in kn else "rows" if "normal_rows" in kn else
+            key = ("panel2" if "panel2" in kn else "panel" if "panel" in kn else "rows" if "normal_rows" in kn else
                    "csr" if ("csr_rows" in kn or "sell_rows" in kn) else "direct" if "direct_rows" in kn else None)
             if key:
                 agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -35,8 +35,13 @@ def main():
             lines.append(f"{k:6s} {c:24s} {v:.6g}")
     # HBM-side traffic per H*v = sum over the H*v kernels of (FETCH_SIZE + WRITE_SIZE) KiB
     # gfx950: FETCH_SIZE reports 1/2 of the bytes of 16-byte-per-lane coalesced streams (MI355X_MICROARCH.md,
-    # HBM section): the row kernel stages V with double2 loads -> doubled; the panel kernel and the CSR kernel
-    # load 8 bytes per lane (their TCC_EA0_RDREQ*64 B agrees with FETCH_SIZE) -> taken as is.
+    # HBM section): the row kernel stages V as one contiguous double2 stream -> doubled (98 MB = V once, as it must
+    # be).  The panel kernels read 512..1024-byte row segments at a row stride: taken as is -- measured on config 2,
+    # the two-column kernel (16 B per lane) at the one-column kernel's panel width reports the same FETCH_SIZE,
+    # TCC_REQ and TCC_MISS as the one-column kernel (8 B per lane), and FETCH_SIZE does not move between 512- and
+    # 1024-byte segments (165.6 / 162.3 / 161.7 thousand KiB at widths 64 / 112 / 128), so no halving shows for this
+    # access shape; the value also sits at the physical minimum V + result minus what kernel A left in the L2s.
+    # The CSR / SELL kernels load 8 bytes per lane -> taken as is.
     tr = 0.0
     for k, d in pmc.items():
         f = d.get("FETCH_SIZE", 0.0) * (2.0 if k == "rows" else 1.0)
