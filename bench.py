@@ -164,7 +164,16 @@ def run_multi(args):
     from edipack_amd.sharding import gpu_sharded_hamiltonian, gpu_transposed_hamiltonian
     from edipack_amd.synthetic import WORKLOADS, synthetic_model
 
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    # RCCL prints a version banner on stdout when the communicator comes up: keep the real stdout for the one
+    # JSON line and send everything else (from any library, any rank) to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", str(rank))
+    os.environ.setdefault("WORLD_SIZE", str(world))
     local = int(os.environ.get("LOCAL_RANK", rank))
     # one rank per GPU; EDIGPU_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the
     # N>1 data flow on a single-GPU box; the timed configuration is always nccl = RCCL over xGMI)
@@ -246,7 +255,7 @@ def run_multi(args):
                          "note": "whole-job: sum of shard algorithmic bytes / slowest rank's H*v time "
                                  "(exchange included)", "ms_per_launch": ms_hv_max},
         }
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     h.destroy()
     dist.destroy_process_group()
 
@@ -260,7 +269,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
-    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # EDIGPU_FORCE_MULTI=1: take the N > 1 code path with a single rank (RCCL world of one; with
+    # EDIGPU_FORCE_COLLECTIVES=1 the collectives are issued too) -- a one-GPU rehearsal of the nccl calls
+    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("EDIGPU_FORCE_MULTI"):
         run_multi(args)
     else:
         run_single(args)

@@ -159,15 +159,20 @@ class ShardedLanczos:
         self.vfull = torch.zeros(n * plan.world, dtype=dtype, device=device) if gathered else None
 
     # -- collectives --------------------------------------------------------------------------
+    def _collectives(self) -> bool:
+        # a single rank needs no exchange; EDIGPU_FORCE_COLLECTIVES=1 issues them anyway (exercises the RCCL calls
+        # of the N > 1 path on a one-GPU box)
+        return self.plan.world > 1 or bool(os.environ.get("EDIGPU_FORCE_COLLECTIVES"))
+
     def _allreduce(self, t: torch.Tensor) -> torch.Tensor:
-        if self.plan.world > 1:
+        if self._collectives():
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def hv(self) -> None:
         """tmp <- (H vin) restricted to the local rows, exchange overlapped with the local part."""
         work = None
-        if self.plan.world > 1:
+        if self._collectives():
             # complex vectors travel as (re,im) pairs: every backend handles real tensors
             src = torch.view_as_real(self.vin) if self.vin.is_complex() else self.vin
             dst = torch.view_as_real(self.vfull) if self.vfull.is_complex() else self.vfull
@@ -310,7 +315,7 @@ class TransposedLanczos(ShardedLanczos):
         return 2 * 8 * (self.plan.world - 1) * self.plan.q * self.pw
 
     def _a2a(self, dst, src, async_op=False):
-        if self.plan.world == 1:
+        if not self._collectives():
             dst.copy_(src)
             return None
         if self.stage_host:

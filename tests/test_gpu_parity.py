@@ -1326,3 +1326,25 @@ def test_transposed_fused_vector_kernels(gpu, world, du, nrows, q, halo):
     assert torch.allclose(w[:n], w_ref2, rtol=1e-14, atol=1e-15) and torch.equal(w[n:], vout[n:])
     assert abs(float(out2[0]) - float(torch.dot(vin[:n], w_ref2))) < 1e-10 * max(1.0, n ** 0.5)
     assert abs(float(out2[1]) - float(torch.dot(w_ref2, w_ref2))) < 1e-12 * float(torch.dot(w_ref2, w_ref2))
+
+
+@pytest.mark.parametrize("workload,exchange", [("cfg3", "transpose"), ("cfg3", "allgather"), ("cfg4", "allgather")])
+def test_bench_multi_path_one_rank_rccl(gpu, workload, exchange):
+    """bench.py's N > 1 code path as a child process with an RCCL world of one rank and the collectives forced
+    (all_to_all_single / all_gather_into_tensor / all_reduce / barrier really go through RCCL): exactly one line on
+    stdout, and it is the JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EDIGPU_FORCE_MULTI="1", EDIGPU_FORCE_COLLECTIVES="1", EDIGPU_EXCHANGE=exchange,
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--steps", "20",
+                        "--warmup", "3"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
+    assert ("transposed" in d["config"]["parallelism"]) == (exchange == "transpose")
