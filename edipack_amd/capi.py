@@ -67,6 +67,7 @@ SIGNATURES = {
     "edigpu_csr_create_d": (C.c_int, [C.POINTER(_vp), _i64, _i64, _i64, _pi64, _pi32, _pd]),
     "edigpu_csr_create_z": (C.c_int, [C.POINTER(_vp), _i64, _i64, _i64, _pi64, _pi32, _pd]),
     "edigpu_normal_build": (C.c_int, [C.POINTER(_vp), C.POINTER(EdigpuModel), C.c_int, C.c_int, _i64, _i64]),
+    "edigpu_normal_build_z": (C.c_int, [C.POINTER(_vp), C.POINTER(EdigpuModel), C.c_int, C.c_int]),
     "edigpu_flat_build": (C.c_int, [C.POINTER(_vp), C.POINTER(EdigpuModel), C.c_int, _i64, _i64]),
     "edigpu_direct_build": (C.c_int, [C.POINTER(_vp), C.POINTER(EdigpuModel), C.c_int, _i64, _i64]),
     "edigpu_sector_dim": (C.c_int, [C.POINTER(EdigpuModel), C.c_int, C.c_int, _pi64]),

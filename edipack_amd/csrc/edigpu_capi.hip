@@ -633,6 +633,19 @@ static int ensure_workspace(edigpu_sector* s) {
 
 static int apply_any(edigpu_sector* s, const double* v_local, const double* v_full, double* hv,
                      int phase, hipStream_t st) {
+  if (s->kind == 4) {
+    // _CMPLX_NORMAL: (S + iA)(xr + i xi) = (S xr - A xi) + i (S xi + A xr) on planar work vectors
+    if (phase != 3) {
+      set_error("complex normal-mode sectors are single-shard: use the fused product");
+      return 1;
+    }
+    const int64_t n = s->dim;
+    double *xr = s->d_cz, *xi = xr + n, *yr = xi + n, *yi = yr + n, *t1 = yi + n, *t2 = t1 + n;
+    if (launch_deinterleave(n, v_full, xr, xi, st)) return 1;
+    if (apply_any(s->sub_s, xr, xr, yr, 3, st) || apply_any(s->sub_s, xi, xi, yi, 3, st)) return 1;
+    if (s->sub_a && (apply_any(s->sub_a, xi, xi, t1, 3, st) || apply_any(s->sub_a, xr, xr, t2, 3, st))) return 1;
+    return launch_combine_interleave(n, yr, yi, s->sub_a ? t1 : nullptr, s->sub_a ? t2 : nullptr, hv, st);
+  }
   if (s->kind == 0 && s->nph > 0) {
     // phonon branches: the electronic product on every phonon block, then the phonon / electron-phonon pass
     if (phase != 3) {
@@ -997,6 +1010,54 @@ int edigpu_normal_build(edigpu_handle* h, const edigpu_model* model, int nup, in
   return 0;
 }
 
+int edigpu_normal_build_z(edigpu_handle* h, const edigpu_model* model, int nup, int ndw) {
+  if (!h || !model) {
+    set_error("edigpu_normal_build_z: NULL argument");
+    return 1;
+  }
+  *h = nullptr;
+  if (model->ed_mode != 0) {
+    set_error("edigpu_normal_build_z: ed_mode must be normal");
+    return 1;
+  }
+  if (model->nph > 0) {
+    set_error("edigpu_normal_build_z: phonons are not supported with complex algebra");
+    return 1;
+  }
+  edigpu_handle hs = nullptr, ha = nullptr;
+  if (edigpu_normal_build(&hs, model, nup, ndw, 0, -1)) return 1;
+  bool any = false;
+  const edigpu_model mi = imag_part_model(*model, any);
+  if (any && edigpu_normal_build(&ha, &mi, nup, ndw, 0, -1)) {
+    edigpu_destroy(hs);
+    return 1;
+  }
+  std::unique_ptr<edigpu_sector> s(new edigpu_sector());
+  s->kind = 4;
+  s->is_complex = 1;
+  s->device = g_device;
+  s->dim = s->nloc = hs->dim;
+  s->dim_up = hs->dim_up;
+  s->dim_dw = hs->dim_dw;
+  s->model = *model;
+  s->sec_a = nup;
+  s->sec_b = ndw;
+  s->built_by_library = true;
+  s->sub_s = hs;
+  s->sub_a = ha;
+  if (hipMalloc((void**)&s->d_cz, (size_t)6 * (size_t)std::max<int64_t>(s->dim, 1) * sizeof(double)) != hipSuccess) {
+    set_error("edigpu_normal_build_z: out of device memory");
+    edigpu_destroy(s.release());
+    return 1;
+  }
+  if (finish_handle(s.get())) {
+    edigpu_destroy(s.release());
+    return 1;
+  }
+  *h = s.release();
+  return 0;
+}
+
 // phonon branches for a library-built superc / nonsu2 handle holding a whole sector: g_el per row from the map
 static int attach_phonons_flat(edigpu_sector* s, const edigpu_model& m, const std::vector<int32_t>& states, int ns) {
   if (m.nph <= 0) return 0;
@@ -1270,6 +1331,9 @@ int edigpu_info(edigpu_handle s, int64_t info[10]) {
   if (s->kind == 0) {
     info[7] = s->h_up.nnz() + s->h_dw.nnz();
     info[8] = s->nd_nnz;
+  } else if (s->kind == 4) {
+    info[7] = s->sub_s->h_up.nnz() + s->sub_s->h_dw.nnz();  // pattern of Hup / Hdw (A shares it or is a subset)
+    info[8] = s->sub_s->nd_nnz;
   } else if (s->kind == 2) {
     info[7] = s->dir_nterms;
     info[8] = 0;
@@ -1293,7 +1357,14 @@ int edigpu_algorithmic_bytes(edigpu_handle s, double* bytes_hv, double* bytes_st
   // reference storage format, every array read once, v read once, Hv written once
   double b = 0.0;
   const double sz = s->is_complex ? 16.0 : 8.0;
-  if (s->kind == 0) {
+  if (s->kind == 4) {
+    // the reference's complex(8) normal-mode arrays: same pattern as the real build, 16-byte values and vectors
+    const edigpu_sector* r = s->sub_s;
+    const double n = (double)s->nloc;
+    b = 3.0 * sz * n;
+    if (r->has_nd) b += (sz + 4.0) * (double)r->nd_nnz + 4.0 * (n + 1.0);
+    b += (sz + 4.0) * (double)(r->h_up.nnz() + r->h_dw.nnz()) + 4.0 * (double)(r->dim_up + r->dim_dw + 2);
+  } else if (s->kind == 0) {
     const double n = (double)s->nloc;
     b = 3.0 * sz * n;
     if (s->has_nd) b += (sz + 4.0) * (double)s->nd_nnz + 4.0 * (n + 1.0);
@@ -2149,6 +2220,9 @@ int edigpu_destroy(edigpu_handle s) {
     (void)hipStreamSynchronize(s->stream);
     (void)hipStreamDestroy(s->stream);
   }
+  if (s->sub_s) edigpu_destroy(s->sub_s);
+  if (s->sub_a) edigpu_destroy(s->sub_a);
+  dev_free(s->d_cz);
   dev_free(s->d_hd);
   dev_free(s->d_gu);
   dev_free(s->d_gd);

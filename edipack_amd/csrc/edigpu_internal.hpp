@@ -105,6 +105,10 @@ struct edigpu_sector {
   uint8_t* d_impd = nullptr;    // dim_dw
   double* d_ndcoef = nullptr;   // nterms
   uint32_t* d_jup = nullptr;    // nterms * dim_up
+  // kind 4 (_CMPLX_NORMAL): H = S + iA as two real normal-mode handles + planar work vectors (6 * dim doubles)
+  edigpu_sector* sub_s = nullptr;
+  edigpu_sector* sub_a = nullptr;
+  double* d_cz = nullptr;
   int col_halo = 0;             // max |partner column - column| over the factored Hnd terms (transposed exchange)
   uint32_t* d_jdw = nullptr;    // nterms * dim_dw
   int32_t* d_mx_rowptr = nullptr;  // per local row: Hdw entries + applicable Hnd terms

@@ -147,7 +147,7 @@ OneBody one_body_normal(const edigpu_model& m, int spin) {
           if (a == b)
             ob.eps[ix.bath_pos(a, k)] += h;
           else
-            ob.a[ix.bath_pos(b, k) * ns + ix.bath_pos(a, k)] += h;  // c^+_{a,k} c_{b,k}
+            ob.a[ix.bath_pos(a, k) * ns + ix.bath_pos(b, k)] += h;  // c^+_{a,k} c_{b,k}
         }
     return ob;
   }
@@ -192,6 +192,46 @@ void hop_csr(const OneBody& ob, const CombBasis& b, HostCsr& out) {
 }
 
 }  // namespace
+
+// _CMPLX_NORMAL: H = S + iA with S built from the real parts (the ordinary real-valued build) and A, real and
+// antisymmetric, from the imaginary parts of the one-body hops (impHloc off-diagonal, replica / general bath
+// matrices).  Returns the model whose ordinary build gives the hop matrices of A (everything else zero);
+// any = false when all imaginary parts vanish.
+edigpu_model imag_part_model(const edigpu_model& m, bool& any) {
+  edigpu_model r = m;
+  any = false;
+  r.hfmode = 0;
+  r.xmu = 0.0;
+  r.nph = 0;
+  std::fill(std::begin(r.uloc), std::end(r.uloc), 0.0);
+  std::fill(std::begin(r.ust), std::end(r.ust), 0.0);
+  std::fill(std::begin(r.jh), std::end(r.jh), 0.0);
+  std::fill(std::begin(r.jx), std::end(r.jx), 0.0);
+  std::fill(std::begin(r.jp), std::end(r.jp), 0.0);
+  std::fill(std::begin(r.be), std::end(r.be), 0.0);
+  std::fill(std::begin(r.bv), std::end(r.bv), 0.0);
+  std::fill(std::begin(r.g_ph), std::end(r.g_ph), 0.0);
+  // (re, im) -> (im, 0) off the orbital diagonal, 0 on it (a Hermitian matrix has a real diagonal)
+  const size_t nh = sizeof(r.hloc) / sizeof(double) / 2;
+  for (size_t i = 0; i < nh; i++) {
+    const size_t ab = i % ((size_t)EDIGPU_MAXORB * EDIGPU_MAXORB);
+    const bool diag = ab / EDIGPU_MAXORB == ab % EDIGPU_MAXORB;
+    const double im = diag ? 0.0 : m.hloc[2 * i + 1];
+    r.hloc[2 * i] = im;
+    r.hloc[2 * i + 1] = 0.0;
+    any = any || im != 0.0;
+  }
+  const size_t nb = sizeof(r.hb) / sizeof(double) / 2;
+  for (size_t i = 0; i < nb; i++) {
+    const size_t ab = (i / EDIGPU_MAXBATH) % ((size_t)EDIGPU_MAXORB * EDIGPU_MAXORB);
+    const bool diag = ab / EDIGPU_MAXORB == ab % EDIGPU_MAXORB;
+    const double im = (diag || !(m.bath_type == 2 || m.bath_type == 3)) ? 0.0 : m.hb[2 * i + 1];
+    r.hb[2 * i] = im;
+    r.hb[2 * i + 1] = 0.0;
+    any = any || im != 0.0;
+  }
+  return r;
+}
 
 std::string sector_dim(const edigpu_model& m, int q1, int q2, int64_t& dim) {
   std::string e = check_model(m);

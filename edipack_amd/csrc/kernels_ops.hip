@@ -85,6 +85,50 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- _CMPLX_NORMAL (complex algebra in normal mode): planar work vectors around four real products ----
+__global__ void __launch_bounds__(256)
+    deinterleave_kernel(int64_t n, const double2* __restrict__ z, double* __restrict__ re, double* __restrict__ im) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double2 x = z[i];
+    re[i] = x.x;
+    im[i] = x.y;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    combine_interleave_kernel(int64_t n, const double* __restrict__ yr, const double* __restrict__ yi,
+                              const double* __restrict__ t1, const double* __restrict__ t2, double2* __restrict__ z) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    double a = yr[i], b = yi[i];
+    if (t1) {
+      a -= t1[i];
+      b += t2[i];
+    }
+    z[i] = make_double2(a, b);
+  }
+}
+
+int launch_deinterleave(int64_t n, const double* z, double* re, double* im, hipStream_t st) {
+  if (n <= 0) return 0;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 256 * 32) nb = 256 * 32;
+  hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)nb), dim3(256), 0, st, n,
+                     reinterpret_cast<const double2*>(z), re, im);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_combine_interleave(int64_t n, const double* yr, const double* yi, const double* t1, const double* t2,
+                              double* z, hipStream_t st) {
+  if (n <= 0) return 0;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 256 * 32) nb = 256 * 32;
+  hipLaunchKernelGGL(combine_interleave_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, yr, yi, t1, t2,
+                     reinterpret_cast<double2*>(z));
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---- transposed exchange (reference vector_transpose_MPI, ED_NORMAL/ED_HAMILTONIAN_NORMAL_COMMON.f90:66-167) ----
 // A rank owns q down rows of V[idw][iup] (row shard).  For the down half of the product every rank needs ALL rows of
 // a block of pcol up columns (+ halo columns on both sides for Hnd): block (r -> c) = rows of rank r, columns

@@ -150,6 +150,15 @@ class SectorHamiltonian:
         return cls(h)
 
     @classmethod
+    def normal_cmplx_from_model(cls, model: ImpurityModel, nup: int, ndw: int) -> "SectorHamiltonian":
+        """ed_mode=normal with complex algebra (the reference's -D_CMPLX_NORMAL build): complex impHloc / replica
+        bath matrices, complex vectors."""
+        h = C.c_void_p()
+        cm = model.to_c()
+        capi.check(capi.lib().edigpu_normal_build_z(C.byref(h), C.byref(cm), nup, ndw), "edigpu_normal_build_z")
+        return cls(h)
+
+    @classmethod
     def flat_from_model(cls, model: ImpurityModel, sector: int, row_first: int = 0,
                         row_count: int = -1) -> "SectorHamiltonian":
         h = C.c_void_p()

@@ -79,6 +79,13 @@ module EDIGPU_SHIM
        integer(c_int64_t), value :: dw_first, dw_count
        integer(c_int) :: ierr
      end function edigpu_normal_build
+     function edigpu_normal_build_z(h, model, nup, ndw) bind(C, name="edigpu_normal_build_z") result(ierr)
+       import :: c_ptr, c_int, edigpu_model_t
+       type(c_ptr) :: h
+       type(edigpu_model_t), intent(in) :: model
+       integer(c_int), value :: nup, ndw
+       integer(c_int) :: ierr
+     end function edigpu_normal_build_z
      function edigpu_flat_build(h, model, sector, row_first, row_count) &
           bind(C, name="edigpu_flat_build") result(ierr)
        import :: c_ptr, c_int, c_int64_t, edigpu_model_t
@@ -161,7 +168,7 @@ module EDIGPU_SHIM
   public :: gpu_init, gpu_delete_sector
   public :: gpu_set_normal, gpu_set_csr_d, gpu_set_csr_c
   public :: gpu_model_set_kanamori, gpu_model_set_hloc, gpu_model_set_bath
-  public :: gpu_build_normal, gpu_build_flat, gpu_build_orbs
+  public :: gpu_build_normal, gpu_build_normal_cmplx, gpu_build_flat, gpu_build_orbs
   public :: spMatVec_gpu_d, spMatVec_gpu_c
   public :: gpu_lanc_tridiag_d, gpu_lanc_tridiag_c
   public :: flatten_rows_count
@@ -298,6 +305,15 @@ contains
     call gpu_check(edigpu_normal_build(gpu_sector, m, int(nup, c_int), int(ndw, c_int), &
          int(dw_first, c_int64_t), int(dw_count, c_int64_t)), "gpu_build_normal")
   end subroutine gpu_build_normal
+
+  !> build_Hv_sector_normal in a -D_CMPLX_NORMAL build: complex impHloc / bath matrices, complex vectors
+  !> (use the complex spMatVec / tridiag wrappers afterwards)
+  subroutine gpu_build_normal_cmplx(m, nup, ndw)
+    type(edigpu_model_t), intent(in) :: m
+    integer, intent(in) :: nup, ndw
+    if (c_associated(gpu_sector)) stop "gpu_build_normal_cmplx: a sector is already allocated"
+    call gpu_check(edigpu_normal_build_z(gpu_sector, m, int(nup, c_int), int(ndw, c_int)), "gpu_build_normal_cmplx")
+  end subroutine gpu_build_normal_cmplx
 
   !> build_Hv_sector_superc / _nonsu2: sector = Sz / Ntot; direct=.true. selects ed_sparse_H=F
   subroutine gpu_build_flat(m, sector, row_first, row_count, direct)

@@ -146,6 +146,14 @@ typedef struct edigpu_model {
  * (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:31-206). */
 int edigpu_normal_build(edigpu_handle *h, const edigpu_model *model, int nup, int ndw,
                         int64_t dw_first, int64_t dw_count);
+/* The same sector with complex algebra: the reference's -D_CMPLX_NORMAL build (CMakeLists.txt:43-48), where
+ * spH0ups / spH0dws and the vectors of ed_mode=normal are complex(8) and the imaginary parts of impHloc(1,1,a,b)
+ * and of the replica / general bath matrices enter the hops (ED_NORMAL/stored/H_up.f90:8-50, H_dw.f90).  The handle
+ * is complex (edigpu_apply_z, interleaved re/im vectors, real alpha / beta) and holds the whole sector.  Inside,
+ * H = S + iA runs as four products of the real-valued kernels on planar work vectors (S: the real parts = the
+ * ordinary build; A: the antisymmetric hop matrices of the imaginary parts) -- about 4.5x the cost of a real
+ * product; a native complex kernel is not built for this compile-time variant.  No phonons. */
+int edigpu_normal_build_z(edigpu_handle *h, const edigpu_model *model, int nup, int ndw);
 /* superc sector Sz / nonsu2 sector Ntot; the shard owns rows [row_first, row_first+row_count)
  * (row_count < 0: all).  Equivalent to build_Hv_sector_superc / _nonsu2
  * (ED_SUPERC/ED_HAMILTONIAN_SUPERC.f90:33-135, ED_NONSU2/ED_HAMILTONIAN_NONSU2.f90:31-128). */

@@ -427,6 +427,81 @@ class HOrbs:
             pass
 
 
+class HNormalCmplx:
+    """Normal mode with complex algebra (the reference's -D_CMPLX_NORMAL build: the same builder and product with
+    complex(8) spH0ups / spH0dws and vectors; ED_NORMAL/stored/H_up.f90:8-22,26-50 insert impHloc(1,1,iorb,jorb) and
+    hbath_tmp(1,1,iorb,jorb,kp) as they are).  The builder is linear in the hop amplitudes, so H = S + iA with S the
+    restated real build of the real parts and A = 1 (x) A_up + A_dw (x) 1 the same build applied to the imaginary
+    parts of the off-diagonal one-body terms (everything else zero).  PARITY UNPINNED against fixtures (the
+    reference ships none for this build); cross-checked against the fixture-pinned nonsu2 restatement in
+    tests/test_oracle_golden.py."""
+
+    def __init__(self, model: Model, nup: int, ndw: int):
+        import copy
+        self.model = model
+        self.S = HNormal(model, nup, ndw)
+        mi = copy.deepcopy(model)
+        hl = np.asarray(model.hloc)
+        im = np.zeros_like(hl)
+        for a in range(model.norb):
+            for b in range(model.norb):
+                if a != b:
+                    im[:, :, a, b] = hl[:, :, a, b].imag
+        mi.hloc = im
+        mi.hfmode, mi.xmu = False, 0.0
+        mi.uloc = tuple([0.0] * model.norb)
+        mi.ust = mi.jh = mi.jx = mi.jp = 0.0
+        for name in ("be", "bv", "vr", "vg"):
+            x = getattr(mi, name, None)
+            if x is not None:
+                setattr(mi, name, np.zeros_like(np.asarray(x)))
+        if getattr(model, "hb", None) is not None:
+            hb = np.asarray(model.hb)
+            hbi = np.zeros_like(hb)
+            for a in range(model.norb):
+                for b in range(model.norb):
+                    if a != b:
+                        hbi[:, :, a, b, :] = hb[:, :, a, b, :].imag
+            mi.hb = hbi
+        self.A = HNormal(mi, nup, ndw)
+        assert not self.A.has_nd and np.max(np.abs(self.A.hd)) == 0.0
+        self.dim, self.dimup, self.dimdw = self.S.dim, self.S.dimup, self.S.dimdw
+
+    def matvec(self, v: np.ndarray) -> np.ndarray:
+        v = np.asarray(v, dtype=np.complex128)
+        re, im = np.ascontiguousarray(v.real), np.ascontiguousarray(v.imag)
+        return (self.S.matvec(re) - self.A.matvec(im)) + 1j * (self.S.matvec(im) + self.A.matvec(re))
+
+    def dense(self) -> np.ndarray:
+        return self.S.dense() + 1j * self.A.dense()
+
+    def lanc_tridiag(self, vin: np.ndarray, nitermax: int, threshold: float = 0.0):
+        """sp_lanc_tridiag on complex vectors (the recurrence of lanc_tridiag in edipack_oracle.c, w = 2)."""
+        v = np.array(vin, dtype=np.complex128)
+        a, b = np.zeros(nitermax), np.zeros(nitermax)
+        vout = np.zeros_like(v)
+        done, b_ = 0, 0.0
+        for it in range(1, nitermax + 1):
+            if it == 1:
+                nrm = np.sqrt(np.vdot(v, v).real)
+                if nrm == 0.0:
+                    break
+                v = v / nrm
+            else:
+                v, vout = vout / b_, -b_ * v
+            vout = vout + self.matvec(v)
+            a_ = np.vdot(v, vout).real
+            vout = vout - a_ * v
+            b_ = np.sqrt(np.vdot(vout, vout).real)
+            a[it - 1] = a_
+            done = it
+            if abs(b_) < threshold:
+                break
+            if it < nitermax:
+                b[it] = b_
+        return a, b, done
+
+
 class HFlat:
     """Oracle-built flat-CSR sector Hamiltonian (superc: sector=Sz, nonsu2: sector=Ntot)."""
 

@@ -1348,3 +1348,78 @@ def test_bench_multi_path_one_rank_rccl(gpu, workload, exchange):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "strong"
     assert ("transposed" in d["config"]["parallelism"]) == (exchange == "transpose")
+
+
+# --------------------------------------------------------------------------------------------
+# normal mode with complex algebra (the reference's -D_CMPLX_NORMAL build).  No reference fixture: the oracle
+# composite is cross-checked against the fixture-pinned nonsu2 restatement (tests/test_oracle_golden.py).
+# --------------------------------------------------------------------------------------------
+def _complexify(om, pm, seed):
+    """complex Hermitian impHloc (and replica bath matrices) on an oracle / product model pair"""
+    rng = np.random.default_rng(seed)
+    no = om.norb
+    t = rng.uniform(-0.4, 0.4, (no, no))
+    t = t - t.T                                   # antisymmetric imaginary part
+    for m in (om, pm):
+        hl = np.asarray(m.hloc, complex).copy()
+        hl[0, 0] = hl[0, 0] + 1j * t
+        if hl.shape[0] == 2:
+            hl[1, 1] = hl[1, 1] + 1j * t
+        m.hloc = hl
+    if getattr(om, "hb", None) is not None:
+        x = rng.uniform(-0.3, 0.3, (no, no, om.nbath))
+        x = x - x.transpose(1, 0, 2)
+        for m in (om, pm):
+            hb = np.asarray(m.hb, complex).copy()
+            hb[0, 0] = hb[0, 0] + 1j * x
+            m.hb = hb
+
+
+@pytest.mark.parametrize("bath,norb,nbath,sec", [
+    ("normal", 2, 2, (3, 2)),
+    ("hybrid", 3, 3, (3, 4)),      # Hnd (spin-exchange / pair-hopping) + complex impHloc
+    ("replica", 2, 2, (3, 3)),     # complex bath matrices
+    ("general", 2, 3, (4, 4)),
+])
+def test_cmplx_normal_matches_oracle(gpu, bath, norb, nbath, sec):
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("normal", bath, norb, nbath, seed=95)
+    _complexify(om, pm, 96)
+    ho = O.HNormalCmplx(om, *sec)
+    assert np.max(np.abs(ho.A.dense())) > 0.05
+    hg = SectorHamiltonian.normal_cmplx_from_model(pm, *sec)
+    assert hg.is_complex and hg.dim == ho.dim and hg.dim_up == ho.dimup
+    rng = np.random.default_rng(4)
+    v = rng.standard_normal(ho.dim) + 1j * rng.standard_normal(ho.dim)
+    assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
+    ao, bo, _ = ho.lanc_tridiag(v, 20)
+    ag, bg, _ = hg.lanczos_tridiag(v, 20)
+    assert rel_err(ag[:12], ao[:12]) < 1e-9 and rel_err(bg[:12], bo[:12]) < 1e-9
+    w = np.linalg.eigvalsh(ho.dense())
+    e_gpu, vec, _ = hg.lanczos_eigh(nitermax=min(300, ho.dim), tol=1e-13)
+    assert abs(e_gpu - w[0]) < 1e-9
+    assert np.linalg.norm(ho.matvec(vec) - e_gpu * vec) < 1e-6
+    ev, _, nconv, _ = hg.lanczos_eigh_multi(2, ncv=min(30, ho.dim), tol=1e-11, want_vectors=False)
+    assert nconv == 2 and np.max(np.abs(ev[:2] - w[:2])) < 1e-8
+    hg.destroy()
+
+
+def test_cmplx_normal_real_model_and_errors(gpu):
+    """A real model through the complex entry point equals the real build; phonons and the other modes are refused."""
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("normal", "hybrid", 2, 3, seed=97)
+    ho = O.HNormal(om, 3, 2)
+    hg = SectorHamiltonian.normal_cmplx_from_model(pm, 3, 2)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(ho.dim) + 1j * rng.standard_normal(ho.dim)
+    ref = ho.matvec(np.ascontiguousarray(v.real)) + 1j * ho.matvec(np.ascontiguousarray(v.imag))
+    assert rel_err(hg.apply(v), ref) < TOL
+    hg.destroy()
+    pm.nph, pm.w0_ph = 2, 0.5
+    with pytest.raises(RuntimeError, match="phonons"):
+        SectorHamiltonian.normal_cmplx_from_model(pm, 3, 2)
+    _, ps = make_models("superc", "normal", 2, 2, seed=97)
+    with pytest.raises(RuntimeError, match="ed_mode"):
+        SectorHamiltonian.normal_cmplx_from_model(ps, 0, 0)

@@ -255,3 +255,67 @@ def test_oracle_flat_phonon_limits():
     w_norm = np.sort(np.concatenate([np.linalg.eigvalsh(O.HNormal(on, nu, ntot - nu).dense())
                                      for nu in range(ntot + 1) if nu <= ns and ntot - nu <= ns]))
     assert w_flat.shape == w_norm.shape and np.max(np.abs(w_flat - w_norm)) < 1e-11
+
+
+def test_oracle_cmplx_normal_matches_nonsu2():
+    """Normal mode with complex algebra (-D_CMPLX_NORMAL; PARITY UNPINNED against fixtures): Hermiticity, and with
+    a complex Hermitian impHloc the nonsu2 N sector without spin mixing (fixture-pinned restatement, complex
+    natively) must reproduce the union of the complex normal-mode (nup, ndw) sectors -- this fixes the sign
+    convention of the imaginary parts.  With a real impHloc the complex build equals the real one."""
+    on, _ = make_models("normal", "normal", 2, 2, seed=7)
+    hc = O.HNormalCmplx(on, 3, 2)
+    assert np.max(np.abs(hc.A.dense())) == 0.0
+    t = np.array([[0.0, 0.3 - 0.45j], [0.3 + 0.45j, 0.0]])
+    on.hloc = np.asarray(on.hloc, complex).copy()
+    on.hloc[0, 0] += t
+    o2, _ = make_models("nonsu2", "normal", 2, 2, seed=7)
+    hl = np.zeros((2, 2, 2, 2), complex)
+    hl[0, 0] = hl[1, 1] = on.hloc[0, 0]
+    o2.hloc, o2.bu = hl, np.zeros_like(o2.bu)
+    o2.be, o2.bv = np.stack([on.be[0]] * 2), np.stack([on.bv[0]] * 2)
+    ntot, ns = 5, 6
+    w_flat = np.linalg.eigvalsh(O.HFlat(o2, ntot).dense())
+    parts = []
+    for nu in range(ntot + 1):
+        if nu <= ns and ntot - nu <= ns:
+            d = O.HNormalCmplx(on, nu, ntot - nu).dense()
+            assert np.max(np.abs(d - d.conj().T)) < 1e-14
+            parts.append(np.linalg.eigvalsh(d))
+    w_norm = np.sort(np.concatenate(parts))
+    assert w_flat.shape == w_norm.shape and np.max(np.abs(w_flat - w_norm)) < 1e-11
+    # the imaginary part matters: the real-part-only build has a different spectrum
+    w_real = np.sort(np.concatenate([np.linalg.eigvalsh(O.HNormal(on, nu, ntot - nu).dense())
+                                     for nu in range(ntot + 1) if nu <= ns and ntot - nu <= ns]))
+    assert np.max(np.abs(w_real - w_norm)) > 1e-3
+    h = O.HNormalCmplx(on, 3, 2)
+    x = np.random.default_rng(8).standard_normal(h.dim) + 1j * np.random.default_rng(9).standard_normal(h.dim)
+    assert rel_err(h.matvec(x), h.dense() @ x) < 1e-13
+    a, b, n = h.lanc_tridiag(x, 12)
+    w = np.linalg.eigvalsh(np.diag(a) + np.diag(b[1:], 1) + np.diag(b[1:], -1))
+    assert n == 12 and w[0] >= np.linalg.eigvalsh(h.dense())[0] - 1e-10
+
+
+def test_oracle_cmplx_normal_replica_matches_nonsu2():
+    """The same identity with complex replica bath matrices hbath_tmp(1,1,a,b,k) and a complex impHloc."""
+    on, _ = make_models("normal", "replica", 2, 2, seed=9)
+    o2, _ = make_models("nonsu2", "replica", 2, 2, seed=9)
+    hb = np.asarray(on.hb, complex).copy()
+    rng = np.random.default_rng(1)
+    for k in range(hb.shape[-1]):
+        x = rng.uniform(-0.3, 0.3)
+        hb[0, 0, 0, 1, k] += 1j * x
+        hb[0, 0, 1, 0, k] -= 1j * x
+    on.hb = hb
+    on.hloc = np.asarray(on.hloc, complex).copy()
+    on.hloc[0, 0, 0, 1] += 0.2j
+    on.hloc[0, 0, 1, 0] -= 0.2j
+    hb2 = np.zeros_like(np.asarray(o2.hb, complex))
+    hb2[0, 0] = hb2[1, 1] = hb[0, 0]
+    hl = np.zeros((2, 2, 2, 2), complex)
+    hl[0, 0] = hl[1, 1] = on.hloc[0, 0]
+    o2.hb, o2.hloc, o2.vr = hb2, hl, on.vr.copy()
+    ntot, ns = 5, 6
+    w_flat = np.linalg.eigvalsh(O.HFlat(o2, ntot).dense())
+    w_norm = np.sort(np.concatenate([np.linalg.eigvalsh(O.HNormalCmplx(on, nu, ntot - nu).dense())
+                                     for nu in range(ntot + 1) if nu <= ns and ntot - nu <= ns]))
+    assert w_flat.shape == w_norm.shape and np.max(np.abs(w_flat - w_norm)) < 1e-11
