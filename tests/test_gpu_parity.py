@@ -1423,3 +1423,40 @@ def test_cmplx_normal_real_model_and_errors(gpu):
     _, ps = make_models("superc", "normal", 2, 2, seed=97)
     with pytest.raises(RuntimeError, match="ed_mode"):
         SectorHamiltonian.normal_cmplx_from_model(ps, 0, 0)
+
+
+@pytest.mark.parametrize("mode,sec", [("nonsu2", 5), ("superc", 0)])
+@pytest.mark.parametrize("form", ["stored", "direct", "hostbuild"])
+def test_flat_complex_replica_matrices(gpu, monkeypatch, mode, sec, form):
+    """Complex (Hermitian, not real-symmetric) replica bath matrices and impHloc in the superc / nonsu2 builders:
+    the orientation of c^+_{a,k} c_{b,k} only shows with an imaginary part."""
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models(mode, "replica", 2, 2, seed=98)
+    rng = np.random.default_rng(99)
+    n1 = np.asarray(om.hb).shape[0]
+    x = rng.uniform(-0.3, 0.3, (2, 2, om.nbath))
+    x = x - x.transpose(1, 0, 2)
+    t = rng.uniform(-0.3, 0.3, (2, 2))
+    t = t - t.T
+    for m in (om, pm):
+        hb = np.asarray(m.hb, complex).copy()
+        hl = np.asarray(m.hloc, complex).copy()
+        for s_ in range(n1):
+            # superc: the Nambu (2,2) block is -conj of the (1,1) block in build_Hreplica; keep what the model holds
+            # real there and make only the particle block complex
+            if mode == "superc" and s_ == 1:
+                continue
+            hb[s_, s_] = hb[s_, s_] + 1j * x
+        for s_ in range(hl.shape[0]):
+            hl[s_, s_] = hl[s_, s_] + 1j * t
+        m.hb, m.hloc = hb, hl
+    ho = O.HFlat(om, sec)
+    d = ho.dense()
+    assert np.max(np.abs(d - d.conj().T)) < 1e-13 and np.max(np.abs(d.imag)) > 0.05
+    if form == "hostbuild":
+        monkeypatch.setenv("EDIGPU_FLAT_HOSTBUILD", "1")
+    hg = (SectorHamiltonian.direct_from_model if form == "direct" else SectorHamiltonian.flat_from_model)(pm, sec)
+    v = rng.standard_normal(ho.dim) + 1j * rng.standard_normal(ho.dim)
+    assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
+    hg.destroy()
