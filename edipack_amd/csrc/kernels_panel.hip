@@ -198,7 +198,13 @@ __global__ void __launch_bounds__(kPanelNT)
 // 1024-byte segment of up to 128 columns, and the down-hop gathers are 16-byte loads -- the L2 serves 16-byte
 // accesses at ~1.5-1.8x the rate of 8-byte ones (MI355X_MICROARCH.md, scope/cache-policy table).  The panel is
 // twice as wide, i.e. twice the L2 footprint.  Needs an even DimUp (16-byte aligned rows).
-template <bool DO_ND, bool ALPHA>
+// EDGE: odd DimUp -- rows are only 8-byte aligned (d2u below: the hardware takes 16-byte loads at 4-byte alignment)
+// and the last column has no right-hand partner: that one lane falls back to 8-byte accesses.
+struct alignas(8) d2u {
+  double x, y;
+};
+
+template <bool DO_ND, bool ALPHA, bool EDGE>
 __global__ void __launch_bounds__(kPanelNT)
     normal_dw_panel2_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full, double* __restrict__ hv) {
   __shared__ double red[2 * (kPanelNT / 64)];
@@ -220,16 +226,37 @@ __global__ void __launch_bounds__(kPanelNT)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t DimUp = a.dim_up;
-  const int64_t c = (int64_t)panel * p.width + 2 * lane;  // even (width and DimUp are even)
+  const int64_t c = (int64_t)panel * p.width + 2 * lane;  // even (the width is even)
   const bool ok = 2 * lane < p.width && c < DimUp;
-  const int64_t cc = ok ? c : DimUp - 2;
+  const int64_t cc = ok ? c : (EDGE ? DimUp - 1 : DimUp - 2);
+  const bool pair = !EDGE || cc + 1 < DimUp;  // false only on the lane that owns the last column of an odd DimUp
+  auto ld2 = [&](const double* q) -> double2 {
+    if (!EDGE) return *reinterpret_cast<const double2*>(q);
+    if (pair) {
+      const d2u t = *reinterpret_cast<const d2u*>(q);
+      return make_double2(t.x, t.y);
+    }
+    return make_double2(q[0], 0.0);
+  };
+  auto st2 = [&](double* q, double2 t) {
+    if (!EDGE) {
+      *reinterpret_cast<double2*>(q) = t;
+    } else if (pair) {
+      d2u u;
+      u.x = t.x;
+      u.y = t.y;
+      *reinterpret_cast<d2u*>(q) = u;
+    } else {
+      q[0] = t.x;
+    }
+  };
   int64_t rend = (int64_t)(chunk + 1) * p.rows_per_block;
   if (rend > a.dw_count) rend = a.dw_count;
   constexpr int NW = kPanelNT / 64;
   if (DO_ND)
     for (int t = 0; t < a.nterms; t++) {
       ju2[(2 * t) * kPanelNT + threadIdx.x] = a.jup[(int64_t)t * DimUp + cc];
-      ju2[(2 * t + 1) * kPanelNT + threadIdx.x] = a.jup[(int64_t)t * DimUp + cc + 1];
+      ju2[(2 * t + 1) * kPanelNT + threadIdx.x] = pair ? a.jup[(int64_t)t * DimUp + cc + 1] : 0xFFFFFFFFu;
     }
   auto row_sum = [&](int64_t r, double2 acc) -> double2 {
     if (!DO_ND) {
@@ -238,7 +265,7 @@ __global__ void __launch_bounds__(kPanelNT)
 #pragma unroll 4
       for (int32_t jj = b0; jj < e0; jj++) {
         const double w = a.dw_val[jj];
-        const double2 y = *reinterpret_cast<const double2*>(&v_full[(int64_t)a.dw_col[jj] * DimUp + cc]);
+        const double2 y = ld2(&v_full[(int64_t)a.dw_col[jj] * DimUp + cc]);
         acc.x += w * y.x;
         acc.y += w * y.y;
       }
@@ -251,7 +278,7 @@ __global__ void __launch_bounds__(kPanelNT)
         const double w = a.mx_val[jj];
         const int64_t base = (int64_t)(cw & 0xFFFFFFu) * DimUp;
         if (tag == 0) {
-          const double2 y = *reinterpret_cast<const double2*>(&v_full[base + cc]);
+          const double2 y = ld2(&v_full[base + cc]);
           acc.x += w * y.x;
           acc.y += w * y.y;
         } else {
@@ -269,18 +296,18 @@ __global__ void __launch_bounds__(kPanelNT)
   for (int64_t r = (int64_t)chunk * p.rows_per_block + wave; r < rend; r += 2 * NW) {
     const int64_t r2 = r + NW;
     const bool two = r2 < rend;
-    double2 acc0 = *reinterpret_cast<const double2*>(&hv[r * DimUp + cc]);
-    double2 acc1 = two ? *reinterpret_cast<const double2*>(&hv[r2 * DimUp + cc]) : make_double2(0.0, 0.0);
+    double2 acc0 = ld2(&hv[r * DimUp + cc]);
+    double2 acc1 = two ? ld2(&hv[r2 * DimUp + cc]) : make_double2(0.0, 0.0);
     double2 own0 = make_double2(0.0, 0.0), own1 = own0;
     if (ALPHA) {
-      own0 = *reinterpret_cast<const double2*>(&v_full[(a.dw_first + r) * DimUp + cc]);
-      if (two) own1 = *reinterpret_cast<const double2*>(&v_full[(a.dw_first + r2) * DimUp + cc]);
+      own0 = ld2(&v_full[(a.dw_first + r) * DimUp + cc]);
+      if (two) own1 = ld2(&v_full[(a.dw_first + r2) * DimUp + cc]);
     }
     acc0 = row_sum(r, acc0);
     if (two) acc1 = row_sum(r2, acc1);
     if (ok) {
-      *reinterpret_cast<double2*>(&hv[r * DimUp + c]) = acc0;
-      if (two) *reinterpret_cast<double2*>(&hv[r2 * DimUp + c]) = acc1;
+      st2(&hv[r * DimUp + c], acc0);
+      if (two) st2(&hv[r2 * DimUp + c], acc1);
       if (ALPHA) {
         asum += own0.x * acc0.x + own0.y * acc0.y;
         qsum += acc0.x * acc0.x + acc0.y * acc0.y;
@@ -382,8 +409,15 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
   static const bool vec2_env = !getenv("EDIGPU_PANEL_VEC2") || atoi(getenv("EDIGPU_PANEL_VEC2")) != 0;
   // measured: config 2 H*v 0.145 -> 0.132 ms, Ns=16 ladder 5.07 -> 4.87 ms; cache-resident sectors (cfg3, 213 k rows)
   // are 13 % SLOWER with the wider panels (fewer, fatter waves), hence the size gate
-  const bool vec2 = vec2_env && do_dw && (a.dim_up % 2) == 0 && a.dim_up * a.dw_count >= ((int64_t)1 << 21) &&
-                    (((uintptr_t)v_full | (uintptr_t)hv) & 15) == 0;
+  const bool edge = (a.dim_up % 2) != 0;  // odd DimUp: 8-byte aligned rows, see d2u
+  // EDIGPU_PANEL_VEC2_MIN: smallest sector (rows) that takes the two-column kernel (tests force it on small ones)
+  static const int64_t vec2_min = getenv("EDIGPU_PANEL_VEC2_MIN") ? atoll(getenv("EDIGPU_PANEL_VEC2_MIN")) : ((int64_t)1 << 21);
+  // L2 fit: a 128-column panel over all DimDw rows must still live in the 4 MiB L2 (config 2: 3432 rows, 3.5 MB),
+  // unless the 64-column panel of the one-column kernel does not fit either (measured: Ns=15 ladder, 6435 rows:
+  // one-column 1.23 ms, two-column 1.35 ms; Ns=16, 12870 rows: 5.07 vs 4.87 ms)
+  const bool l2_ok = a.dim_dw <= 3700 || a.dim_dw > 8000 || getenv("EDIGPU_PANEL_VEC2_MIN") != nullptr;
+  const bool vec2 = vec2_env && do_dw && l2_ok && a.dim_up >= 2 && a.dim_up * a.dw_count >= vec2_min &&
+                    (((uintptr_t)v_full | (uintptr_t)hv) & (edge ? 7 : 15)) == 0;
   PanelArgs p;
   if (vec2) {
     int wmax = 128;
@@ -416,7 +450,7 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
     const size_t lds = do_nd ? (size_t)2 * a.nterms * kPanelNT * sizeof(uint32_t) : 0;
 #define EDIGPU_LAUNCH_P2(ND, AL)                                                                               \
   do {                                                                                                         \
-    auto kern = normal_dw_panel2_kernel<ND, AL>;                                                               \
+    auto kern = edge ? normal_dw_panel2_kernel<ND, AL, true> : normal_dw_panel2_kernel<ND, AL, false>;         \
     if (lds > 48 * 1024)                                                                                       \
       EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(kern, grid, block, lds, st, a, p, v_full, hv);                                          \
