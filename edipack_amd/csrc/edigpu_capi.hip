@@ -631,6 +631,7 @@ static int ensure_workspace(edigpu_sector* s) {
   return 0;
 }
 
+static int apply_eph_operator(const edigpu_sector* s, const double* v, double* hv, int w, hipStream_t st);
 static int apply_any(edigpu_sector* s, const double* v_local, const double* v_full, double* hv,
                      int phase, hipStream_t st) {
   if (s->kind == 4) {
@@ -656,7 +657,8 @@ static int apply_any(edigpu_sector* s, const double* v_local, const double* v_fu
       const int64_t o = (int64_t)iph * s->dim_el;
       if (launch_normal(s, v_local + o, v_full + o, hv + o, 3, st)) return 1;
     }
-    return launch_phonon(s, v_full, hv, st);
+    if (launch_phonon(s, v_full, hv, st)) return 1;
+    return apply_eph_operator(s, v_full, hv, 1, st);
   }
   if (s->kind == 0) return launch_normal(s, v_local, v_full, hv, phase, st);
   if ((s->kind == 1 || s->kind == 2) && s->nph > 0) {
@@ -673,7 +675,8 @@ static int apply_any(edigpu_sector* s, const double* v_local, const double* v_fu
         return 1;
       }
     }
-    return launch_phonon(s, v_full, hv, st);
+    if (launch_phonon(s, v_full, hv, st)) return 1;
+    return apply_eph_operator(s, v_full, hv, 2, st);
   }
   if (s->kind == 3) {
     // ed_total_ud = F: single shard only (phase 1 = everything, phase 2 = nothing left to add)
@@ -692,6 +695,20 @@ static int apply_any(edigpu_sector* s, const double* v_local, const double* v_fu
   }
   if (phase & 2) {
     if (launch_csr(s->nonloc, s->is_complex, v_full, hv, 1, st)) return 1;
+  }
+  return 0;
+}
+
+// general g_ph(a,b): t = O v[jph] with the electron-phonon operator as its own sector handle (sub_a), then
+// hv[jph+1] += sqrt(jph+1) t, hv[jph-1] += sqrt(jph) t   (stored/H_e_ph.f90 x (b + b^+); w = doubles per element)
+static int apply_eph_operator(const edigpu_sector* s, const double* v, double* hv, int w, hipStream_t st) {
+  if (!s->sub_a) return 0;
+  const int64_t n = s->dim_el * w;
+  for (int jph = 0; jph <= s->nph; jph++) {
+    if (apply_any(s->sub_a, v + jph * n, v + jph * n, s->d_cz, 3, st)) return 1;
+    double* up = jph < s->nph ? hv + (jph + 1) * n : nullptr;
+    double* dn = jph > 0 ? hv + (jph - 1) * n : nullptr;
+    if (launch_eph_scatter(n, s->d_cz, up, sqrt((double)(jph + 1)), dn, sqrt((double)jph), st)) return 1;
   }
   return 0;
 }
@@ -975,21 +992,25 @@ int edigpu_normal_build(edigpu_handle* h, const edigpu_model* model, int nup, in
       edigpu_destroy(s.release());
       return 1;
     }
-    for (int a = 0; a < model->norb; a++)
-      for (int b = 0; b < model->norb; b++)
-        if (a != b && model->g_ph[a * EDIGPU_MAXORB + b] != 0.0) {
-          set_error("edigpu_normal_build: only the density couplings g_ph(a,a) are built (off-diagonal g_ph: hand "
-                    "the matrices over)");
-          edigpu_destroy(s.release());
-          return 1;
-        }
+    // density couplings g_aa: per-row tables inside the phonon pass.  A general g_ab (GPHFILE in the reference):
+    // the whole electron-phonon operator as its own sector handle (apply_eph_operator), the tables stay zero.
+    const bool offd = eph_offdiagonal(*model);
     std::vector<double> gu((size_t)hn.dim_up, 0.0), gd((size_t)hn.dim_dw, 0.0);
-    for (int64_t i = 0; i < hn.dim_up; i++)
+    for (int64_t i = 0; !offd && i < hn.dim_up; i++)
       for (int a = 0; a < model->norb; a++)
         if ((hn.bup.states[i] >> a) & 1) gu[i] += model->g_ph[a * EDIGPU_MAXORB + a];
-    for (int64_t i = 0; i < hn.dim_dw; i++)
+    for (int64_t i = 0; !offd && i < hn.dim_dw; i++)
       for (int a = 0; a < model->norb; a++)
         if ((hn.bdw.states[i] >> a) & 1) gd[i] += model->g_ph[a * EDIGPU_MAXORB + a];
+    if (offd) {
+      const edigpu_model om = eph_operator_model(*model);
+      if (edigpu_normal_build(&s->sub_a, &om, nup, ndw, 0, -1) ||
+          hipMalloc((void**)&s->d_cz, (size_t)s->dim * sizeof(double)) != hipSuccess) {
+        if (g_err.empty()) set_error("edigpu_normal_build: electron-phonon operator: out of device memory");
+        edigpu_destroy(s.release());
+        return 1;
+      }
+    }
     if (dev_upload(&s->d_gu, gu.data(), gu.size()) || dev_upload(&s->d_gd, gd.data(), gd.size())) {
       edigpu_destroy(s.release());
       return 1;
@@ -1065,18 +1086,24 @@ static int attach_phonons_flat(edigpu_sector* s, const edigpu_model& m, const st
     set_error("phonons (nph > 0) need the whole sector on one shard");
     return 1;
   }
-  for (int a = 0; a < m.norb; a++)
-    for (int b = 0; b < m.norb; b++)
-      if (a != b && m.g_ph[a * EDIGPU_MAXORB + b] != 0.0) {
-        set_error("only the density couplings g_ph(a,a) are built (off-diagonal g_ph: hand the matrices over)");
-        return 1;
-      }
   if (s->dim * (m.nph + 1) >= ((int64_t)1 << 31)) {
     set_error("sector dimension x (Nph+1) >= 2^31");
     return 1;
   }
+  const bool offd = eph_offdiagonal(m);
+  if (offd) {
+    // general g_ab: the electron-phonon operator as a sector handle of the same kind (apply_eph_operator)
+    const edigpu_model om = eph_operator_model(m);
+    const int rc = s->kind == 2 ? edigpu_direct_build(&s->sub_a, &om, s->sec_a, 0, -1)
+                                : edigpu_flat_build(&s->sub_a, &om, s->sec_a, 0, -1);
+    if (rc) return 1;
+    if (hipMalloc((void**)&s->d_cz, (size_t)2 * (size_t)s->dim * sizeof(double)) != hipSuccess) {
+      set_error("electron-phonon operator: out of device memory");
+      return 1;
+    }
+  }
   std::vector<double> gel(states.size(), 0.0);
-  for (size_t i = 0; i < states.size(); i++)
+  for (size_t i = 0; !offd && i < states.size(); i++)
     for (int a = 0; a < m.norb; a++)
       gel[i] += m.g_ph[a * EDIGPU_MAXORB + a] * (double)(((states[i] >> a) & 1) + ((states[i] >> (a + ns)) & 1));
   if (dev_upload(&s->d_gu, gel.data(), gel.size())) return 1;

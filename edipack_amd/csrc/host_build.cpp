@@ -233,6 +233,30 @@ edigpu_model imag_part_model(const edigpu_model& m, bool& any) {
   return r;
 }
 
+// Electron-phonon operator O = sum_{ab} g_ph(a,b) sum_sigma c^+_{a sigma} c_{b sigma} (stored/H_e_ph.f90: the
+// electronic factor of g (b + b^+)) as the model whose ordinary sector build gives exactly O: impHloc = g, all else 0.
+bool eph_offdiagonal(const edigpu_model& m) {
+  for (int a = 0; a < m.norb; a++)
+    for (int b = 0; b < m.norb; b++)
+      if (a != b && m.g_ph[a * EDIGPU_MAXORB + b] != 0.0) return true;
+  return false;
+}
+
+edigpu_model eph_operator_model(const edigpu_model& m) {
+  edigpu_model r;
+  std::memset(&r, 0, sizeof(r));
+  r.ed_mode = m.ed_mode;
+  r.bath_type = m.bath_type;
+  r.norb = m.norb;
+  r.nbath = m.nbath;
+  r.nspin = m.nspin;
+  for (int s = 0; s < 2; s++)
+    for (int a = 0; a < m.norb; a++)
+      for (int b = 0; b < m.norb; b++)
+        r.hloc[((((s * 2) + s) * EDIGPU_MAXORB + a) * EDIGPU_MAXORB + b) * 2] = m.g_ph[a * EDIGPU_MAXORB + b];
+  return r;
+}
+
 std::string sector_dim(const edigpu_model& m, int q1, int q2, int64_t& dim) {
   std::string e = check_model(m);
   if (!e.empty()) return e;

@@ -130,6 +130,8 @@ std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int
 std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
                          HostDirect& out);
 edigpu_model imag_part_model(const edigpu_model& m, bool& any);
+bool eph_offdiagonal(const edigpu_model& m);
+edigpu_model eph_operator_model(const edigpu_model& m);
 std::string sector_dim(const edigpu_model& m, int q1, int q2, int64_t& dim);
 
 }  // namespace edigpu

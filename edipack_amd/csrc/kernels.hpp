@@ -21,6 +21,8 @@ int launch_normal_rows(const edigpu_sector* s, int64_t dw_first, int64_t dw_coun
                        double* hv_rows, hipStream_t st);
 int launch_normal_cols(const edigpu_sector* s, int64_t col_first, int64_t ncol, int64_t stride, int halo,
                        const double* w, double* hv, hipStream_t st);
+// electron-phonon ladder: up[i] += c_up t[i], dn[i] += c_dn t[i] (either target may be NULL); n doubles
+int launch_eph_scatter(int64_t n, const double* t, double* up, double c_up, double* dn, double c_dn, hipStream_t st);
 // _CMPLX_NORMAL: interleaved complex <-> planar, y = (yr - t1) + i (yi + t2)  (kernels_ops.hip)
 int launch_deinterleave(int64_t n, const double* z, double* re, double* im, hipStream_t st);
 int launch_combine_interleave(int64_t n, const double* yr, const double* yi, const double* t1, const double* t2,

@@ -85,6 +85,26 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- electron-phonon coupling with a general g_ph(a,b): t = O v[jph] goes to the blocks jph +- 1 ----
+__global__ void __launch_bounds__(256)
+    eph_scatter_kernel(int64_t n, const double* __restrict__ t, double* __restrict__ up, double c_up,
+                       double* __restrict__ dn, double c_dn) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double x = t[i];
+    if (up) up[i] = fma(c_up, x, up[i]);
+    if (dn) dn[i] = fma(c_dn, x, dn[i]);
+  }
+}
+
+int launch_eph_scatter(int64_t n, const double* t, double* up, double c_up, double* dn, double c_dn, hipStream_t st) {
+  if (n <= 0 || (!up && !dn)) return 0;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 256 * 32) nb = 256 * 32;
+  hipLaunchKernelGGL(eph_scatter_kernel, dim3((unsigned)nb), dim3(256), 0, st, n, t, up, c_up, dn, c_dn);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---- _CMPLX_NORMAL (complex algebra in normal mode): planar work vectors around four real products ----
 __global__ void __launch_bounds__(256)
     deinterleave_kernel(int64_t n, const double2* __restrict__ z, double* __restrict__ re, double* __restrict__ im) {

@@ -132,8 +132,9 @@ typedef struct edigpu_model {
    * be, bd, bu are not read for these bath types. */
   double hb[2 * 2 * EDIGPU_MAXORB * EDIGPU_MAXORB * EDIGPU_MAXBATH * 2];
   /* phonons, all modes (ED_INPUT_VARS.f90:184-198; ED_NORMAL/stored/H_ph.f90, H_e_ph.f90): nph = phonon cut-off
-   * Nph (DimPh = Nph + 1; 0 = no phonons), w0_ph, a_ph, g_ph[iorb][jorb] (only the density couplings g_aa are built
-   * by the library: GPHFILE=NONE in the reference).  With nph > 0 edigpu_normal_build / edigpu_flat_build / edigpu_direct_build make a handle whose vectors
+   * Nph (DimPh = Nph + 1; 0 = no phonons), w0_ph, a_ph, g_ph[iorb][jorb] (real symmetric; density couplings g_aa
+   * run inside the phonon pass, a general matrix -- GPHFILE in the reference -- as one extra product per phonon block
+   * with the operator sum_ab g_ab sum_s c+_as c_bs held as its own sector).  With nph > 0 edigpu_normal_build / edigpu_flat_build / edigpu_direct_build make a handle whose vectors
    * have dim_el * (Nph + 1) elements, index i_el + iph * dim_el (whole sectors only). */
   int32_t nph;
   int32_t pad_;

@@ -1141,9 +1141,7 @@ def test_phonon_branches_flat_match_oracle(gpu, monkeypatch, form, mode, bath, n
 def test_phonon_flat_error_paths(gpu):
     from edipack_amd.hamiltonian import SectorHamiltonian
     _, pm = make_models("superc", "normal", 2, 2, seed=92)
-    pm.nph, pm.w0_ph, pm.g_ph = 2, 0.8, np.array([[0.3, 0.1], [0.1, 0.5]])
-    with pytest.raises(RuntimeError, match="density couplings"):
-        SectorHamiltonian.flat_from_model(pm, 0)
+    pm.nph, pm.w0_ph = 2, 0.8
     pm.g_ph = np.diag([0.3, 0.5])
     with pytest.raises(RuntimeError, match="one shard"):
         SectorHamiltonian.direct_from_model(pm, 0, row_first=0, row_count=8)
@@ -1499,3 +1497,41 @@ def test_concurrent_sectors_from_host_threads(gpu):
     assert rel_err(res[0][0][:12], ao[:12]) < 1e-9
     for h in hs:
         h.destroy()
+
+
+@pytest.mark.parametrize("mode,bath,norb,nbath,sec,form", [
+    ("normal", "normal", 2, 2, (3, 2), "stored"),
+    ("normal", "hybrid", 3, 2, (2, 3), "stored"),
+    ("superc", "normal", 2, 2, 0, "stored"),
+    ("superc", "hybrid", 2, 3, 1, "direct"),
+    ("nonsu2", "normal", 2, 2, 5, "stored"),
+    ("nonsu2", "hybrid", 3, 2, 5, "direct"),
+    ("nonsu2", "normal", 2, 2, 6, "hostbuild"),
+])
+def test_phonon_general_coupling_matrix(gpu, monkeypatch, mode, bath, norb, nbath, sec, form):
+    """Electron-phonon coupling with a general (symmetric) g_ph(a,b) -- GPHFILE in the reference, stored/H_e_ph.f90:
+    off-diagonal entries hop an electron between impurity orbitals while a phonon is created / destroyed."""
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models(mode, bath, norb, nbath, seed=105)
+    rng = np.random.default_rng(106)
+    g = rng.uniform(-0.3, 0.3, (norb, norb))
+    g = 0.5 * (g + g.T) + np.diag(rng.uniform(0.1, 0.5, norb))
+    for m in (om, pm):
+        m.nph, m.w0_ph, m.a_ph, m.g_ph = 2, 0.7, 0.1, g
+    if form == "hostbuild":
+        monkeypatch.setenv("EDIGPU_FLAT_HOSTBUILD", "1")
+    if mode == "normal":
+        ho = O.HNormal(om, *sec)
+        hg = SectorHamiltonian.normal_from_model(pm, *sec)
+        v = rng.standard_normal(ho.dim)
+    else:
+        ho = O.HFlat(om, sec)
+        hg = (SectorHamiltonian.direct_from_model if form == "direct" else SectorHamiltonian.flat_from_model)(pm, sec)
+        v = rng.standard_normal(ho.dim) + 1j * rng.standard_normal(ho.dim)
+    assert hg.dim == ho.dim == ho.dim_el * 3
+    assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
+    ao, bo, _ = ho.lanc_tridiag(v, 15)
+    ag, bg, _ = hg.lanczos_tridiag(v, 15)
+    assert rel_err(ag[:10], ao[:10]) < 1e-9 and rel_err(bg[:10], bo[:10]) < 1e-9
+    hg.destroy()
