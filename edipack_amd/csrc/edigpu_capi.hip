@@ -2041,9 +2041,19 @@ int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, 
     ~Free2() { (void)hipFree(a); (void)hipFree(b); }
   } free2{d_coef, d_nrm};
   std::vector<double> hcoef(2 * hstride * (size_t)m), hnrm(2 * (size_t)m + 32);
+  static const bool twopass = getenv("EDIGPU_TRL_TWOPASS") != nullptr;  // always two Gram-Schmidt passes
+  // coefficients below thr_skip * |w_new| are left in w: three orders below the requested residual
+  const double thr_skip = getenv("EDIGPU_TRL_THR") ? atof(getenv("EDIGPU_TRL_THR")) : 1e-3 * tol;
+  int* d_skip = nullptr;
+  EDIGPU_HIP(hipMalloc((void**)&d_skip, sizeof(int)));
+  struct Free1 {
+    int*& p;
+    ~Free1() { (void)hipFree(p); }
+  } free1{d_skip};
   for (int restart = 0; restart <= maxrestart; restart++) {
     invariant = false;
     meff = m;
+    EDIGPU_HIP(hipMemsetAsync(d_coef, 0, sizeof(double) * 2 * hstride * (size_t)m, st));
     for (int j = k; j < m; j++) {
       double* w = q(j + 1);
       if (apply_any(s, q(j), q(j), w, 3, st)) return 1;
@@ -2051,8 +2061,19 @@ int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, 
       // classical Gram-Schmidt against q_0..q_j, twice; the coefficients are column j of Q^H H Q
       double* c1 = d_coef + (size_t)(2 * j) * hstride;
       double* c2 = d_coef + (size_t)(2 * j + 1) * hstride;
-      if (trl_orthogonalize(cplx, n, j + 1, b.Q, len, w, c1, b.part, st)) return 1;
-      if (trl_orthogonalize(cplx, n, j + 1, b.Q, len, w, c2, b.part, st)) return 1;
+      // second pass only when the first one removed more than 99 % of |w|^2 ("twice is enough" with eta = 0.1:
+      // orthogonality ~10 eps otherwise); decided on the device, c2 stays zero when skipped
+      // coefficients below 1e-11 |w_new| (pure rounding: the three-term recurrence makes them zero) are not
+      // subtracted, their basis vectors not read (trl_decide_kernel)
+      if (twopass) {
+        if (trl_orthogonalize(cplx, n, j + 1, b.Q, len, w, c1, b.part, st)) return 1;
+        if (trl_orthogonalize(cplx, n, j + 1, b.Q, len, w, c2, b.part, st)) return 1;
+      } else {
+        if (trl_dots(cplx, n, j + 2, b.Q, len, w, c1, b.part, st)) return 1;  // column j+1 is w itself: <w|w>
+        if (trl_decide(c1, j + 1, 0.01, thr_skip * thr_skip, b.h, d_skip, st)) return 1;
+        if (trl_subtract(cplx, n, j + 1, b.Q, len, b.h, w, st)) return 1;
+        if (trl_orthogonalize(cplx, n, j + 1, b.Q, len, w, c2, b.part, st, d_skip)) return 1;
+      }
       if (trl_norm2(cplx, n, w, d_nrm + 2 * j, b.part, st)) return 1;
       if (vec_scale(len, w, d_nrm + 2 * j, st)) return 1;  // w / sqrt(<w|w>) with the norm read on the device
     }

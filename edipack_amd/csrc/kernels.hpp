@@ -82,7 +82,14 @@ int vec_unpack_add_dot2(int64_t dim_up, int64_t nrows, int64_t q, int64_t pcol, 
 // ---- thick-restart Lanczos multi-vector kernels (kernels_trl.hip) ----
 // h_dev (2 doubles per basis vector: re, im) = Q^H w, then w -= Q h; n counts complex or real elements
 int trl_orthogonalize(int cplx, int64_t n, int nvec, const double* Q, int64_t ldq, double* w, double* h_dev,
-                      double* partial, hipStream_t st);
+                      double* partial, hipStream_t st, const int* skip = nullptr);
+int trl_dots(int cplx, int64_t n, int ndot, const double* Q, int64_t ldq, const double* w, double* h_dev,
+             double* partial, hipStream_t st, const int* skip = nullptr);
+int trl_subtract(int cplx, int64_t n, int nvec, const double* Q, int64_t ldq, const double* h_dev, double* w,
+                 hipStream_t st, const int* skip = nullptr);
+// after the first sweep (nvec coefficients + <w|w> in h_dev): skip <- 1 when at least eta2 of |w|^2 is left (no second
+// pass); hf_dev <- the coefficients with those below thr * |w_new| set to exactly zero (all kept when skip = 0)
+int trl_decide(const double* h_dev, int nvec, double eta2, double thr2, double* hf_dev, int* skip, hipStream_t st);
 int trl_norm2(int cplx, int64_t n, const double* w, double* h_dev, double* partial, hipStream_t st);
 int trl_partial_doubles(void);
 int trl_rotate_basis(int64_t len, int m, int k, const double* Q, int64_t ldq, const double* Y_dev, int ldy,

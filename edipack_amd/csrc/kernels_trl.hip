@@ -19,8 +19,9 @@ constexpr int kTrlNC = 8;
 template <bool CPLX>
 __global__ void __launch_bounds__(kTrlNT)
     trl_mdot_kernel(int64_t n, int nc, const double* __restrict__ Q, int64_t ldq, const double* __restrict__ w,
-                    double* __restrict__ partial) {
+                    double* __restrict__ partial, const int* __restrict__ skip) {
   __shared__ double red[kTrlNT / 64][2 * kTrlNC];
+  if (skip && *skip) return;  // second Gram-Schmidt pass not needed (trl_decide_kernel)
   double sr[kTrlNC], si[kTrlNC];
 #pragma unroll
   for (int c = 0; c < kTrlNC; c++) sr[c] = si[c] = 0.0;
@@ -65,8 +66,10 @@ __global__ void __launch_bounds__(kTrlNT)
 }
 
 // h[2*c+q] = sum_b partial[(2*c+q) * nb + b]
-__global__ void __launch_bounds__(256) trl_msum_kernel(const double* __restrict__ partial, int nb, double* __restrict__ h) {
+__global__ void __launch_bounds__(256)
+    trl_msum_kernel(const double* __restrict__ partial, int nb, double* __restrict__ h, const int* __restrict__ skip) {
   __shared__ double sh[256];
+  if (skip && *skip) return;
   const int k = blockIdx.x;  // 0 .. 2*NC-1
   double s = 0.0;
   for (int b = threadIdx.x; b < nb; b += 256) s += partial[(int64_t)k * nb + b];
@@ -83,19 +86,23 @@ __global__ void __launch_bounds__(256) trl_msum_kernel(const double* __restrict_
 template <bool CPLX>
 __global__ void __launch_bounds__(kTrlNT)
     trl_maxpy_kernel(int64_t n, int nc, const double* __restrict__ Q, int64_t ldq, const double* __restrict__ h,
-                     double* __restrict__ w) {
+                     double* __restrict__ w, const int* __restrict__ skip) {
   double hr[kTrlNC], hi[kTrlNC];
+  if (skip && *skip) return;
+  bool any = false;
 #pragma unroll
   for (int c = 0; c < kTrlNC; c++) {
     hr[c] = c < nc ? h[2 * c] : 0.0;
     hi[c] = c < nc ? h[2 * c + 1] : 0.0;
+    any = any || hr[c] != 0.0 || hi[c] != 0.0;
   }
+  if (!any) return;  // every coefficient of this group was filtered out (trl_decide_kernel): w stays as it is
   for (int64_t i = (int64_t)blockIdx.x * kTrlNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTrlNT) {
     if (CPLX) {
       double2 x = reinterpret_cast<double2*>(w)[i];
 #pragma unroll
       for (int c = 0; c < kTrlNC; c++)
-        if (c < nc) {
+        if (c < nc && (hr[c] != 0.0 || hi[c] != 0.0)) {  // uniform: a filtered vector is not even read
           const double2 q = reinterpret_cast<const double2*>(Q + c * ldq)[i];
           x.x -= hr[c] * q.x - hi[c] * q.y;
           x.y -= hr[c] * q.y + hi[c] * q.x;
@@ -105,7 +112,7 @@ __global__ void __launch_bounds__(kTrlNT)
       double x = w[i];
 #pragma unroll
       for (int c = 0; c < kTrlNC; c++)
-        if (c < nc) x -= hr[c] * Q[c * ldq + i];
+        if (c < nc && hr[c] != 0.0) x -= hr[c] * Q[c * ldq + i];
       w[i] = x;
     }
   }
@@ -141,26 +148,76 @@ static inline int trl_grid(int64_t n) {
 }
 
 // h (device, 2*nvec doubles: re, im) = Q[0..nvec)^H w ; then w -= Q h.  n = complex or real element count.
-int trl_orthogonalize(int cplx, int64_t n, int nvec, const double* Q, int64_t ldq, double* w, double* h_dev,
-                      double* partial, hipStream_t st) {
+// Decisions after the first classical Gram-Schmidt sweep of a Lanczos step.  h: nvec coefficient pairs followed
+// by <w_old|w_old> (the sweep dots w with itself as one more column).
+//  * "twice is enough" (Kahan / Parlett): a second pass is needed only when the first removed most of the vector,
+//    |w_new|^2 = |w_old|^2 - |h|^2 < eta^2 |w_old|^2  ->  skip = 0.
+//  * in exact arithmetic only the last two coefficients are non-zero (three-term recurrence; after a restart also
+//    those of the kept Ritz vectors).  The others measure the loss of orthogonality; while they are below
+//    thr * |w_new| they are not subtracted -- hf gets exact zeros there and the subtraction kernel does not read
+//    those basis vectors -- which keeps the basis orthogonal to thr (1e-11 by default, far below the 1e-8 of
+//    semi-orthogonality schemes) at about half the traffic.  When a second pass is needed nothing is filtered.
+__global__ void trl_decide_kernel(const double* __restrict__ h, int nvec, double eta2, double thr2,
+                                  double* __restrict__ hf, int* __restrict__ skip) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double hh = 0.0;
+  for (int c = 0; c < nvec; c++) hh += h[2 * c] * h[2 * c] + h[2 * c + 1] * h[2 * c + 1];
+  const double ww = h[2 * nvec];
+  const bool enough = ww - hh >= eta2 * ww;
+  *skip = enough ? 1 : 0;
+  const double cut = enough ? thr2 * (ww - hh) : -1.0;
+  for (int c = 0; c < nvec; c++) {
+    const double a = h[2 * c], b = h[2 * c + 1];
+    const bool keep = c >= nvec - 2 || a * a + b * b > cut;
+    hf[2 * c] = keep ? a : 0.0;
+    hf[2 * c + 1] = keep ? b : 0.0;
+  }
+}
+
+// h_dev[2c..2c+1] = <Q_c|w> for c < ndot (Q_c = Q + c*ldq; the caller may count w itself as the last column)
+int trl_dots(int cplx, int64_t n, int ndot, const double* Q, int64_t ldq, const double* w, double* h_dev,
+             double* partial, hipStream_t st, const int* skip) {
+  const int nb = trl_grid(n);
+  for (int c0 = 0; c0 < ndot; c0 += kTrlNC) {
+    const int nc = ndot - c0 < kTrlNC ? ndot - c0 : kTrlNC;
+    const double* q0 = Q + (int64_t)c0 * ldq;
+    if (cplx)
+      hipLaunchKernelGGL((trl_mdot_kernel<true>), dim3(nb), dim3(kTrlNT), 0, st, n, nc, q0, ldq, w, partial, skip);
+    else
+      hipLaunchKernelGGL((trl_mdot_kernel<false>), dim3(nb), dim3(kTrlNT), 0, st, n, nc, q0, ldq, w, partial, skip);
+    hipLaunchKernelGGL(trl_msum_kernel, dim3(2 * kTrlNC), dim3(256), 0, st, partial, nb, h_dev + 2 * c0, skip);
+  }
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+// w -= sum_c h_c Q_c for c < nvec; basis vectors with an exactly zero coefficient are not read
+int trl_subtract(int cplx, int64_t n, int nvec, const double* Q, int64_t ldq, const double* h_dev, double* w,
+                 hipStream_t st, const int* skip) {
   const int nb = trl_grid(n);
   for (int c0 = 0; c0 < nvec; c0 += kTrlNC) {
     const int nc = nvec - c0 < kTrlNC ? nvec - c0 : kTrlNC;
     const double* q0 = Q + (int64_t)c0 * ldq;
     if (cplx)
-      hipLaunchKernelGGL((trl_mdot_kernel<true>), dim3(nb), dim3(kTrlNT), 0, st, n, nc, q0, ldq, w, partial);
+      hipLaunchKernelGGL((trl_maxpy_kernel<true>), dim3(nb), dim3(kTrlNT), 0, st, n, nc, q0, ldq, h_dev + 2 * c0, w,
+                         skip);
     else
-      hipLaunchKernelGGL((trl_mdot_kernel<false>), dim3(nb), dim3(kTrlNT), 0, st, n, nc, q0, ldq, w, partial);
-    hipLaunchKernelGGL(trl_msum_kernel, dim3(2 * kTrlNC), dim3(256), 0, st, partial, nb, h_dev + 2 * c0);
+      hipLaunchKernelGGL((trl_maxpy_kernel<false>), dim3(nb), dim3(kTrlNT), 0, st, n, nc, q0, ldq, h_dev + 2 * c0, w,
+                         skip);
   }
-  for (int c0 = 0; c0 < nvec; c0 += kTrlNC) {
-    const int nc = nvec - c0 < kTrlNC ? nvec - c0 : kTrlNC;
-    const double* q0 = Q + (int64_t)c0 * ldq;
-    if (cplx)
-      hipLaunchKernelGGL((trl_maxpy_kernel<true>), dim3(nb), dim3(kTrlNT), 0, st, n, nc, q0, ldq, h_dev + 2 * c0, w);
-    else
-      hipLaunchKernelGGL((trl_maxpy_kernel<false>), dim3(nb), dim3(kTrlNT), 0, st, n, nc, q0, ldq, h_dev + 2 * c0, w);
-  }
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+// w -= Q (Q^H w) over nvec basis vectors; h_dev receives the coefficients; skip: device flag, set = no-op
+int trl_orthogonalize(int cplx, int64_t n, int nvec, const double* Q, int64_t ldq, double* w, double* h_dev,
+                      double* partial, hipStream_t st, const int* skip) {
+  if (trl_dots(cplx, n, nvec, Q, ldq, w, h_dev, partial, st, skip)) return 1;
+  return trl_subtract(cplx, n, nvec, Q, ldq, h_dev, w, st, skip);
+}
+
+int trl_decide(const double* h_dev, int nvec, double eta2, double thr2, double* hf_dev, int* skip, hipStream_t st) {
+  hipLaunchKernelGGL(trl_decide_kernel, dim3(1), dim3(64), 0, st, h_dev, nvec, eta2, thr2, hf_dev, skip);
   EDIGPU_HIP(hipGetLastError());
   return 0;
 }
@@ -169,10 +226,11 @@ int trl_orthogonalize(int cplx, int64_t n, int nvec, const double* Q, int64_t ld
 int trl_norm2(int cplx, int64_t n, const double* w, double* h_dev, double* partial, hipStream_t st) {
   const int nb = trl_grid(n);
   if (cplx)
-    hipLaunchKernelGGL((trl_mdot_kernel<true>), dim3(nb), dim3(kTrlNT), 0, st, n, 1, w, (int64_t)0, w, partial);
+    hipLaunchKernelGGL((trl_mdot_kernel<true>), dim3(nb), dim3(kTrlNT), 0, st, n, 1, w, (int64_t)0, w, partial, nullptr);
   else
-    hipLaunchKernelGGL((trl_mdot_kernel<false>), dim3(nb), dim3(kTrlNT), 0, st, n, 1, w, (int64_t)0, w, partial);
-  hipLaunchKernelGGL(trl_msum_kernel, dim3(2 * kTrlNC), dim3(256), 0, st, partial, nb, h_dev);
+    hipLaunchKernelGGL((trl_mdot_kernel<false>), dim3(nb), dim3(kTrlNT), 0, st, n, 1, w, (int64_t)0, w, partial,
+                       nullptr);
+  hipLaunchKernelGGL(trl_msum_kernel, dim3(2 * kTrlNC), dim3(256), 0, st, partial, nb, h_dev, nullptr);
   EDIGPU_HIP(hipGetLastError());
   return 0;
 }
