@@ -2000,11 +2000,11 @@ int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, 
     ~Bufs() { (void)hipFree(Q); (void)hipFree(Qt); (void)hipFree(h); (void)hipFree(part); (void)hipFree(Y); }
   } b;
   EDIGPU_HIP(hipMalloc((void**)&b.Q, vbytes * (size_t)(m + 1)));
-  EDIGPU_HIP(hipMalloc((void**)&b.h, sizeof(double) * 2 * (size_t)(m + 16)));
+  EDIGPU_HIP(hipMalloc((void**)&b.h, sizeof(double) * 2 * (size_t)(m + 40)));
   EDIGPU_HIP(hipMalloc((void**)&b.part, sizeof(double) * (size_t)trl_partial_doubles()));
   EDIGPU_HIP(hipMalloc((void**)&b.Y, sizeof(double) * (size_t)m * m));
   auto q = [&](int j) { return b.Q + (size_t)j * len; };
-  std::vector<double> hh(2 * (size_t)(m + 16));
+  std::vector<double> hh(2 * (size_t)(m + 40));
   auto norm_of = [&](double* w, double& out) -> int {
     if (trl_norm2(cplx, n, w, b.h, b.part, st)) return 1;
     EDIGPU_HIP(hipMemcpyAsync(hh.data(), b.h, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -2032,15 +2032,15 @@ int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, 
   bool invariant = false;
   // per cycle the Gram-Schmidt coefficients (two passes) and the squared norms stay on the device and are
   // fetched once: no host synchronisation inside the Lanczos steps
-  const size_t hstride = 2 * (size_t)(m + 16);
+  const size_t hstride = 2 * (size_t)(m + 40);
   double *d_coef = nullptr, *d_nrm = nullptr;
   EDIGPU_HIP(hipMalloc((void**)&d_coef, sizeof(double) * 2 * hstride * (size_t)m));
-  EDIGPU_HIP(hipMalloc((void**)&d_nrm, sizeof(double) * (2 * (size_t)m + 32)));  // the reduction writes 16 slots
+  EDIGPU_HIP(hipMalloc((void**)&d_nrm, sizeof(double) * (2 * (size_t)m + 80)));  // the reduction writes 2 * kTrlNC slots
   struct Free2 {
     double *&a, *&b;
     ~Free2() { (void)hipFree(a); (void)hipFree(b); }
   } free2{d_coef, d_nrm};
-  std::vector<double> hcoef(2 * hstride * (size_t)m), hnrm(2 * (size_t)m + 32);
+  std::vector<double> hcoef(2 * hstride * (size_t)m), hnrm(2 * (size_t)m + 80);
   static const bool twopass = getenv("EDIGPU_TRL_TWOPASS") != nullptr;  // always two Gram-Schmidt passes
   // coefficients below thr_skip * |w_new| are left in w: three orders below the requested residual
   const double thr_skip = getenv("EDIGPU_TRL_THR") ? atof(getenv("EDIGPU_TRL_THR")) : 1e-3 * tol;

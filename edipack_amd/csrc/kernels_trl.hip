@@ -13,7 +13,7 @@
 namespace edigpu {
 
 constexpr int kTrlNT = 256;
-constexpr int kTrlNC = 8;
+constexpr int kTrlNC = 16;  // basis vectors per sweep launch (w is read once per group; 8 per launch measured 4 % slower)
 
 // partial[(c*2+q) * gridDim + block] = sum over the block's elements of conj(Q_c) * w  (q: re, im)
 template <bool CPLX>
