@@ -2113,11 +2113,13 @@ int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, 
     int kk = want + (meff - want) / 2;
     if (kk > meff - 1) kk = meff - 1;
     if (kk < 1) kk = 1;
-    if (!b.Qt) EDIGPU_HIP(hipMalloc((void**)&b.Qt, vbytes * (size_t)m));
+    // the rotated Ritz vectors land in the second basis buffer, the residual vector follows them there, and the
+    // two buffers change roles (no copy back)
+    if (!b.Qt) EDIGPU_HIP(hipMalloc((void**)&b.Qt, vbytes * (size_t)(m + 1)));
     EDIGPU_HIP(hipMemcpyAsync(b.Y, Y.data(), sizeof(double) * (size_t)meff * meff, hipMemcpyHostToDevice, st));
     if (trl_rotate_basis(len, meff, kk, b.Q, len, b.Y, meff, b.Qt, len, st)) return 1;
-    EDIGPU_HIP(hipMemcpyAsync(b.Q, b.Qt, vbytes * (size_t)kk, hipMemcpyDeviceToDevice, st));
-    EDIGPU_HIP(hipMemcpyAsync(q(kk), q(meff), vbytes, hipMemcpyDeviceToDevice, st));
+    EDIGPU_HIP(hipMemcpyAsync(b.Qt + (size_t)kk * len, q(meff), vbytes, hipMemcpyDeviceToDevice, st));
+    std::swap(b.Q, b.Qt);
     std::fill(T.begin(), T.end(), 0.0);
     for (int i = 0; i < kk; i++) T[(size_t)i * m + i] = theta[i];
     k = kk;
@@ -2127,7 +2129,7 @@ int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, 
   if (nconv_out) *nconv_out = nconv;
   if (nmatvec_out) *nmatvec_out = nmv;
   if (evecs) {
-    if (!b.Qt) EDIGPU_HIP(hipMalloc((void**)&b.Qt, vbytes * (size_t)m));
+    if (!b.Qt) EDIGPU_HIP(hipMalloc((void**)&b.Qt, vbytes * (size_t)(m + 1)));
     EDIGPU_HIP(hipMemcpyAsync(b.Y, Y.data(), sizeof(double) * (size_t)meff * meff, hipMemcpyHostToDevice, st));
     if (trl_rotate_basis(len, meff, want, b.Q, len, b.Y, meff, b.Qt, len, st)) return 1;
     EDIGPU_HIP(hipMemcpyAsync(evecs, b.Qt, vbytes * (size_t)want, hipMemcpyDefault, st));
