@@ -13,6 +13,11 @@
 namespace edigpu {
 
 constexpr int kTrlNT = 256;
+
+// two consecutive doubles at 8-byte alignment (the compiler emits one 16-byte load / store for it)
+struct alignas(8) trl_d2 {
+  double x, y;
+};
 constexpr int kTrlNC = 16;  // basis vectors per sweep launch (w is read once per group; 8 per launch measured 4 % slower)
 
 // partial[(c*2+q) * gridDim + block] = sum over the block's elements of conj(Q_c) * w  (q: re, im)
@@ -25,7 +30,8 @@ __global__ void __launch_bounds__(kTrlNT)
   double sr[kTrlNC], si[kTrlNC];
 #pragma unroll
   for (int c = 0; c < kTrlNC; c++) sr[c] = si[c] = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * kTrlNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTrlNT) {
+  const int64_t nit = CPLX ? n : (n + 1) / 2;  // complex: one element per step; real: a pair
+  for (int64_t i = (int64_t)blockIdx.x * kTrlNT + threadIdx.x; i < nit; i += (int64_t)gridDim.x * kTrlNT) {
     if (CPLX) {
       const double2 x = reinterpret_cast<const double2*>(w)[i];
 #pragma unroll
@@ -35,11 +41,20 @@ __global__ void __launch_bounds__(kTrlNT)
           sr[c] += q.x * x.x + q.y * x.y;
           si[c] += q.x * x.y - q.y * x.x;
         }
-    } else {
-      const double x = w[i];
+    } else if (2 * i + 1 < n) {
+      // real vectors: the loop runs over pairs of elements (16-byte accesses), see the loop bound below
+      const trl_d2 x = reinterpret_cast<const trl_d2*>(w)[i];
 #pragma unroll
       for (int c = 0; c < kTrlNC; c++)
-        if (c < nc) sr[c] += Q[c * ldq + i] * x;
+        if (c < nc) {
+          const trl_d2 q = *reinterpret_cast<const trl_d2*>(Q + c * ldq + 2 * i);
+          sr[c] += q.x * x.x + q.y * x.y;
+        }
+    } else {  // odd tail element
+      const double x = w[2 * i];
+#pragma unroll
+      for (int c = 0; c < kTrlNC; c++)
+        if (c < nc) sr[c] += Q[c * ldq + 2 * i] * x;
     }
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -97,7 +112,8 @@ __global__ void __launch_bounds__(kTrlNT)
     any = any || hr[c] != 0.0 || hi[c] != 0.0;
   }
   if (!any) return;  // every coefficient of this group was filtered out (trl_decide_kernel): w stays as it is
-  for (int64_t i = (int64_t)blockIdx.x * kTrlNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kTrlNT) {
+  const int64_t nit = CPLX ? n : (n + 1) / 2;
+  for (int64_t i = (int64_t)blockIdx.x * kTrlNT + threadIdx.x; i < nit; i += (int64_t)gridDim.x * kTrlNT) {
     if (CPLX) {
       double2 x = reinterpret_cast<double2*>(w)[i];
 #pragma unroll
@@ -108,12 +124,22 @@ __global__ void __launch_bounds__(kTrlNT)
           x.y -= hr[c] * q.y + hi[c] * q.x;
         }
       reinterpret_cast<double2*>(w)[i] = x;
-    } else {
-      double x = w[i];
+    } else if (2 * i + 1 < n) {
+      trl_d2 x = reinterpret_cast<trl_d2*>(w)[i];
 #pragma unroll
       for (int c = 0; c < kTrlNC; c++)
-        if (c < nc && hr[c] != 0.0) x -= hr[c] * Q[c * ldq + i];
-      w[i] = x;
+        if (c < nc && hr[c] != 0.0) {
+          const trl_d2 q = *reinterpret_cast<const trl_d2*>(Q + c * ldq + 2 * i);
+          x.x -= hr[c] * q.x;
+          x.y -= hr[c] * q.y;
+        }
+      reinterpret_cast<trl_d2*>(w)[i] = x;
+    } else {
+      double x = w[2 * i];
+#pragma unroll
+      for (int c = 0; c < kTrlNC; c++)
+        if (c < nc && hr[c] != 0.0) x -= hr[c] * Q[c * ldq + 2 * i];
+      w[2 * i] = x;
     }
   }
 }
@@ -122,24 +148,56 @@ __global__ void __launch_bounds__(kTrlNT)
 __global__ void __launch_bounds__(kTrlNT)
     trl_rotate_kernel(int64_t len, int m, int nc, const double* __restrict__ Q, int64_t ldq,
                       const double* __restrict__ Y, int ldy, int c0, double* __restrict__ out, int64_t ldo) {
-  for (int64_t i = (int64_t)blockIdx.x * kTrlNT + threadIdx.x; i < len; i += (int64_t)gridDim.x * kTrlNT) {
-    double acc[kTrlNC];
+  // pairs of doubles per step (16-byte accesses), a single element at an odd tail
+  const int64_t nit = (len + 1) / 2;
+  for (int64_t i = (int64_t)blockIdx.x * kTrlNT + threadIdx.x; i < nit; i += (int64_t)gridDim.x * kTrlNT) {
+    const bool pair = 2 * i + 1 < len;
+    double ax[kTrlNC], ay[kTrlNC];
 #pragma unroll
-    for (int c = 0; c < kTrlNC; c++) acc[c] = 0.0;
+    for (int c = 0; c < kTrlNC; c++) ax[c] = ay[c] = 0.0;
     for (int j = 0; j < m; j++) {
-      const double q = Q[j * ldq + i];
+      trl_d2 q;
+      if (pair) {
+        q = *reinterpret_cast<const trl_d2*>(Q + j * ldq + 2 * i);
+      } else {
+        q.x = Q[j * ldq + 2 * i];
+        q.y = 0.0;
+      }
 #pragma unroll
       for (int c = 0; c < kTrlNC; c++)
-        if (c < nc) acc[c] = fma(Y[j * ldy + c0 + c], q, acc[c]);
+        if (c < nc) {
+          const double y = Y[j * ldy + c0 + c];
+          ax[c] = fma(y, q.x, ax[c]);
+          ay[c] = fma(y, q.y, ay[c]);
+        }
     }
 #pragma unroll
     for (int c = 0; c < kTrlNC; c++)
-      if (c < nc) out[c * ldo + i] = acc[c];
+      if (c < nc) {
+        if (pair) {
+          trl_d2 r;
+          r.x = ax[c];
+          r.y = ay[c];
+          *reinterpret_cast<trl_d2*>(out + c * ldo + 2 * i) = r;
+        } else {
+          out[c * ldo + 2 * i] = ax[c];
+        }
+      }
   }
 }
 
 __global__ void __launch_bounds__(kTrlNT) trl_scale_kernel(int64_t len, double* __restrict__ v, double f) {
-  for (int64_t i = (int64_t)blockIdx.x * kTrlNT + threadIdx.x; i < len; i += (int64_t)gridDim.x * kTrlNT) v[i] *= f;
+  const int64_t nit = (len + 1) / 2;
+  for (int64_t i = (int64_t)blockIdx.x * kTrlNT + threadIdx.x; i < nit; i += (int64_t)gridDim.x * kTrlNT) {
+    if (2 * i + 1 < len) {
+      trl_d2 x = reinterpret_cast<trl_d2*>(v)[i];
+      x.x *= f;
+      x.y *= f;
+      reinterpret_cast<trl_d2*>(v)[i] = x;
+    } else {
+      v[2 * i] *= f;
+    }
+  }
 }
 
 static inline int trl_grid(int64_t n) {
