@@ -97,6 +97,7 @@ SIGNATURES = {
                                             C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "edigpu_apply_op_normal": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "edigpu_apply_op_flat": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "edigpu_apply_cops_normal": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _pd, _pi32, _pi32, _pi32, _vp]),
     "edigpu_lanczos_tridiag_dev": (C.c_int, [_vp, _vp, C.c_int, _pd, _pd, C.c_double, C.POINTER(C.c_int), _pd]),
     "edigpu_vec_work_doubles": (C.c_int, []),
     "edigpu_vec_rotate": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),

@@ -1723,30 +1723,30 @@ int edigpu_lanczos_tridiag_dev(edigpu_handle s, const double* vin_dev, int nlanc
   return tridiag_impl(s, vin_dev, nlanc, alanc, blanc, threshold, niter_done, norm2);
 }
 
-int edigpu_apply_op_normal(edigpu_handle src, edigpu_handle dst, const double* v_src_dev, double* v_dst_dev,
-                           int iorb, int ispin, int create, void* stream) {
-  if (!src || !dst || !v_src_dev || !v_dst_dev) {
-    set_error("edigpu_apply_op_normal: NULL argument");
-    return 1;
-  }
+// one term of apply_Cops / apply_op_C / apply_op_CDG on device vectors of two normal-mode sectors:
+// v_dst (=|+=) coef * c^(+)_{iorb,ispin} v_src
+static int apply_op_normal_term(edigpu_handle src, edigpu_handle dst, const double* v_src_dev, double* v_dst_dev,
+                                int iorb, int ispin, int create, double coef, int accumulate, hipStream_t st,
+                                const char* who) {
+  const std::string w(who);
   if (src->kind != 0 || dst->kind != 0 || !src->from_model() || !dst->from_model() || src->nph > 0 || dst->nph > 0) {
-    set_error("edigpu_apply_op_normal: both handles must be normal-mode sectors built by edigpu_normal_build");
+    set_error(w + ": both handles must be normal-mode sectors built by edigpu_normal_build");
     return 1;
   }
   if (src->nloc != src->dim || dst->nloc != dst->dim) {
-    set_error("edigpu_apply_op_normal: handles must hold whole sectors (single shard)");
+    set_error(w + ": handles must hold whole sectors (single shard)");
     return 1;
   }
   const int ns = model_ns(src->model);
   if (iorb < 0 || iorb >= src->model.norb || ispin < 0 || ispin > 1) {
-    set_error("edigpu_apply_op_normal: orbital / spin out of range");
+    set_error(w + ": orbital / spin out of range");
     return 1;
   }
   const int d = create ? 1 : -1;
   const int nup_s = src->sec_a, ndw_s = src->sec_b;
   if (dst->sec_a != nup_s + (ispin == 0 ? d : 0) || dst->sec_b != ndw_s + (ispin == 1 ? d : 0) ||
       model_ns(dst->model) != ns) {
-    set_error("edigpu_apply_op_normal: destination sector is not (source sector +- one particle of that spin)");
+    set_error(w + ": destination sector is not (source sector +- one particle of that spin)");
     return 1;
   }
   EDIGPU_HIP(hipSetDevice(src->device));
@@ -1765,11 +1765,35 @@ int edigpu_apply_op_normal(edigpu_handle src, edigpu_handle dst, const double* v
   }
   uint32_t* d_part = nullptr;
   if (dev_upload(&d_part, part.data(), part.size())) return 1;
-  const int rc = launch_apply_op_normal(dst->dim_up, dst->dim_dw, src->dim_up, ispin, d_part, v_src_dev, v_dst_dev,
-                                        (hipStream_t)stream);
-  (void)hipStreamSynchronize((hipStream_t)stream);
+  const int rc = launch_apply_op_normal(dst->dim_up, dst->dim_dw, src->dim_up, ispin, d_part, v_src_dev, v_dst_dev, st,
+                                        coef, accumulate);
+  (void)hipStreamSynchronize(st);
   (void)hipFree(d_part);
   return rc;
+}
+
+int edigpu_apply_op_normal(edigpu_handle src, edigpu_handle dst, const double* v_src_dev, double* v_dst_dev,
+                           int iorb, int ispin, int create, void* stream) {
+  if (!src || !dst || !v_src_dev || !v_dst_dev) {
+    set_error("edigpu_apply_op_normal: NULL argument");
+    return 1;
+  }
+  return apply_op_normal_term(src, dst, v_src_dev, v_dst_dev, iorb, ispin, create, 1.0, 0, (hipStream_t)stream,
+                              "edigpu_apply_op_normal");
+}
+
+int edigpu_apply_cops_normal(edigpu_handle src, edigpu_handle dst, const double* v_src_dev, double* v_dst_dev,
+                             int nops, const double* coef, const int32_t* create, const int32_t* iorb,
+                             const int32_t* ispin, void* stream) {
+  if (!src || !dst || !v_src_dev || !v_dst_dev || nops <= 0 || !coef || !create || !iorb || !ispin) {
+    set_error("edigpu_apply_cops_normal: bad argument");
+    return 1;
+  }
+  for (int s = 0; s < nops; s++)
+    if (apply_op_normal_term(src, dst, v_src_dev, v_dst_dev, iorb[s], ispin[s], create[s] > 0, coef[s], s > 0,
+                             (hipStream_t)stream, "edigpu_apply_cops_normal"))
+      return 1;
+  return 0;
 }
 
 int edigpu_apply_op_flat(edigpu_handle src, edigpu_handle dst, const double* v_src_dev, double* v_dst_dev,

@@ -98,7 +98,8 @@ int trl_scale(int64_t len, double* v, double f, hipStream_t st);
 
 // ---- c / c^+ between normal-mode sectors (kernels_ops.hip) ----
 int launch_apply_op_normal(int64_t dst_dimup, int64_t dst_dimdw, int64_t src_dimup, int spin_down,
-                           const uint32_t* part, const double* src, double* dst, hipStream_t st);
+                           const uint32_t* part, const double* src, double* dst, hipStream_t st, double coef = 1.0,
+                           int accumulate = 0);
 
 int launch_phonon(const edigpu_sector* s, const double* v, double* hv, hipStream_t st);
 int launch_apply_op_flat(int64_t ndst, int ns, uint32_t bit, int create, const int32_t* dst_states,

@@ -16,7 +16,7 @@ namespace edigpu {
 __global__ void __launch_bounds__(256)
     apply_op_normal_kernel(int64_t dst_dimup, int64_t dst_dimdw, int64_t src_dimup, int spin_down,
                            const uint32_t* __restrict__ part, const double* __restrict__ src,
-                           double* __restrict__ dst) {
+                           double* __restrict__ dst, double coef, int accumulate) {
   const int64_t n = dst_dimup * dst_dimdw;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int64_t jdw = i / dst_dimup, jup = i - jdw * dst_dimup;
@@ -27,7 +27,8 @@ __global__ void __launch_bounds__(256)
       x = spin_down ? src[k * src_dimup + jup] : src[jdw * src_dimup + k];
       if (p >> 31) x = -x;
     }
-    dst[i] = x;
+    // apply_Cops: a coefficient per operator, the operators after the first add to the result
+    dst[i] = accumulate ? fma(coef, x, dst[i]) : coef * x;
   }
 }
 
@@ -253,13 +254,14 @@ int launch_phonon(const edigpu_sector* s, const double* v, double* hv, hipStream
 }
 
 int launch_apply_op_normal(int64_t dst_dimup, int64_t dst_dimdw, int64_t src_dimup, int spin_down,
-                           const uint32_t* part, const double* src, double* dst, hipStream_t st) {
+                           const uint32_t* part, const double* src, double* dst, hipStream_t st, double coef,
+                           int accumulate) {
   const int64_t n = dst_dimup * dst_dimdw;
   if (n == 0) return 0;
   int64_t nb = (n + 255) / 256;
   if (nb > 256 * 16) nb = 256 * 16;
   hipLaunchKernelGGL(apply_op_normal_kernel, dim3((unsigned)nb), dim3(256), 0, st, dst_dimup, dst_dimdw, src_dimup,
-                     spin_down, part, src, dst);
+                     spin_down, part, src, dst, coef, accumulate);
   EDIGPU_HIP(hipGetLastError());
   return 0;
 }

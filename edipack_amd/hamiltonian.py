@@ -304,6 +304,18 @@ class SectorHamiltonian:
         capi.check(capi.lib().edigpu_apply_remote_dev(self._h, v_full_ptr, hv_ptr, stream if stream else None),
                    "edigpu_apply_remote_dev")
 
+    def apply_cops_to(self, dst: "SectorHamiltonian", v_src_ptr: int, v_dst_ptr: int, coefs, creates, iorbs, ispins,
+                      stream: int = 0) -> None:
+        """apply_Cops on device vectors: |dst> = sum_s coefs[s] * c^(+)_{iorbs[s], ispins[s]} |src> (normal mode;
+        creates[s] truthy = c^+)."""
+        n = len(coefs)
+        a = (C.c_double * n)(*[float(x) for x in coefs])
+        o = (C.c_int32 * n)(*[1 if x else -1 for x in creates])
+        io = (C.c_int32 * n)(*[int(x) for x in iorbs])
+        sp = (C.c_int32 * n)(*[int(x) for x in ispins])
+        capi.check(capi.lib().edigpu_apply_cops_normal(self._h, dst._h, v_src_ptr, v_dst_ptr, n, a, o, io, sp,
+                                                       stream if stream else None), "edigpu_apply_cops_normal")
+
     # ---- transposed exchange (normal mode, N > 1; include/edigpu.h) ---------------------------
     def transpose_halo(self) -> int:
         h = C.c_int32(0)

@@ -327,6 +327,16 @@ int edigpu_lanczos_eigh_multi(edigpu_handle h, int neigen, int ncv, double tol, 
  */
 int edigpu_apply_op_normal(edigpu_handle src, edigpu_handle dst, const double *v_src_dev, double *v_dst_dev,
                            int iorb, int ispin, int create, void *stream);
+/*
+ * apply_Cops (ED_SECTOR.f90:839-960; the seeds of the off-diagonal Green's functions, ED_NORMAL/ED_GF_NORMAL.f90:
+ * 216-261: (c^+_a + c^+_b)|gs>, (c_a + c_b)|gs>): v_dst = sum_s coef[s] * O_s v_src with O_s = c^+ (create[s] > 0)
+ * or c (create[s] <= 0; the reference's Os = +1 / -1) of orbital iorb[s] (0-based), spin ispin[s] (0 up, 1 down).
+ * Every term must lead from the source sector to the same destination sector.  Real coefficients (the complex
+ * combinations c_a + i c_b belong to the _CMPLX_NORMAL build).
+ */
+int edigpu_apply_cops_normal(edigpu_handle src, edigpu_handle dst, const double *v_src_dev, double *v_dst_dev,
+                             int nops, const double *coef, const int32_t *create, const int32_t *iorb,
+                             const int32_t *ispin, void *stream);
 /* the same for superc / nonsu2 sectors (handles from edigpu_flat_build / edigpu_direct_build, complex vectors):
  * superc sectors are labelled by Sz, so c^+_up / c_dw lead to Sz+1 and c^+_dw / c_up to Sz-1; nonsu2 by Ntot.
  * The sign counts every occupied level below the operator's level in the 2*Ns-bit state (up levels first). */

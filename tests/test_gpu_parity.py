@@ -1535,3 +1535,35 @@ def test_phonon_general_coupling_matrix(gpu, monkeypatch, mode, bath, norb, nbat
     ag, bg, _ = hg.lanczos_tridiag(v, 15)
     assert rel_err(ag[:10], ao[:10]) < 1e-9 and rel_err(bg[:10], bo[:10]) < 1e-9
     hg.destroy()
+
+
+def test_apply_cops_normal(gpu):
+    """edigpu_apply_cops_normal = apply_Cops (ED_SECTOR.f90:839-960): the seeds of the off-diagonal Green's
+    functions, (c^+_a + c^+_b)|v> and (c_a - 0.5 c_b)|v>, against the test-side restatement of apply_op_C/CDG;
+    a term that leads to a different sector is refused."""
+    import torch
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from tests.gf_normal import apply_c_up
+    om, pm = make_models("normal", "hybrid", 3, 3, seed=43)
+    nup, ndw = 3, 3
+    hs_o = O.HNormal(om, nup, ndw)
+    hs = SectorHamiltonian.normal_from_model(pm, nup, ndw)
+    v = np.random.default_rng(10).standard_normal(hs.dim)
+    vd = torch.from_numpy(v).cuda()
+    for create, coefs, orbs in ((True, (1.0, 1.0), (0, 2)), (False, (1.0, -0.5), (1, 2)), (True, (0.3, 1.0, -2.0), (0, 1, 2))):
+        n2 = nup + (1 if create else -1)
+        ht_o = O.HNormal(om, n2, ndw)
+        ht = SectorHamiltonian.normal_from_model(pm, n2, ndw)
+        out = torch.full((ht.dim,), 7.0, dtype=torch.float64, device="cuda")
+        hs.apply_cops_to(ht, vd.data_ptr(), out.data_ptr(), coefs, [create] * len(orbs), orbs, [0] * len(orbs))
+        ref = sum(c * apply_c_up(hs_o, ht_o, v, a, create) for c, a in zip(coefs, orbs))
+        assert np.max(np.abs(out.cpu().numpy() - ref)) < 1e-14
+        # the off-diagonal GF seed goes straight into the device-seeded tridiagonalisation
+        a1, b1, n1, nrm2 = ht.lanczos_tridiag_dev(out.data_ptr(), 20)
+        a0, b0, n0 = ht.lanczos_tridiag(ref, 20)
+        assert n0 == n1 and rel_err(a1, a0) < 1e-12 and abs(nrm2 - ref @ ref) < 1e-12 * (ref @ ref)
+        with pytest.raises(RuntimeError, match="destination sector"):
+            hs.apply_cops_to(ht, vd.data_ptr(), out.data_ptr(), (1.0, 1.0), [create, create], (0, 1), [0, 1])
+        ht.destroy()
+    hs.destroy()
