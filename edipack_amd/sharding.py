@@ -276,6 +276,47 @@ class TransposedKernels:
                                                            self._st()))
 
 
+def _bind_fused_kernels(k: "TransposedKernels", lz, ab: torch.Tensor):
+    """The four kernel launches of one fused step with every argument converted once (ctypes objects, raw
+    pointers, the stream): the per-step host cost of the N > 1 loop is launch-bound at 8 ranks, and argument
+    marshalling was half of it.  Returns (rotate_pack(it), rows(), cols(), unpack_dot2(it))."""
+    import ctypes as C
+    from . import capi
+    L, pl, h = k.L, k.plan, k.h
+    if k.work is None:
+        k.work = torch.zeros(L.edigpu_vec_work_doubles(), dtype=torch.float64, device=lz.vin.device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    vp = lambda t: C.c_void_p(t.data_ptr())                      # noqa: E731
+    vin, vout, tmp, send, recv, hvc, back, work = map(vp, (lz.vin, lz.vout, lz.tmp, lz.send, lz.recv, lz.hvc,
+                                                            lz.back, k.work))
+    ab0 = ab.data_ptr()
+    du, cnt, q = C.c_int64(k.dim_up), C.c_int64(pl.count), C.c_int64(pl.q)
+    world, pcol, halo = C.c_int32(pl.world), C.c_int64(lz.pcol), C.c_int32(lz.halo)
+    first, ncol, pw = C.c_int64(pl.first), C.c_int64(lz.col_count), C.c_int64(lz.pw)
+    col_first, hnd, one, zero, null = C.c_int64(lz.col_first), h._h, C.c_int32(1), C.c_int32(0), C.c_void_p(None)
+    f_rp, f_rows, f_cols, f_un = (L.edigpu_transpose_rotate_pack, L.edigpu_normal_apply_rows_dev,
+                                  L.edigpu_normal_apply_cols_dev, L.edigpu_transpose_unpack_add_dot2)
+
+    def rotate_pack(it):
+        prev = null if it == 0 else C.c_void_p(ab0 + 16 * (it - 1))
+        if f_rp(one if it == 0 else zero, du, cnt, q, world, pcol, halo, vin, vout, prev, send, st):
+            capi.check(1, "edigpu_transpose_rotate_pack")
+
+    def rows():
+        if f_rows(hnd, first, cnt, vin, tmp, st):
+            capi.check(1, "edigpu_normal_apply_rows_dev")
+
+    def cols():
+        if f_cols(hnd, col_first, ncol, pw, halo, recv, hvc, st):
+            capi.check(1, "edigpu_normal_apply_cols_dev")
+
+    def unpack_dot2(it):
+        if f_un(du, cnt, q, world, pcol, halo, vin, vout, tmp, back, C.c_void_p(ab0 + 16 * it), work, st):
+            capi.check(1, "edigpu_transpose_unpack_add_dot2")
+
+    return rotate_pack, rows, cols, unpack_dot2
+
+
 class TransposedLanczos(ShardedLanczos):
     """Normal mode with the transposed exchange (reference spMatVec_mpi_normal_main,
     ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:834-866, with vector_transpose_MPI,
@@ -364,8 +405,24 @@ class TransposedLanczos(ShardedLanczos):
         self._allreduce(nrm2)
         self.ops.scale(self.vin, nrm2)
         ab = torch.zeros(2 * nlanc, dtype=torch.float64, device=self.device)
-        for it in range(nlanc):
-            self.fused_step(it, ab)
+        if isinstance(self.k, TransposedKernels) and type(self).fused_step is TransposedLanczos.fused_step \
+                and "fused_step" not in self.__dict__:
+            # library kernels: pre-bound launches (same sequence as fused_step, less host work per step)
+            rotate_pack, rows, cols, unpack_dot2 = _bind_fused_kernels(self.k, self, ab)
+            views = [ab[2 * i:2 * i + 2] for i in range(nlanc)]
+            for it in range(nlanc):
+                rotate_pack(it)
+                work = self._a2a(self.recv, self.send, async_op=True)
+                rows()
+                if work is not None:
+                    work.wait()
+                cols()
+                self._a2a(self.back, self.hvc)
+                unpack_dot2(it)
+                self._allreduce(views[it])
+        else:
+            for it in range(nlanc):
+                self.fused_step(it, ab)
         abh = ab.cpu().numpy()
         al, qq = abh[0::2], abh[1::2]
         b2 = qq - al * al
