@@ -104,6 +104,8 @@ SIGNATURES = {
     "edigpu_vec_add_dot": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "edigpu_vec_axpy_nrm2": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "edigpu_vec_scale": (C.c_int, [_i64, _vp, _vp, _vp]),
+    "edigpu_vec_rotate_lazy": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
+    "edigpu_vec_add_dot2": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "edigpu_time_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _pd]),
     "edigpu_lanczos_bench": (C.c_int, [_vp, C.c_int, C.c_int, _pd, _pd]),
     "edigpu_destroy": (C.c_int, [_vp]),

@@ -2190,6 +2190,23 @@ int edigpu_vec_axpy_nrm2(int64_t n, const double* vin_dev, double* vout_dev, con
   return vec_axpy_nrm2(n, vin_dev, vout_dev, alpha_dev, out_dev, work_dev, (hipStream_t)stream);
 }
 
+int edigpu_vec_rotate_lazy(int64_t n, double* vin_dev, double* vout_dev, const double* ab_dev, void* stream) {
+  if (n < 0 || !vin_dev || !vout_dev || !ab_dev) {
+    set_error("edigpu_vec_rotate_lazy: bad argument");
+    return 1;
+  }
+  return vec_rotate_lazy(n, vin_dev, vout_dev, ab_dev, (hipStream_t)stream);
+}
+
+int edigpu_vec_add_dot2(int64_t n, const double* vin_dev, double* vout_dev, const double* tmp_dev, double* out2_dev,
+                        double* work_dev, void* stream) {
+  if (n < 0 || !vin_dev || !vout_dev || !tmp_dev || !out2_dev || !work_dev) {
+    set_error("edigpu_vec_add_dot2: bad argument");
+    return 1;
+  }
+  return vec_add_dot2(n, vin_dev, vout_dev, tmp_dev, out2_dev, work_dev, (hipStream_t)stream);
+}
+
 int edigpu_vec_scale(int64_t n, double* v_dev, const double* nrm2_dev, void* stream) {
   if (n < 0 || !v_dev || !nrm2_dev) {
     set_error("edigpu_vec_scale: bad argument");

@@ -72,6 +72,11 @@ int vec_rotate(int64_t n, double* vin, double* vout, const double* beta2, hipStr
 int vec_add_dot(int64_t n, const double* vin, double* vout, const double* tmp, double* out, double* work, hipStream_t st);
 int vec_axpy_nrm2(int64_t n, const double* vin, double* vout, const double* alpha, double* out, double* work, hipStream_t st);
 int vec_scale(int64_t n, double* v, const double* nrm2, hipStream_t st);
+// one-reduction recurrence on any sharded vector: (v, w) <- ((w - alpha v)/beta, -beta v) from ab = (<v|w>, <w|w>),
+// and w += tmp with this rank's (<v|w>, <w|w>) (work: kRedBlocks doubles)
+int vec_rotate_lazy(int64_t n, double* vin, double* vout, const double* ab, hipStream_t st);
+int vec_add_dot2(int64_t n, const double* vin, double* vout, const double* tmp, double* out2, double* work,
+                 hipStream_t st);
 // fused vector updates of the transposed-exchange Lanczos step (work: kRedBlocks doubles)
 int vec_rotate_pack(int first, int64_t dim_up, int64_t nrows, int64_t q, int world, int64_t pcol, int halo,
                     double* vin, double* vout, const double* ab, double* send, hipStream_t st);

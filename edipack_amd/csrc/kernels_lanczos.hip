@@ -445,6 +445,53 @@ __global__ void __launch_bounds__(1024) kv_sum2(const double* __restrict__ parti
   }
 }
 
+// the same fused updates for any row-sharded vector (flat modes, all-gather form); n counts doubles
+__global__ void __launch_bounds__(kLzNT)
+    kv_rotate_lazy(int64_t n, double* __restrict__ vin, double* __restrict__ vout, const double* __restrict__ ab) {
+  const double a = ab[0], b = sqrt(ab[1] - a * a), ib = 1.0 / b;
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) {
+    const double t = vin[i];
+    vin[i] = (vout[i] - a * t) * ib;
+    vout[i] = -b * t;
+  }
+}
+
+__global__ void __launch_bounds__(kLzNT)
+    kv_add_dot2(int64_t n, const double* __restrict__ vin, double* __restrict__ vout, const double* __restrict__ tmp,
+                double* __restrict__ partial) {
+  double s = 0.0, qq = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) {
+    const double w = vout[i] + tmp[i];
+    vout[i] = w;
+    s += vin[i] * w;
+    qq += w * w;
+  }
+  s = block_sum(s);
+  qq = block_sum(qq);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = s;
+    partial[kRedBlocks / 2 + blockIdx.x] = qq;
+  }
+}
+
+int vec_rotate_lazy(int64_t n, double* vin, double* vout, const double* ab, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(kv_rotate_lazy, ew_grid(n), dim3(kLzNT), 0, st, n, vin, vout, ab);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int vec_add_dot2(int64_t n, const double* vin, double* vout, const double* tmp, double* out2, double* work,
+                 hipStream_t st) {
+  int64_t nb = (n + kLzNT - 1) / kLzNT;
+  if (nb > kRedBlocks / 2) nb = kRedBlocks / 2;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(kv_add_dot2, dim3((unsigned)nb), dim3(kLzNT), 0, st, n, vin, vout, tmp, work);
+  hipLaunchKernelGGL(kv_sum2, dim3(1), dim3(1024), 0, st, work, (int)nb, out2);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 int vec_rotate_pack(int first, int64_t dim_up, int64_t nrows, int64_t q, int world, int64_t pcol, int halo,
                     double* vin, double* vout, const double* ab, double* send, hipStream_t st) {
   if (nrows * dim_up <= 0) return 0;

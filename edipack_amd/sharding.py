@@ -96,6 +96,22 @@ class TorchVecOps:
         b = torch.sqrt(nrm2)
         v.div_(b.to(v.dtype) if v.is_complex() else b)
 
+    # one-reduction recurrence (see ShardedLanczos.tridiag)
+    def rotate_lazy(self, vin, vout, ab):
+        a = ab[0]
+        b = torch.sqrt(ab[1] - a * a)
+        if vin.is_complex():
+            a, b = a.to(vin.dtype), b.to(vin.dtype)
+        t = vin.clone()
+        torch.div(vout - a * t, b, out=vin)
+        torch.mul(t, -b, out=vout)
+
+    def add_dot2(self, vin, vout, tmp, out2):
+        vout.add_(tmp)
+        r = self._real(vout)
+        out2[0] = torch.sum(self._real(vin) * r)
+        out2[1] = torch.sum(r * r)
+
 
 class NativeVecOps:
     """The same through the library's fused vector kernels (edigpu_vec_*, include/edigpu.h): one
@@ -136,6 +152,14 @@ class NativeVecOps:
 
     def scale(self, v, nrm2):
         self.check(self.L.edigpu_vec_scale(self._n(v), v.data_ptr(), nrm2.data_ptr(), self._st()))
+
+    def rotate_lazy(self, vin, vout, ab):
+        self.check(self.L.edigpu_vec_rotate_lazy(self._n(vin), vin.data_ptr(), vout.data_ptr(), ab.data_ptr(),
+                                                 self._st()))
+
+    def add_dot2(self, vin, vout, tmp, out2):
+        self.check(self.L.edigpu_vec_add_dot2(self._n(vin), vin.data_ptr(), vout.data_ptr(), tmp.data_ptr(),
+                                              out2.data_ptr(), self.work.data_ptr(), self._st()))
 
 
 class ShardedLanczos:
@@ -196,9 +220,60 @@ class ShardedLanczos:
         self._allreduce(beta2s[it:it + 1])
 
     # -- sp_lanc_tridiag ------------------------------------------------------------------------
-    def tridiag(self, v_local: torch.Tensor, nlanc: int, threshold: float = 0.0):
-        """v_local: this rank's slice (length plan.nloc).  Returns (alanc, blanc, niter) on the host."""
+    def _start(self, v_local: torch.Tensor) -> None:
+        nl = self.plan.nloc
+        self.vin.zero_()
+        self.vin[:nl].copy_(v_local)
+        self.vout.zero_()
+        nrm2 = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.ops.nrm2(self.vin, nrm2)
+        self._allreduce(nrm2)
+        self.ops.scale(self.vin, nrm2)
+
+    @staticmethod
+    def _coefficients_from_ab(abh, nlanc: int, threshold: float):
+        """alanc, blanc, niter from the history of (<v|w>, <w|w>); None when beta^2 = <w|w> - alpha^2 lost more than
+        three digits somewhere (or the recurrence broke down): the caller repeats the run with the exact form."""
         import numpy as np
+        al, qq = abh[0::2], abh[1::2]
+        b2 = qq - al * al
+        alanc, blanc, ndone = np.zeros(nlanc), np.zeros(nlanc), nlanc
+        for k in range(nlanc):
+            if not (b2[k] > 1e-3 * qq[k]):
+                return None
+            alanc[k] = al[k]
+            be = np.sqrt(b2[k])
+            if abs(be) < threshold:
+                ndone = k + 1
+                break
+            if k + 1 < nlanc:
+                blanc[k + 1] = be
+        alanc[ndone:] = 0.0
+        blanc[ndone:] = 0.0
+        return alanc, blanc, ndone
+
+    def tridiag(self, v_local: torch.Tensor, nlanc: int, threshold: float = 0.0, exact: bool = False):
+        """v_local: this rank's slice (length plan.nloc).  Returns (alanc, blanc, niter) on the host.
+
+        Default: one all-reduce of (<v|w>, <w|w>) per step, beta^2 = <w|w> - alpha^2, the axpy folded into the next
+        rotate (vec_ops.add_dot2 / rotate_lazy).  exact=True (or EDIGPU_LANCZOS_EXACTBETA, or vec_ops without these
+        two methods, or cancellation seen in the history): the literal two-reduction recurrence."""
+        import numpy as np
+        exact = exact or bool(os.environ.get("EDIGPU_LANCZOS_EXACTBETA")) or not hasattr(self.ops, "add_dot2")
+        if not exact:
+            self._start(v_local)
+            ab = torch.zeros(2 * nlanc, dtype=torch.float64, device=self.device)
+            views = [ab[2 * i:2 * i + 2] for i in range(nlanc)]
+            for it in range(nlanc):
+                if it > 0:
+                    self.ops.rotate_lazy(self.vin, self.vout, views[it - 1])
+                self.hv()
+                self.ops.add_dot2(self.vin, self.vout, self.tmp, views[it])
+                self._allreduce(views[it])
+            res = self._coefficients_from_ab(ab.cpu().numpy(), nlanc, threshold)
+            if res is not None:
+                return res
+            # the same values on every rank, so every rank takes this branch together
         nl = self.plan.nloc
         self.vin.zero_()
         self.vin[:nl].copy_(v_local)
@@ -394,16 +469,8 @@ class TransposedLanczos(ShardedLanczos):
 
     def tridiag(self, v_local: torch.Tensor, nlanc: int, threshold: float = 0.0):
         if not self.fused:
-            return super().tridiag(v_local, nlanc, threshold)
-        import numpy as np
-        nl = self.plan.nloc
-        self.vin.zero_()
-        self.vin[:nl].copy_(v_local)
-        self.vout.zero_()
-        nrm2 = torch.zeros(1, dtype=torch.float64, device=self.device)
-        self.ops.nrm2(self.vin, nrm2)
-        self._allreduce(nrm2)
-        self.ops.scale(self.vin, nrm2)
+            return super().tridiag(v_local, nlanc, threshold, exact=True)
+        self._start(v_local)
         ab = torch.zeros(2 * nlanc, dtype=torch.float64, device=self.device)
         if isinstance(self.k, TransposedKernels) and type(self).fused_step is TransposedLanczos.fused_step \
                 and "fused_step" not in self.__dict__:
@@ -423,29 +490,12 @@ class TransposedLanczos(ShardedLanczos):
         else:
             for it in range(nlanc):
                 self.fused_step(it, ab)
-        abh = ab.cpu().numpy()
-        al, qq = abh[0::2], abh[1::2]
-        b2 = qq - al * al
-        alanc, blanc, ndone = np.zeros(nlanc), np.zeros(nlanc), nlanc
-        for k in range(nlanc):
-            if not (b2[k] > 1e-3 * qq[k]):
-                # beta^2 = <w|w> - alpha^2 lost more than three digits (or the recurrence broke down): the same
-                # values on every rank, so every rank repeats the run with the exact two-reduction recurrence
-                self.exact = True
-                try:
-                    return super().tridiag(v_local, nlanc, threshold)
-                finally:
-                    self.exact = False
-            alanc[k] = al[k]
-            be = np.sqrt(b2[k])
-            if abs(be) < threshold:
-                ndone = k + 1
-                break
-            if k + 1 < nlanc:
-                blanc[k + 1] = be
-        alanc[ndone:] = 0.0
-        blanc[ndone:] = 0.0
-        return alanc, blanc, ndone
+        res = self._coefficients_from_ab(ab.cpu().numpy(), nlanc, threshold)
+        if res is not None:
+            return res
+        # beta^2 = <w|w> - alpha^2 lost more than three digits (or the recurrence broke down): the same values on
+        # every rank, so every rank repeats the run with the exact two-reduction recurrence
+        return super().tridiag(v_local, nlanc, threshold, exact=True)
 
 
 def gpu_transposed_hamiltonian(model, sector, world: int, rank: int, group=None, stage_host: bool = False):

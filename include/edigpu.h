@@ -376,6 +376,14 @@ int edigpu_vec_add_dot(int64_t n, const double *vin_dev, double *vout_dev, const
 int edigpu_vec_axpy_nrm2(int64_t n, const double *vin_dev, double *vout_dev, const double *alpha_dev,
                          double *out_dev, double *work_dev, void *stream);
 int edigpu_vec_scale(int64_t n, double *v_dev, const double *nrm2_dev, void *stream);
+/* One-reduction form of the same step (one all-reduce of two doubles per step instead of two of one):
+ *   edigpu_vec_add_dot2     w += tmp; out2 = this rank's (<v|w>, <w|w>)
+ *   edigpu_vec_rotate_lazy  ab = the summed (<v|w>, <w|w>) of the previous step: alpha = ab[0],
+ *                           beta^2 = ab[1] - alpha^2; (v, w) <- ((w - alpha v) / beta, -beta v)
+ * The caller checks the history for cancellation in beta^2 and falls back to the two-reduction calls above. */
+int edigpu_vec_rotate_lazy(int64_t n, double *vin_dev, double *vout_dev, const double *ab_dev, void *stream);
+int edigpu_vec_add_dot2(int64_t n, const double *vin_dev, double *vout_dev, const double *tmp_dev, double *out2_dev,
+                        double *work_dev, void *stream);
 
 /*
  * Timing helper for bench.py: runs `warmup` untimed and `steps` timed H*v

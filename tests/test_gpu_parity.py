@@ -567,6 +567,9 @@ def test_sharded_lanczos_gpu_world1(gpu, mode, bath, norb, nbath, sec):
     a, b, n = lz.tridiag(torch.from_numpy(v).cuda(), 30)
     a_ref, b_ref, _ = ho.lanc_tridiag(v, 30)
     assert rel_err(a[:12], a_ref[:12]) < 1e-10 and rel_err(b[:12], b_ref[:12]) < 1e-10
+    # the literal two-reduction recurrence (what the one-reduction default falls back to) gives the same
+    a2, b2, n2 = lz.tridiag(torch.from_numpy(v).cuda(), 30, exact=True)
+    assert n2 == n and rel_err(a2[:12], a[:12]) < 1e-10 and rel_err(b2[:12], b[:12]) < 1e-10
     h.destroy()
 
 
