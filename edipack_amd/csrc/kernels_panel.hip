@@ -253,10 +253,21 @@ __global__ void __launch_bounds__(kPanelNT)
   int64_t rend = (int64_t)(chunk + 1) * p.rows_per_block;
   if (rend > a.dw_count) rend = a.dw_count;
   constexpr int NW = kPanelNT / 64;
+  // Hnd partner of a column, per term: 0xFFFFFFFF = the term does not apply to this column; bit 31 = sign;
+  // inside this wave's segment: bits 0..6 = (lane << 1) | component of the lane that holds the partner column
+  // (the partner row's segment is loaded once, coalesced, and the element fetched with a cross-lane read);
+  // bit 30 = outside the segment (panel edge): bits 0..29 = the column, fetched with its own 8-byte load
+  const int64_t pbase = (int64_t)panel * p.width;
+  auto encode = [&](uint32_t jt) -> uint32_t {
+    if (jt == 0xFFFFFFFFu) return jt;
+    const int64_t rel = (int64_t)(jt & 0x7FFFFFFFu) - pbase;
+    if (rel >= 0 && rel < p.width) return (jt & 0x80000000u) | (uint32_t)rel;
+    return (jt & 0x80000000u) | 0x40000000u | (jt & 0x3FFFFFFFu);
+  };
   if (DO_ND)
     for (int t = 0; t < a.nterms; t++) {
-      ju2[(2 * t) * kPanelNT + threadIdx.x] = a.jup[(int64_t)t * DimUp + cc];
-      ju2[(2 * t + 1) * kPanelNT + threadIdx.x] = pair ? a.jup[(int64_t)t * DimUp + cc + 1] : 0xFFFFFFFFu;
+      ju2[(2 * t) * kPanelNT + threadIdx.x] = encode(a.jup[(int64_t)t * DimUp + cc]);
+      ju2[(2 * t + 1) * kPanelNT + threadIdx.x] = pair ? encode(a.jup[(int64_t)t * DimUp + cc + 1]) : 0xFFFFFFFFu;
     }
   auto row_sum = [&](int64_t r, double2 acc) -> double2 {
     if (!DO_ND) {
@@ -270,25 +281,36 @@ __global__ void __launch_bounds__(kPanelNT)
         acc.y += w * y.y;
       }
     } else {
+      // merged list of the row: its down hops first (as many as the row of Hdw holds), then the applicable Hnd terms
       const int32_t b0 = a.mx_rowptr[r], e0 = a.mx_rowptr[r + 1];
-#pragma unroll 2
-      for (int32_t jj = b0; jj < e0; jj++) {
+      const int64_t g = a.dw_first + r;
+      const int32_t mid = b0 + (a.dw_rowptr[g + 1] - a.dw_rowptr[g]);
+#pragma unroll 4
+      for (int32_t jj = b0; jj < mid; jj++) {
+        const double w = a.mx_val[jj];
+        const double2 y = ld2(&v_full[(int64_t)((uint32_t)a.mx_col[jj] & 0xFFFFFFu) * DimUp + cc]);
+        acc.x += w * y.x;
+        acc.y += w * y.y;
+      }
+      for (int32_t jj = mid; jj < e0; jj++) {
         const uint32_t cw = (uint32_t)a.mx_col[jj];
-        const int tag = (int)(cw >> 24);  // wave-uniform
+        const int tag = (int)(cw >> 24);  // wave-uniform, >= 1
         const double w = a.mx_val[jj];
         const int64_t base = (int64_t)(cw & 0xFFFFFFu) * DimUp;
-        if (tag == 0) {
-          const double2 y = ld2(&v_full[base + cc]);
-          acc.x += w * y.x;
-          acc.y += w * y.y;
-        } else {
-          const uint32_t j0 = ju2[(2 * (tag - 1)) * kPanelNT + threadIdx.x];
-          const uint32_t j1 = ju2[(2 * (tag - 1) + 1) * kPanelNT + threadIdx.x];
-          const bool v0 = j0 != 0xFFFFFFFFu, v1 = j1 != 0xFFFFFFFFu;
-          const double w0 = v0 ? ((j0 >> 31) ? -w : w) : 0.0, w1 = v1 ? ((j1 >> 31) ? -w : w) : 0.0;
-          acc.x += w0 * v_full[base + (v0 ? (int64_t)(j0 & 0x7FFFFFFFu) : cc)];
-          acc.y += w1 * v_full[base + (v1 ? (int64_t)(j1 & 0x7FFFFFFFu) : cc)];
-        }
+        const uint32_t j0 = ju2[(2 * (tag - 1)) * kPanelNT + threadIdx.x];
+        const uint32_t j1 = ju2[(2 * (tag - 1) + 1) * kPanelNT + threadIdx.x];
+        const bool v0 = j0 != 0xFFFFFFFFu, v1 = j1 != 0xFFFFFFFFu;
+        const double w0 = v0 ? ((j0 >> 31) ? -w : w) : 0.0, w1 = v1 ? ((j1 >> 31) ? -w : w) : 0.0;
+        // the partner row's segment, coalesced like a down hop; the partner columns sit a few lanes away
+        const double2 y = ld2(&v_full[base + cc]);
+        const int l0 = (int)((j0 >> 1) & 63u), l1 = (int)((j1 >> 1) & 63u);
+        const double s0x = __shfl(y.x, l0, 64), s0y = __shfl(y.y, l0, 64);
+        const double s1x = __shfl(y.x, l1, 64), s1y = __shfl(y.y, l1, 64);
+        double p0 = (j0 & 1u) ? s0y : s0x, p1 = (j1 & 1u) ? s1y : s1x;
+        if (v0 && (j0 & 0x40000000u)) p0 = v_full[base + (int64_t)(j0 & 0x3FFFFFFFu)];  // panel edge
+        if (v1 && (j1 & 0x40000000u)) p1 = v_full[base + (int64_t)(j1 & 0x3FFFFFFFu)];
+        acc.x += w0 * p0;
+        acc.y += w1 * p1;
       }
     }
     return acc;
