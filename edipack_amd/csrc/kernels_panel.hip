@@ -434,11 +434,7 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
   const bool edge = (a.dim_up % 2) != 0;  // odd DimUp: 8-byte aligned rows, see d2u
   // EDIGPU_PANEL_VEC2_MIN: smallest sector (rows) that takes the two-column kernel (tests force it on small ones)
   static const int64_t vec2_min = getenv("EDIGPU_PANEL_VEC2_MIN") ? atoll(getenv("EDIGPU_PANEL_VEC2_MIN")) : ((int64_t)1 << 21);
-  // L2 fit: a 128-column panel over all DimDw rows must still live in the 4 MiB L2 (config 2: 3432 rows, 3.5 MB),
-  // unless the 64-column panel of the one-column kernel does not fit either (measured: Ns=15 ladder, 6435 rows:
-  // one-column 1.23 ms, two-column 1.35 ms; Ns=16, 12870 rows: 5.07 vs 4.87 ms)
-  const bool l2_ok = a.dim_dw <= 3700 || a.dim_dw > 8000 || getenv("EDIGPU_PANEL_VEC2_MIN") != nullptr;
-  const bool vec2 = vec2_env && do_dw && l2_ok && a.dim_up >= 2 && a.dim_up * a.dw_count >= vec2_min &&
+  const bool vec2 = vec2_env && do_dw && a.dim_up >= 2 && a.dim_up * a.dw_count >= vec2_min &&
                     (((uintptr_t)v_full | (uintptr_t)hv) & (edge ? 7 : 15)) == 0;
   PanelArgs p;
   if (vec2) {
