@@ -1570,3 +1570,33 @@ def test_apply_cops_normal(gpu):
             hs.apply_cops_to(ht, vd.data_ptr(), out.data_ptr(), (1.0, 1.0), [create, create], (0, 1), [0, 1])
         ht.destroy()
     hs.destroy()
+
+
+def test_transposed_entry_points_reject_bad_arguments(gpu):
+    """Row / column ranges outside the sector, a halo smaller than the sector needs, a row stride that cannot
+    hold the columns, inconsistent block sizes: every entry point of the transposed exchange fails with a
+    message instead of launching."""
+    import torch
+    from edipack_amd import capi
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    _, pm = make_models("normal", "hybrid", 2, 3, seed=66)
+    h = SectorHamiltonian.normal_from_model(pm, 3, 2)
+    halo = h.transpose_halo()
+    assert halo >= 1
+    buf = torch.zeros(4 * h.dim, dtype=torch.float64, device="cuda")
+    p0, st = buf.data_ptr(), torch.cuda.current_stream().cuda_stream
+    with pytest.raises(RuntimeError, match="row range"):
+        h.apply_rows_dev(h.dim_dw - 1, 2, p0, p0, st)
+    with pytest.raises(RuntimeError, match="column range"):
+        h.apply_cols_dev(h.dim_up - 1, 2, 2 + 2 * halo, halo, p0, p0, st)
+    with pytest.raises(RuntimeError, match="halo"):
+        h.apply_cols_dev(0, 4, 4 + 2 * halo, halo - 1, p0, p0, st)
+    with pytest.raises(RuntimeError, match="row stride"):
+        h.apply_cols_dev(0, 4, 4 + 2 * halo - 1, halo, p0, p0, st)
+    L = capi.lib()
+    for rc in (L.edigpu_transpose_pack(h.dim_up, 3, 2, 2, 5, halo, p0, p0, st),             # nrows > q
+               L.edigpu_transpose_pack(h.dim_up, 2, 2, 2, 1, halo, p0, p0, st),             # pcol * world < DimUp
+               L.edigpu_transpose_unpack_add(h.dim_up, 2, 2, 0, 5, halo, p0, p0, st),       # world = 0
+               L.edigpu_transpose_rotate_pack(0, h.dim_up, 2, 2, 2, 5, halo, p0, p0, None, p0, st)):  # no ab
+        assert rc != 0 and capi.last_error()
+    h.destroy()
