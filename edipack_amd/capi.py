@@ -92,6 +92,7 @@ SIGNATURES = {
     "edigpu_lanczos_tridiag": (C.c_int, [_vp, _pd, C.c_int, _pd, _pd, C.c_double, _pint]),
     "edigpu_lanczos_eigh": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int, _pd, _pd, _pd, _pint]),
     "edigpu_orbs_build": (C.c_int, [C.POINTER(_vp), C.POINTER(EdigpuModel), _pi32, _pi32]),
+    "edigpu_orbs_build_rows": (C.c_int, [C.POINTER(_vp), C.POINTER(EdigpuModel), _pi32, _pi32, _i64, _i64]),
     "edigpu_orbs_create": (C.c_int, [C.POINTER(_vp), C.c_int, _pi64, _pd, _pi64, _pi32, _pd]),
     "edigpu_lanczos_eigh_multi": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, _vp, _pd, _vp,
                                             C.POINTER(C.c_int), C.POINTER(C.c_int)]),

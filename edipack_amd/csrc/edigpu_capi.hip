@@ -679,8 +679,13 @@ static int apply_any(edigpu_sector* s, const double* v_local, const double* v_fu
     return apply_eph_operator(s, v_full, hv, 2, st);
   }
   if (s->kind == 3) {
-    // ed_total_ud = F: single shard only (phase 1 = everything, phase 2 = nothing left to add)
-    if (phase == 2) return 0;
+    // ed_total_ud = F.  Whole sector: phase 1 = everything, phase 2 = nothing left to add.  Row shard
+    // (edigpu_orbs_build_rows): like the on-the-fly sectors the whole product needs the gathered vector.
+    if (s->nloc == s->dim) {
+      if (phase == 2) return 0;
+      return launch_orbs(s, v_full, hv, st);
+    }
+    if (phase == 1) return launch_zero(hv, s->nloc, st);
     return launch_orbs(s, v_full, hv, st);
   }
   if (s->kind == 2) {
@@ -1245,6 +1250,11 @@ int edigpu_direct_build(edigpu_handle* h, const edigpu_model* model, int sector,
 }
 
 int edigpu_orbs_build(edigpu_handle* h, const edigpu_model* model, const int32_t* nups, const int32_t* ndws) {
+  return edigpu_orbs_build_rows(h, model, nups, ndws, 0, -1);
+}
+
+int edigpu_orbs_build_rows(edigpu_handle* h, const edigpu_model* model, const int32_t* nups, const int32_t* ndws,
+                           int64_t row_first, int64_t row_count) {
   if (!h || !model || !nups || !ndws) {
     set_error("edigpu_orbs_build: NULL argument");
     return 1;
@@ -1261,12 +1271,19 @@ int edigpu_orbs_build(edigpu_handle* h, const edigpu_model* model, const int32_t
     set_error("edigpu_orbs_build: empty sector");
     return 1;
   }
+  if (row_count < 0) row_count = ho.dim - row_first;
+  if (row_first < 0 || row_count < 0 || row_first + row_count > ho.dim) {
+    set_error("edigpu_orbs_build_rows: row range outside the sector");
+    return 1;
+  }
   std::unique_ptr<edigpu_sector> s(new edigpu_sector());
   s->model = *model;
   if (setup_orbs(s.get(), ho, nullptr)) {
     edigpu_destroy(s.release());
     return 1;
   }
+  s->row_first = row_first;  // the factored tables describe the whole sector; only the rows computed differ
+  s->nloc = row_count;
   *h = s.release();
   return 0;
 }

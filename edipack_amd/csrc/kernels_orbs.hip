@@ -16,8 +16,12 @@ namespace edigpu {
 constexpr int kOrbsNT = 256;
 
 __global__ void __launch_bounds__(kOrbsNT)
-    orbs_rows_kernel(OrbsArgs a, const double* __restrict__ v, double* __restrict__ hv) {
-  for (int64_t i = (int64_t)blockIdx.x * kOrbsNT + threadIdx.x; i < a.dim; i += (int64_t)gridDim.x * kOrbsNT) {
+    orbs_rows_kernel(OrbsArgs a, int64_t row_first, int64_t row_count, const double* __restrict__ v,
+                     double* __restrict__ hv) {
+  // rows [row_first, row_first + row_count) of the sector (a shard: spMatVec_mpi_normal_orbs, :932-1082, as the
+  // all-gather form); v is the whole vector, hv holds the shard's rows
+  for (int64_t il = (int64_t)blockIdx.x * kOrbsNT + threadIdx.x; il < row_count; il += (int64_t)gridDim.x * kOrbsNT) {
+    const int64_t i = row_first + il;
     uint32_t rem = (uint32_t)i;
     int idx[kOrbsMaxAxes];
     uint32_t bits = 0;
@@ -37,7 +41,7 @@ __global__ void __launch_bounds__(kOrbsNT)
         idx[k] = 0;
       }
     }
-    dg = a.hd != nullptr ? a.hd[i] : dg + a.xtab[bits];
+    dg = a.hd != nullptr ? a.hd[il] : dg + a.xtab[bits];
     double acc = dg * v[i];
 #pragma unroll
     for (int k = 0; k < kOrbsMaxAxes; k++) {
@@ -52,15 +56,15 @@ __global__ void __launch_bounds__(kOrbsNT)
         }
       }
     }
-    hv[i] = acc;
+    hv[il] = acc;
   }
 }
 
 int launch_orbs(const edigpu_sector* s, const double* v, double* hv, hipStream_t st) {
-  if (s->dim == 0) return 0;
-  int64_t nb = (s->dim + kOrbsNT - 1) / kOrbsNT;
+  if (s->nloc == 0) return 0;
+  int64_t nb = (s->nloc + kOrbsNT - 1) / kOrbsNT;
   if (nb > 256 * 32) nb = 256 * 32;
-  hipLaunchKernelGGL(orbs_rows_kernel, dim3((unsigned)nb), dim3(kOrbsNT), 0, st, s->orbs, v, hv);
+  hipLaunchKernelGGL(orbs_rows_kernel, dim3((unsigned)nb), dim3(kOrbsNT), 0, st, s->orbs, s->row_first, s->nloc, v, hv);
   EDIGPU_HIP(hipGetLastError());
   return 0;
 }

@@ -178,8 +178,10 @@ class SectorHamiltonian:
         return cls(h)
 
     @classmethod
-    def orbs_from_model(cls, model: ImpurityModel, nups, ndws) -> "SectorHamiltonian":
-        """ed_total_ud=F: sector with per-orbital (Nup_a, Ndw_a) (build_Hv_sector_normal -> ed_buildh_normal_orbs)."""
+    def orbs_from_model(cls, model: ImpurityModel, nups, ndws, row_first: int = 0,
+                        row_count: int = -1) -> "SectorHamiltonian":
+        """ed_total_ud=F: sector with per-orbital (Nup_a, Ndw_a) (build_Hv_sector_normal -> ed_buildh_normal_orbs);
+        row_first / row_count: a row shard (spMatVec_mpi_normal_orbs, all-gather form)."""
         no = model.norb
         a = np.ascontiguousarray(nups, dtype=np.int32)
         b = np.ascontiguousarray(ndws, dtype=np.int32)
@@ -187,8 +189,8 @@ class SectorHamiltonian:
             raise capi.EdigpuError("orbs_from_model: nups/ndws need Norb entries each")
         h = C.c_void_p()
         cm = model.to_c()
-        capi.check(capi.lib().edigpu_orbs_build(C.byref(h), C.byref(cm), capi.pi32(a), capi.pi32(b)),
-                   "edigpu_orbs_build")
+        capi.check(capi.lib().edigpu_orbs_build_rows(C.byref(h), C.byref(cm), capi.pi32(a), capi.pi32(b), row_first,
+                                                     row_count), "edigpu_orbs_build")
         return cls(h)
 
     @classmethod

@@ -181,6 +181,12 @@ int edigpu_direct_build(edigpu_handle *h, const edigpu_model *model, int sector,
  * Single shard only (the MPI variant :932-1082 is not built).  All apply / Lanczos entry points work on it.
  */
 int edigpu_orbs_build(edigpu_handle *h, const edigpu_model *model, const int32_t *nups, const int32_t *ndws);
+/* The same sector as a row shard (rows [row_first, row_first + row_count) of the tensor-ordered vector; row_count < 0:
+ * to the end), for spMatVec_mpi_normal_orbs (ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:932-1082) in the
+ * all-gather form: edigpu_apply_local_dev zeroes hv, edigpu_apply_remote_dev computes the shard's rows from the
+ * gathered vector (the factored tables are O(sum of the axis sizes), every rank holds them whole). */
+int edigpu_orbs_build_rows(edigpu_handle *h, const edigpu_model *model, const int32_t *nups, const int32_t *ndws,
+                           int64_t row_first, int64_t row_count);
 /* hand-over of the reference's own arrays: spH0d (dim values) and spH0ups(1:Norb), spH0dws(1:Norb) as ONE
  * CSR with the rows of the 2*Norb factors stacked (rowptr of sum(dims)+1 entries, columns local to their
  * factor, 0-based).  dims[k]: k < Norb = DimUps(k+1), k >= Norb = DimDws(k-Norb+1). */

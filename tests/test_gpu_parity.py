@@ -1600,3 +1600,35 @@ def test_transposed_entry_points_reject_bad_arguments(gpu):
                L.edigpu_transpose_rotate_pack(0, h.dim_up, 2, 2, 2, 5, halo, p0, p0, None, p0, st)):  # no ab
         assert rc != 0 and capi.last_error()
     h.destroy()
+
+
+@pytest.mark.parametrize("norb,nbath,nups,ndws,nshard", [(2, 2, (1, 2), (2, 1), 2), (3, 2, (1, 1, 2), (2, 1, 1), 3),
+                                                         (2, 3, (2, 2), (1, 3), 5)])
+def test_orbs_row_shards(gpu, norb, nbath, nups, ndws, nshard):
+    """ed_total_ud=F sector as row shards (spMatVec_mpi_normal_orbs in the all-gather form): local phase zeroes,
+    remote phase computes the shard's rows from the gathered vector; ragged last shard."""
+    import torch
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from edipack_amd.sharding import ShardPlan
+    om, pm = _orbs_models(norb, nbath, seed=71)
+    ho = O.HOrbs(om, nups, ndws)
+    v = np.random.default_rng(12).standard_normal(ho.dim)
+    ref = ho.matvec(v)
+    vd = torch.from_numpy(v).cuda()
+    out, st = [], torch.cuda.current_stream().cuda_stream
+    for r in range(nshard):
+        pl = ShardPlan(units=ho.dim, unit_len=1, world=nshard, rank=r)
+        hs = SectorHamiltonian.orbs_from_model(pm, nups, ndws, row_first=pl.first, row_count=pl.count)
+        assert hs.dim == ho.dim and hs.nloc == pl.count and hs.row_first == pl.first
+        hv = torch.full((max(pl.count, 1),), 7.0, dtype=torch.float64, device="cuda")
+        hs.apply_local_dev(vd[pl.first:].data_ptr() if pl.count else vd.data_ptr(), hv.data_ptr(), st)
+        hs.apply_remote_dev(vd.data_ptr(), hv.data_ptr(), st)
+        torch.cuda.synchronize()
+        out.append(hv[:pl.count].cpu().numpy())
+        with pytest.raises(RuntimeError, match="shard"):
+            hs.lanczos_tridiag(v[:max(pl.count, 1)], 3)
+        hs.destroy()
+    assert rel_err(np.concatenate(out), ref) < TOL
+    with pytest.raises(RuntimeError, match="row range"):
+        SectorHamiltonian.orbs_from_model(pm, nups, ndws, row_first=ho.dim - 1, row_count=5)
