@@ -189,9 +189,10 @@ __global__ void __launch_bounds__(NT)
           for (int e = 0; e < kE; e++) acc[r][e] = h[e] * x[e];
         }
       // ---- (1 (x) Hup): gather inside the row; one 16-byte load brings 4 packed slots.
-      // Slots are fetched KU at a time into registers first, so that KU independent L2 loads are
+      // Slots are fetched KU at a time into registers first (KU = 4 measured 2 % faster than 6 on config 2 and the
+      // Ns=16 ladder, 12 is 7 % slower: registers, not load latency, are the limit), so that KU independent L2 loads are
       // in flight per lane before the first LDS gather is issued. ----
-      constexpr int KU = 6;
+      constexpr int KU = 4;
       // Typed ELL of an LDS sector (the normal case): slot k = one hop type with a wave-uniform
       // amplitude; an entry is (byte offset in the staged row) | sign << 31, dead entries name the
       // row's zero slot.  Per gather: v_and, ds_read_b64, v_bitop3 (sign), v_fma_f64.
