@@ -90,7 +90,18 @@ def main():
                 nl = min(ho.dim, 8)
                 ao, bo, _ = ho.lanc_tridiag(v, nl)
                 ag, bg, _ = h.lanczos_tridiag(v, nl)
-                assert rel(ag[:4], ao[:4]) < 1e-9 and rel(bg[:4], bo[:4]) < 1e-9, (tag, sec)
+                # compare up to the first (near) breakdown of the recurrence: tiny sectors with symmetric baths have
+                # Krylov spaces of a few dimensions, and past beta ~ 0 both sides amplify rounding
+                nc = 4
+                for kk in range(1, 4):
+                    if abs(bo[kk]) < 1e-6 * max(1.0, float(np.max(np.abs(ao[:4])))):
+                        nc = kk
+                        break
+                okc = rel(ag[:nc], ao[:nc]) < 1e-8 and (nc < 2 or rel(bg[:nc], bo[:nc]) < 1e-8)
+                if not okc:
+                    print("TRIDIAG MISMATCH", tag, sec, "\n gpu a", ag[:5], "b", bg[:5], "\n ref a", ao[:5], "b", bo[:5],
+                          flush=True)
+                assert okc, (tag, sec)
         # transposed exchange, emulated, on the plain real normal sectors
         if mode == "normal" and not cmplx and nph == 0 and ho.dim > 0:
             h = hs[0]
