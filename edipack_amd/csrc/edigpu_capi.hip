@@ -324,7 +324,30 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
   s->h_up = up;
   s->h_dw = dw;
   s->rows_per_block = normal_pick_rows_per_block(dim_up, dw_count);
-  if (upload_ell(s->up_ell, up, s->rows_per_block != 0)) return 1;
+  // Rows longer than the LDS (rows_per_block == 0): staged in column parts when the typed LDS image exists
+  // (normal_rows_kernel SPLIT); EDIGPU_ROW_SPLIT=<parts> forces it on any sector (tests), =0 switches it off.
+  {
+    const char* e = getenv("EDIGPU_ROW_SPLIT");
+    int parts = 0;
+    if (e) {
+      parts = atoi(e);
+      if (parts > 1) s->rows_per_block = 0;
+    } else if (s->rows_per_block == 0) {
+      parts = (int)(((dim_up + 2) * 8 + 140 * 1024 - 1) / (140 * 1024));
+    }
+    if (s->rows_per_block == 0 && parts > 1 && dim_up >= 4 * parts) {
+      if (upload_ell(s->up_ell, up, true)) return 1;
+      if (s->up_ell.typed && s->up_ell.pk) {
+        s->row_split = parts;
+      } else {
+        dev_free(s->up_ell.pk);
+        dev_free(s->up_ell.coef);
+        dev_free(s->up_ell.col);
+        dev_free(s->up_ell.val);
+      }
+    }
+  }
+  if (s->row_split == 1 && upload_ell(s->up_ell, up, s->rows_per_block != 0)) return 1;
   if (upload_csr(s->dw, dim_dw, dw.rowptr.data(), dw.col.data(), dw.val.data(), 0)) return 1;
   for (int64_t i = 0; i < dim_dw; i++)
     s->dw_maxrow = std::max<int>(s->dw_maxrow, (int)(dw.rowptr[i + 1] - dw.rowptr[i]));

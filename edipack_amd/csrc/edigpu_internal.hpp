@@ -109,6 +109,7 @@ struct edigpu_sector {
   edigpu_sector* sub_s = nullptr;
   edigpu_sector* sub_a = nullptr;
   double* d_cz = nullptr;
+  int row_split = 1;  // rows longer than the LDS: number of column parts the row kernel stages them in (SPLIT)
   int col_halo = 0;             // max |partner column - column| over the factored Hnd terms (transposed exchange)
   uint32_t* d_jdw = nullptr;    // nterms * dim_dw
   int32_t* d_mx_rowptr = nullptr;  // per local row: Hdw entries + applicable Hnd terms

@@ -64,7 +64,12 @@ __device__ inline double lds_abs_read(uint32_t byte_addr) { return *reinterpret_
 //   2: x = Q/beta (the new Lanczos vector), P <- x, Q <- (Hd+Hup) x - beta*P_old.
 //   3: as 2 with the pending axpy folded in: x = (Q - alpha*P)/beta  (no separate beta kernel).
 // NT: threads per workgroup (512; 1024 when the staged rows leave room for one workgroup per CU only)
-template <int NT, int TD, bool USE_LDS, bool LOCAL, bool ND, bool PACKED, bool VEC, bool HDF, int FUSE>
+// SPLIT (rows too long for the LDS, e.g. the Ns=17 ladder: 194 KB): the row is staged in column parts, one launch
+//   per part [split_first, split_first + split_count); a launch adds the hops whose SOURCE column lies in its part
+//   to every output column (entries pointing elsewhere are redirected to the zero slot), the first launch also
+//   the diagonal, the later ones accumulate into hv.  All gathers come from the LDS instead of global memory.
+template <int NT, int TD, bool USE_LDS, bool LOCAL, bool ND, bool PACKED, bool VEC, bool HDF, int FUSE,
+          bool SPLIT = false>
 __global__ void __launch_bounds__(NT)
     normal_rows_kernel(NormalArgs a, const double* v_local, const double* __restrict__ v_full,
                        double* hv) {
@@ -73,8 +78,10 @@ __global__ void __launch_bounds__(NT)
   extern __shared__ double vs[];
 
   const int64_t DimUp = a.dim_up;
-  // staged row stride: DimUp columns + a zero slot at index DimUp (target of the dead ELL slots), even
-  const int S = ((int)DimUp + 2) & ~1;
+  // staged part of a row: all of it, or the columns [sf, sf + sc) of this launch (SPLIT)
+  const int64_t sf = SPLIT ? a.split_first : 0, sc = SPLIT ? a.split_count : DimUp;
+  // staged row stride: sc columns + a zero slot at index sc (target of the dead ELL slots), even
+  const int S = ((int)sc + 2) & ~1;
   const int rowB = S * 8;
   double* coef_s = vs + (USE_LDS ? TD * S : 0);
   const int64_t r0 = (int64_t)blockIdx.x * TD;  // first local row of this block
@@ -96,10 +103,10 @@ __global__ void __launch_bounds__(NT)
   if (LOCAL && PACKED && tid < 128) coef_s[tid] = a.ell_coef[tid];
   if (LOCAL && USE_LDS) {
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)vs != 0u) __builtin_trap();
-    if (tid < TD) vs[tid * S + DimUp] = 0.0;
+    if (tid < TD) vs[tid * S + sc] = 0.0;
     // stage the TD rows: 4 independent loads in flight per thread and row
     if (VEC) {
-      const int64_t n2 = DimUp >> 1;
+      const int64_t n2 = sc >> 1;  // SPLIT: sf and sc are even
       for (int64_t j0 = 0; j0 < n2; j0 += 4 * NT) {
         double2 t[TD][4];
 #pragma unroll
@@ -108,7 +115,7 @@ __global__ void __launch_bounds__(NT)
           for (int u = 0; u < 4; u++) {
             const int64_t j = j0 + tid + u * NT;
             const int rr = r < nr ? r : 0;  // clamped: always a valid address
-            t[r][u] = reinterpret_cast<const double2*>(v_src + (r0 + rr) * DimUp)[j < n2 ? j : n2 - 1];
+            t[r][u] = reinterpret_cast<const double2*>(v_src + (r0 + rr) * DimUp + sf)[j < n2 ? j : n2 - 1];
             if (FUSE == 3) {
               const double2 pp = reinterpret_cast<const double2*>(v_local + (r0 + rr) * DimUp)[j < n2 ? j : n2 - 1];
               t[r][u].x -= alpha * pp.x;
@@ -128,7 +135,7 @@ __global__ void __launch_bounds__(NT)
           }
       }
     } else {
-      for (int64_t j0 = 0; j0 < DimUp; j0 += 4 * NT) {
+      for (int64_t j0 = 0; j0 < sc; j0 += 4 * NT) {
         double t[TD][4];
 #pragma unroll
         for (int r = 0; r < TD; r++)
@@ -136,7 +143,7 @@ __global__ void __launch_bounds__(NT)
           for (int u = 0; u < 4; u++) {
             const int64_t j = j0 + tid + u * NT;
             const int rr = r < nr ? r : 0;
-            t[r][u] = v_src[(r0 + rr) * DimUp + (j < DimUp ? j : DimUp - 1)];
+            t[r][u] = v_src[(r0 + rr) * DimUp + sf + (j < sc ? j : sc - 1)];
             if (FUSE == 3) t[r][u] -= alpha * v_local[(r0 + rr) * DimUp + (j < DimUp ? j : DimUp - 1)];
             if (FUSE >= 2) t[r][u] *= ibeta;
           }
@@ -145,7 +152,7 @@ __global__ void __launch_bounds__(NT)
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const int64_t j = j0 + tid + u * NT;
-            if (r < nr && j < DimUp) vs[r * S + j] = t[r][u];
+            if (r < nr && j < sc) vs[r * S + j] = t[r][u];
           }
       }
     }
@@ -179,14 +186,14 @@ __global__ void __launch_bounds__(NT)
           } else {
             load4<VEC>(a.hd, (r0 + r) * DimUp + col0, ok, h);
           }
-          if (USE_LDS) {
+          if (USE_LDS && !SPLIT) {
 #pragma unroll
             for (int e = 0; e < kE; e++) x[e] = ok[e] ? vs[r * S + col0 + e] : 0.0;
           } else {
             load4<VEC>(v_local, (r0 + r) * DimUp + col0, ok, x);
           }
 #pragma unroll
-          for (int e = 0; e < kE; e++) acc[r][e] = h[e] * x[e];
+          for (int e = 0; e < kE; e++) acc[r][e] = (SPLIT && sf != 0) ? 0.0 : h[e] * x[e];  // the diagonal: first part only
         }
       // ---- (1 (x) Hup): gather inside the row; one 16-byte load brings 4 packed slots.
       // Slots are fetched KU at a time into registers first (KU = 4 measured 2 % faster than 6 on config 2 and the
@@ -218,7 +225,14 @@ __global__ void __launch_bounds__(NT)
               if (TD == 1 || r < nr) {
 #pragma unroll
                 for (int e = 0; e < kE; e++) {
-                  double x = lds_abs_read((uint32_t)(r * rowB) + (p[e] & 0xFFFFFFu));
+                  uint32_t off = p[e] & 0xFFFFFFu;
+                  if (SPLIT) {
+                    // byte offset in the full row -> in the staged part, or the zero slot when the source column
+                    // is not in this part (unsigned compare also catches the columns below sf)
+                    const uint32_t rel = off - (uint32_t)(sf * 8);
+                    off = rel < (uint32_t)(sc * 8) ? rel : (uint32_t)(sc * 8);
+                  }
+                  double x = lds_abs_read((uint32_t)(r * rowB) + off);
                   x = __hiloint2double(__double2hiint(x) ^ (int)(p[e] & 0x80000000u), __double2loint(x));
                   acc[r][e] = fma(tk[u], x, acc[r][e]);
                 }
@@ -329,7 +343,7 @@ __global__ void __launch_bounds__(NT)
     for (int r = 0; r < TD; r++)
       if (r < nr) {
         double* dst = hv + (r0 + r) * DimUp + col0;
-        if (!LOCAL) {
+        if (!LOCAL || (SPLIT && sf != 0)) {
           double old[kE];
           load4<VEC>(hv, (r0 + r) * DimUp + col0, ok, old);
 #pragma unroll
@@ -445,10 +459,40 @@ static int launch_td(const NormalArgs& a, bool packed, bool hdf, const double* v
 #undef EDIGPU_TD
 }
 
+// rows longer than the LDS, staged in s->row_split column parts: one launch per part (see SPLIT)
+template <bool VEC, bool HDF>
+static int launch_split_t(const edigpu_sector* s, NormalArgs a, const double* vl, double* hv, hipStream_t st) {
+  constexpr int NT = 1024;
+  // equal even parts
+  const int64_t part = (((a.dim_up + s->row_split - 1) / s->row_split) + 1) & ~(int64_t)1;
+  auto kern = normal_rows_kernel<NT, 1, true, true, false, true, VEC, HDF, 0, true>;
+  const size_t lds = (size_t)((part + 2) & ~(int64_t)1) * sizeof(double) + 128 * sizeof(double);
+  EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int64_t first = 0; first < a.dim_up; first += part) {
+    a.split_first = first;
+    a.split_count = std::min<int64_t>(part, a.dim_up - first);
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.dw_count), dim3(NT), lds, st, a, vl, nullptr, hv);
+  }
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 static int launch_rows(const edigpu_sector* s, const NormalArgs& a, const double* vl,
                        const double* vf, double* hv, int what, hipStream_t st) {
   const bool packed = s->up_ell.pk != nullptr;
   const bool hdf = s->factored != 0;
+  if (s->row_split > 1 && what != 4) {
+    // what = 1: diagonal + up part; what = 5: the same, then the CSR Hnd pass (accumulate)
+    if (what != 1 && what != 5) {
+      set_error("launch_normal: fused Lanczos is not available for split rows");
+      return 1;
+    }
+    const bool vec = (a.dim_up % 2) == 0;
+    const int rc = vec ? (hdf ? launch_split_t<true, true>(s, a, vl, hv, st) : launch_split_t<true, false>(s, a, vl, hv, st))
+                       : (hdf ? launch_split_t<false, true>(s, a, vl, hv, st) : launch_split_t<false, false>(s, a, vl, hv, st));
+    if (rc || what == 1) return rc;
+    return launch_td<1, false>(a, false, hdf, vl, vf, hv, 4, st);
+  }
   switch (s->rows_per_block) {
     case 0: return launch_td<1, false>(a, packed, hdf, vl, vf, hv, what, st);
     case 1: return launch_td<1, true>(a, packed, hdf, vl, vf, hv, what, st);
@@ -493,6 +537,8 @@ static void fill_args(const edigpu_sector* s, NormalArgs& a) {
   a.mx_val = s->d_mx_val;
   a.scal = nullptr;
   a.partial = nullptr;
+  a.split_first = 0;
+  a.split_count = s->dim_up;
 }
 
 int launch_normal(const edigpu_sector* s, const double* v_local, const double* v_full, double* hv,

@@ -21,6 +21,7 @@ struct NormalArgs {
   const double* ell_val;
   int ell_w;
   int ell_typed;  // packed ELL whose slot k holds the hop with amplitude ell_coef[k]
+  int64_t split_first, split_count;  // SPLIT row kernel: the columns staged by this launch
   int64_t ell_pitch;
   const int32_t* dw_rowptr;
   const int32_t* dw_col;
