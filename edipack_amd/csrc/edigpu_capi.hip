@@ -1913,7 +1913,10 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
     (void)hipFree(d_v0);
     return 1;
   };
-  if (lanczos_prepare(s, nitermax, 0.0, st)) return fail();
+  // breakdown guard: a beta below 1e-12 means the Krylov space is exhausted (tiny sectors with nitermax ~ dim); the
+  // recurrence stops there instead of dividing by it
+  constexpr double kBreakdown = 1e-12;
+  if (lanczos_prepare(s, nitermax, kBreakdown, st)) return fail();
   if (v0_host) {
     if (hipMemcpyAsync(s->d_vin, v0_host, vbytes, hipMemcpyDefault, st) != hipSuccess) return fail();
   } else if (lz_fill_random(s->d_vin, len, 0x5eed1234ull, st)) {
@@ -1965,7 +1968,7 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
     }
     (void)hipMemsetAsync(d_acc, 0, vbytes, st);
     (void)hipMemcpyAsync(s->d_vin, d_v0, vbytes, hipMemcpyDeviceToDevice, st);
-    if (lanczos_prepare(s, ndone, 0.0, st)) {
+    if (lanczos_prepare(s, ndone, kBreakdown, st)) {
       (void)hipFree(d_acc);
       return fail();
     }
