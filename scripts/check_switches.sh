@@ -1,0 +1,10 @@
+#!/bin/bash
+# The GPU parity suite under every documented switch of the library ("Environment switches"):
+#   gpurun -- 'bash scripts/check_switches.sh'
+for sw in EDIGPU_LANCZOS_UNFUSED EDIGPU_NORMAL_EXPLICIT EDIGPU_FLAT_HOSTBUILD EDIGPU_LANCZOS_EXACTBETA EDIGPU_TRL_TWOPASS \
+          EDIGPU_ELL_UNTYPED EDIGPU_CSR_NOSELL EDIGPU_CSR_UNPACKED EDIGPU_DIRECT_TERMORDER EDIGPU_PANEL_VEC2_MIN \
+          "EDIGPU_ROW_SPLIT=2" "EDIGPU_PANEL_VEC2=0" EDIGPU_ND_IN_ROWS; do
+  case $sw in *=*) kv=$sw;; *) kv=$sw=1;; esac
+  env $kv timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/sw_${sw%%=*}.log 2>&1
+  echo "$kv: $(tail -1 gpurun_out/sw_${sw%%=*}.log)"
+done
