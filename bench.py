@@ -273,7 +273,13 @@ def main():
     args = ap.parse_args()
     # EDIGPU_FORCE_MULTI=1: take the N > 1 code path with a single rank (RCCL world of one; with
     # EDIGPU_FORCE_COLLECTIVES=1 the collectives are issued too) -- a one-GPU rehearsal of the nccl calls
-    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("EDIGPU_FORCE_MULTI"):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        # a scaling script that forgets the launcher must not record one-GPU numbers as N-GPU ones
+        sys.exit(f"bench.py: --gpus {args.gpus} needs one rank per GPU (WORLD_SIZE={world}): launch it as\n"
+                 f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                 f"--master-port 29533 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
+    if args.gpus > 1 or world > 1 or os.environ.get("EDIGPU_FORCE_MULTI"):
         run_multi(args)
     else:
         run_single(args)

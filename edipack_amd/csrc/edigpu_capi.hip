@@ -8,7 +8,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 
 #include "kernels.hpp"
 
@@ -297,6 +299,20 @@ static std::string check_csr(int64_t nrow, int64_t ncol, const int64_t* rowptr, 
   return "";
 }
 
+int ensure_dynamic_lds(const void* kernel, size_t bytes) {
+  if (bytes <= 48 * 1024) return 0;
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> done;
+  int dev = 0;
+  EDIGPU_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  size_t& have = done[{dev, kernel}];
+  if (have >= bytes) return 0;
+  EDIGPU_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  have = bytes;
+  return 0;
+}
+
 static int finish_handle(edigpu_sector* s) {
   EDIGPU_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   return 0;
@@ -305,6 +321,42 @@ static int finish_handle(edigpu_sector* s) {
 static bool env_flag(const char* name) {
   const char* e = getenv(name);
   return e && e[0] == '1';
+}
+
+// Row chunks of the LDS-tiled panel sweep (kernels_panel.hip, normal_dw_tile_kernel): consecutive local down rows,
+// at most rmax per chunk, cut where few SHORT hops (|partner - row| < rmax: the ones a chunk could keep inside)
+// cross.  The sorted basis puts rows that share their high bath bits next to each other and the hops among the low
+// levels stay inside such a block, so the cheapest cuts are the block boundaries.  Any partition is valid -- the
+// kernel tests "partner inside my chunk" by range -- the plan only decides how many gathers are served from LDS.
+static void plan_tile_chunks(const HostCsr& dw, int64_t dw_first, int64_t dw_count, int rmax,
+                             std::vector<int32_t>& starts, int& longest) {
+  const int64_t n = dw_count;
+  std::vector<int32_t> cross((size_t)n + 2, 0);
+  for (int64_t r = 0; r < n; r++) {
+    const int64_t g = dw_first + r;
+    for (int64_t q = dw.rowptr[g]; q < dw.rowptr[g + 1]; q++) {
+      const int64_t pl = (int64_t)dw.col[q] - dw_first;
+      if (pl > r && pl < n && pl - r < rmax) {  // crosses every cut i with r < i <= pl
+        cross[r + 1]++;
+        cross[pl + 1]--;
+      }
+    }
+  }
+  for (int64_t i = 1; i <= n; i++) cross[i] += cross[i - 1];
+  starts.assign(1, 0);
+  longest = 0;
+  int64_t s0 = 0;
+  while (s0 < n) {
+    int64_t cut = n;
+    if (n - s0 > rmax) {
+      cut = s0 + rmax;
+      for (int64_t i = s0 + rmax; i > s0 + rmax / 2; i--)
+        if (cross[i] < cross[cut]) cut = i;
+    }
+    longest = std::max<int>(longest, (int)(cut - s0));
+    starts.push_back((int32_t)cut);
+    s0 = cut;
+  }
 }
 
 static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_t dw_first,
@@ -351,6 +403,27 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
   if (upload_csr(s->dw, dim_dw, dw.rowptr.data(), dw.col.data(), dw.val.data(), 0)) return 1;
   for (int64_t i = 0; i < dim_dw; i++)
     s->dw_maxrow = std::max<int>(s->dw_maxrow, (int)(dw.rowptr[i + 1] - dw.rowptr[i]));
+  {
+    // panel sweep variant (kernels_panel.hip).  Measured: cache-resident sectors are 13 % SLOWER with the two-column
+    // panels (fewer, fatter waves), hence the size gate; EDIGPU_PANEL_VEC2_MIN (rows) moves it (tests force the
+    // large-sector kernels on small sectors), EDIGPU_PANEL_VEC2=0 / EDIGPU_PANEL_TILE=0 switch the variants off,
+    // EDIGPU_TILE_ROWS sets the chunk length (KiB of LDS per workgroup).
+    const char* e;
+    const bool vec2_env = !(e = getenv("EDIGPU_PANEL_VEC2")) || atoi(e) != 0;
+    const int64_t vec2_min = (e = getenv("EDIGPU_PANEL_VEC2_MIN")) ? atoll(e) : ((int64_t)1 << 21);
+    const bool tile_env = !(e = getenv("EDIGPU_PANEL_TILE")) || atoi(e) != 0;
+    int rmax = (e = getenv("EDIGPU_TILE_ROWS")) ? atoi(e) : 72;
+    if (rmax < 8) rmax = 8;
+    if (rmax > 152) rmax = 152;
+    if (vec2_env && dim_up >= 2 && dim_up * dw_count >= vec2_min) s->panel_mode = 1;
+    if (s->panel_mode == 1 && tile_env && dw_count > 0 && dim_dw < ((int64_t)1 << 24)) {
+      std::vector<int32_t> starts;
+      plan_tile_chunks(dw, dw_first, dw_count, rmax, starts, s->tile_rows);
+      s->tile_nchunks = (int)starts.size() - 1;
+      if (dev_upload(&s->d_tile_chunks, starts.data(), starts.size())) return 1;
+      s->panel_mode = 2;
+    }
+  }
   s->has_nd = nd_rowptr != nullptr && nd_rowptr[s->nloc] > 0;
   s->nd_nnz = s->has_nd ? nd_rowptr[s->nloc] : 0;
   if (built && !nd_rowptr) {  // factored-only build: no explicit arrays were made
@@ -813,14 +886,10 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
   if (normal_lanczos_fusable(s)) {
     // rotate (and the pending axpy) fused into the row kernel, alpha and <Q|Q> into the panel sweep
     // (kernels_normal.hip); EDIGPU_LANCZOS_EXACTBETA=1 keeps the separate axpy+norm kernel
-    static const bool exactbeta = getenv("EDIGPU_LANCZOS_EXACTBETA") != nullptr;
+    const bool exactbeta = s->lz_exactbeta;  // read once per run in lanczos_prepare
     int np = 0;
-    if (launch_normal_lanczos(s, s->d_vin, s->d_vout, s->d_scal, s->d_partial, iter == 0, !exactbeta, st, &np))
+    if (launch_normal_lanczos(s, s->d_vin, s->d_vout, s->d_scal, s->d_partial, s->partial_cap, iter == 0, !exactbeta, st, &np))
       return 1;
-    if (2 * (int64_t)np > s->partial_cap) {
-      set_error("lanczos_step: partial buffer too small");
-      return 1;
-    }
     if (exactbeta) {
       if (lz_finalize_alpha(s->d_partial, np, s->d_scal, iter, nlanc, st)) return 1;
       return lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, iter, nlanc, st);
@@ -833,12 +902,8 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
     int np = 0;
     if (iter > 0 && lz_rotate_lazy(s->d_vin, s->d_vout, len, s->d_scal, st)) return 1;
     if (s->kind == 2) {
-      if (launch_direct_lanczos(s, s->d_vin, s->d_vout, s->d_partial, &np, st)) return 1;
-    } else if (launch_csr_lanczos(s->loc, s->is_complex, s->d_vin, s->d_vout, s->d_partial, &np, st)) {
-      return 1;
-    }
-    if (2 * (int64_t)np > s->partial_cap) {
-      set_error("lanczos_step: partial buffer too small");
+      if (launch_direct_lanczos(s, s->d_vin, s->d_vout, s->d_partial, s->partial_cap, &np, s->d_scal + SC_ALPHA, st)) return 1;
+    } else if (launch_csr_lanczos(s->loc, s->is_complex, s->d_vin, s->d_vout, s->d_partial, s->partial_cap, &np, s->d_scal + SC_ALPHA, st)) {
       return 1;
     }
     return lz_finalize_alpha_beta(s->d_vin, s->d_vout, len, s->d_partial, np, s->d_scal, iter, nlanc, st);
@@ -851,6 +916,7 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
 }
 
 static int lanczos_prepare(edigpu_sector* s, int nlanc, double threshold, hipStream_t st) {
+  s->lz_exactbeta = getenv("EDIGPU_LANCZOS_EXACTBETA") != nullptr;
   dev_free(s->d_scal);
   const size_t ns = (size_t)SC_AB + 2 * (size_t)nlanc;
   EDIGPU_HIP(hipMalloc((void**)&s->d_scal, ns * sizeof(double)));
@@ -2361,6 +2427,7 @@ int edigpu_destroy(edigpu_handle s) {
   dev_free(s->d_gu);
   dev_free(s->d_gd);
   dev_free(s->d_mx_rowptr);
+  dev_free(s->d_tile_chunks);
   dev_free(s->d_mx_col);
   dev_free(s->d_mx_val);
   dev_free(s->d_eux);

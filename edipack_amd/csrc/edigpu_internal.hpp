@@ -109,6 +109,9 @@ struct edigpu_sector {
   edigpu_sector* sub_s = nullptr;
   edigpu_sector* sub_a = nullptr;
   double* d_cz = nullptr;
+  int panel_mode = 0;           // panel sweep variant (NormalArgs::panel_mode), fixed at set-up
+  int tile_nchunks = 0, tile_rows = 0;
+  int32_t* d_tile_chunks = nullptr;
   int row_split = 1;  // rows longer than the LDS: number of column parts the row kernel stages them in (SPLIT)
   int col_halo = 0;             // max |partner column - column| over the factored Hnd terms (transposed exchange)
   uint32_t* d_jdw = nullptr;    // nterms * dim_dw
@@ -151,5 +154,6 @@ struct edigpu_sector {
   double* d_tmp = nullptr;
   double* d_partial = nullptr;  // reduction partials
   double* d_scal = nullptr;     // alpha/beta/flags on device
+  bool lz_exactbeta = false;    // EDIGPU_LANCZOS_EXACTBETA at the start of the current recurrence
   int64_t ws_len = 0;           // in doubles per vector
 };

@@ -9,6 +9,9 @@ enum { SC_ALPHA = 0, SC_BETA = 1, SC_STOP = 2, SC_NDONE = 3, SC_NORM = 4, SC_THR
 constexpr int kRedBlocks = 1024;
 constexpr int kMaxPartials = 1 << 16;  // minimum capacity of the per-workgroup partial buffer (edigpu_sector::partial_cap)
 
+// opt a kernel into more than 48 KiB of dynamic LDS, once per (device, kernel, size) instead of on every launch
+int ensure_dynamic_lds(const void* kernel, size_t bytes);
+
 // ---- normal mode (kernels_normal.hip) ----
 // phase: 3 = fused (local+remote, overwrite), 1 = local only (overwrite), 2 = remote only (accumulate)
 // v_local : first element of the shard's own rows, v_full : element 0 of the whole vector.
@@ -35,7 +38,7 @@ int launch_transpose_unpack_add(int64_t dim_up, int64_t nrows, int64_t q, int wo
 // fused Lanczos step (normal, single shard): P = Lanczos vector, Q = work vector, see kernels_normal.hip
 bool normal_lanczos_fusable(const edigpu_sector* s);
 int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const double* scal,
-                          double* partial, bool first, bool lazy_axpy, hipStream_t st, int* npartial);
+                          double* partial, int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial);
 // alpha = sum(partial[0:np]), beta = sqrt(sum(partial[np:2np]) - alpha^2) with an exact fallback pass
 int lz_finalize_alpha_beta(const double* P, const double* Q, int64_t n, double* partial, int np,
                            double* scal, int iter, int nlanc, hipStream_t st);
@@ -48,11 +51,13 @@ int launch_csr(const DevCsr& a, int cplx, const double* x, double* y, int accumu
 int launch_zero(double* y, int64_t n, hipStream_t st);
 
 // ---- direct / on-the-fly (kernels_direct.hip): hv[local rows] = H v_full ----
-int launch_direct_lanczos(const edigpu_sector* s, const double* v_full, double* q, double* partial, int* np,
-                          hipStream_t st);
+// sig: device scalar the <Q|Q> partial is accumulated about (the previous alpha, scal + SC_ALPHA; see k_finalize_ab)
+// cap: capacity of `partial` in doubles, checked BEFORE anything is enqueued (2 partials per workgroup)
+int launch_direct_lanczos(const edigpu_sector* s, const double* v_full, double* q, double* partial, int64_t cap, int* np,
+                          const double* sig, hipStream_t st);
 bool csr_lanczos_fusable(const DevCsr& a);
-int launch_csr_lanczos(const DevCsr& a, int cplx, const double* x, double* y, double* partial, int* np,
-                       hipStream_t st);
+int launch_csr_lanczos(const DevCsr& a, int cplx, const double* x, double* y, double* partial, int64_t cap, int* np,
+                       const double* sig, hipStream_t st);
 // (P, Q) <- ((Q - alpha*P)/beta, -beta*P): rotate with the pending axpy of the fused step folded in
 int lz_rotate_lazy(double* P, double* Q, int64_t n, const double* scal, hipStream_t st);
 int launch_direct(const edigpu_sector* s, const double* v_full, double* hv, hipStream_t st);

@@ -152,14 +152,12 @@ int launch_build_fill(const BuildArgs& a, int which, int maxlen, const int32_t* 
   const int64_t nb = (a.nrow + kBuildNT - 1) / kBuildNT;
   if (which == 0) {
     auto kern = build_fill_kernel<0>;
-    if (lds > 48 * 1024)
-      EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (ensure_dynamic_lds((const void*)kern, lds)) return 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kBuildNT), lds, st, a, maxlen, sptr, pk,
                        reinterpret_cast<double2*>(diag));
   } else {
     auto kern = build_fill_kernel<1>;
-    if (lds > 48 * 1024)
-      EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (ensure_dynamic_lds((const void*)kern, lds)) return 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kBuildNT), lds, st, a, maxlen, sptr, pk,
                        reinterpret_cast<double2*>(diag));
   }

@@ -91,7 +91,9 @@ template <bool CPLX, bool ACC, bool DOT>
 __global__ void __launch_bounds__(kCsrNT)
     sell_rows_kernel(int64_t nrow, int64_t nslice, const int32_t* __restrict__ sptr,
                      const int32_t* __restrict__ col, const double* __restrict__ val,
-                     const double* __restrict__ x, double* __restrict__ y, double* __restrict__ partial) {
+                     const double* __restrict__ x, double* __restrict__ y, double* __restrict__ partial,
+                     const double* __restrict__ sig) {
+  const double sg = (DOT && sig) ? sig[0] : 0.0;  // <y|y> accumulated about the previous alpha, see k_finalize_ab
   const int lane = threadIdx.x & 63;
   const int64_t slice = (int64_t)blockIdx.x * (kCsrNT / 64) + (threadIdx.x >> 6);
   if (!DOT && slice >= nslice) return;
@@ -122,14 +124,14 @@ __global__ void __launch_bounds__(kCsrNT)
       if (DOT) {
         const double2 xo = reinterpret_cast<const double2*>(x)[row];
         da = xo.x * o2.x + xo.y * o2.y;
-        dq = o2.x * o2.x + o2.y * o2.y;
+        dq = (o2.x - sg * xo.x) * (o2.x - sg * xo.x) + (o2.y - sg * xo.y) * (o2.y - sg * xo.y);
       }
     } else {
       const double o = (ACC ? y[row] : 0.0) + sr;
       y[row] = o;
       if (DOT) {
         da = x[row] * o;
-        dq = o * o;
+        dq = (o - sg * x[row]) * (o - sg * x[row]);
       }
     }
   }
@@ -143,7 +145,8 @@ __global__ void __launch_bounds__(kCsrNT)
     sell_rows_packed_kernel(int64_t nrow, int64_t nslice, const int32_t* __restrict__ sptr,
                             const uint32_t* __restrict__ pk, const double* __restrict__ dict,
                             const double* __restrict__ diag, const double* __restrict__ x,
-                            double* __restrict__ y, double* __restrict__ partial) {
+                            double* __restrict__ y, double* __restrict__ partial, const double* __restrict__ sig) {
+  const double sg = (DOT && sig) ? sig[0] : 0.0;
   __shared__ double dict_s[CPLX ? 512 : 256];
   for (int i = threadIdx.x; i < (CPLX ? 512 : 256); i += kCsrNT) dict_s[i] = dict[i];
   __syncthreads();
@@ -188,14 +191,14 @@ __global__ void __launch_bounds__(kCsrNT)
       if (DOT) {
         const double2 xo = reinterpret_cast<const double2*>(x)[row];
         da = xo.x * o2.x + xo.y * o2.y;
-        dq = o2.x * o2.x + o2.y * o2.y;
+        dq = (o2.x - sg * xo.x) * (o2.x - sg * xo.x) + (o2.y - sg * xo.y) * (o2.y - sg * xo.y);
       }
     } else {
       const double o = (ACC ? y[row] : 0.0) + sr;
       y[row] = o;
       if (DOT) {
         da = x[row] * o;
-        dq = o * o;
+        dq = (o - sg * x[row]) * (o - sg * x[row]);
       }
     }
   }
@@ -238,12 +241,12 @@ static int launch_pick(const DevCsr& a, const double* x, double* y, hipStream_t 
     const int64_t nb = (a.nslice + kCsrNT / 64 - 1) / (kCsrNT / 64);
     if (a.sell_packed) {
       hipLaunchKernelGGL((sell_rows_packed_kernel<CPLX, ACC, false>), dim3((unsigned)nb), dim3(kCsrNT), 0, st,
-                         a.nrow, a.nslice, a.sell_ptr, a.sell_pk, a.sell_dict, a.sell_diag, x, y, nullptr);
+                         a.nrow, a.nslice, a.sell_ptr, a.sell_pk, a.sell_dict, a.sell_diag, x, y, (double*)nullptr, (const double*)nullptr);
       EDIGPU_HIP(hipGetLastError());
       return 0;
     }
     hipLaunchKernelGGL((sell_rows_kernel<CPLX, ACC, false>), dim3((unsigned)nb), dim3(kCsrNT), 0, st, a.nrow,
-                       a.nslice, a.sell_ptr, a.sell_col, a.sell_val, x, y, nullptr);
+                       a.nslice, a.sell_ptr, a.sell_col, a.sell_val, x, y, (double*)nullptr, (const double*)nullptr);
     EDIGPU_HIP(hipGetLastError());
     return 0;
   }
@@ -270,26 +273,30 @@ int launch_csr(const DevCsr& a, int cplx, const double* x, double* y, int accumu
 // y += A x with the <x|y>, <y|y> partials.  Returns the number of partial pairs in *np.
 bool csr_lanczos_fusable(const DevCsr& a) { return a.sell != 0 && a.nrow > 0 && a.nnz > 0; }
 
-int launch_csr_lanczos(const DevCsr& a, int cplx, const double* x, double* y, double* partial, int* np,
-                       hipStream_t st) {
+int launch_csr_lanczos(const DevCsr& a, int cplx, const double* x, double* y, double* partial, int64_t cap, int* np,
+                       const double* sig, hipStream_t st) {
   const int64_t nb = (a.nslice + kCsrNT / 64 - 1) / (kCsrNT / 64);
+  if (2 * nb > cap) {
+    set_error("launch_csr_lanczos: partial buffer too small");
+    return 1;
+  }
   *np = (int)nb;
   // the caller's partial buffer holds 2 * nb doubles (ensure_workspace sizes it from the row count)
   const dim3 g((unsigned)nb), blk(kCsrNT);
   if (a.sell_packed) {
     if (cplx)
       hipLaunchKernelGGL((sell_rows_packed_kernel<true, true, true>), g, blk, 0, st, a.nrow, a.nslice, a.sell_ptr,
-                         a.sell_pk, a.sell_dict, a.sell_diag, x, y, partial);
+                         a.sell_pk, a.sell_dict, a.sell_diag, x, y, partial, sig);
     else
       hipLaunchKernelGGL((sell_rows_packed_kernel<false, true, true>), g, blk, 0, st, a.nrow, a.nslice, a.sell_ptr,
-                         a.sell_pk, a.sell_dict, a.sell_diag, x, y, partial);
+                         a.sell_pk, a.sell_dict, a.sell_diag, x, y, partial, sig);
   } else {
     if (cplx)
       hipLaunchKernelGGL((sell_rows_kernel<true, true, true>), g, blk, 0, st, a.nrow, a.nslice, a.sell_ptr,
-                         a.sell_col, a.sell_val, x, y, partial);
+                         a.sell_col, a.sell_val, x, y, partial, sig);
     else
       hipLaunchKernelGGL((sell_rows_kernel<false, true, true>), g, blk, 0, st, a.nrow, a.nslice, a.sell_ptr,
-                         a.sell_col, a.sell_val, x, y, partial);
+                         a.sell_col, a.sell_val, x, y, partial, sig);
   }
   EDIGPU_HIP(hipGetLastError());
   return 0;

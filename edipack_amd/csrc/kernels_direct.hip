@@ -35,7 +35,8 @@ __global__ void __launch_bounds__(kDirNT)
                        const int32_t* __restrict__ rk_up, const DirectTerm* __restrict__ terms,
                        const uint2* __restrict__ tests, const double* __restrict__ dtab,
                        const double* __restrict__ xtab, const double2* __restrict__ v_full,
-                       double2* __restrict__ hv, double* __restrict__ partial) {
+                       double2* __restrict__ hv, double* __restrict__ partial, const double* __restrict__ sig) {
+  const double sgm = (LZ && sig) ? sig[0] : 0.0;  // <Q|Q> accumulated about the previous alpha, see k_finalize_ab
   extern __shared__ int32_t tabs[];  // [off_dw | rk_up] when LDS_TABLES
   __shared__ double red_a[kDirNT / 64], red_q[kDirNT / 64];
   double da = 0.0, dq = 0.0;
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(kDirNT)
       ar += q.x;
       ai += q.y;
       da += x0.x * ar + x0.y * ai;
-      dq += ar * ar + ai * ai;
+      dq += (ar - sgm * x0.x) * (ar - sgm * x0.x) + (ai - sgm * x0.y) * (ai - sgm * x0.y);
     }
     hv[r] = make_double2(ar, ai);
   }
@@ -175,12 +176,16 @@ __global__ void __launch_bounds__(kDirNT)
 }
 
 template <bool LZ>
-static int launch_direct_t(const edigpu_sector* s, const double* v_full, double* hv, double* partial, int* np,
-                           hipStream_t st) {
+static int launch_direct_t(const edigpu_sector* s, const double* v_full, double* hv, double* partial, int64_t cap,
+                           int* np, const double* sig, hipStream_t st) {
   const int64_t nrow = s->nph > 0 ? s->dim_el : s->nloc;  // phonon sectors: one electronic block per launch
   int64_t nb = (nrow + kDirNT - 1) / kDirNT;
   static const int wgs_per_cu = getenv("EDIGPU_DIRECT_WGS") ? atoi(getenv("EDIGPU_DIRECT_WGS")) : 2;
   if (nb > 256 * wgs_per_cu) nb = 256 * wgs_per_cu;  // persistent workgroups sweep the rows
+  if (LZ && 2 * nb > cap) {
+    set_error("launch_direct_lanczos: partial buffer too small");
+    return 1;
+  }
   if (np) *np = (int)nb;
   const size_t tab_bytes = (size_t)2 * sizeof(int32_t) << s->dir_ns;
   const size_t term_bytes = (size_t)kDirMaxTerms * (3 * sizeof(uint32_t) + sizeof(double2));
@@ -191,11 +196,10 @@ static int launch_direct_t(const edigpu_sector* s, const double* v_full, double*
 #define EDIGPU_LAUNCH_DIRECT(LT, CP, LDSB)                                                                       \
   do {                                                                                                           \
     auto kern = direct_rows_kernel<LT, LZ, CP>;                                                                  \
-    if ((LDSB) > 48 * 1024)                                                                                      \
-      EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB))); \
+    if (ensure_dynamic_lds((const void*)kern, (LDSB))) return 1; \
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(kDirNT), (LDSB), st, nrow, s->row_first, s->dir_ns,        \
                        s->dir_norb, s->dir_nterms, s->d_dir_states, s->d_dir_offdw, s->d_dir_rkup,              \
-                       s->d_dir_terms, s->d_dir_tests, s->d_dir_dtab, s->d_dir_xtab, v2, h2, partial);          \
+                       s->d_dir_terms, s->d_dir_tests, s->d_dir_dtab, s->d_dir_xtab, v2, h2, partial, sig);     \
   } while (0)
   if (tab_bytes <= 64 * 1024) {
     if (compact)
@@ -215,13 +219,13 @@ static int launch_direct_t(const edigpu_sector* s, const double* v_full, double*
 
 int launch_direct(const edigpu_sector* s, const double* v_full, double* hv, hipStream_t st) {
   if (s->nloc == 0) return 0;
-  return launch_direct_t<false>(s, v_full, hv, nullptr, nullptr, st);
+  return launch_direct_t<false>(s, v_full, hv, nullptr, 0, nullptr, nullptr, st);
 }
 
 // fused Lanczos step (single shard): Q += H*v with the alpha / <Q|Q> partials
-int launch_direct_lanczos(const edigpu_sector* s, const double* v_full, double* q, double* partial, int* np,
-                          hipStream_t st) {
-  return launch_direct_t<true>(s, v_full, q, partial, np, st);
+int launch_direct_lanczos(const edigpu_sector* s, const double* v_full, double* q, double* partial, int64_t cap, int* np,
+                          const double* sig, hipStream_t st) {
+  return launch_direct_t<true>(s, v_full, q, partial, cap, np, sig, st);
 }
 
 }  // namespace edigpu

@@ -78,7 +78,9 @@ __global__ void __launch_bounds__(1024)
     } else {
       const double b = sqrt(tot);
       scal[SC_BETA] = b;
-      if (fabs(b) < scal[SC_THR])
+      // breakdown: |beta| below the threshold, or an exact zero / NaN whatever the threshold is (a zero threshold
+      // must not let 1/beta through: seed = eigenvector, diagonal H, Nlanc = Dim)
+      if (!(fabs(b) > 0.0) || fabs(b) < scal[SC_THR])
         scal[SC_STOP] = 1.0;
       else if (iter + 1 < nlanc)
         scal[SC_AB + nlanc + iter + 1] = b;
@@ -219,7 +221,9 @@ int lz_alpha(const double* vin, double* vout, const double* tmp, int64_t n, doub
   return 0;
 }
 
-// alpha and beta from the sweep's partials: beta^2 = <Q|Q> - alpha^2 (|v| = 1).  When that difference loses
+// alpha and beta from the sweep's partials.  The sweeps accumulate qq = sum (Q - sg v)^2 about sg = the previous
+// alpha (still in scal[SC_ALPHA] when they run), so beta^2 = |Q - alpha v|^2 = qq - (alpha - sg)^2 (|v| = 1): a
+// spectrum far from zero (large xmu / Hartree shifts: |alpha| >> beta on every step) no longer cancels.  When the difference still loses
 // more than ~3 digits to cancellation (near-invariant subspace, rare) the same single workgroup recomputes
 // beta^2 = |Q - alpha v|^2 directly by sweeping the two vectors (Q is left untouched: the axpy stays pending).
 // One launch per step: the former separate fallback kernel cost ~4.7 us per step while idle.
@@ -244,8 +248,8 @@ __global__ void __launch_bounds__(1024)
     }
     __syncthreads();
   }
-  const double alpha = sa[0], qq = sq[0];
-  double b2 = qq - alpha * alpha;
+  const double alpha = sa[0], qq = sq[0], sg = scal[SC_ALPHA];
+  double b2 = qq - (alpha - sg) * (alpha - sg);
   if (threadIdx.x == 0) exact = b2 < 1e-3 * qq;
   __syncthreads();
   if (exact) {  // uniform
@@ -270,7 +274,7 @@ __global__ void __launch_bounds__(1024)
     scal[SC_EXACT] = 0.0;
     const double b = sqrt(b2 > 0.0 ? b2 : 0.0);
     scal[SC_BETA] = b;
-    if (fabs(b) < scal[SC_THR])
+    if (!(fabs(b) > 0.0) || fabs(b) < scal[SC_THR])  // see k_finalize
       scal[SC_STOP] = 1.0;
     else if (iter + 1 < nlanc)
       scal[SC_AB + nlanc + iter + 1] = b;

@@ -405,9 +405,7 @@ static int launch_te(const NormalArgs& a, const double* vl, const double* vf, do
 #define EDIGPU_LAUNCH_ROWS(LOC, NDF, LDSB, UL, PK, HF)                                           \
   do {                                                                                           \
     auto kern = normal_rows_kernel<NT, TD, UL, LOC, NDF, PK, VEC, HF, 0>;                            \
-    if ((LDSB) > 48 * 1024)                                                                      \
-      EDIGPU_HIP(hipFuncSetAttribute((const void*)kern,                                          \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB)));  \
+    if (ensure_dynamic_lds((const void*)kern, (LDSB))) return 1; \
     hipLaunchKernelGGL(kern, grid, block, (LDSB), st, a, vl, vf, hv);                            \
   } while (0)
   switch (what) {
@@ -415,22 +413,19 @@ static int launch_te(const NormalArgs& a, const double* vl, const double* vf, do
     case 5: EDIGPU_LAUNCH_ROWS(true, true, lds, USE_LDS, PACKED, HDF); break;
     case 101: {  // fused Lanczos, first step
       auto kern = normal_rows_kernel<NT, TD, USE_LDS, true, false, PACKED, VEC, HDF, 1>;
-      if (lds > 48 * 1024)
-        EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (ensure_dynamic_lds((const void*)kern, lds)) return 1;
       hipLaunchKernelGGL(kern, grid, block, lds, st, a, vl, vf, hv);
       break;
     }
     case 102: {  // fused Lanczos, rotate + H*v
       auto kern = normal_rows_kernel<NT, TD, USE_LDS, true, false, PACKED, VEC, HDF, 2>;
-      if (lds > 48 * 1024)
-        EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (ensure_dynamic_lds((const void*)kern, lds)) return 1;
       hipLaunchKernelGGL(kern, grid, block, lds, st, a, vl, vf, hv);
       break;
     }
     case 103: {  // fused Lanczos, pending axpy + rotate + H*v
       auto kern = normal_rows_kernel<NT, TD, USE_LDS, true, false, PACKED, VEC, HDF, 3>;
-      if (lds > 48 * 1024)
-        EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (ensure_dynamic_lds((const void*)kern, lds)) return 1;
       hipLaunchKernelGGL(kern, grid, block, lds, st, a, vl, vf, hv);
       break;
     }
@@ -467,7 +462,7 @@ static int launch_split_t(const edigpu_sector* s, NormalArgs a, const double* vl
   const int64_t part = (((a.dim_up + s->row_split - 1) / s->row_split) + 1) & ~(int64_t)1;
   auto kern = normal_rows_kernel<NT, 1, true, true, false, true, VEC, HDF, 0, true>;
   const size_t lds = (size_t)((part + 2) & ~(int64_t)1) * sizeof(double) + 128 * sizeof(double);
-  EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (ensure_dynamic_lds((const void*)kern, lds)) return 1;
   for (int64_t first = 0; first < a.dim_up; first += part) {
     a.split_first = first;
     a.split_count = std::min<int64_t>(part, a.dim_up - first);
@@ -532,11 +527,16 @@ static void fill_args(const edigpu_sector* s, NormalArgs& a) {
   a.nd_coef = s->d_ndcoef;
   a.jup = s->d_jup;
   a.jdw = s->d_jdw;
+  a.panel_mode = s->panel_mode;
+  a.tile_nchunks = s->tile_nchunks;
+  a.tile_rows = s->tile_rows;
+  a.tile_chunks = s->d_tile_chunks;
   a.mx_rowptr = s->d_mx_rowptr;
   a.mx_col = s->d_mx_col;
   a.mx_val = s->d_mx_val;
   a.scal = nullptr;
   a.partial = nullptr;
+  a.partial_cap = 0;
   a.split_first = 0;
   a.split_count = s->dim_up;
 }
@@ -606,18 +606,19 @@ bool normal_lanczos_fusable(const edigpu_sector* s) {
 }
 
 int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const double* scal,
-                          double* partial, bool first, bool lazy_axpy, hipStream_t st, int* npartial) {
+                          double* partial, int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial) {
   NormalArgs a;
   fill_args(s, a);
   a.scal = scal;
   a.partial = partial;
+  a.partial_cap = partial_cap;
   if (launch_rows(s, a, P, P, Q, first ? 101 : (lazy_axpy ? 103 : 102), st)) return 1;
   const bool fac_nd = s->factored && a.nterms > 0 && s->d_mx_rowptr != nullptr;
   if (!s->factored && s->has_nd && s->nd.sell) {
     // explicit image (hand-over arrays): panels without the dot, then Q += Hnd v as a SELL pass whose
     // epilogue carries the <v|Q>, <Q|Q> partials
     if (launch_dw_panels(a, true, false, P, Q, st)) return 1;
-    return launch_csr_lanczos(s->nd, 0, P, Q, partial, npartial, st);
+    return launch_csr_lanczos(s->nd, 0, P, Q, partial, partial_cap, npartial, scal + SC_ALPHA, st);
   }
   return launch_dw_panels(a, true, fac_nd, P, Q, st, true, npartial);
 }

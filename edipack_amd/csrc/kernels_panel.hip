@@ -32,6 +32,7 @@ struct PanelArgs {
   // [col_first - halo, col_first + ncol + halo) of every row at the given row stride (>= ncol + 2 * halo)
   int64_t col_first, ncol, stride;
   int halo;
+  int tile_rows;  // LDS-tiled form: rows of the largest chunk (LDS = tile_rows KiB + the Hnd partner table)
 };
 
 constexpr int kPanelNT = 512;
@@ -58,6 +59,9 @@ __global__ void __launch_bounds__(kPanelNT)
   }
   if (panel >= p.npanels) return;
   double asum = 0.0, qsum = 0.0;
+  // <Q|Q> is accumulated about the previous alpha (sg): beta^2 = sum (Q - sg v)^2 - (alpha - sg)^2 stays well
+  // conditioned when the spectrum sits far from zero (|alpha| >> beta), see k_finalize_ab
+  const double sg = ALPHA ? a.scal[SC_ALPHA] : 0.0;
   const int chunk = k % p.blocks_per_panel;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -160,10 +164,10 @@ __global__ void __launch_bounds__(kPanelNT)
       if (two) hv[r2 * DimUp + c] = acc1;
       if (ALPHA) {
         asum += own0 * acc0;
-        qsum += acc0 * acc0;
+        qsum += (acc0 - sg * own0) * (acc0 - sg * own0);
         if (two) {
           asum += own1 * acc1;
-          qsum += acc1 * acc1;
+          qsum += (acc1 - sg * own1) * (acc1 - sg * own1);
         }
       }
     }
@@ -222,6 +226,7 @@ __global__ void __launch_bounds__(kPanelNT)
   }
   if (panel >= p.npanels) return;
   double asum = 0.0, qsum = 0.0;
+  const double sg = ALPHA ? a.scal[SC_ALPHA] : 0.0;  // see normal_dw_panel_kernel
   const int chunk = k % p.blocks_per_panel;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -331,11 +336,209 @@ __global__ void __launch_bounds__(kPanelNT)
       st2(&hv[r * DimUp + c], acc0);
       if (two) st2(&hv[r2 * DimUp + c], acc1);
       if (ALPHA) {
+        const double d0x = acc0.x - sg * own0.x, d0y = acc0.y - sg * own0.y;
         asum += own0.x * acc0.x + own0.y * acc0.y;
-        qsum += acc0.x * acc0.x + acc0.y * acc0.y;
+        qsum += d0x * d0x + d0y * d0y;
         if (two) {
+          const double d1x = acc1.x - sg * own1.x, d1y = acc1.y - sg * own1.y;
           asum += own1.x * acc1.x + own1.y * acc1.y;
-          qsum += acc1.x * acc1.x + acc1.y * acc1.y;
+          qsum += d1x * d1x + d1y * d1y;
+        }
+      }
+    }
+  }
+  if (ALPHA) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      asum += __shfl_down(asum, off, 64);
+      qsum += __shfl_down(qsum, off, 64);
+    }
+    if (lane == 0) {
+      red[wave] = asum;
+      red[kPanelNT / 64 + wave] = qsum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0, q = 0.0;
+#pragma unroll
+      for (int i = 0; i < kPanelNT / 64; i++) {
+        t += red[i];
+        q += red[kPanelNT / 64 + i];
+      }
+      a.partial[blockIdx.x] = t;
+      a.partial[gridDim.x + blockIdx.x] = q;
+    }
+  }
+}
+
+// LDS-tiled form of the two-column sweep (default for large sectors; EDIGPU_PANEL_TILE=0 switches it off).
+// The sweep above is bound by the L2 -> CU gather rate (~60 % of its time on config 2, rocprofv3 r01).  Here a
+// workgroup owns a CHUNK of consecutive down rows of its panel (host-planned so that most hops stay inside it:
+// rows that share their high bath bits are contiguous and closed under the hops among the low levels) and stages
+// the chunk's row segments in LDS once -- coalesced 1 KiB loads that the alpha partial needs anyway.  A wave still owns
+// one output row; a neighbour row inside the chunk is read from LDS (a contiguous 1 KiB ds_read_b128 sweep, no bank
+// conflicts), only the hops that leave the chunk go to L2.  The neighbour list is wave-uniform, so is the
+// LDS-or-global decision.  Hnd partner segments come the same way.
+constexpr int kTileSeg = 64;  // double2 per staged row segment (128 columns)
+
+template <bool DO_ND, bool ALPHA, bool EDGE>
+__global__ void __launch_bounds__(kPanelNT)
+    normal_dw_tile_kernel(NormalArgs a, PanelArgs p, const int32_t* __restrict__ chunk_start,
+                          const double* __restrict__ v_full, double* __restrict__ hv) {
+  __shared__ double red[2 * (kPanelNT / 64)];
+  extern __shared__ double2 tile[];  // [chunk rows][kTileSeg], then the Hnd partner table [2 * nterms][64]
+  const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const int panel = (k / p.blocks_per_panel) * 8 + x;
+  if (ALPHA) {
+    if (panel >= p.npanels || a.scal[SC_STOP] != 0.0) {
+      if (threadIdx.x == 0) {
+        a.partial[blockIdx.x] = 0.0;
+        a.partial[gridDim.x + blockIdx.x] = 0.0;
+      }
+      return;
+    }
+  }
+  if (panel >= p.npanels) return;
+  double asum = 0.0, qsum = 0.0;
+  const double sg = ALPHA ? a.scal[SC_ALPHA] : 0.0;  // see normal_dw_panel_kernel
+  const int chunk = k % p.blocks_per_panel;
+  const int rb = chunk_start[chunk], nrows = chunk_start[chunk + 1] - rb;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int NW = kPanelNT / 64;
+  const int64_t DimUp = a.dim_up;
+  const int64_t pbase = (int64_t)panel * p.width;
+  auto col_of = [&](int l, bool& okl, bool& pairl) -> int64_t {
+    const int64_t cl = pbase + 2 * l;
+    okl = 2 * l < p.width && cl < DimUp;
+    const int64_t ccl = okl ? cl : (EDGE ? DimUp - 1 : DimUp - 2);
+    pairl = !EDGE || ccl + 1 < DimUp;
+    return ccl;
+  };
+  bool ok, pair;
+  const int64_t cc = col_of(lane, ok, pair);
+  const int64_t c = pbase + 2 * lane;
+  auto ld2 = [&](const double* q) -> double2 {
+    if (!EDGE) return *reinterpret_cast<const double2*>(q);
+    if (pair) {
+      const d2u t = *reinterpret_cast<const d2u*>(q);
+      return make_double2(t.x, t.y);
+    }
+    return make_double2(q[0], 0.0);
+  };
+  auto st2 = [&](double* q, double2 t) {
+    if (!EDGE) {
+      *reinterpret_cast<double2*>(q) = t;
+    } else if (pair) {
+      d2u u;
+      u.x = t.x;
+      u.y = t.y;
+      *reinterpret_cast<d2u*>(q) = u;
+    } else {
+      q[0] = t.x;
+    }
+  };
+  // ---- stage the chunk's own row segments: four independent 1 KiB loads in flight per wave ----
+  const int64_t g0 = a.dw_first + rb;  // global index of the first staged row
+  for (int r = wave; r < nrows; r += 4 * NW) {
+    double2 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int rr = r + u * NW < nrows ? r + u * NW : nrows - 1;
+      t[u] = ld2(&v_full[(g0 + rr) * DimUp + cc]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (r + u * NW < nrows) tile[(r + u * NW) * kTileSeg + lane] = t[u];
+  }
+  // Hnd partner of a column, per term and component (encoding of normal_dw_panel2_kernel), one word per LANE
+  uint32_t* ju2 = reinterpret_cast<uint32_t*>(tile + (size_t)p.tile_rows * kTileSeg);
+  if (DO_ND) {
+    auto encode = [&](uint32_t jt) -> uint32_t {
+      if (jt == 0xFFFFFFFFu) return jt;
+      const int64_t rel = (int64_t)(jt & 0x7FFFFFFFu) - pbase;
+      if (rel >= 0 && rel < p.width) return (jt & 0x80000000u) | (uint32_t)rel;
+      return (jt & 0x80000000u) | 0x40000000u | (jt & 0x3FFFFFFFu);
+    };
+    for (int i = threadIdx.x; i < 2 * a.nterms * 64; i += kPanelNT) {
+      const int t2 = i >> 6, l = i & 63;
+      bool okl, pairl;
+      const int64_t ccl = col_of(l, okl, pairl);
+      const int64_t src = (int64_t)(t2 >> 1) * DimUp + ccl;
+      ju2[i] = (t2 & 1) ? (pairl ? encode(a.jup[src + 1]) : 0xFFFFFFFFu) : encode(a.jup[src]);
+    }
+  }
+  __syncthreads();
+  // a neighbour row's segment: from the staged chunk when it lies inside, else from L2 / HBM (wave-uniform choice)
+  auto fetch = [&](int64_t prow) -> double2 {
+    const uint32_t rel = (uint32_t)(prow - g0);
+    if (rel < (uint32_t)nrows) return tile[rel * kTileSeg + lane];
+    return ld2(&v_full[prow * DimUp + cc]);
+  };
+  auto row_sum = [&](int lr, double2 acc) -> double2 {
+    const int64_t g = a.dw_first + lr;
+    if (!DO_ND) {
+      const int32_t b0 = a.dw_rowptr[g], e0 = a.dw_rowptr[g + 1];
+#pragma unroll 4
+      for (int32_t jj = b0; jj < e0; jj++) {
+        const double w = a.dw_val[jj];
+        const double2 y = fetch(a.dw_col[jj]);
+        acc.x += w * y.x;
+        acc.y += w * y.y;
+      }
+    } else {
+      const int32_t b0 = a.mx_rowptr[lr], e0 = a.mx_rowptr[lr + 1];
+      const int32_t mid = b0 + (a.dw_rowptr[g + 1] - a.dw_rowptr[g]);
+#pragma unroll 4
+      for (int32_t jj = b0; jj < mid; jj++) {
+        const double w = a.mx_val[jj];
+        const double2 y = fetch((int64_t)((uint32_t)a.mx_col[jj] & 0xFFFFFFu));
+        acc.x += w * y.x;
+        acc.y += w * y.y;
+      }
+      for (int32_t jj = mid; jj < e0; jj++) {
+        const uint32_t cw = (uint32_t)a.mx_col[jj];
+        const int tag = (int)(cw >> 24);  // wave-uniform, >= 1
+        const double w = a.mx_val[jj];
+        const int64_t prow = (int64_t)(cw & 0xFFFFFFu);
+        const uint32_t j0 = ju2[(2 * (tag - 1)) * 64 + lane];
+        const uint32_t j1 = ju2[(2 * (tag - 1) + 1) * 64 + lane];
+        const bool v0 = j0 != 0xFFFFFFFFu, v1 = j1 != 0xFFFFFFFFu;
+        const double w0 = v0 ? ((j0 >> 31) ? -w : w) : 0.0, w1 = v1 ? ((j1 >> 31) ? -w : w) : 0.0;
+        const double2 y = fetch(prow);
+        const int l0 = (int)((j0 >> 1) & 63u), l1 = (int)((j1 >> 1) & 63u);
+        const double s0x = __shfl(y.x, l0, 64), s0y = __shfl(y.y, l0, 64);
+        const double s1x = __shfl(y.x, l1, 64), s1y = __shfl(y.y, l1, 64);
+        double p0 = (j0 & 1u) ? s0y : s0x, p1 = (j1 & 1u) ? s1y : s1x;
+        if (v0 && (j0 & 0x40000000u)) p0 = v_full[prow * DimUp + (int64_t)(j0 & 0x3FFFFFFFu)];  // panel edge
+        if (v1 && (j1 & 0x40000000u)) p1 = v_full[prow * DimUp + (int64_t)(j1 & 0x3FFFFFFFu)];
+        acc.x += w0 * p0;
+        acc.y += w1 * p1;
+      }
+    }
+    return acc;
+  };
+  for (int r = wave; r < nrows; r += 2 * NW) {
+    const int r2 = r + NW;
+    const bool two = r2 < nrows;
+    const int64_t o0 = (int64_t)(rb + r) * DimUp, o1 = (int64_t)(rb + r2) * DimUp;
+    double2 acc0 = ld2(&hv[o0 + cc]);
+    double2 acc1 = two ? ld2(&hv[o1 + cc]) : make_double2(0.0, 0.0);
+    acc0 = row_sum(rb + r, acc0);
+    if (two) acc1 = row_sum(rb + r2, acc1);
+    if (ok) {
+      st2(&hv[o0 + c], acc0);
+      if (two) st2(&hv[o1 + c], acc1);
+      if (ALPHA) {
+        const double2 own0 = tile[r * kTileSeg + lane];
+        const double d0x = acc0.x - sg * own0.x, d0y = acc0.y - sg * own0.y;
+        asum += own0.x * acc0.x + own0.y * acc0.y;
+        qsum += d0x * d0x + d0y * d0y;
+        if (two) {
+          const double2 own1 = tile[r2 * kTileSeg + lane];
+          const double d1x = acc1.x - sg * own1.x, d1y = acc1.y - sg * own1.y;
+          asum += own1.x * acc1.x + own1.y * acc1.y;
+          qsum += d1x * d1x + d1y * d1y;
         }
       }
     }
@@ -428,14 +631,10 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
     set_error("launch_dw_panels: too many factored Hnd terms");
     return 1;
   }
-  static const bool vec2_env = !getenv("EDIGPU_PANEL_VEC2") || atoi(getenv("EDIGPU_PANEL_VEC2")) != 0;
-  // measured: config 2 H*v 0.145 -> 0.132 ms, Ns=16 ladder 5.07 -> 4.87 ms; cache-resident sectors (cfg3, 213 k rows)
-  // are 13 % SLOWER with the wider panels (fewer, fatter waves), hence the size gate
   const bool edge = (a.dim_up % 2) != 0;  // odd DimUp: 8-byte aligned rows, see d2u
-  // EDIGPU_PANEL_VEC2_MIN: smallest sector (rows) that takes the two-column kernel (tests force it on small ones)
-  static const int64_t vec2_min = getenv("EDIGPU_PANEL_VEC2_MIN") ? atoll(getenv("EDIGPU_PANEL_VEC2_MIN")) : ((int64_t)1 << 21);
-  const bool vec2 = vec2_env && do_dw && a.dim_up >= 2 && a.dim_up * a.dw_count >= vec2_min &&
-                    (((uintptr_t)v_full | (uintptr_t)hv) & (edge ? 7 : 15)) == 0;
+  // the variant was fixed when the sector was set up (NormalArgs::panel_mode); the buffers must be aligned for it
+  const bool vec2 = a.panel_mode >= 1 && do_dw && (((uintptr_t)v_full | (uintptr_t)hv) & (edge ? 7 : 15)) == 0;
+  const bool tiled = vec2 && a.panel_mode == 2 && a.tile_chunks != nullptr;
   PanelArgs p;
   if (vec2) {
     int wmax = 128;
@@ -455,22 +654,50 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
   p.ncol = a.dim_up;
   p.stride = a.dim_up;
   p.halo = 0;
+  p.tile_rows = 0;
   int bpp = panel_resident_blocks();
   if (vec2 && !getenv("EDIGPU_PANEL_BPP")) bpp = 256;  // half as many panels: twice the workgroups on each (measured)
   p.rows_per_block = (int)((a.dw_count + bpp - 1) / bpp);
   if (p.rows_per_block < 16) p.rows_per_block = 16;
   bpp = (int)((a.dw_count + p.rows_per_block - 1) / p.rows_per_block);
+  if (tiled) {  // one workgroup per planned row chunk
+    bpp = a.tile_nchunks;
+    p.tile_rows = a.tile_rows;
+  }
   p.blocks_per_panel = bpp;
   const int panel_groups = (p.npanels + 7) / 8;
   const dim3 grid((unsigned)((int64_t)panel_groups * bpp * 8)), block(kPanelNT);
   if (nblocks) *nblocks = (int)grid.x;
+  if (alpha && 2 * (int64_t)grid.x > a.partial_cap) {  // before anything that writes the partials is enqueued
+    set_error("launch_dw_panels: partial buffer too small for this grid");
+    return 1;
+  }
+  if (tiled) {
+    const size_t lds = (size_t)p.tile_rows * kTileSeg * sizeof(double2) + (do_nd ? (size_t)2 * a.nterms * 64 * sizeof(uint32_t) : 0);
+#define EDIGPU_LAUNCH_P3(ND, AL)                                                                               \
+  do {                                                                                                         \
+    auto kern = edge ? normal_dw_tile_kernel<ND, AL, true> : normal_dw_tile_kernel<ND, AL, false>;             \
+    if (ensure_dynamic_lds((const void*)kern, lds)) return 1;                                                  \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a, p, a.tile_chunks, v_full, hv);                           \
+  } while (0)
+    if (do_nd && alpha)
+      EDIGPU_LAUNCH_P3(true, true);
+    else if (do_nd)
+      EDIGPU_LAUNCH_P3(true, false);
+    else if (alpha)
+      EDIGPU_LAUNCH_P3(false, true);
+    else
+      EDIGPU_LAUNCH_P3(false, false);
+#undef EDIGPU_LAUNCH_P3
+    EDIGPU_HIP(hipGetLastError());
+    return 0;
+  }
   if (vec2) {
     const size_t lds = do_nd ? (size_t)2 * a.nterms * kPanelNT * sizeof(uint32_t) : 0;
 #define EDIGPU_LAUNCH_P2(ND, AL)                                                                               \
   do {                                                                                                         \
     auto kern = edge ? normal_dw_panel2_kernel<ND, AL, true> : normal_dw_panel2_kernel<ND, AL, false>;         \
-    if (lds > 48 * 1024)                                                                                       \
-      EDIGPU_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    if (ensure_dynamic_lds((const void*)kern, lds)) return 1; \
     hipLaunchKernelGGL(kern, grid, block, lds, st, a, p, v_full, hv);                                          \
   } while (0)
     if (do_nd && alpha)

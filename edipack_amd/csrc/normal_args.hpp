@@ -41,6 +41,13 @@ struct NormalArgs {
   // fused Lanczos step (device scalars, see kernels.hpp SC_*) and per-workgroup alpha partials
   const double* scal;
   double* partial;
+  int64_t partial_cap;  // doubles in `partial`; the panel launch checks its grid against it before enqueueing
+  // panel sweep variant chosen when the sector was set up (environment switches are read there):
+  // 0 one column per lane, 1 two columns per lane, 2 two columns + LDS-staged row chunks (tile_chunks: nchunks + 1
+  // local row offsets, tile_rows: the longest chunk)
+  int panel_mode;
+  int tile_nchunks, tile_rows;
+  const int32_t* tile_chunks;
   const int32_t* mx_rowptr;  // merged list: ptr[dw_count+1]
   const int32_t* mx_col;     // partner row (24 bit) | tag << 24
   const double* mx_val;

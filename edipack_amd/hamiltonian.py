@@ -336,7 +336,7 @@ class SectorHamiltonian:
                    "edigpu_normal_apply_cols_dev")
 
     # ---- Lanczos ------------------------------------------------------------------------------
-    def lanczos_tridiag(self, vin: np.ndarray, nlanc: int, threshold: float = 0.0):
+    def lanczos_tridiag(self, vin: np.ndarray, nlanc: int, threshold: float = 1e-12):
         """sp_lanc_tridiag semantics, vector resident on the device."""
         vin = np.ascontiguousarray(vin, dtype=self.dtype)
         a = np.zeros(nlanc)
@@ -364,7 +364,7 @@ class SectorHamiltonian:
             "edigpu_lanczos_eigh_multi")
         return ev, vec, nc.value, nmv.value
 
-    def lanczos_tridiag_dev(self, vin_ptr: int, nlanc: int, threshold: float = 0.0):
+    def lanczos_tridiag_dev(self, vin_ptr: int, nlanc: int, threshold: float = 1e-12):
         """tridiag_Hv_sector_* with the seed already on the device: -> (alanc, blanc, niter, norm2)."""
         a = np.zeros(nlanc)
         b = np.zeros(nlanc)

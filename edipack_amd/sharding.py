@@ -252,7 +252,7 @@ class ShardedLanczos:
         blanc[ndone:] = 0.0
         return alanc, blanc, ndone
 
-    def tridiag(self, v_local: torch.Tensor, nlanc: int, threshold: float = 0.0, exact: bool = False):
+    def tridiag(self, v_local: torch.Tensor, nlanc: int, threshold: float = 1e-12, exact: bool = False):
         """v_local: this rank's slice (length plan.nloc).  Returns (alanc, blanc, niter) on the host.
 
         Default: one all-reduce of (<v|w>, <w|w>) per step, beta^2 = <w|w> - alpha^2, the axpy folded into the next
@@ -467,7 +467,7 @@ class TransposedLanczos(ShardedLanczos):
         self.k.unpack_add_dot2(self, self.vin, self.vout, self.tmp, self.back, ab[2 * it:2 * it + 2])
         self._allreduce(ab[2 * it:2 * it + 2])
 
-    def tridiag(self, v_local: torch.Tensor, nlanc: int, threshold: float = 0.0):
+    def tridiag(self, v_local: torch.Tensor, nlanc: int, threshold: float = 1e-12):
         if not self.fused:
             return super().tridiag(v_local, nlanc, threshold, exact=True)
         self._start(v_local)

@@ -22,6 +22,8 @@ module EDIGPU_SHIM
   type(c_ptr), save :: gpu_sector = c_null_ptr   !< the live edigpu_handle
 
   integer, parameter, public :: EDIGPU_MAXORB = 5, EDIGPU_MAXBATH = 16
+  !> breakdown threshold of the tridiagonalisation (sp_lanc_tridiag is called without one: SciFortran's default)
+  real(c_double), public :: lanc_threshold = 1.0e-12_c_double
 
   !> struct edigpu_model (include/edigpu.h): the module globals the reference's builders read.  C arrays
   !! are row-major, so the Fortran index order is reversed: uloc(iorb), ust(jorb,iorb) ... ,
@@ -383,6 +385,9 @@ contains
   end subroutine spMatVec_gpu_c
 
   !> device-resident replacement of  call sp_lanc_tridiag(spHtimesV_p, vvinit, alanc, blanc)
+  !! The reference passes no threshold there, i.e. SciFortran's default breakdown threshold applies (believed
+  !! 1d-12; the SciFortran source is not part of the reference tree): the recurrence exits when |beta| falls below
+  !! it, and the library additionally stops on an exact zero whatever the threshold is.
   !! (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:360-365): the vector never leaves HBM between steps
   subroutine gpu_lanc_tridiag_d(vin, alanc, blanc)
     real(8), intent(in), target :: vin(:)
@@ -390,7 +395,7 @@ contains
     integer(c_int) :: niter
     if (.not. c_associated(gpu_sector)) stop "gpu_lanc_tridiag_d: Hsector NOT allocated"
     call gpu_check(edigpu_lanczos_tridiag(gpu_sector, c_loc(vin), int(size(alanc), c_int), &
-         alanc, blanc, 0.0_c_double, niter), "gpu_lanc_tridiag_d")
+         alanc, blanc, lanc_threshold, niter), "gpu_lanc_tridiag_d")
   end subroutine gpu_lanc_tridiag_d
 
   subroutine gpu_lanc_tridiag_c(vin, alanc, blanc)
@@ -399,7 +404,7 @@ contains
     integer(c_int) :: niter
     if (.not. c_associated(gpu_sector)) stop "gpu_lanc_tridiag_c: Hsector NOT allocated"
     call gpu_check(edigpu_lanczos_tridiag(gpu_sector, c_loc(vin), int(size(alanc), c_int), &
-         alanc, blanc, 0.0_c_double, niter), "gpu_lanc_tridiag_c")
+         alanc, blanc, lanc_threshold, niter), "gpu_lanc_tridiag_c")
   end subroutine gpu_lanc_tridiag_c
 
   !> delete_Hv_sector_* counterpart (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:212-279)

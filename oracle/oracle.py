@@ -346,7 +346,7 @@ class HNormal:
         self._L.orc_hnormal_dense(self._h, _dp(out))
         return out
 
-    def lanc_tridiag(self, vin: np.ndarray, nitermax: int, threshold: float = 0.0):
+    def lanc_tridiag(self, vin: np.ndarray, nitermax: int, threshold: float = 1e-12):
         v = np.array(vin, dtype=np.float64, copy=True)
         a = np.zeros(nitermax)
         b = np.zeros(nitermax)
@@ -408,7 +408,7 @@ class HOrbs:
         self._L.orc_horbs_dense(self._h, _dp(out))
         return out
 
-    def lanc_tridiag(self, vin: np.ndarray, nitermax: int, threshold: float = 0.0):
+    def lanc_tridiag(self, vin: np.ndarray, nitermax: int, threshold: float = 1e-12):
         v = np.array(vin, dtype=np.float64, copy=True)
         a = np.zeros(nitermax)
         b = np.zeros(nitermax)
@@ -475,7 +475,7 @@ class HNormalCmplx:
     def dense(self) -> np.ndarray:
         return self.S.dense() + 1j * self.A.dense()
 
-    def lanc_tridiag(self, vin: np.ndarray, nitermax: int, threshold: float = 0.0):
+    def lanc_tridiag(self, vin: np.ndarray, nitermax: int, threshold: float = 1e-12):
         """sp_lanc_tridiag on complex vectors (the recurrence of lanc_tridiag in edipack_oracle.c, w = 2)."""
         v = np.array(vin, dtype=np.complex128)
         a, b = np.zeros(nitermax), np.zeros(nitermax)
@@ -547,7 +547,7 @@ class HFlat:
         self._L.orc_hflat_dense(self._h, _dp(out.view(np.float64)))
         return out
 
-    def lanc_tridiag(self, vin: np.ndarray, nitermax: int, threshold: float = 0.0):
+    def lanc_tridiag(self, vin: np.ndarray, nitermax: int, threshold: float = 1e-12):
         v = np.array(vin, dtype=np.complex128, copy=True)
         a = np.zeros(nitermax)
         b = np.zeros(nitermax)

@@ -1,0 +1,196 @@
+"""Self-energy moments of the reference's superc / nonsu2 regression tests, rebuilt from the COMPLEX Lanczos
+tridiagonalisation -- the fixtures (`Sigma_momenta.check`, `Self_momenta.check` of *_SUPERC; `Sigma11_momenta.check`,
+`Sigma12_momenta.check` of *_NONSU2) that exercise tridiag_Hv_sector_superc / _nonsu2 + sp_lanc_tridiag with
+complex vectors, i.e. row a19 of SURVEY.md 8.
+
+Restated for checking only (T=0, bath_type=normal, paths relative to /root/reference/src/singlesite):
+  lanc_build_gf_superc_Gdiag / _Fmix   ED_SUPERC/ED_GF_SUPERC.f90:130-198, 287-361  (channels and seeds)
+  add_to_lanczos_gf_superc             ED_SUPERC/ED_GF_SUPERC.f90:440-513  (poles isign (E_j - E_i), weights vnorm2 Z_1j^2 / zeta)
+  get_impG_superc / get_impF_superc    ED_SUPERC/ED_GF_SUPERC.f90:578-843  (F = (aux - (1 - i)(G + barG)) / 2)
+  get_Sigma_superc / get_Self_superc   ED_SUPERC/ED_GF_SUPERC.f90:938-1102 (normal bath, Matsubara axis)
+  delta / fdelta / invg0 / invf0       ED_BATH/delta_functions/delta_normal.f90:44-62, fdelta_normal.f90,
+                                       ED_BATH/invg0_functions/invg0_normal.f90, invf0_normal.f90
+  lanc_build_gf_nonsu2_diagOrb_diagSpin / _mixOrb_mixSpin   ED_NONSU2/ED_GF_NONSU2.f90:159-301
+  get_impG_nonsu2 / get_Sigma_nonsu2   ED_NONSU2/ED_GF_NONSU2.f90:491-634, 716-748
+  tridiag_Hv_sector_superc / _nonsu2   ED_SUPERC/ED_HAMILTONIAN_SUPERC.f90:227-272, ED_NONSU2/ED_HAMILTONIAN_NONSU2.f90:202-244
+  compute_momentum                     test/src/COMMON.f90:170-192
+The tridiagonalisation itself is a plug-in `tridiag(sector, unit seed, nlanc) -> (alanc, blanc)`, so the same
+driver checks the oracle (CPU) and the GPU library.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import oracle as O
+
+
+def _popcount(x: np.ndarray) -> np.ndarray:
+    y = x.astype(np.int64).copy()
+    c = np.zeros_like(y)
+    while np.any(y):
+        c += y & 1
+        y >>= 1
+    return c
+
+
+def apply_cops(h_from, h_to, vec, ops, ns):
+    """apply_Cops (ED_SECTOR.f90:839-960) on the 2*Ns-bit states of a superc / nonsu2 sector:
+    sum_s coef_s c^(+)_{orb_s, spin_s} |vec>; ops = [(coef, create, iorb, ispin)], up levels first, the sign counts
+    every occupied level below the operator's."""
+    out = np.zeros(h_to.dim, complex)
+    rank_to = {int(s): i for i, s in enumerate(h_to.map)}
+    smap = h_from.map.astype(np.int64)
+    for coef, create, iorb, ispin in ops:
+        bit = 1 << (iorb + ispin * ns)
+        occ = (smap & bit) != 0
+        sel = np.nonzero(~occ if create else occ)[0]
+        if sel.size == 0:
+            continue
+        sgn = 1.0 - 2.0 * (_popcount(smap[sel] & (bit - 1)) & 1)
+        tgt = np.array([rank_to[int(s) ^ bit] for s in smap[sel]], dtype=np.int64)
+        out[tgt] += coef * sgn * vec[sel]
+    return out
+
+
+def _ground_states(om, gs_threshold):
+    secs = []
+    for sec in O.sectors(om):
+        try:
+            h = O.HFlat(om, sec)
+        except Exception:
+            continue
+        if h.dim:
+            w, v = np.linalg.eigh(h.dense())
+            secs.append((sec, h, w, v))
+    e0 = min(w[0] for _, _, w, _ in secs)
+    return e0, [(sec, h, w[k], v[:, k]) for sec, h, w, v in secs for k in range(len(w)) if w[k] - e0 <= gs_threshold]
+
+
+def _pole_sum(z, tridiag, hcache, om, states, zeta, ngfiter, channels):
+    """sum over ground states and channels of weight / (z - pole); channels(sec) yields
+    (target sector | None, ops, isign, complex prefactor of norm2)."""
+    g = np.zeros(z.shape[0], complex)
+    ns = om.ns
+    for sec, h, ei, vec in states:
+        for sec2, ops, isign, pref in channels(sec):
+            if sec2 is None:
+                continue
+            if sec2 not in hcache:
+                try:
+                    hcache[sec2] = O.HFlat(om, sec2)
+                except Exception:
+                    hcache[sec2] = None
+            h2 = hcache[sec2]
+            if h2 is None or h2.dim == 0:
+                continue
+            vv = apply_cops(h, h2, vec, ops, ns)
+            norm2 = float(np.real(np.vdot(vv, vv)))
+            if norm2 == 0.0:
+                continue
+            nl = min(h2.dim, ngfiter)
+            al, bl = tridiag(sec2, vv / np.sqrt(norm2), nl)
+            t = np.diag(al[:nl]) + np.diag(bl[1:nl], 1) + np.diag(bl[1:nl], -1)
+            ev, zz = np.linalg.eigh(t)
+            poles = isign * (ev - ei)
+            wts = pref * norm2 / zeta * zz[0, :] ** 2
+            g += np.sum(wts[None, :] / (z[:, None] - poles[None, :]), axis=1)
+    return g
+
+
+def _moments(f, wm, nmom):
+    a = np.abs(f)
+    return np.array([np.sum(a * wm ** n) / np.sum(a) for n in range(1, nmom + 1)])
+
+
+def momenta_superc(om, tridiag, beta=1000.0, lmats=4096, ngfiter=200, gs_threshold=1e-9, nmom=4):
+    """-> (Sigma_momenta[norb, nmom], Self_momenta[norb, nmom]) as the *_SUPERC fixtures store them; bath normal."""
+    assert om.ed_mode == "superc" and om.bath_type == "normal"
+    ns, no = om.ns, om.norb
+    e0, states = _ground_states(om, gs_threshold)
+    zeta = float(len(states))
+    wm = np.pi / beta * (2.0 * np.arange(1, lmats + 1) - 1.0)
+    z = 1j * wm
+    hcache = {}
+    up, dw = 0, 1
+
+    def sz_ok(s):
+        return s if -ns <= s <= ns else None
+
+    sig = np.zeros((no, nmom))
+    slf = np.zeros((no, nmom))
+    for a in range(no):
+        # G_upup(aa): c^+_up (Sz+1, isign +1), c_up (Sz-1, isign -1)      (lanc_build_gf_superc_Gdiag)
+        g = _pole_sum(z, tridiag, hcache, om, states, zeta, ngfiter, lambda s: [
+            (sz_ok(s + 1), [(1.0, True, a, up)], 1, 1.0), (sz_ok(s - 1), [(1.0, False, a, up)], -1, 1.0)])
+        # barG(aa): c_dw (Sz+1, isign +1), c^+_dw (Sz-1, isign -1)
+        gb = _pole_sum(z, tridiag, hcache, om, states, zeta, ngfiter, lambda s: [
+            (sz_ok(s + 1), [(1.0, False, a, dw)], 1, 1.0), (sz_ok(s - 1), [(1.0, True, a, dw)], -1, 1.0)])
+        # F mix channels: O^+ = c^+_up + c_dw, O = c_up + c^+_dw, P^+ = c^+_up + i c_dw, P = c_up - i c^+_dw  (_Fmix)
+        aux = _pole_sum(z, tridiag, hcache, om, states, zeta, ngfiter, lambda s: [
+            (sz_ok(s + 1), [(1.0, True, a, up), (1.0, False, a, dw)], 1, 1.0),
+            (sz_ok(s - 1), [(1.0, False, a, up), (1.0, True, a, dw)], -1, 1.0),
+            (sz_ok(s + 1), [(1.0, True, a, up), (1j, False, a, dw)], 1, -1j),
+            (sz_ok(s - 1), [(1.0, False, a, up), (-1j, True, a, dw)], -1, -1j)])
+        f12 = 0.5 * (aux - (1.0 - 1j) * (g + gb))
+        e, d, v = om.be[0, a, :], om.bd[0, a, :], om.bv[0, a, :]
+        den = wm[:, None] ** 2 + e[None, :] ** 2 + d[None, :] ** 2
+        delta = -np.sum(v[None, :] ** 2 * (z[:, None] + e[None, :]) / den, axis=1)
+        fdelta = np.sum(d[None, :] * v[None, :] ** 2 / den, axis=1)
+        invg0 = z + om.xmu - om.hloc[0, 0, a, a].real - delta
+        invf0 = -fdelta                      # impHloc_anomalous = 0 (no pair field in the fixtures)
+        gdet = np.real(np.abs(g) ** 2 + f12 ** 2)
+        sig[a] = _moments(invg0 - np.conj(g) / gdet, wm, nmom)
+        slf[a] = _moments(invf0 - f12 / gdet, wm, nmom)
+    return sig, slf
+
+
+def momenta_nonsu2(om, tridiag, beta=300.0, lmats=2000, ngfiter=300, gs_threshold=1e-9, nmom=4):
+    """-> (Sigma11_momenta[norb, nmom], Sigma12_momenta[norb, nmom]) as the *_NONSU2 fixtures store them; bath normal."""
+    assert om.ed_mode == "nonsu2" and om.bath_type == "normal" and om.nspin == 2
+    ns, no = om.ns, om.norb
+    nlev = 2 * ns
+    e0, states = _ground_states(om, gs_threshold)
+    zeta = float(len(states))
+    wm = np.pi / beta * (2.0 * np.arange(1, lmats + 1) - 1.0)
+    z = 1j * wm
+    hcache = {}
+
+    def n_ok(n):
+        return n if 0 <= n <= nlev else None
+
+    gf = np.zeros((2, 2, no, lmats), complex)
+    for a in range(no):
+        for s in range(2):
+            gf[s, s, a] = _pole_sum(z, tridiag, hcache, om, states, zeta, ngfiter, lambda n: [
+                (n_ok(n + 1), [(1.0, True, a, s)], 1, 1.0), (n_ok(n - 1), [(1.0, False, a, s)], -1, 1.0)])
+        for s in range(2):
+            for t in range(2):
+                if s == t:
+                    continue
+                aux = _pole_sum(z, tridiag, hcache, om, states, zeta, ngfiter, lambda n: [
+                    (n_ok(n + 1), [(1.0, True, a, s), (1.0, True, a, t)], 1, 1.0),
+                    (n_ok(n - 1), [(1.0, False, a, s), (1.0, False, a, t)], -1, 1.0),
+                    (n_ok(n + 1), [(1.0, True, a, s), (1j, True, a, t)], 1, -1j),
+                    (n_ok(n - 1), [(1.0, False, a, s), (-1j, False, a, t)], -1, -1j)])
+                gf[s, t, a] = 0.5 * (aux - (1.0 - 1j) * (gf[s, s, a] + gf[t, t, a]))
+    s11 = np.zeros((no, nmom))
+    s12 = np.zeros((no, nmom))
+    # bath normal: G, G0^-1 are diagonal in the orbitals, 2x2 in spin; the (Nspin*Norb) inverse factorises
+    for a in range(no):
+        w = np.zeros((2, 2, om.nbath))
+        w[0, 0], w[1, 1] = om.bv[0, a, :], om.bv[1, a, :]
+        w[0, 1], w[1, 0] = om.bu[0, a, :], om.bu[1, a, :]          # get_Whyb_matrix (ED_BATH_AUX.f90:75-102)
+        delta = np.zeros((2, 2, lmats), complex)
+        for s in range(2):
+            for t in range(2):
+                for ih in range(2):
+                    delta[s, t] += np.sum((w[s, ih, :] * w[t, ih, :])[None, :] / (z[:, None] - om.be[ih, a, :][None, :]), axis=1)
+        g0inv = np.zeros((2, 2, lmats), complex)
+        for s in range(2):
+            for t in range(2):
+                g0inv[s, t] = ((z + om.xmu) if s == t else 0.0) - om.hloc[s, t, a, a] - delta[s, t]
+        gm = np.moveaxis(gf[:, :, a, :], 2, 0)                      # [lmats, 2, 2]
+        sg = np.moveaxis(g0inv, 2, 0) - np.linalg.inv(gm)
+        s11[a] = _moments(sg[:, 0, 0], wm, nmom)
+        s12[a] = _moments(sg[:, 0, 1], wm, nmom)
+    return s11, s12
