@@ -11,6 +11,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <tuple>
 
 #include "kernels.hpp"
 
@@ -65,8 +66,13 @@ static int upload_csr(DevCsr& d, int64_t nrow, const int64_t* rowptr, const int3
     for (int64_t i = 0; i <= nrow; i++) rp[i] = (int32_t)rowptr[i];
     if (dev_upload(&d.rowptr32, rp.data(), rp.size())) return 1;
   }
-  if (dev_upload(&d.col, col, (size_t)d.nnz)) return 1;
-  if (dev_upload(&d.val, val, (size_t)d.nnz * (cplx ? 2 : 1))) return 1;
+  // 8 zero entries behind the last row: the panel sweep reads a row's list in batches of 8 (kernels_panel.hip)
+  std::vector<int32_t> cpad(col, col + d.nnz);
+  cpad.resize((size_t)d.nnz + 8, 0);
+  std::vector<double> vpad(val, val + (size_t)d.nnz * (cplx ? 2 : 1));
+  vpad.resize(vpad.size() + 8, 0.0);
+  if (dev_upload(&d.col, cpad.data(), cpad.size())) return 1;
+  if (dev_upload(&d.val, vpad.data(), vpad.size())) return 1;
   return 0;
 }
 
@@ -313,6 +319,39 @@ int ensure_dynamic_lds(const void* kernel, size_t bytes) {
   return 0;
 }
 
+int device_cu_count() {
+  static thread_local int cached_dev = -1, cached = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev != cached_dev) {
+    hipDeviceProp_t pr;
+    cached = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    cached_dev = dev;
+  }
+  return cached;
+}
+
+int resident_blocks(const void* kernel, int threads, size_t dyn_lds) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, const void*, int, size_t>, int> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    set_error("resident_blocks: hipGetDevice failed");
+    return -1;
+  }
+  std::lock_guard<std::mutex> lk(mu);
+  auto key = std::make_tuple(dev, kernel, threads, dyn_lds);
+  auto it = done.find(key);
+  if (it != done.end()) return it->second;
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, dyn_lds) != hipSuccess || n < 1) {
+    set_error("resident_blocks: occupancy query failed (kernel does not fit a CU?)");
+    return -1;
+  }
+  done[key] = n;
+  return n;
+}
+
 static int finish_handle(edigpu_sector* s) {
   EDIGPU_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   return 0;
@@ -375,6 +414,7 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
   s->row_first = dw_first * dim_up;
   s->h_up = up;
   s->h_dw = dw;
+  std::vector<int32_t> tile_starts;  // row chunks of the LDS-tiled panel sweep (empty: not planned)
   s->rows_per_block = normal_pick_rows_per_block(dim_up, dw_count);
   // Rows longer than the LDS (rows_per_block == 0): staged in column parts when the typed LDS image exists
   // (normal_rows_kernel SPLIT); EDIGPU_ROW_SPLIT=<parts> forces it on any sector (tests), =0 switches it off.
@@ -412,15 +452,16 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
     const bool vec2_env = !(e = getenv("EDIGPU_PANEL_VEC2")) || atoi(e) != 0;
     const int64_t vec2_min = (e = getenv("EDIGPU_PANEL_VEC2_MIN")) ? atoll(e) : ((int64_t)1 << 21);
     const bool tile_env = !(e = getenv("EDIGPU_PANEL_TILE")) || atoi(e) != 0;
-    int rmax = (e = getenv("EDIGPU_TILE_ROWS")) ? atoi(e) : 72;
+    int rmax = (e = getenv("EDIGPU_TILE_ROWS")) ? atoi(e) : 32;
     if (rmax < 8) rmax = 8;
-    if (rmax > 152) rmax = 152;
+    if (rmax > 64) rmax = 64;   // kTileMaxRows of kernels_panel.hip: 4 rows per wave (their results live in registers), 16 waves
     if (vec2_env && dim_up >= 2 && dim_up * dw_count >= vec2_min) s->panel_mode = 1;
     if (s->panel_mode == 1 && tile_env && dw_count > 0 && dim_dw < ((int64_t)1 << 24)) {
       std::vector<int32_t> starts;
       plan_tile_chunks(dw, dw_first, dw_count, rmax, starts, s->tile_rows);
       s->tile_nchunks = (int)starts.size() - 1;
       if (dev_upload(&s->d_tile_chunks, starts.data(), starts.size())) return 1;
+      tile_starts = starts;
       s->panel_mode = 2;
     }
   }
@@ -469,6 +510,8 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
           }
           mp[r + 1] = (int32_t)mc.size();
         }
+        mc.resize(mc.size() + 8, 0);   // batched list reads run past the last row's end
+        mv.resize(mv.size() + 8, 0.0);
         if (dev_upload(&s->d_mx_rowptr, mp.data(), mp.size())) return 1;
         if (dev_upload(&s->d_mx_col, mc.data(), mc.size())) return 1;
         if (dev_upload(&s->d_mx_val, mv.data(), mv.size())) return 1;
@@ -484,6 +527,70 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
     if (s->has_nd && !env_flag("EDIGPU_ND_IN_ROWS") &&
         upload_sell(s->nd, s->nloc, dim_up * dim_dw, nd_rowptr, nd_col, nd_val, 0, false, 16.0))
       return 1;
+  }
+  if (s->panel_mode == 2) {
+    // per-row lists of the tiled sweep: the hops of a row split into those that stay inside its chunk (entry =
+    // staged row index) and those that leave it (entry = global row), then the applicable factored Hnd terms
+    const HostFactored* f = (s->factored && built) ? &built->fac : nullptr;
+    const bool with_nd = f && f->nterms > 0 && s->d_mx_rowptr != nullptr;
+    std::vector<int4> meta((size_t)dw_count);
+    std::vector<int32_t> tc;
+    std::vector<double> tv;
+    tc.reserve((size_t)dw.rowptr[dim_dw] + 8);
+    tv.reserve((size_t)dw.rowptr[dim_dw] + 8);
+    for (size_t ch = 0; ch + 1 < tile_starts.size(); ch++) {
+      const int64_t cs = tile_starts[ch], ce = tile_starts[ch + 1];
+      for (int64_t r = cs; r < ce; r++) {
+        const int64_t g = dw_first + r;
+        int4 m;
+        m.x = (int)tc.size();
+        m.y = m.z = m.w = 0;
+        for (int pass = 0; pass < 2; pass++) {
+          for (int64_t q = dw.rowptr[g]; q < dw.rowptr[g + 1]; q++) {
+            const int64_t pl = (int64_t)dw.col[q] - dw_first;
+            const bool inside = pl >= cs && pl < ce;
+            if (inside == (pass == 0)) {
+              tc.push_back(inside ? (int32_t)(pl - cs) : dw.col[q]);
+              tv.push_back(dw.val[q]);
+              (inside ? m.y : m.z)++;
+            }
+          }
+          // whole batches of 4 (the kernel reads int4 / 4 doubles at a time): pad with (own row, weight 0)
+          int& cnt = pass == 0 ? m.y : m.z;
+          while (cnt % 4) {
+            tc.push_back(pass == 0 ? (int32_t)(r - cs) : (int32_t)g);
+            tv.push_back(0.0);
+            cnt++;
+          }
+        }
+        if (with_nd)
+          for (int t = 0; t < f->nterms; t++) {
+            const uint32_t jd = f->jdw[(size_t)t * dim_dw + g];
+            if (jd != 0xFFFFFFFFu) {
+              tc.push_back((int32_t)((jd & 0xFFFFFFu) | ((uint32_t)(t + 1) << 24)));
+              tv.push_back((jd >> 31) ? -f->coef[t] : f->coef[t]);
+              m.w++;
+            }
+          }
+        while (tc.size() % 4) {  // the next row starts on a batch boundary (entries never read)
+          tc.push_back(0);
+          tv.push_back(0.0);
+        }
+        meta[(size_t)r] = m;
+      }
+    }
+    std::vector<int32_t> lbeg;
+    for (size_t ch = 0; ch + 1 < tile_starts.size(); ch++) lbeg.push_back(meta[(size_t)tile_starts[ch]].x);
+    lbeg.push_back((int32_t)tc.size());
+    s->tile_list_cap = 4;
+    for (size_t ch = 0; ch + 1 < lbeg.size(); ch++) s->tile_list_cap = std::max(s->tile_list_cap, lbeg[ch + 1] - lbeg[ch]);
+    if (dev_upload(&s->d_tile_lbeg, lbeg.data(), lbeg.size())) return 1;
+    tc.resize(tc.size() + 8, 0);  // batched list reads run past a row's end
+    tv.resize(tv.size() + 8, 0.0);
+    if (dev_upload(&s->d_tl_meta, meta.data(), meta.size())) return 1;
+    if (dev_upload(&s->d_tl_col, tc.data(), tc.size())) return 1;
+    if (dev_upload(&s->d_tl_val, tv.data(), tv.size())) return 1;
+    s->tl_has_nd = with_nd ? 1 : 0;
   }
   return finish_handle(s);
 }
@@ -2428,6 +2535,10 @@ int edigpu_destroy(edigpu_handle s) {
   dev_free(s->d_gd);
   dev_free(s->d_mx_rowptr);
   dev_free(s->d_tile_chunks);
+  dev_free(s->d_tile_lbeg);
+  dev_free(s->d_tl_meta);
+  dev_free(s->d_tl_col);
+  dev_free(s->d_tl_val);
   dev_free(s->d_mx_col);
   dev_free(s->d_mx_val);
   dev_free(s->d_eux);

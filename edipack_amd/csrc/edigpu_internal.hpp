@@ -112,6 +112,12 @@ struct edigpu_sector {
   int panel_mode = 0;           // panel sweep variant (NormalArgs::panel_mode), fixed at set-up
   int tile_nchunks = 0, tile_rows = 0;
   int32_t* d_tile_chunks = nullptr;
+  int32_t* d_tile_lbeg = nullptr;
+  int tile_list_cap = 0;
+  int4* d_tl_meta = nullptr;    // tile form of the panel sweep: per-row lists split by chunk membership
+  int32_t* d_tl_col = nullptr;
+  double* d_tl_val = nullptr;
+  int tl_has_nd = 0;
   int row_split = 1;  // rows longer than the LDS: number of column parts the row kernel stages them in (SPLIT)
   int col_halo = 0;             // max |partner column - column| over the factored Hnd terms (transposed exchange)
   uint32_t* d_jdw = nullptr;    // nterms * dim_dw

@@ -11,6 +11,9 @@ constexpr int kMaxPartials = 1 << 16;  // minimum capacity of the per-workgroup 
 
 // opt a kernel into more than 48 KiB of dynamic LDS, once per (device, kernel, size) instead of on every launch
 int ensure_dynamic_lds(const void* kernel, size_t bytes);
+// workgroups of a kernel that stay resident on one CU (cached occupancy query; < 1 on error) and the CU count
+int resident_blocks(const void* kernel, int threads, size_t dyn_lds);
+int device_cu_count();
 
 // ---- normal mode (kernels_normal.hip) ----
 // phase: 3 = fused (local+remote, overwrite), 1 = local only (overwrite), 2 = remote only (accumulate)

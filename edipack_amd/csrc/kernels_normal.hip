@@ -531,6 +531,12 @@ static void fill_args(const edigpu_sector* s, NormalArgs& a) {
   a.tile_nchunks = s->tile_nchunks;
   a.tile_rows = s->tile_rows;
   a.tile_chunks = s->d_tile_chunks;
+  a.tile_lbeg = s->d_tile_lbeg;
+  a.tile_list_cap = s->tile_list_cap;
+  a.tl_meta = s->d_tl_meta;
+  a.tl_col = s->d_tl_col;
+  a.tl_val = s->d_tl_val;
+  a.tl_has_nd = s->tl_has_nd;
   a.mx_rowptr = s->d_mx_rowptr;
   a.mx_col = s->d_mx_col;
   a.mx_val = s->d_mx_val;

@@ -20,7 +20,9 @@
 // row, lists staged in LDS: half as many gather instructions) measured 1.8x SLOWER (175 us).  What does pay is
 // two columns per lane with a FULL wave per row (normal_dw_panel2_kernel below: 1024-byte segments, 16-byte
 // gathers, panels twice as wide): 95 -> 81 us.
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "normal_args.hpp"
 
@@ -32,7 +34,8 @@ struct PanelArgs {
   // [col_first - halo, col_first + ncol + halo) of every row at the given row stride (>= ncol + 2 * halo)
   int64_t col_first, ncol, stride;
   int halo;
-  int tile_rows;  // LDS-tiled form: rows of the largest chunk (LDS = tile_rows KiB + the Hnd partner table)
+  int tile_rows;  // LDS-tiled form: rows of the largest chunk
+  int list_cap;   // LDS-tiled form: list entries of the fullest chunk (multiple of 4)
 };
 
 constexpr int kPanelNT = 512;
@@ -371,177 +374,229 @@ __global__ void __launch_bounds__(kPanelNT)
   }
 }
 
-// LDS-tiled form of the two-column sweep (default for large sectors; EDIGPU_PANEL_TILE=0 switches it off).
-// The sweep above is bound by the L2 -> CU gather rate (~60 % of its time on config 2, rocprofv3 r01).  Here a
-// workgroup owns a CHUNK of consecutive down rows of its panel (host-planned so that most hops stay inside it:
-// rows that share their high bath bits are contiguous and closed under the hops among the low levels) and stages
-// the chunk's row segments in LDS once -- coalesced 1 KiB loads that the alpha partial needs anyway.  A wave still owns
-// one output row; a neighbour row inside the chunk is read from LDS (a contiguous 1 KiB ds_read_b128 sweep, no bank
-// conflicts), only the hops that leave the chunk go to L2.  The neighbour list is wave-uniform, so is the
-// LDS-or-global decision.  Hnd partner segments come the same way.
-constexpr int kTileSeg = 64;  // double2 per staged row segment (128 columns)
+// LDS-tiled, persistent form of the two-column sweep (default for large sectors; EDIGPU_PANEL_TILE=0 switches it off).
+//
+// What the profiles of the sweep above showed (config 2, r02): its waves spend two thirds of their cycles waiting
+// (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.71) and it moves V + result once (FETCH = 155 MB) but at 3.2 TB/s.  In-kernel
+// time stamps and the ISA explain it:
+//  * the launch is bound by the WAVE LAUNCH RATE: 8192 workgroups x 8 waves at the ~0.5-0.8 waves/ns the dispatcher
+//    sustains for 512-thread groups IS the 86 us the sweep takes (the row kernel: 3432 x 8 waves, 52 us) -- so the
+//    grid here is persistent: one launch of as many workgroups as stay resident, each looping over its tasks;
+//  * a row's neighbour list was walked entry by entry -- s_load, wait, gather -- paying a scalar-cache miss (~0.5 us
+//    under load) per dependent step; here the lists of a task are copied to LDS once, coalesced, next to the data;
+//  * the result row (an HBM miss) was waited for together with the first gather (vmcnt retires in order) and two
+//    rows per wave were all the memory parallelism there was; here every HBM-latency access of a task is issued up
+//    front: each wave loads the result segments of ALL its rows into registers and its share of the task's own V
+//    segments, which go to LDS (the alpha partial needs them anyway).
+// A task = a CHUNK of <= 40 consecutive down rows of one panel (host-planned so that most hops stay inside it: rows
+// that share their high bath bits are contiguous and closed under the hops among the low levels).  The host has split
+// a row's hops into those that stay inside the chunk (entry = staged row index) and those that leave it (entry =
+// global row), NormalArgs::tl_*; both lists are padded to whole batches of four with (own row, weight 0) entries, so a
+// batch is four accesses issued back to back behind one wait, never branched over entry by entry (hipcc guards every
+// load behind a branch with a full vmcnt(0)): from LDS a contiguous 1 KiB ds_read_b128 sweep without bank
+// conflicts, from L2 a 1 KiB segment.  Workgroups with equal blockIdx % 8 (one XCD under the observed round-robin
+// placement; speed only) walk the tasks of the same panel together.
+constexpr int kTileSeg = 64;       // double2 per staged row segment (128 columns)
+constexpr int kTileRowsPerWave = 4;
+constexpr int kTileMaxRows = kTileRowsPerWave * 16;  // 1024-thread workgroups; 512-thread ones take half as many
+constexpr int kTileBatch = 4;      // list entries per batch (a row's two hop lists are padded to whole batches)
 
-template <bool DO_ND, bool ALPHA, bool EDGE>
-__global__ void __launch_bounds__(kPanelNT)
-    normal_dw_tile_kernel(NormalArgs a, PanelArgs p, const int32_t* __restrict__ chunk_start,
-                          const double* __restrict__ v_full, double* __restrict__ hv) {
-  __shared__ double red[2 * (kPanelNT / 64)];
-  extern __shared__ double2 tile[];  // [chunk rows][kTileSeg], then the Hnd partner table [2 * nterms][64]
-  const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
-  const int panel = (k / p.blocks_per_panel) * 8 + x;
-  if (ALPHA) {
-    if (panel >= p.npanels || a.scal[SC_STOP] != 0.0) {
-      if (threadIdx.x == 0) {
-        a.partial[blockIdx.x] = 0.0;
-        a.partial[gridDim.x + blockIdx.x] = 0.0;
-      }
-      return;
+template <int NT, bool DO_ND, bool ALPHA, bool EDGE>
+__global__ void __launch_bounds__(NT)
+    normal_dw_tile_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full, double* __restrict__ hv) {
+  __shared__ double red[2 * (NT / 64)];
+  // [tile_rows][kTileSeg] double2 | list weights [list_cap] | list columns [list_cap] | row meta [tile_rows] int4 |
+  // Hnd partner table [2 * nterms][64]
+  extern __shared__ double2 tile[];
+  double* lval = reinterpret_cast<double*>(tile + (size_t)p.tile_rows * kTileSeg);
+  int32_t* lcol = reinterpret_cast<int32_t*>(lval + p.list_cap);
+  int4* lmeta = reinterpret_cast<int4*>(lcol + p.list_cap);
+  uint32_t* ju2 = reinterpret_cast<uint32_t*>(lmeta + p.tile_rows);
+  if (ALPHA && a.scal[SC_STOP] != 0.0) {
+    if (threadIdx.x == 0) {
+      a.partial[blockIdx.x] = 0.0;
+      a.partial[gridDim.x + blockIdx.x] = 0.0;
     }
+    return;
   }
-  if (panel >= p.npanels) return;
   double asum = 0.0, qsum = 0.0;
   const double sg = ALPHA ? a.scal[SC_ALPHA] : 0.0;  // see normal_dw_panel_kernel
-  const int chunk = k % p.blocks_per_panel;
-  const int rb = chunk_start[chunk], nrows = chunk_start[chunk + 1] - rb;
+  const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int NW = kPanelNT / 64;
+  constexpr int NW = NT / 64;
   const int64_t DimUp = a.dim_up;
-  const int64_t pbase = (int64_t)panel * p.width;
-  auto col_of = [&](int l, bool& okl, bool& pairl) -> int64_t {
-    const int64_t cl = pbase + 2 * l;
-    okl = 2 * l < p.width && cl < DimUp;
-    const int64_t ccl = okl ? cl : (EDGE ? DimUp - 1 : DimUp - 2);
-    pairl = !EDGE || ccl + 1 < DimUp;
-    return ccl;
-  };
-  bool ok, pair;
-  const int64_t cc = col_of(lane, ok, pair);
-  const int64_t c = pbase + 2 * lane;
-  auto ld2 = [&](const double* q) -> double2 {
-    if (!EDGE) return *reinterpret_cast<const double2*>(q);
-    if (pair) {
-      const d2u t = *reinterpret_cast<const d2u*>(q);
-      return make_double2(t.x, t.y);
-    }
-    return make_double2(q[0], 0.0);
-  };
-  auto st2 = [&](double* q, double2 t) {
-    if (!EDGE) {
-      *reinterpret_cast<double2*>(q) = t;
-    } else if (pair) {
-      d2u u;
-      u.x = t.x;
-      u.y = t.y;
-      *reinterpret_cast<d2u*>(q) = u;
-    } else {
-      q[0] = t.x;
-    }
-  };
-  // ---- stage the chunk's own row segments: four independent 1 KiB loads in flight per wave ----
-  const int64_t g0 = a.dw_first + rb;  // global index of the first staged row
-  for (int r = wave; r < nrows; r += 4 * NW) {
-    double2 t[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int rr = r + u * NW < nrows ? r + u * NW : nrows - 1;
-      t[u] = ld2(&v_full[(g0 + rr) * DimUp + cc]);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (r + u * NW < nrows) tile[(r + u * NW) * kTileSeg + lane] = t[u];
-  }
-  // Hnd partner of a column, per term and component (encoding of normal_dw_panel2_kernel), one word per LANE
-  uint32_t* ju2 = reinterpret_cast<uint32_t*>(tile + (size_t)p.tile_rows * kTileSeg);
-  if (DO_ND) {
-    auto encode = [&](uint32_t jt) -> uint32_t {
-      if (jt == 0xFFFFFFFFu) return jt;
-      const int64_t rel = (int64_t)(jt & 0x7FFFFFFFu) - pbase;
-      if (rel >= 0 && rel < p.width) return (jt & 0x80000000u) | (uint32_t)rel;
-      return (jt & 0x80000000u) | 0x40000000u | (jt & 0x3FFFFFFFu);
+  int cur_panel = -1;
+  for (int task = slot;; task += nslots) {
+    const int panel = (task / p.blocks_per_panel) * 8 + x;
+    if (panel >= p.npanels) break;  // uniform: the whole workgroup leaves together
+    const int chunk = task % p.blocks_per_panel;
+    const int rb = a.tile_chunks[chunk], nrows = a.tile_chunks[chunk + 1] - rb;
+    const int lb = a.tile_lbeg[chunk], ln = a.tile_lbeg[chunk + 1] - lb;
+    const int64_t pbase = (int64_t)panel * p.width;
+    auto col_of = [&](int l, bool& okl, bool& pairl) -> int64_t {
+      const int64_t cl = pbase + 2 * l;
+      okl = 2 * l < p.width && cl < DimUp;
+      const int64_t ccl = okl ? cl : (EDGE ? DimUp - 1 : DimUp - 2);
+      pairl = !EDGE || ccl + 1 < DimUp;
+      return ccl;
     };
-    for (int i = threadIdx.x; i < 2 * a.nterms * 64; i += kPanelNT) {
-      const int t2 = i >> 6, l = i & 63;
-      bool okl, pairl;
-      const int64_t ccl = col_of(l, okl, pairl);
-      const int64_t src = (int64_t)(t2 >> 1) * DimUp + ccl;
-      ju2[i] = (t2 & 1) ? (pairl ? encode(a.jup[src + 1]) : 0xFFFFFFFFu) : encode(a.jup[src]);
+    bool ok, pair;
+    const int64_t cc = col_of(lane, ok, pair);
+    const int64_t c = pbase + 2 * lane;
+    auto ld2 = [&](const double* q) -> double2 {
+      if (!EDGE) return *reinterpret_cast<const double2*>(q);
+      if (pair) {
+        const d2u t = *reinterpret_cast<const d2u*>(q);
+        return make_double2(t.x, t.y);
+      }
+      return make_double2(q[0], 0.0);
+    };
+    auto st2 = [&](double* q, double2 t) {
+      if (!EDGE) {
+        *reinterpret_cast<double2*>(q) = t;
+      } else if (pair) {
+        d2u u;
+        u.x = t.x;
+        u.y = t.y;
+        *reinterpret_cast<d2u*>(q) = u;
+      } else {
+        q[0] = t.x;
+      }
+    };
+    // ---- every HBM-latency load first: the result segments of this wave's rows (kept in registers) and the
+    // chunk's own V segments (to LDS); rows wave, wave + NW, ... in both cases; then the task's lists ----
+    const int64_t g0 = a.dw_first + rb;  // global index of the first staged row
+    double2 acc[kTileRowsPerWave];
+    {
+      double2 own[kTileRowsPerWave];
+#pragma unroll
+      for (int j = 0; j < kTileRowsPerWave; j++) {
+        const int r = wave + j * NW;
+        const int rr = r < nrows ? r : nrows - 1;  // clamped: a valid address
+        acc[j] = ld2(&hv[(int64_t)(rb + rr) * DimUp + cc]);
+      }
+#pragma unroll
+      for (int j = 0; j < kTileRowsPerWave; j++) {
+        const int r = wave + j * NW;
+        const int rr = r < nrows ? r : nrows - 1;
+        own[j] = ld2(&v_full[(g0 + rr) * DimUp + cc]);
+      }
+      for (int i = threadIdx.x; i < ln; i += NT) {
+        lcol[i] = a.tl_col[lb + i];
+        lval[i] = a.tl_val[lb + i];
+      }
+      if ((int)threadIdx.x < nrows) {
+        int4 m = a.tl_meta[rb + threadIdx.x];
+        m.x -= lb;
+        lmeta[threadIdx.x] = m;
+      }
+#pragma unroll
+      for (int j = 0; j < kTileRowsPerWave; j++) {
+        const int r = wave + j * NW;
+        const int rr = r < nrows ? r : nrows - 1;  // the clamped rows rewrite the last row with its own data
+        tile[rr * kTileSeg + lane] = own[j];
+      }
     }
-  }
-  __syncthreads();
-  // a neighbour row's segment: from the staged chunk when it lies inside, else from L2 / HBM (wave-uniform choice)
-  auto fetch = [&](int64_t prow) -> double2 {
-    const uint32_t rel = (uint32_t)(prow - g0);
-    if (rel < (uint32_t)nrows) return tile[rel * kTileSeg + lane];
-    return ld2(&v_full[prow * DimUp + cc]);
-  };
-  auto row_sum = [&](int lr, double2 acc) -> double2 {
-    const int64_t g = a.dw_first + lr;
-    if (!DO_ND) {
-      const int32_t b0 = a.dw_rowptr[g], e0 = a.dw_rowptr[g + 1];
-#pragma unroll 4
-      for (int32_t jj = b0; jj < e0; jj++) {
-        const double w = a.dw_val[jj];
-        const double2 y = fetch(a.dw_col[jj]);
-        acc.x += w * y.x;
-        acc.y += w * y.y;
+    // Hnd partner of a column, per term and component (encoding of normal_dw_panel2_kernel), one word per LANE
+    if (DO_ND && panel != cur_panel) {
+      auto encode = [&](uint32_t jt) -> uint32_t {
+        if (jt == 0xFFFFFFFFu) return jt;
+        const int64_t rel = (int64_t)(jt & 0x7FFFFFFFu) - pbase;
+        if (rel >= 0 && rel < p.width) return (jt & 0x80000000u) | (uint32_t)rel;
+        return (jt & 0x80000000u) | 0x40000000u | (jt & 0x3FFFFFFFu);
+      };
+      for (int i = threadIdx.x; i < 2 * a.nterms * 64; i += NT) {
+        const int t2 = i >> 6, l = i & 63;
+        bool okl, pairl;
+        const int64_t ccl = col_of(l, okl, pairl);
+        const int64_t src = (int64_t)(t2 >> 1) * DimUp + ccl;
+        ju2[i] = (t2 & 1) ? (pairl ? encode(a.jup[src + 1]) : 0xFFFFFFFFu) : encode(a.jup[src]);
       }
-    } else {
-      const int32_t b0 = a.mx_rowptr[lr], e0 = a.mx_rowptr[lr + 1];
-      const int32_t mid = b0 + (a.dw_rowptr[g + 1] - a.dw_rowptr[g]);
-#pragma unroll 4
-      for (int32_t jj = b0; jj < mid; jj++) {
-        const double w = a.mx_val[jj];
-        const double2 y = fetch((int64_t)((uint32_t)a.mx_col[jj] & 0xFFFFFFu));
-        acc.x += w * y.x;
-        acc.y += w * y.y;
-      }
-      for (int32_t jj = mid; jj < e0; jj++) {
-        const uint32_t cw = (uint32_t)a.mx_col[jj];
-        const int tag = (int)(cw >> 24);  // wave-uniform, >= 1
-        const double w = a.mx_val[jj];
-        const int64_t prow = (int64_t)(cw & 0xFFFFFFu);
-        const uint32_t j0 = ju2[(2 * (tag - 1)) * 64 + lane];
-        const uint32_t j1 = ju2[(2 * (tag - 1) + 1) * 64 + lane];
-        const bool v0 = j0 != 0xFFFFFFFFu, v1 = j1 != 0xFFFFFFFFu;
-        const double w0 = v0 ? ((j0 >> 31) ? -w : w) : 0.0, w1 = v1 ? ((j1 >> 31) ? -w : w) : 0.0;
-        const double2 y = fetch(prow);
-        const int l0 = (int)((j0 >> 1) & 63u), l1 = (int)((j1 >> 1) & 63u);
-        const double s0x = __shfl(y.x, l0, 64), s0y = __shfl(y.y, l0, 64);
-        const double s1x = __shfl(y.x, l1, 64), s1y = __shfl(y.y, l1, 64);
-        double p0 = (j0 & 1u) ? s0y : s0x, p1 = (j1 & 1u) ? s1y : s1x;
-        if (v0 && (j0 & 0x40000000u)) p0 = v_full[prow * DimUp + (int64_t)(j0 & 0x3FFFFFFFu)];  // panel edge
-        if (v1 && (j1 & 0x40000000u)) p1 = v_full[prow * DimUp + (int64_t)(j1 & 0x3FFFFFFFu)];
-        acc.x += w0 * p0;
-        acc.y += w1 * p1;
-      }
+      cur_panel = panel;
     }
-    return acc;
-  };
-  for (int r = wave; r < nrows; r += 2 * NW) {
-    const int r2 = r + NW;
-    const bool two = r2 < nrows;
-    const int64_t o0 = (int64_t)(rb + r) * DimUp, o1 = (int64_t)(rb + r2) * DimUp;
-    double2 acc0 = ld2(&hv[o0 + cc]);
-    double2 acc1 = two ? ld2(&hv[o1 + cc]) : make_double2(0.0, 0.0);
-    acc0 = row_sum(rb + r, acc0);
-    if (two) acc1 = row_sum(rb + r2, acc1);
-    if (ok) {
-      st2(&hv[o0 + c], acc0);
-      if (two) st2(&hv[o1 + c], acc1);
-      if (ALPHA) {
-        const double2 own0 = tile[r * kTileSeg + lane];
-        const double d0x = acc0.x - sg * own0.x, d0y = acc0.y - sg * own0.y;
-        asum += own0.x * acc0.x + own0.y * acc0.y;
-        qsum += d0x * d0x + d0y * d0y;
-        if (two) {
-          const double2 own1 = tile[r2 * kTileSeg + lane];
-          const double d1x = acc1.x - sg * own1.x, d1y = acc1.y - sg * own1.y;
-          asum += own1.x * acc1.x + own1.y * acc1.y;
-          qsum += d1x * d1x + d1y * d1y;
+    __syncthreads();
+    auto row_sum = [&](int r, double2 s) -> double2 {
+      const int4 m = lmeta[r];  // first entry, hops inside the chunk, hops leaving it, Hnd terms (LDS broadcast)
+      const int mb = __builtin_amdgcn_readfirstlane(m.x), ni = __builtin_amdgcn_readfirstlane(m.y),
+                no = __builtin_amdgcn_readfirstlane(m.z), nn = __builtin_amdgcn_readfirstlane(m.w);
+      // hops that leave the chunk first (L2 latency), then the staged ones
+      const int ob = mb + ni, oe = ob + no;
+      for (int jb = ob; jb < oe; jb += kTileBatch) {
+        const int4 cw = *reinterpret_cast<const int4*>(lcol + jb);
+        const double2 wa = *reinterpret_cast<const double2*>(lval + jb);
+        const double2 wb = *reinterpret_cast<const double2*>(lval + jb + 2);
+        const double2 y0 = ld2(&v_full[(int64_t)__builtin_amdgcn_readfirstlane(cw.x) * DimUp + cc]);
+        const double2 y1 = ld2(&v_full[(int64_t)__builtin_amdgcn_readfirstlane(cw.y) * DimUp + cc]);
+        const double2 y2 = ld2(&v_full[(int64_t)__builtin_amdgcn_readfirstlane(cw.z) * DimUp + cc]);
+        const double2 y3 = ld2(&v_full[(int64_t)__builtin_amdgcn_readfirstlane(cw.w) * DimUp + cc]);
+        s.x += wa.x * y0.x;
+        s.y += wa.x * y0.y;
+        s.x += wa.y * y1.x;
+        s.y += wa.y * y1.y;
+        s.x += wb.x * y2.x;
+        s.y += wb.x * y2.y;
+        s.x += wb.y * y3.x;
+        s.y += wb.y * y3.y;
+      }
+      for (int jb = mb; jb < ob; jb += kTileBatch) {
+        const int4 cw = *reinterpret_cast<const int4*>(lcol + jb);
+        const double2 wa = *reinterpret_cast<const double2*>(lval + jb);
+        const double2 wb = *reinterpret_cast<const double2*>(lval + jb + 2);
+        const double2 y0 = tile[__builtin_amdgcn_readfirstlane(cw.x) * kTileSeg + lane];
+        const double2 y1 = tile[__builtin_amdgcn_readfirstlane(cw.y) * kTileSeg + lane];
+        const double2 y2 = tile[__builtin_amdgcn_readfirstlane(cw.z) * kTileSeg + lane];
+        const double2 y3 = tile[__builtin_amdgcn_readfirstlane(cw.w) * kTileSeg + lane];
+        s.x += wa.x * y0.x;
+        s.y += wa.x * y0.y;
+        s.x += wa.y * y1.x;
+        s.y += wa.y * y1.y;
+        s.x += wb.x * y2.x;
+        s.y += wb.x * y2.y;
+        s.x += wb.y * y3.x;
+        s.y += wb.y * y3.y;
+      }
+      if (DO_ND) {
+        for (int jj = oe; jj < oe + nn; jj++) {
+          const uint32_t cw = (uint32_t)__builtin_amdgcn_readfirstlane(lcol[jj]);
+          const int tag = (int)(cw >> 24);  // wave-uniform, >= 1
+          const double w = lval[jj];
+          const int64_t prow = (int64_t)(cw & 0xFFFFFFu);
+          const uint32_t j0 = ju2[(2 * (tag - 1)) * 64 + lane];
+          const uint32_t j1 = ju2[(2 * (tag - 1) + 1) * 64 + lane];
+          const bool v0 = j0 != 0xFFFFFFFFu, v1 = j1 != 0xFFFFFFFFu;
+          const double w0 = v0 ? ((j0 >> 31) ? -w : w) : 0.0, w1 = v1 ? ((j1 >> 31) ? -w : w) : 0.0;
+          // the partner row's segment, coalesced like a down hop; the partner columns sit a few lanes away
+          const double2 y = ld2(&v_full[prow * DimUp + cc]);
+          const int l0 = (int)((j0 >> 1) & 63u), l1 = (int)((j1 >> 1) & 63u);
+          const double s0x = __shfl(y.x, l0, 64), s0y = __shfl(y.y, l0, 64);
+          const double s1x = __shfl(y.x, l1, 64), s1y = __shfl(y.y, l1, 64);
+          double p0 = (j0 & 1u) ? s0y : s0x, p1 = (j1 & 1u) ? s1y : s1x;
+          if (v0 && (j0 & 0x40000000u)) p0 = v_full[prow * DimUp + (int64_t)(j0 & 0x3FFFFFFFu)];  // panel edge
+          if (v1 && (j1 & 0x40000000u)) p1 = v_full[prow * DimUp + (int64_t)(j1 & 0x3FFFFFFFu)];
+          s.x += w0 * p0;
+          s.y += w1 * p1;
+        }
+      }
+      return s;
+    };
+#pragma unroll
+    for (int j = 0; j < kTileRowsPerWave; j++) {
+      const int r = wave + j * NW;
+      if (r < nrows) {  // wave-uniform
+        acc[j] = row_sum(r, acc[j]);
+        if (ok) {
+          st2(&hv[(int64_t)(rb + r) * DimUp + c], acc[j]);
+          if (ALPHA) {
+            const double2 o = tile[r * kTileSeg + lane];  // the row's own segment of v
+            const double dx = acc[j].x - sg * o.x, dy = acc[j].y - sg * o.y;
+            asum += o.x * acc[j].x + o.y * acc[j].y;
+            qsum += dx * dx + dy * dy;
+          }
         }
       }
     }
+    __syncthreads();  // the next task overwrites the staged data
   }
   if (ALPHA) {
 #pragma unroll
@@ -551,15 +606,15 @@ __global__ void __launch_bounds__(kPanelNT)
     }
     if (lane == 0) {
       red[wave] = asum;
-      red[kPanelNT / 64 + wave] = qsum;
+      red[NT / 64 + wave] = qsum;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
       double t = 0.0, q = 0.0;
 #pragma unroll
-      for (int i = 0; i < kPanelNT / 64; i++) {
+      for (int i = 0; i < NT / 64; i++) {
         t += red[i];
-        q += red[kPanelNT / 64 + i];
+        q += red[NT / 64 + i];
       }
       a.partial[blockIdx.x] = t;
       a.partial[gridDim.x + blockIdx.x] = q;
@@ -634,7 +689,8 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
   const bool edge = (a.dim_up % 2) != 0;  // odd DimUp: 8-byte aligned rows, see d2u
   // the variant was fixed when the sector was set up (NormalArgs::panel_mode); the buffers must be aligned for it
   const bool vec2 = a.panel_mode >= 1 && do_dw && (((uintptr_t)v_full | (uintptr_t)hv) & (edge ? 7 : 15)) == 0;
-  const bool tiled = vec2 && a.panel_mode == 2 && a.tile_chunks != nullptr;
+  const bool tiled = vec2 && a.panel_mode == 2 && a.tile_chunks != nullptr && a.tl_meta != nullptr && a.tile_rows <= kTileMaxRows &&
+                     (!do_nd || a.tl_has_nd);
   PanelArgs p;
   if (vec2) {
     int wmax = 128;
@@ -646,6 +702,11 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
     if (np < 8) np = 8;
     p.width = (int)((a.dim_up + np - 1) / np);
     p.width += p.width & 1;
+    if (const char* e = getenv("EDIGPU_PANEL_ALIGN")) {  // EXPERIMENT: panel boundaries on multiples of this many columns
+      const int al = atoi(e);
+      if (al > 1) p.width = (p.width + al - 1) / al * al;
+      if (p.width > 128) p.width = 128;
+    }
     p.npanels = (int)((a.dim_up + p.width - 1) / p.width);
   } else {
     plan_panels(p, a.dim_up);
@@ -668,18 +729,48 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
   const int panel_groups = (p.npanels + 7) / 8;
   const dim3 grid((unsigned)((int64_t)panel_groups * bpp * 8)), block(kPanelNT);
   if (nblocks) *nblocks = (int)grid.x;
-  if (alpha && 2 * (int64_t)grid.x > a.partial_cap) {  // before anything that writes the partials is enqueued
+  if (!tiled && alpha && 2 * (int64_t)grid.x > a.partial_cap) {  // before anything that writes the partials is enqueued
     set_error("launch_dw_panels: partial buffer too small for this grid");
     return 1;
   }
   if (tiled) {
-    const size_t lds = (size_t)p.tile_rows * kTileSeg * sizeof(double2) + (do_nd ? (size_t)2 * a.nterms * 64 * sizeof(uint32_t) : 0);
-#define EDIGPU_LAUNCH_P3(ND, AL)                                                                               \
+    p.list_cap = a.tile_list_cap;
+    const size_t lds = (size_t)p.tile_rows * kTileSeg * sizeof(double2) + (size_t)p.list_cap * (sizeof(double) + sizeof(int32_t)) +
+                       (size_t)p.tile_rows * sizeof(int4) + (do_nd ? (size_t)2 * a.nterms * 64 * sizeof(uint32_t) : 0);
+    // persistent grid: as many workgroups as stay resident (a multiple of 8: one stream of tasks per XCD), never
+    // more than there are tasks
+    const int64_t ntasks = (int64_t)panel_groups * bpp * 8;
+    // workgroup size: 512 threads (4 per CU) while a chunk fits their registers, else 1024 (2 per CU, twice the rows);
+    // EDIGPU_TILE_PERSIST=1: a persistent grid (as many workgroups as stay resident, each looping over its tasks)
+    // instead of one task per workgroup -- measured 3-5 % slower on config 2 and the Ns=15 ladder
+    static const bool persist = getenv("EDIGPU_TILE_PERSIST") && atoi(getenv("EDIGPU_TILE_PERSIST")) != 0;
+    const bool big = p.tile_rows > kTileRowsPerWave * (kPanelNT / 64);
+#define EDIGPU_LAUNCH_P3T(NTV, ND, AL)                                                                         \
   do {                                                                                                         \
-    auto kern = edge ? normal_dw_tile_kernel<ND, AL, true> : normal_dw_tile_kernel<ND, AL, false>;             \
+    auto kern = edge ? normal_dw_tile_kernel<NTV, ND, AL, true> : normal_dw_tile_kernel<NTV, ND, AL, false>;   \
     if (ensure_dynamic_lds((const void*)kern, lds)) return 1;                                                  \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, a, p, a.tile_chunks, v_full, hv);                           \
+    const int per_cu = resident_blocks((const void*)kern, NTV, lds);                                           \
+    if (per_cu < 1) return 1;                                                                                  \
+    int64_t g = (int64_t)per_cu * device_cu_count();                                                           \
+    g -= g % 8;                                                                                                \
+    if (g > ntasks || !persist) g = ntasks;                                                                    \
+    if (g < 8) g = 8;                                                                                          \
+    pgrid = dim3((unsigned)g);                                                                                 \
+    if (nblocks) *nblocks = (int)g;                                                                            \
+    if (alpha && 2 * g > a.partial_cap) {                                                                      \
+      set_error("launch_dw_panels: partial buffer too small for this grid");                                   \
+      return 1;                                                                                                \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kern, pgrid, dim3(NTV), lds, st, a, p, v_full, hv);                                     \
   } while (0)
+#define EDIGPU_LAUNCH_P3(ND, AL)             \
+  do {                                       \
+    if (big)                                 \
+      EDIGPU_LAUNCH_P3T(1024, ND, AL);       \
+    else                                     \
+      EDIGPU_LAUNCH_P3T(kPanelNT, ND, AL);   \
+  } while (0)
+    dim3 pgrid;
     if (do_nd && alpha)
       EDIGPU_LAUNCH_P3(true, true);
     else if (do_nd)
@@ -689,6 +780,7 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
     else
       EDIGPU_LAUNCH_P3(false, false);
 #undef EDIGPU_LAUNCH_P3
+#undef EDIGPU_LAUNCH_P3T
     EDIGPU_HIP(hipGetLastError());
     return 0;
   }

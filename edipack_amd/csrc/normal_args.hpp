@@ -48,6 +48,14 @@ struct NormalArgs {
   int panel_mode;
   int tile_nchunks, tile_rows;
   const int32_t* tile_chunks;
+  const int32_t* tile_lbeg;  // nchunks + 1: first list entry of a chunk's rows (tl_col / tl_val)
+  int tile_list_cap;         // list entries of the fullest chunk
+  // per local row (tile form): tl_meta = (first entry, hops inside the row's chunk, hops leaving it, Hnd terms);
+  // tl_col: staged row index / global row / (partner row | tag << 24); tl_val: weights; both padded by 8 entries
+  const int4* tl_meta;
+  const int32_t* tl_col;
+  const double* tl_val;
+  int tl_has_nd;  // the lists carry the factored Hnd terms
   const int32_t* mx_rowptr;  // merged list: ptr[dw_count+1]
   const int32_t* mx_col;     // partner row (24 bit) | tag << 24
   const double* mx_val;

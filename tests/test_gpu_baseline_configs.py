@@ -185,7 +185,14 @@ def test_shifted_spectrum_keeps_the_fused_step_accurate(gpu):
     from oracle import oracle as O
     from edipack_amd.hamiltonian import SectorHamiltonian
     from tests.common import make_models
-    om, pm = make_models("normal", "normal", 2, 3, seed=11, xmu=-400.0)
+    om, pm = make_models("normal", "normal", 2, 3, seed=11)
+    # every level (impurity and bath) raised by E0: H -> H + E0 (Nup + Ndw), a constant 8 E0 in this sector
+    e0 = 100.0
+    hl = np.array(om.hloc, complex)
+    for a in range(2):
+        hl[0, 0, a, a] += e0
+    for m in (om, pm):
+        m.hloc, m.be = hl, np.asarray(m.be) + e0
     ho = O.HNormal(om, 4, 4)
     hg = SectorHamiltonian.normal_from_model(pm, 4, 4)
     v = np.random.default_rng(3).standard_normal(ho.dim)
