@@ -827,8 +827,8 @@ static int ensure_workspace(edigpu_sector* s) {
   EDIGPU_HIP(hipMalloc((void**)&s->d_vin, n * sizeof(double)));
   EDIGPU_HIP(hipMalloc((void**)&s->d_vout, n * sizeof(double)));
   EDIGPU_HIP(hipMalloc((void**)&s->d_tmp, n * sizeof(double)));
-  // per-workgroup partials: two per 256-row workgroup of the SELL dot epilogue is the largest user
-  s->partial_cap = std::max<int64_t>(kMaxPartials, 2 * ((s->nloc + 255) / 256) + 64);
+  // per-workgroup partials: three per 256-row workgroup of the SELL dot epilogue is the largest user
+  s->partial_cap = std::max<int64_t>(kMaxPartials, 3 * ((s->nloc + 255) / 256) + 64);
   EDIGPU_HIP(hipMalloc((void**)&s->d_partial, (size_t)s->partial_cap * sizeof(double)));
   s->ws_len = len;
   return 0;

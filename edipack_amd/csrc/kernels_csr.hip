@@ -58,28 +58,33 @@ __global__ void __launch_bounds__(kCsrNT)
 
 // DOT epilogue (fused Lanczos step, y = Q accumulates H*x on top of -beta*v_prev): per-workgroup
 // partials of <x|y_new> and <y_new|y_new> over the real view, written to partial[blockIdx] and
-// partial[gridDim + blockIdx] (deterministic two-stage reduction, finalised by k_finalize_ab).
-__device__ inline void block_dot_partials(double a, double q, double* __restrict__ partial) {
-  __shared__ double red_a[kCsrNT / 64], red_q[kCsrNT / 64];
+// partial[gridDim + blockIdx], and <x|x> to partial[2 gridDim + blockIdx] (deterministic two-stage reduction,
+// finalised by k_finalize_ab).
+__device__ inline void block_dot_partials(double a, double q, double n, double* __restrict__ partial) {
+  __shared__ double red_a[kCsrNT / 64], red_q[kCsrNT / 64], red_n[kCsrNT / 64];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     a += __shfl_down(a, off, 64);
     q += __shfl_down(q, off, 64);
+    n += __shfl_down(n, off, 64);
   }
   if ((threadIdx.x & 63) == 0) {
     red_a[threadIdx.x >> 6] = a;
     red_q[threadIdx.x >> 6] = q;
+    red_n[threadIdx.x >> 6] = n;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double ta = 0.0, tq = 0.0;
+    double ta = 0.0, tq = 0.0, tn = 0.0;
 #pragma unroll
     for (int i = 0; i < kCsrNT / 64; i++) {
       ta += red_a[i];
       tq += red_q[i];
+      tn += red_n[i];
     }
     partial[blockIdx.x] = ta;
     partial[gridDim.x + blockIdx.x] = tq;
+    partial[2 * gridDim.x + blockIdx.x] = tn;
   }
 }
 
@@ -100,7 +105,7 @@ __global__ void __launch_bounds__(kCsrNT)
   const int64_t row = slice * 64 + lane;
   const bool in = slice < nslice;
   const int32_t b = in ? sptr[slice] : 0, e = in ? sptr[slice + 1] : 0;
-  double sr = 0.0, si = 0.0, da = 0.0, dq = 0.0;
+  double sr = 0.0, si = 0.0, da = 0.0, dq = 0.0, dn = 0.0;
 #pragma unroll 8
   for (int32_t k = b; k < e; k++) {
     const int64_t o = (int64_t)k * 64 + lane;
@@ -125,6 +130,7 @@ __global__ void __launch_bounds__(kCsrNT)
         const double2 xo = reinterpret_cast<const double2*>(x)[row];
         da = xo.x * o2.x + xo.y * o2.y;
         dq = (o2.x - sg * xo.x) * (o2.x - sg * xo.x) + (o2.y - sg * xo.y) * (o2.y - sg * xo.y);
+        dn = xo.x * xo.x + xo.y * xo.y;
       }
     } else {
       const double o = (ACC ? y[row] : 0.0) + sr;
@@ -132,10 +138,11 @@ __global__ void __launch_bounds__(kCsrNT)
       if (DOT) {
         da = x[row] * o;
         dq = (o - sg * x[row]) * (o - sg * x[row]);
+        dn = x[row] * x[row];
       }
     }
   }
-  if (DOT) block_dot_partials(da, dq, partial);
+  if (DOT) block_dot_partials(da, dq, dn, partial);
 }
 
 // SELL-64 with the value dictionary: 4 bytes per entry, values from a <= 256-entry LDS table, the
@@ -156,7 +163,7 @@ __global__ void __launch_bounds__(kCsrNT)
   const int64_t row = slice * 64 + lane;
   const bool in = slice < nslice;
   const int32_t b = in ? sptr[slice] : 0, e = in ? sptr[slice + 1] : 0;
-  double sr = 0.0, si = 0.0, da = 0.0, dq = 0.0;
+  double sr = 0.0, si = 0.0, da = 0.0, dq = 0.0, dn = 0.0;
 #pragma unroll 8
   for (int32_t k = b; k < e; k++) {
     const uint32_t p = pk[(int64_t)k * 64 + lane];
@@ -192,6 +199,7 @@ __global__ void __launch_bounds__(kCsrNT)
         const double2 xo = reinterpret_cast<const double2*>(x)[row];
         da = xo.x * o2.x + xo.y * o2.y;
         dq = (o2.x - sg * xo.x) * (o2.x - sg * xo.x) + (o2.y - sg * xo.y) * (o2.y - sg * xo.y);
+        dn = xo.x * xo.x + xo.y * xo.y;
       }
     } else {
       const double o = (ACC ? y[row] : 0.0) + sr;
@@ -199,10 +207,11 @@ __global__ void __launch_bounds__(kCsrNT)
       if (DOT) {
         da = x[row] * o;
         dq = (o - sg * x[row]) * (o - sg * x[row]);
+        dn = x[row] * x[row];
       }
     }
   }
-  if (DOT) block_dot_partials(da, dq, partial);
+  if (DOT) block_dot_partials(da, dq, dn, partial);
 }
 
 __global__ void zero_kernel(double* __restrict__ y, int64_t n) {
@@ -276,7 +285,7 @@ bool csr_lanczos_fusable(const DevCsr& a) { return a.sell != 0 && a.nrow > 0 && 
 int launch_csr_lanczos(const DevCsr& a, int cplx, const double* x, double* y, double* partial, int64_t cap, int* np,
                        const double* sig, hipStream_t st) {
   const int64_t nb = (a.nslice + kCsrNT / 64 - 1) / (kCsrNT / 64);
-  if (2 * nb > cap) {
+  if (3 * nb > cap) {
     set_error("launch_csr_lanczos: partial buffer too small");
     return 1;
   }

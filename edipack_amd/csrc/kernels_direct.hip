@@ -38,8 +38,8 @@ __global__ void __launch_bounds__(kDirNT)
                        double2* __restrict__ hv, double* __restrict__ partial, const double* __restrict__ sig) {
   const double sgm = (LZ && sig) ? sig[0] : 0.0;  // <Q|Q> accumulated about the previous alpha, see k_finalize_ab
   extern __shared__ int32_t tabs[];  // [off_dw | rk_up] when LDS_TABLES
-  __shared__ double red_a[kDirNT / 64], red_q[kDirNT / 64];
-  double da = 0.0, dq = 0.0;
+  __shared__ double red_a[kDirNT / 64], red_q[kDirNT / 64], red_n[kDirNT / 64];
+  double da = 0.0, dq = 0.0, dn = 0.0;
   const uint32_t lomask = (1u << ns) - 1u, impmask = (1u << norb) - 1u;
   if (LDS_TABLES) {
     const int n = 1 << ns;
@@ -148,6 +148,7 @@ __global__ void __launch_bounds__(kDirNT)
       ai += q.y;
       da += x0.x * ar + x0.y * ai;
       dq += (ar - sgm * x0.x) * (ar - sgm * x0.x) + (ai - sgm * x0.y) * (ai - sgm * x0.y);
+      dn += x0.x * x0.x + x0.y * x0.y;
     }
     hv[r] = make_double2(ar, ai);
   }
@@ -156,21 +157,25 @@ __global__ void __launch_bounds__(kDirNT)
     for (int off = 32; off > 0; off >>= 1) {
       da += __shfl_down(da, off, 64);
       dq += __shfl_down(dq, off, 64);
+      dn += __shfl_down(dn, off, 64);
     }
     if ((threadIdx.x & 63) == 0) {
       red_a[threadIdx.x >> 6] = da;
       red_q[threadIdx.x >> 6] = dq;
+      red_n[threadIdx.x >> 6] = dn;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      double ta = 0.0, tq = 0.0;
+      double ta = 0.0, tq = 0.0, tn = 0.0;
 #pragma unroll
       for (int i = 0; i < kDirNT / 64; i++) {
         ta += red_a[i];
         tq += red_q[i];
+        tn += red_n[i];
       }
       partial[blockIdx.x] = ta;
       partial[gridDim.x + blockIdx.x] = tq;
+      partial[2 * gridDim.x + blockIdx.x] = tn;
     }
   }
 }
@@ -182,7 +187,7 @@ static int launch_direct_t(const edigpu_sector* s, const double* v_full, double*
   int64_t nb = (nrow + kDirNT - 1) / kDirNT;
   static const int wgs_per_cu = getenv("EDIGPU_DIRECT_WGS") ? atoi(getenv("EDIGPU_DIRECT_WGS")) : 2;
   if (nb > 256 * wgs_per_cu) nb = 256 * wgs_per_cu;  // persistent workgroups sweep the rows
-  if (LZ && 2 * nb > cap) {
+  if (LZ && 3 * nb > cap) {
     set_error("launch_direct_lanczos: partial buffer too small");
     return 1;
   }

@@ -48,7 +48,7 @@ template <bool DO_DW, bool DO_ND, bool ALPHA, bool COLS = false>
 __global__ void __launch_bounds__(kPanelNT)
     normal_dw_panel_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full,
                            double* __restrict__ hv) {
-  __shared__ double red[2 * (kPanelNT / 64)];
+  __shared__ double red[3 * (kPanelNT / 64)];
   const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
   const int panel = (k / p.blocks_per_panel) * 8 + x;
   if (ALPHA) {
@@ -56,12 +56,13 @@ __global__ void __launch_bounds__(kPanelNT)
       if (threadIdx.x == 0) {
         a.partial[blockIdx.x] = 0.0;
         a.partial[gridDim.x + blockIdx.x] = 0.0;
+        a.partial[2 * gridDim.x + blockIdx.x] = 0.0;
       }
       return;
     }
   }
   if (panel >= p.npanels) return;
-  double asum = 0.0, qsum = 0.0;
+  double asum = 0.0, qsum = 0.0, nsum = 0.0;  // <v|w>, sum (w - sg v)^2, <v|v> (k_finalize_ab)
   // <Q|Q> is accumulated about the previous alpha (sg): beta^2 = sum (Q - sg v)^2 - (alpha - sg)^2 stays well
   // conditioned when the spectrum sits far from zero (|alpha| >> beta), see k_finalize_ab
   const double sg = ALPHA ? a.scal[SC_ALPHA] : 0.0;
@@ -168,9 +169,11 @@ __global__ void __launch_bounds__(kPanelNT)
       if (ALPHA) {
         asum += own0 * acc0;
         qsum += (acc0 - sg * own0) * (acc0 - sg * own0);
+        nsum += own0 * own0;
         if (two) {
           asum += own1 * acc1;
           qsum += (acc1 - sg * own1) * (acc1 - sg * own1);
+          nsum += own1 * own1;
         }
       }
     }
@@ -181,21 +184,25 @@ __global__ void __launch_bounds__(kPanelNT)
     for (int off = 32; off > 0; off >>= 1) {
       asum += __shfl_down(asum, off, 64);
       qsum += __shfl_down(qsum, off, 64);
+      nsum += __shfl_down(nsum, off, 64);
     }
     if (lane == 0) {
       red[wave] = asum;
       red[kPanelNT / 64 + wave] = qsum;
+      red[2 * (kPanelNT / 64) + wave] = nsum;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      double t = 0.0, q = 0.0;
+      double t = 0.0, q = 0.0, n = 0.0;
 #pragma unroll
       for (int i = 0; i < kPanelNT / 64; i++) {
         t += red[i];
         q += red[kPanelNT / 64 + i];
+        n += red[2 * (kPanelNT / 64) + i];
       }
       a.partial[blockIdx.x] = t;
       a.partial[gridDim.x + blockIdx.x] = q;
+      a.partial[2 * gridDim.x + blockIdx.x] = n;
     }
   }
 }
@@ -214,7 +221,7 @@ struct alignas(8) d2u {
 template <bool DO_ND, bool ALPHA, bool EDGE>
 __global__ void __launch_bounds__(kPanelNT)
     normal_dw_panel2_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full, double* __restrict__ hv) {
-  __shared__ double red[2 * (kPanelNT / 64)];
+  __shared__ double red[3 * (kPanelNT / 64)];
   extern __shared__ uint32_t ju2[];  // [2 * nterms][kPanelNT]: partner columns of the lane's two columns
   const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
   const int panel = (k / p.blocks_per_panel) * 8 + x;
@@ -223,12 +230,13 @@ __global__ void __launch_bounds__(kPanelNT)
       if (threadIdx.x == 0) {
         a.partial[blockIdx.x] = 0.0;
         a.partial[gridDim.x + blockIdx.x] = 0.0;
+        a.partial[2 * gridDim.x + blockIdx.x] = 0.0;
       }
       return;
     }
   }
   if (panel >= p.npanels) return;
-  double asum = 0.0, qsum = 0.0;
+  double asum = 0.0, qsum = 0.0, nsum = 0.0;  // <v|w>, sum (w - sg v)^2, <v|v> (k_finalize_ab)
   const double sg = ALPHA ? a.scal[SC_ALPHA] : 0.0;  // see normal_dw_panel_kernel
   const int chunk = k % p.blocks_per_panel;
   const int lane = threadIdx.x & 63;
@@ -342,10 +350,12 @@ __global__ void __launch_bounds__(kPanelNT)
         const double d0x = acc0.x - sg * own0.x, d0y = acc0.y - sg * own0.y;
         asum += own0.x * acc0.x + own0.y * acc0.y;
         qsum += d0x * d0x + d0y * d0y;
+        nsum += own0.x * own0.x + own0.y * own0.y;
         if (two) {
           const double d1x = acc1.x - sg * own1.x, d1y = acc1.y - sg * own1.y;
           asum += own1.x * acc1.x + own1.y * acc1.y;
           qsum += d1x * d1x + d1y * d1y;
+          nsum += own1.x * own1.x + own1.y * own1.y;
         }
       }
     }
@@ -355,21 +365,25 @@ __global__ void __launch_bounds__(kPanelNT)
     for (int off = 32; off > 0; off >>= 1) {
       asum += __shfl_down(asum, off, 64);
       qsum += __shfl_down(qsum, off, 64);
+      nsum += __shfl_down(nsum, off, 64);
     }
     if (lane == 0) {
       red[wave] = asum;
       red[kPanelNT / 64 + wave] = qsum;
+      red[2 * (kPanelNT / 64) + wave] = nsum;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      double t = 0.0, q = 0.0;
+      double t = 0.0, q = 0.0, n = 0.0;
 #pragma unroll
       for (int i = 0; i < kPanelNT / 64; i++) {
         t += red[i];
         q += red[kPanelNT / 64 + i];
+        n += red[2 * (kPanelNT / 64) + i];
       }
       a.partial[blockIdx.x] = t;
       a.partial[gridDim.x + blockIdx.x] = q;
+      a.partial[2 * gridDim.x + blockIdx.x] = n;
     }
   }
 }
@@ -404,7 +418,7 @@ constexpr int kTileBatch = 4;      // list entries per batch (a row's two hop li
 template <int NT, bool DO_ND, bool ALPHA, bool EDGE>
 __global__ void __launch_bounds__(NT)
     normal_dw_tile_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full, double* __restrict__ hv) {
-  __shared__ double red[2 * (NT / 64)];
+  __shared__ double red[3 * (NT / 64)];
   // [tile_rows][kTileSeg] double2 | list weights [list_cap] | list columns [list_cap] | row meta [tile_rows] int4 |
   // Hnd partner table [2 * nterms][64]
   extern __shared__ double2 tile[];
@@ -419,7 +433,7 @@ __global__ void __launch_bounds__(NT)
     }
     return;
   }
-  double asum = 0.0, qsum = 0.0;
+  double asum = 0.0, qsum = 0.0, nsum = 0.0;  // <v|w>, sum (w - sg v)^2, <v|v> (k_finalize_ab)
   const double sg = ALPHA ? a.scal[SC_ALPHA] : 0.0;  // see normal_dw_panel_kernel
   const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int lane = threadIdx.x & 63;
@@ -592,6 +606,7 @@ __global__ void __launch_bounds__(NT)
             const double dx = acc[j].x - sg * o.x, dy = acc[j].y - sg * o.y;
             asum += o.x * acc[j].x + o.y * acc[j].y;
             qsum += dx * dx + dy * dy;
+            nsum += o.x * o.x + o.y * o.y;
           }
         }
       }
@@ -603,21 +618,25 @@ __global__ void __launch_bounds__(NT)
     for (int off = 32; off > 0; off >>= 1) {
       asum += __shfl_down(asum, off, 64);
       qsum += __shfl_down(qsum, off, 64);
+      nsum += __shfl_down(nsum, off, 64);
     }
     if (lane == 0) {
       red[wave] = asum;
       red[NT / 64 + wave] = qsum;
+      red[2 * (NT / 64) + wave] = nsum;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      double t = 0.0, q = 0.0;
+      double t = 0.0, q = 0.0, n = 0.0;
 #pragma unroll
       for (int i = 0; i < NT / 64; i++) {
         t += red[i];
         q += red[NT / 64 + i];
+        n += red[2 * (NT / 64) + i];
       }
       a.partial[blockIdx.x] = t;
       a.partial[gridDim.x + blockIdx.x] = q;
+      a.partial[2 * gridDim.x + blockIdx.x] = n;
     }
   }
 }
@@ -729,7 +748,7 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
   const int panel_groups = (p.npanels + 7) / 8;
   const dim3 grid((unsigned)((int64_t)panel_groups * bpp * 8)), block(kPanelNT);
   if (nblocks) *nblocks = (int)grid.x;
-  if (!tiled && alpha && 2 * (int64_t)grid.x > a.partial_cap) {  // before anything that writes the partials is enqueued
+  if (!tiled && alpha && 3 * (int64_t)grid.x > a.partial_cap) {  // before anything that writes the partials is enqueued
     set_error("launch_dw_panels: partial buffer too small for this grid");
     return 1;
   }
@@ -757,7 +776,7 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
     if (g < 8) g = 8;                                                                                          \
     pgrid = dim3((unsigned)g);                                                                                 \
     if (nblocks) *nblocks = (int)g;                                                                            \
-    if (alpha && 2 * g > a.partial_cap) {                                                                      \
+    if (alpha && 3 * g > a.partial_cap) {                                                                      \
       set_error("launch_dw_panels: partial buffer too small for this grid");                                   \
       return 1;                                                                                                \
     }                                                                                                          \
