@@ -33,14 +33,36 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 
 
 def _traffic_from_profiles(workload: str):
-    """HBM bytes per H*v launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json)."""
+    """HBM bytes per H*v launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by
+    scripts/collect_profiles.sh with the gfx950 corrections of profiles/r02_fetch_calibration.txt).  The file is
+    stamped with a hash of the kernel sources it was measured on: for any other build the figure is stale -> None."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(p):
         return None
     try:
-        return json.load(open(p)).get(workload, {}).get("hbm_bytes_per_launch")
+        from edipack_amd import capi
+        rec = json.load(open(p)).get(workload, {})
+        if rec.get("source_hash") != capi.kernel_source_hash():
+            return None
+        return rec.get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+def _hbm_resident(steps: int):
+    """The sector the 0.60 target is phrased on with a working set beyond the 256 MiB Infinity Cache: the 3-orbital
+    hybrid structure at Ns=16 (Dim 165 636 900, 1.33 GB per vector).  Plain H*v, HIP events."""
+    from edipack_amd.synthetic import WORKLOADS, build_workload
+    w = WORKLOADS["cfg3_ns16"]
+    h = build_workload(w)
+    try:
+        bytes_hv, _ = h.algorithmic_bytes()
+        ms = h.time_apply(2, max(5, min(steps, 20)), lanczos=False)
+        return {"workload": f"{w.name}: 3 orbitals, hybrid bath, Ns=16, sector {w.sector}, Dim={h.dim}",
+                "ms_hv": ms, "achieved": bytes_hv / (ms * 1e-3) / 1e9, "unit": "GB/s",
+                "frac": bytes_hv / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_hv}
+    finally:
+        h.destroy()
 
 
 def _host_cores() -> int:
@@ -135,6 +157,8 @@ def run_single(args):
     ms_step, ms_hv = h.lanczos_bench(args.warmup, args.steps)
     ms_hv_only = h.time_apply(max(2, args.warmup), args.steps, lanczos=False)
     achieved = bytes_hv / (ms_hv * 1e-3) / 1e9
+    traffic = _traffic_from_profiles(w.name)
+    rd, cp, tr = capi.membw(1 << 30)
     out = {
         "metric": "Lanczos H*v iterations/sec, largest (Nup,Ndw) sector",
         "value": 1e3 / ms_step, "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -146,7 +170,13 @@ def run_single(args):
                    "parallelism": "1 GPU, device-resident Lanczos", "build_s": round(t_build, 3),
                    "hv_only_ms": ms_hv_only, "lanczos_step_GBs": bytes_step / (ms_step * 1e-3) / 1e9},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profiles(w.name),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     # counter-based rate: what actually crossed the fabric per launch / launch duration (for the flat
+                     # modes the algorithmic figure exceeds it: their device format moves ~3x fewer bytes)
+                     "traffic_GBs": (traffic / (ms_hv * 1e-3) / 1e9) if traffic else None,
+                     "traffic_frac": (traffic / (ms_hv * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "measured_ceiling_GBs": {"read": rd, "copy": cp, "triad": tr,
+                                              "note": "streaming kernels on 1 GiB buffers, this device, this run"},
                      "kernel": {0: "normal_rows_kernel + normal_dw_panel2_kernel (normal_dw_panel_kernel for odd DimUp / small sectors)", 1: "sell_rows_packed_kernel (SELL-64 + value dictionary; csr_rows_kernel fallback)",
                                 2: "direct_rows_kernel"}[h.kind],
                      "algorithmic_bytes_per_launch": bytes_hv, "ms_per_launch": ms_hv},
@@ -154,14 +184,20 @@ def run_single(args):
     if not args.no_cpu and h.kind != 2:
         out["cpu_baseline"] = cpu_baseline(h, w.name, args.cpu_seconds)
     h.destroy()
+    if args.workload == "cfg2" and not args.no_resident:
+        out["config"]["hbm_resident"] = _hbm_resident(args.steps)
     print(json.dumps(out), flush=True)
 
 
 def run_multi(args):
+    """N > 1: one rank per GPU.  torch.distributed is only the rendezvous (it hands the 128-byte RCCL id of rank 0 to
+    the other ranks and reduces the timings at the end); the communicator, the exchange and the whole sharded
+    recurrence live in libedigpu.so (csrc/edigpu_shard.hip: edigpu_comm_create + edigpu_lanczos_bench_sharded) --
+    the same entry points the Fortran + MPI host binds (fortran/edigpu_shim.f90)."""
     import torch
     import torch.distributed as dist
     from edipack_amd import capi
-    from edipack_amd.sharding import gpu_sharded_hamiltonian, gpu_transposed_hamiltonian
+    from edipack_amd.sharding import LibraryComm, library_sharded_sector
     from edipack_amd.synthetic import WORKLOADS, synthetic_model
 
     # RCCL prints a version banner on stdout when the communicator comes up: keep the real stdout for the one
@@ -175,90 +211,69 @@ def run_multi(args):
     os.environ.setdefault("RANK", str(rank))
     os.environ.setdefault("WORLD_SIZE", str(world))
     local = int(os.environ.get("LOCAL_RANK", rank))
-    # one rank per GPU; EDIGPU_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the
-    # N>1 data flow on a single-GPU box; the timed configuration is always nccl = RCCL over xGMI)
+    # EDIGPU_DIST_BACKEND=gloo: several ranks share one GPU through the library's shared-memory transport (a
+    # rehearsal of the N > 1 data flow on a one-GPU box; the timed configuration is RCCL over xGMI)
     backend = os.environ.get("EDIGPU_DIST_BACKEND", "nccl")
     dev = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-    else:
-        dist.init_process_group(backend)
+    dist.init_process_group("gloo")          # rendezvous and scalar reductions only: no GPU traffic goes through it
     capi.init(dev)
     w = WORKLOADS[args.workload]
     model = synthetic_model(w)
-    exchange = "allgather"
-    if w.ed_mode == "normal" and os.environ.get("EDIGPU_EXCHANGE", "transpose") != "allgather":
-        try:
-            plan, h, lz = gpu_transposed_hamiltonian(model, w.sector, world, rank, stage_host=backend != "nccl")
-            exchange = "transpose"
-        except RuntimeError:      # sector not servable this way (explicit spH0nd, phonons)
+    if backend == "nccl":
+        ids = [LibraryComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = LibraryComm(rank, world, unique_id=ids[0])
+    else:
+        comm = LibraryComm(rank, world, shm_name=f"edigpu_bench_{os.environ['MASTER_PORT']}", slot_bytes=1 << 30)
+    exchange = os.environ.get("EDIGPU_EXCHANGE", "auto")
+    h, first, count = library_sharded_sector(model, w.sector, comm, direct=w.direct, exchange=exchange)
+    transposed = False
+    if h.kind == 0 and h.nloc == h.dim and exchange != "allgather":
+        try:                      # the library takes the transposed exchange exactly when this query succeeds
+            h.transpose_halo()
+            transposed = True
+        except capi.EdigpuError:
             pass
-    if exchange == "allgather":
-        plan, h, lz = gpu_sharded_hamiltonian(model, w.sector, world, rank, direct=w.direct)
-    bytes_hv, _ = h.algorithmic_bytes()   # this shard's share of the algorithmic bytes
-    if exchange == "transpose":
-        bytes_hv /= world                 # every rank holds the whole sector's (small) tables
-    sent = lz.exchange_bytes if exchange == "transpose" else 8 * plan.chunk * (world - 1) * (2 if lz.dtype.is_complex else 1)
-    gen = torch.Generator(device="cuda").manual_seed(12345 + rank)
-    v0 = torch.randn(plan.nloc, dtype=torch.float64, device="cuda", generator=gen)
-    if lz.dtype.is_complex:
-        v0 = v0.to(lz.dtype)
-    lz.tridiag(v0, max(1, args.warmup))
-    # timed region: K Lanczos steps, barrier + synchronize on both sides
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    # transposed exchange: the product comes fused with the vector updates and the one all-reduce of the step, and
-    # the loop runs on pre-bound launches -- no per-product events there, the step time is the product time
-    fused = bool(getattr(lz, "fused", False))
-    counter = {"k": 0}
-    if not fused:
-        hv_orig = lz.hv
-
-        def hv_timed(*a):
-            k = counter["k"]
-            ev[k][0].record()
-            hv_orig(*a)
-            ev[k][1].record()
-            counter["k"] = k + 1
-
-        lz.hv = hv_timed
+    bytes_hv, _ = h.algorithmic_bytes()   # a shard handle: this shard's share; a whole-sector handle: all of it
+    if transposed:
+        bytes_hv /= world
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    lz.tridiag(v0, args.steps)
+    ms_step, sent = comm.bench(h, args.warmup, args.steps)     # barrier + stream sync on both sides of the K steps
     torch.cuda.synchronize()
     dist.barrier()
-    dt = time.perf_counter() - t0
-    ms_hv = dt * 1e3 / args.steps if fused else sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    t = torch.tensor([dt, ms_hv, bytes_hv], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    tmax = t.clone()
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    tsum = t.clone()
-    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    wall = time.perf_counter() - t0
+    t = torch.tensor([ms_step, wall], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tb = torch.tensor([bytes_hv], dtype=torch.float64)
+    dist.all_reduce(tb, op=dist.ReduceOp.SUM)
     if rank == 0:
-        dt_max, ms_hv_max, bytes_total = float(tmax[0]), float(tmax[1]), float(tsum[2])
-        ms_step = dt_max * 1e3 / args.steps
-        achieved = bytes_total / (ms_hv_max * 1e-3) / 1e9
+        ms = float(t[0])
+        achieved = float(tb[0]) / (ms * 1e-3) / 1e9
         out = {
             "metric": "Lanczos H*v iterations/sec, largest (Nup,Ndw) sector",
-            "value": 1e3 / ms_step, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "c128" if lz.dtype.is_complex else "f64", "data": "synthetic",
+            "value": 1e3 / ms, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "c128" if h.is_complex else "f64", "data": "synthetic",
             "config": {"workload": f"{w.name}: {w.ed_mode} mode, bath={w.bath_type}, Norb={w.norb}, "
                                    f"Nbath={w.nbath}, sector={w.sector}, Dim={h.dim} ({w.note})",
-                       "parallelism": (f"row-sharded over {world} GPUs, transposed exchange: two RCCL all-to-alls per "
-                                       f"H*v, the first overlapped with the row half (Hd + Hup)"
-                                       if exchange == "transpose" else
-                                       f"row-sharded over {world} GPUs, RCCL all-gather of v overlapped with the "
+                       "parallelism": (f"row-sharded over {world} GPUs, in-library loop, transposed exchange: two RCCL "
+                                       f"all-to-alls per H*v, the first beside the row half (Hd + Hup)"
+                                       if transposed else
+                                       f"row-sharded over {world} GPUs, in-library loop, RCCL all-gather of v beside the "
                                        f"shard-local part of H*v"),
+                       "transport": "rccl" if backend == "nccl" else "shared memory (one-GPU rehearsal)",
                        "exchange_bytes_per_rank_per_hv": int(sent)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
-                         "note": "whole-job: sum of shard algorithmic bytes / slowest rank's H*v time "
-                                 "(exchange included)", "ms_per_launch": ms_hv_max},
+                         "note": "whole-job: algorithmic bytes of one H*v / slowest rank's time per Lanczos step "
+                                 "(exchange and vector updates included)", "ms_per_launch": ms},
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     h.destroy()
+    comm.destroy()
     dist.destroy_process_group()
 
 
@@ -269,6 +284,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident (Ns=16 ladder) H*v measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
     # EDIGPU_FORCE_MULTI=1: take the N > 1 code path with a single rank (RCCL world of one; with

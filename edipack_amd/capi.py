@@ -109,6 +109,17 @@ SIGNATURES = {
     "edigpu_vec_add_dot2": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "edigpu_time_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _pd]),
     "edigpu_lanczos_bench": (C.c_int, [_vp, C.c_int, C.c_int, _pd, _pd]),
+    "edigpu_membw": (C.c_int, [_i64, _pd]),
+    "edigpu_shard_plan": (C.c_int, [_i64, C.c_int32, C.c_int32, _pi64, _pi64, _pi64]),
+    "edigpu_comm_unique_id": (C.c_int, [_vp]),
+    "edigpu_comm_create": (C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int32, _vp]),
+    "edigpu_comm_create_shm": (C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int32, C.c_char_p, _i64]),
+    "edigpu_comm_info": (C.c_int, [_vp, _pi32, _pi32, _pi32]),
+    "edigpu_comm_destroy": (C.c_int, [_vp]),
+    "edigpu_apply_sharded_d": (C.c_int, [_vp, _vp, _i64, _pd, _pd]),
+    "edigpu_apply_sharded_z": (C.c_int, [_vp, _vp, _i64, _pd, _pd]),
+    "edigpu_lanczos_tridiag_sharded": (C.c_int, [_vp, _vp, _vp, C.c_int, _pd, _pd, C.c_double, _pint, _pd]),
+    "edigpu_lanczos_bench_sharded": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _pd, _pi64]),
     "edigpu_destroy": (C.c_int, [_vp]),
 }
 
@@ -158,6 +169,25 @@ def device_count() -> int:
 
 def init(device: int = 0) -> None:
     check(lib().edigpu_init(int(device)), "edigpu_init")
+
+
+def membw(nbytes: int = 1 << 30):
+    """(read, copy, triad) GB/s streaming ceilings of the selected device (edigpu_membw)."""
+    out = (C.c_double * 3)()
+    check(lib().edigpu_membw(int(nbytes), out), "edigpu_membw")
+    return tuple(float(x) for x in out)
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the kernel / host sources of libedigpu.so: profiles/pmc_traffic.json is stamped with it, so a
+    counter-derived traffic figure is only reported for the kernels it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(HERE, "csrc", "*.h*")) + glob.glob(os.path.join(HERE, "csrc", "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pd(a: np.ndarray):

@@ -2472,6 +2472,16 @@ int edigpu_time_apply(edigpu_handle s, int warmup, int steps, int lanczos, doubl
   return 0;
 }
 
+int edigpu_membw(int64_t bytes, double* gbs3) {
+  if (!gbs3 || bytes < (1 << 20)) {
+    set_error("edigpu_membw: bad argument");
+    return 1;
+  }
+  if (ensure_device()) return 1;
+  EDIGPU_HIP(hipSetDevice(g_device));
+  return measure_membw(bytes, gbs3);
+}
+
 int edigpu_lanczos_bench(edigpu_handle s, int warmup, int steps, double* ms_wall_per_step,
                          double* ms_hv_per_launch) {
   if (!s || steps <= 0 || warmup < 0 || !ms_wall_per_step || !ms_hv_per_launch) {

@@ -1,0 +1,863 @@
+// edigpu_shard.hip -- the N > 1 path inside the library: communicator, exchange and the sharded recurrence.
+//
+// Takes the place of the MPI data flow of the reference's distributed products and of SciFortran's MPI Lanczos
+// driver (reference paths relative to /root/reference/src/singlesite):
+//   spMatVec_mpi_normal_main   ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:765-929  (two vector_transpose_MPI per
+//                              product, ED_NORMAL/ED_HAMILTONIAN_NORMAL_COMMON.f90:66-167, + allgather for spH0nd)
+//   spMatVec_mpi_superc_main   ED_SUPERC/ED_HAMILTONIAN_SUPERC_STORED_HxV.f90:366-432  (MPI_Allgatherv :418-421)
+//   spMatVec_mpi_nonsu2_main   ED_NONSU2/ED_HAMILTONIAN_NONSU2_STORED_HxV.f90:213-267  (MPI_Allgatherv :256-259)
+//   directMatVec_MPI_*         ED_*/ED_HAMILTONIAN_*_DIRECT_HxV.f90 (gather first, then compute)
+//   sp_lanc_tridiag(MpiComm, spHtimesV_p, vvloc, alanc, blanc)   ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:357-365
+//   scatter / gather of the seed: ED_AUX_FUNX.f90:598-928 (each rank hands over its own shard here)
+//
+// One process per GPU.  The communicator is RCCL over xGMI (loaded at run time: the library a host already mapped --
+// PyTorch ships its own copy -- or /opt/rocm's); a second, host-staged transport through POSIX shared memory lets
+// several ranks of one node share a GPU (tests of the N > 1 data flow on a one-GPU box; no RCCL needed).
+// Every collective is enqueued on a HIP stream; the exchange of a product runs on a side stream and overlaps the part
+// of H*v that needs no remote data.  A whole tridiagonalisation is enqueued without host synchronisation (RCCL) --
+// the coefficients are read back once at the end.
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "kernels.hpp"
+
+namespace edigpu {
+
+// ---------------------------------------------------------------------------------------------------------
+// RCCL, resolved at run time
+// ---------------------------------------------------------------------------------------------------------
+// types and enum values from the vendor header; the entry points themselves are looked up with dlsym
+typedef ncclUniqueId rccl_unique_id;
+typedef ncclComm_t rccl_comm_t;
+#define RCCL_SUM ncclSum
+#define RCCL_FLOAT64 ncclFloat64
+
+struct RcclApi {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+static RcclApi* rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api.lib ? &api : nullptr;
+  tried = true;
+  // a copy the host process already mapped wins (one RCCL per process), then the system one
+  const char* names[] = {"librccl.so", "librccl.so.1"};
+  for (const char* n : names)
+    if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+  for (const char* n : names)
+    if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+  if (!api.lib) api.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!api.lib) return nullptr;
+#define EDIGPU_SYM(field, name)                                  \
+  *(void**)(&api.field) = dlsym(api.lib, name);                 \
+  if (!api.field) {                                              \
+    api.lib = nullptr;                                           \
+    return nullptr;                                              \
+  }
+  EDIGPU_SYM(GetUniqueId, "ncclGetUniqueId")
+  EDIGPU_SYM(CommInitRank, "ncclCommInitRank")
+  EDIGPU_SYM(CommDestroy, "ncclCommDestroy")
+  EDIGPU_SYM(AllReduce, "ncclAllReduce")
+  EDIGPU_SYM(AllGather, "ncclAllGather")
+  EDIGPU_SYM(Send, "ncclSend")
+  EDIGPU_SYM(Recv, "ncclRecv")
+  EDIGPU_SYM(GroupStart, "ncclGroupStart")
+  EDIGPU_SYM(GroupEnd, "ncclGroupEnd")
+  EDIGPU_SYM(GetErrorString, "ncclGetErrorString")
+#undef EDIGPU_SYM
+  return &api;
+}
+
+#define EDIGPU_RCCL(call)                                                                              \
+  do {                                                                                                 \
+    ncclResult_t _r = (call);                                                                          \
+    if (_r != ncclSuccess) {                                                                                     \
+      set_error(std::string(#call) + " failed: " + (rccl() ? rccl()->GetErrorString(_r) : "no RCCL")); \
+      return 1;                                                                                        \
+    }                                                                                                  \
+  } while (0)
+
+}  // namespace edigpu
+
+// ---------------------------------------------------------------------------------------------------------
+// communicator
+// ---------------------------------------------------------------------------------------------------------
+struct ShmHeader {
+  std::atomic<int> ready;       // set by rank 0 once the region is initialised
+  std::atomic<int> arrived;     // barrier: arrivals of the current generation
+  std::atomic<int> generation;  // barrier: bumped by the last arriver
+  int world;
+  int64_t slot_bytes;
+};
+
+struct edigpu_comm_s {
+  int rank = 0, world = 1;
+  int kind = 0;  // 0 RCCL, 1 host-staged through shared memory
+  int device = 0;
+  ncclComm_t nccl = nullptr;
+  hipStream_t side = nullptr;  // exchange stream: the all-to-all / all-gather of a product runs beside its local part
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  // shm transport
+  std::string shm_name;
+  void* shm = nullptr;
+  size_t shm_bytes = 0;
+  ShmHeader* hdr = nullptr;
+  char* slots = nullptr;
+  std::vector<char> stage;
+  // sharded-recurrence workspace (grown on demand)
+  int64_t ws_chunk = 0, ws_x = 0;
+  double *vin = nullptr, *vout = nullptr, *tmp = nullptr, *vfull = nullptr;
+  double *send = nullptr, *recv = nullptr, *hvc = nullptr, *back = nullptr;
+  double *hist = nullptr, *work = nullptr, *scr = nullptr;
+  int64_t hist_cap = 0;
+};
+
+namespace edigpu {
+
+// EDIGPU_FORCE_COLLECTIVES=1: a world of one still issues its collectives through RCCL (one-GPU rehearsal of the calls)
+static bool force_collectives(const edigpu_comm_s* c) {
+  static const bool f = getenv("EDIGPU_FORCE_COLLECTIVES") != nullptr;
+  return f && c->kind == 0 && c->nccl != nullptr;
+}
+
+static int shm_barrier(edigpu_comm_s* c) {
+  ShmHeader* h = c->hdr;
+  const int gen = h->generation.load(std::memory_order_acquire);
+  if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == c->world) {
+    h->arrived.store(0, std::memory_order_relaxed);
+    h->generation.store(gen + 1, std::memory_order_release);
+    return 0;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  while (h->generation.load(std::memory_order_acquire) == gen) {
+    std::this_thread::yield();
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+      set_error("edigpu_comm (shm): barrier timed out after 120 s (a rank is missing)");
+      return 1;
+    }
+  }
+  return 0;
+}
+
+static char* shm_slot(edigpu_comm_s* c, int r) { return c->slots + (size_t)r * (size_t)c->hdr->slot_bytes; }
+
+static int shm_fits(edigpu_comm_s* c, size_t bytes) {
+  if ((int64_t)bytes > c->hdr->slot_bytes) {
+    set_error("edigpu_comm (shm): message of " + std::to_string(bytes) + " bytes exceeds the slot size given at creation");
+    return 1;
+  }
+  return 0;
+}
+
+// recv[s * n .. (s+1) * n) <- block `rank` of rank s's send buffer; n doubles per block (equal split)
+static int comm_all_to_all(edigpu_comm_s* c, const double* send, double* recv, size_t n, hipStream_t st) {
+  const size_t bytes = n * sizeof(double);
+  if (c->world == 1 && !force_collectives(c)) {
+    EDIGPU_HIP(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+  }
+  if (c->kind == 0) {
+    RcclApi* r = rccl();
+    EDIGPU_RCCL(r->GroupStart());
+    for (int p = 0; p < c->world; p++) {
+      EDIGPU_RCCL(r->Send(send + (size_t)p * n, n, RCCL_FLOAT64, p, c->nccl, st));
+      EDIGPU_RCCL(r->Recv(recv + (size_t)p * n, n, RCCL_FLOAT64, p, c->nccl, st));
+    }
+    EDIGPU_RCCL(r->GroupEnd());
+    return 0;
+  }
+  if (shm_fits(c, bytes * c->world)) return 1;
+  EDIGPU_HIP(hipMemcpyAsync(shm_slot(c, c->rank), send, bytes * c->world, hipMemcpyDeviceToHost, st));
+  EDIGPU_HIP(hipStreamSynchronize(st));
+  if (shm_barrier(c)) return 1;
+  c->stage.resize(bytes * c->world);
+  for (int s = 0; s < c->world; s++) memcpy(c->stage.data() + (size_t)s * bytes, shm_slot(c, s) + (size_t)c->rank * bytes, bytes);
+  if (shm_barrier(c)) return 1;  // every rank has read: the slots may be overwritten
+  EDIGPU_HIP(hipMemcpyAsync(recv, c->stage.data(), bytes * c->world, hipMemcpyHostToDevice, st));
+  EDIGPU_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+// recv[s * n .. (s+1) * n) <- send of rank s
+static int comm_all_gather(edigpu_comm_s* c, const double* send, double* recv, size_t n, hipStream_t st) {
+  const size_t bytes = n * sizeof(double);
+  if (c->world == 1 && !force_collectives(c)) {
+    EDIGPU_HIP(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+  }
+  if (c->kind == 0) {
+    EDIGPU_RCCL(rccl()->AllGather(send, recv, n, RCCL_FLOAT64, c->nccl, st));
+    return 0;
+  }
+  if (shm_fits(c, bytes)) return 1;
+  EDIGPU_HIP(hipMemcpyAsync(shm_slot(c, c->rank), send, bytes, hipMemcpyDeviceToHost, st));
+  EDIGPU_HIP(hipStreamSynchronize(st));
+  if (shm_barrier(c)) return 1;
+  c->stage.resize(bytes * c->world);
+  for (int s = 0; s < c->world; s++) memcpy(c->stage.data() + (size_t)s * bytes, shm_slot(c, s), bytes);
+  if (shm_barrier(c)) return 1;
+  EDIGPU_HIP(hipMemcpyAsync(recv, c->stage.data(), bytes * c->world, hipMemcpyHostToDevice, st));
+  EDIGPU_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+// buf[0..n) <- sum over the ranks (the same order on every rank: bit-identical results everywhere)
+static int comm_all_reduce(edigpu_comm_s* c, double* buf, size_t n, hipStream_t st) {
+  if (c->world == 1 && !force_collectives(c)) return 0;
+  if (c->kind == 0) {
+    EDIGPU_RCCL(rccl()->AllReduce(buf, buf, n, RCCL_FLOAT64, RCCL_SUM, c->nccl, st));
+    return 0;
+  }
+  const size_t bytes = n * sizeof(double);
+  if (shm_fits(c, bytes)) return 1;
+  EDIGPU_HIP(hipMemcpyAsync(shm_slot(c, c->rank), buf, bytes, hipMemcpyDeviceToHost, st));
+  EDIGPU_HIP(hipStreamSynchronize(st));
+  if (shm_barrier(c)) return 1;
+  std::vector<double> acc(n, 0.0);
+  for (int s = 0; s < c->world; s++) {
+    const double* p = reinterpret_cast<const double*>(shm_slot(c, s));
+    for (size_t i = 0; i < n; i++) acc[i] += p[i];
+  }
+  if (shm_barrier(c)) return 1;
+  EDIGPU_HIP(hipMemcpyAsync(buf, acc.data(), bytes, hipMemcpyHostToDevice, st));
+  EDIGPU_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// vector kernels of the one-reduction recurrence on shards.  Per step the ranks reduce THREE sums,
+//   T = (<v|w>, sum (w - sg v)^2, <v|v>),   sg = alpha of the previous step (0 on the first),
+// from which alpha = T[0] and beta^2 = |w - alpha v|^2 = T[1] - 2 d (alpha - sg T[2]) + d^2 T[2], d = alpha - sg --
+// an identity (no |v| = 1 assumed), well conditioned for spectra far from zero (see k_finalize_ab).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kShNT = 256;
+
+__device__ inline void ab_from_sums(const double* __restrict__ t, const double* __restrict__ tprev, double& a, double& b) {
+  const double sg = tprev ? tprev[0] : 0.0;
+  a = t[0];
+  const double d = a - sg;
+  const double b2 = t[1] - 2.0 * d * (a - sg * t[2]) + d * d * t[2];
+  b = sqrt(b2 > 0.0 ? b2 : 0.0);
+}
+
+__device__ inline void block_sum3(double s0, double s1, double s2, double* __restrict__ partial, int stride) {
+  __shared__ double ws[3][kShNT / 64];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s0 += __shfl_down(s0, off, 64);
+    s1 += __shfl_down(s1, off, 64);
+    s2 += __shfl_down(s2, off, 64);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+    ws[0][w] = s0;
+    ws[1][w] = s1;
+    ws[2][w] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < kShNT / 64; i++) {
+      t0 += ws[0][i];
+      t1 += ws[1][i];
+      t2 += ws[2][i];
+    }
+    partial[blockIdx.x] = t0;
+    partial[stride + blockIdx.x] = t1;
+    partial[2 * stride + blockIdx.x] = t2;
+  }
+}
+
+// w += tmp (+ back, the down half received from the column shards when dim_up > 0); partials of the three sums
+__global__ void __launch_bounds__(kShNT)
+    ks_add_dot3(int64_t n, int64_t dim_up, int64_t q, int64_t pcol, int halo, const double* __restrict__ vin,
+                double* __restrict__ vout, const double* __restrict__ tmp, const double* __restrict__ back,
+                const double* __restrict__ tprev, double* __restrict__ partial) {
+  const double sg = tprev ? tprev[0] : 0.0;
+  const int64_t pw = pcol + 2 * halo;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * kShNT + threadIdx.x; e < n; e += (int64_t)gridDim.x * kShNT) {
+    double w = vout[e] + tmp[e];
+    if (back) {
+      const int64_t i = e / dim_up, col = e - i * dim_up;
+      const int64_t c = col / pcol, j = col - c * pcol;
+      w += back[(c * q + i) * pw + halo + j];
+    }
+    vout[e] = w;
+    const double v = vin[e], d = w - sg * v;
+    s0 += v * w;
+    s1 += d * d;
+    s2 += v * v;
+  }
+  block_sum3(s0, s1, s2, partial, kRedBlocks);
+}
+
+__global__ void __launch_bounds__(1024) ks_sum3(const double* __restrict__ partial, int np, double* __restrict__ out) {
+  __shared__ double sh[3][1024];
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < np; i += 1024)
+#pragma unroll
+    for (int k = 0; k < 3; k++) s[k] += partial[k * kRedBlocks + i];
+#pragma unroll
+  for (int k = 0; k < 3; k++) sh[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off)
+#pragma unroll
+      for (int k = 0; k < 3; k++) sh[k][threadIdx.x] += sh[k][threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) out[threadIdx.x] = sh[threadIdx.x][0];
+}
+
+// (v, w) <- ((w - alpha v) / beta, -beta v) from the reduced sums of the previous step; with send != null the new v
+// also goes into the all-to-all send buffer [world][q][pcol + 2 halo] (halo columns into every block that holds them)
+__global__ void __launch_bounds__(kShNT)
+    ks_rotate3(int first, int64_t n, int64_t dim_up, int64_t q, int world, int64_t pcol, int halo, double* __restrict__ vin,
+               double* __restrict__ vout, const double* __restrict__ t, const double* __restrict__ tprev,
+               double* __restrict__ send) {
+  double a = 0.0, b = 1.0;
+  if (!first) ab_from_sums(t, tprev, a, b);
+  const double ib = 1.0 / b;
+  const int64_t pw = pcol + 2 * halo;
+  for (int64_t e = (int64_t)blockIdx.x * kShNT + threadIdx.x; e < n; e += (int64_t)gridDim.x * kShNT) {
+    double x = vin[e];
+    if (!first) {
+      const double p = x;
+      x = (vout[e] - a * p) * ib;
+      vin[e] = x;
+      vout[e] = -b * p;
+    }
+    if (send) {
+      const int64_t i = e / dim_up, col = e - i * dim_up;
+      int64_t clo = col >= halo ? (col - halo) / pcol : 0, chi = (col + halo) / pcol;
+      if (chi > world - 1) chi = world - 1;
+      for (int64_t c = clo; c <= chi; c++) send[(c * q + i) * pw + (col - c * pcol + halo)] = x;
+    }
+  }
+}
+
+static inline dim3 sh_grid(int64_t n, int cap) {
+  int64_t nb = (n + kShNT - 1) / kShNT;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  return dim3((unsigned)nb);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the sharded product and recurrence
+// ---------------------------------------------------------------------------------------------------------
+struct ShardGeom {
+  bool transposed = false;  // normal mode, whole-sector handle: two all-to-alls per product
+  int w = 1;                // doubles per element
+  int64_t units = 0, unit_len = 1, q = 0, first = 0, count = 0;
+  int64_t nloc = 0, chunk = 0;  // elements of this rank's shard / of the padded chunk
+  // transposed exchange
+  int halo = 0;
+  int64_t pcol = 0, col_first = 0, col_count = 0, pw = 0, xlen = 0;
+};
+
+static int shard_geometry(const edigpu_sector* s, const edigpu_comm_s* c, ShardGeom& g) {
+  g.w = s->is_complex ? 2 : 1;
+  g.transposed = s->kind == 0 && s->nloc == s->dim && normal_transposable(s);
+  if (s->kind == 0) {
+    g.units = s->dim_dw;
+    g.unit_len = s->dim_up;
+  } else {
+    g.units = s->dim;
+    g.unit_len = 1;
+  }
+  g.q = (g.units + c->world - 1) / c->world;
+  g.first = std::min<int64_t>((int64_t)c->rank * g.q, g.units);
+  g.count = std::max<int64_t>(0, std::min<int64_t>(g.q, g.units - g.first));
+  g.nloc = g.count * g.unit_len;
+  g.chunk = g.q * g.unit_len;
+  if (g.transposed) {
+    g.halo = s->col_halo;
+    g.pcol = (s->dim_up + c->world - 1) / c->world;
+    g.col_first = std::min<int64_t>((int64_t)c->rank * g.pcol, s->dim_up);
+    g.col_count = std::max<int64_t>(0, std::min<int64_t>(g.pcol, s->dim_up - g.col_first));
+    g.pw = g.pcol + 2 * g.halo;
+    g.xlen = (int64_t)c->world * g.q * g.pw;
+    if (g.pcol < 1 || g.halo > g.pcol) g.transposed = false;  // blocks narrower than the halo: all-gather form
+  }
+  if (!g.transposed) {
+    // all-gather form: the handle must BE this rank's shard
+    if (s->nloc != g.nloc || s->row_first != g.first * g.unit_len) {
+      set_error("sharded call: the handle does not hold this rank's shard (build it with the first / count of "
+                "edigpu_shard_plan, or -- normal mode -- build the whole sector for the transposed exchange)");
+      return 1;
+    }
+    if (s->nph > 0 || s->kind == 4) {
+      set_error("sharded call: phonon and complex normal-mode sectors are single-shard");
+      return 1;
+    }
+  }
+  return 0;
+}
+
+template <class T>
+static int regrow(T*& p, size_t n) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  EDIGPU_HIP(hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)));
+  EDIGPU_HIP(hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+  // the memset runs on the null stream, which the handles' non-blocking streams do not wait for
+  EDIGPU_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+static int comm_workspace(edigpu_comm_s* c, const ShardGeom& g, int nlanc) {
+  const int64_t chunk = g.chunk * g.w;
+  if (chunk != c->ws_chunk) {
+    if (regrow(c->vin, chunk) || regrow(c->vout, chunk) || regrow(c->tmp, chunk)) return 1;
+    if (!g.transposed && regrow(c->vfull, (size_t)chunk * c->world)) return 1;
+    c->ws_chunk = chunk;
+  }
+  if (!g.transposed && !c->vfull && regrow(c->vfull, (size_t)chunk * c->world)) return 1;
+  if (g.transposed && g.xlen != c->ws_x) {
+    if (regrow(c->send, g.xlen) || regrow(c->recv, g.xlen) || regrow(c->hvc, g.xlen) || regrow(c->back, g.xlen)) return 1;
+    c->ws_x = g.xlen;
+  }
+  if (3 * (int64_t)nlanc + 8 > c->hist_cap) {
+    if (regrow(c->hist, 3 * (size_t)nlanc + 8)) return 1;
+    c->hist_cap = 3 * (int64_t)nlanc + 8;
+  }
+  if (!c->work && regrow(c->work, 3 * (size_t)kRedBlocks)) return 1;
+  if (!c->scr && regrow(c->scr, 8)) return 1;
+  return 0;
+}
+
+// tmp <- (H vin) on the local rows.  pre_packed: the send buffer already holds vin (fused rotate).  The exchange runs
+// on the side stream beside the part of the product that needs no remote data.
+static int sharded_hv(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, bool pre_packed, hipStream_t st) {
+  if (g.transposed) {
+    if (!pre_packed &&
+        edigpu_transpose_pack(s->dim_up, g.count, g.q, c->world, g.pcol, g.halo, c->vin, c->send, st))
+      return 1;
+    EDIGPU_HIP(hipEventRecord(c->ev_ready, st));
+    EDIGPU_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
+    if (comm_all_to_all(c, c->send, c->recv, (size_t)(g.q * g.pw), c->side)) return 1;
+    EDIGPU_HIP(hipEventRecord(c->ev_done, c->side));
+    if (edigpu_normal_apply_rows_dev(s, g.first, g.count, c->vin, c->tmp, st)) return 1;
+    EDIGPU_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
+    if (edigpu_normal_apply_cols_dev(s, g.col_first, g.col_count, g.pw, g.halo, c->recv, c->hvc, st)) return 1;
+    return comm_all_to_all(c, c->hvc, c->back, (size_t)(g.q * g.pw), st);  // consumed by the caller (unpack)
+  }
+  const size_t n = (size_t)g.chunk * g.w;
+  EDIGPU_HIP(hipEventRecord(c->ev_ready, st));
+  EDIGPU_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
+  if (comm_all_gather(c, c->vin, c->vfull, n, c->side)) return 1;
+  EDIGPU_HIP(hipEventRecord(c->ev_done, c->side));
+  if (edigpu_apply_local_dev(s, c->vin, c->tmp, st)) return 1;
+  EDIGPU_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
+  return edigpu_apply_remote_dev(s, c->vfull, c->tmp, st);
+}
+
+// one step of the one-reduction recurrence; T_it lands in hist[3 it .. 3 it + 3)
+static int sharded_step(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, int it, hipStream_t st) {
+  const int64_t n = g.nloc * g.w;
+  double* t = c->hist + 3 * (size_t)it;
+  const double* tp = it > 0 ? c->hist + 3 * (size_t)(it - 1) : nullptr;
+  const double* tpp = it > 1 ? c->hist + 3 * (size_t)(it - 2) : nullptr;
+  if (n > 0)
+    hipLaunchKernelGGL(ks_rotate3, sh_grid(n, 256 * 16), dim3(kShNT), 0, st, it == 0 ? 1 : 0, n, s->dim_up, g.q, c->world,
+                       g.pcol, g.halo, c->vin, c->vout, tp, tpp, g.transposed ? c->send : nullptr);
+  if (sharded_hv(s, c, g, true, st)) return 1;
+  const dim3 gr = sh_grid(std::max<int64_t>(n, 1), kRedBlocks);
+  hipLaunchKernelGGL(ks_add_dot3, gr, dim3(kShNT), 0, st, n, s->dim_up, g.q, g.pcol, g.halo, c->vin, c->vout, c->tmp,
+                     g.transposed ? c->back : nullptr, tp, c->work);
+  hipLaunchKernelGGL(ks_sum3, dim3(1), dim3(1024), 0, st, c->work, (int)gr.x, t);
+  EDIGPU_HIP(hipGetLastError());
+  return comm_all_reduce(c, t, 3, st);
+}
+
+// literal two-reduction step (beta = |w - alpha v|): alpha_it -> hist[it], beta_it^2 -> hist[nlanc + it]
+static int sharded_step_exact(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, int it, int nlanc, hipStream_t st) {
+  const int64_t n = g.nloc * g.w;
+  double* al = c->hist + it;
+  double* b2 = c->hist + nlanc + it;
+  if (it > 0 && vec_rotate(n, c->vin, c->vout, c->hist + nlanc + it - 1, st)) return 1;
+  if (sharded_hv(s, c, g, false, st)) return 1;
+  if (g.transposed &&
+      edigpu_transpose_unpack_add(s->dim_up, g.count, g.q, c->world, g.pcol, g.halo, c->back, c->tmp, st))
+    return 1;
+  if (vec_add_dot(n, c->vin, c->vout, c->tmp, al, c->work, st)) return 1;
+  if (comm_all_reduce(c, al, 1, st)) return 1;
+  if (vec_axpy_nrm2(n, c->vin, c->vout, al, b2, c->work, st)) return 1;
+  return comm_all_reduce(c, b2, 1, st);
+}
+
+static int load_seed(edigpu_comm_s* c, const ShardGeom& g, const double* vin_shard, hipStream_t st) {
+  const int64_t chunk = g.chunk * g.w, n = g.nloc * g.w;
+  EDIGPU_HIP(hipMemsetAsync(c->vin, 0, (size_t)std::max<int64_t>(chunk, 1) * sizeof(double), st));
+  EDIGPU_HIP(hipMemsetAsync(c->vout, 0, (size_t)std::max<int64_t>(chunk, 1) * sizeof(double), st));
+  if (n > 0) EDIGPU_HIP(hipMemcpyAsync(c->vin, vin_shard, (size_t)n * sizeof(double), hipMemcpyDefault, st));
+  // |v|^2 over all ranks, then scale (lanczos_iteration's first step)
+  if (vec_axpy_nrm2(n, c->vin, c->vin, c->scr + 1, c->scr, c->work, st)) return 1;  // scr[1] = 0: v - 0 v
+  if (comm_all_reduce(c, c->scr, 1, st)) return 1;
+  return vec_scale(n, c->vin, c->scr, st);
+}
+
+static int sharded_tridiag(edigpu_sector* s, edigpu_comm_s* c, const double* vin_shard, int nlanc, double* alanc,
+                           double* blanc, double threshold, int* niter_done, double* norm2) {
+  ShardGeom g;
+  if (shard_geometry(s, c, g)) return 1;
+  EDIGPU_HIP(hipSetDevice(s->device));
+  if (comm_workspace(c, g, 2 * nlanc)) return 1;
+  hipStream_t st = s->stream;
+  std::fill(alanc, alanc + nlanc, 0.0);
+  std::fill(blanc, blanc + nlanc, 0.0);
+  if (niter_done) *niter_done = 0;
+  const bool force_exact = getenv("EDIGPU_LANCZOS_EXACTBETA") != nullptr;
+  std::vector<double> h(3 * (size_t)nlanc + 8);
+  for (int pass = force_exact ? 1 : 0; pass < 2; pass++) {
+    EDIGPU_HIP(hipMemsetAsync(c->hist, 0, (size_t)c->hist_cap * sizeof(double), st));
+    if (load_seed(c, g, vin_shard, st)) return 1;
+    for (int it = 0; it < nlanc; it++)
+      if (pass == 0 ? sharded_step(s, c, g, it, st) : sharded_step_exact(s, c, g, it, nlanc, st)) return 1;
+    EDIGPU_HIP(hipMemcpyAsync(h.data(), c->hist, (3 * (size_t)nlanc) * sizeof(double), hipMemcpyDeviceToHost, st));
+    double n2 = 0.0;
+    EDIGPU_HIP(hipMemcpyAsync(&n2, c->scr, sizeof(double), hipMemcpyDeviceToHost, st));
+    EDIGPU_HIP(hipStreamSynchronize(st));
+    if (norm2) *norm2 = n2;
+    if (!(n2 > 0.0)) return 0;  // zero seed: nothing to do (the reference skips such channels)
+    bool redo = false;
+    int ndone = nlanc;
+    for (int k = 0; k < nlanc; k++) {
+      double a, b;
+      if (pass == 0) {
+        const double* t = &h[3 * (size_t)k];
+        const double sg = k > 0 ? h[3 * (size_t)(k - 1)] : 0.0;
+        a = t[0];
+        const double d = a - sg;
+        const double b2 = t[1] - 2.0 * d * (a - sg * t[2]) + d * d * t[2];
+        // more than three digits lost in the difference (the same numbers on every rank): repeat literally
+        if (!(b2 > 1e-3 * t[1]) && b2 > threshold * threshold) {
+          redo = true;
+          break;
+        }
+        b = sqrt(b2 > 0.0 ? b2 : 0.0);
+      } else {
+        a = h[k];
+        b = sqrt(h[(size_t)nlanc + k] > 0.0 ? h[(size_t)nlanc + k] : 0.0);
+      }
+      alanc[k] = a;
+      if (!(fabs(b) > 0.0) || fabs(b) < threshold) {
+        ndone = k + 1;
+        break;
+      }
+      if (k + 1 < nlanc) blanc[k + 1] = b;
+    }
+    if (redo) {
+      std::fill(alanc, alanc + nlanc, 0.0);
+      std::fill(blanc, blanc + nlanc, 0.0);
+      continue;
+    }
+    if (niter_done) *niter_done = ndone;
+    return 0;
+  }
+  set_error("edigpu_lanczos_tridiag_sharded: internal error");
+  return 1;
+}
+
+}  // namespace edigpu
+
+using namespace edigpu;
+
+extern "C" {
+
+int edigpu_shard_plan(int64_t units, int32_t world, int32_t rank, int64_t* first, int64_t* count, int64_t* q) {
+  if (units < 0 || world < 1 || rank < 0 || rank >= world) {
+    set_error("edigpu_shard_plan: bad argument");
+    return 1;
+  }
+  const int64_t qq = (units + world - 1) / world;
+  const int64_t f = std::min<int64_t>((int64_t)rank * qq, units);
+  if (first) *first = f;
+  if (count) *count = std::max<int64_t>(0, std::min<int64_t>(qq, units - f));
+  if (q) *q = qq;
+  return 0;
+}
+
+int edigpu_comm_unique_id(void* id128) {
+  if (!id128) {
+    set_error("edigpu_comm_unique_id: NULL argument");
+    return 1;
+  }
+  RcclApi* r = rccl();
+  if (!r) {
+    set_error("edigpu_comm_unique_id: RCCL (librccl.so) could not be loaded");
+    return 1;
+  }
+  rccl_unique_id id;
+  EDIGPU_RCCL(r->GetUniqueId(&id));
+  memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+
+static int comm_common(edigpu_comm_s* c) {
+  EDIGPU_HIP(hipGetDevice(&c->device));
+  EDIGPU_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  EDIGPU_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+  EDIGPU_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  return 0;
+}
+
+int edigpu_comm_create(edigpu_comm* out, int32_t rank, int32_t world, const void* id128) {
+  if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) {
+    set_error("edigpu_comm_create: bad argument");
+    return 1;
+  }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    set_error("edigpu_comm_create: no usable HIP device; this library has no CPU fallback");
+    return 1;
+  }
+  auto* c = new edigpu_comm_s();
+  c->rank = rank;
+  c->world = world;
+  c->kind = 0;
+  if (comm_common(c)) {
+    delete c;
+    return 1;
+  }
+  if (world > 1 || id128) {
+    RcclApi* r = rccl();
+    if (!r) {
+      set_error("edigpu_comm_create: RCCL (librccl.so) could not be loaded");
+      delete c;
+      return 1;
+    }
+    rccl_unique_id id;
+    memcpy(&id, id128, sizeof(id));
+    ncclResult_t rc = r->CommInitRank(&c->nccl, world, id, rank);
+    if (rc != ncclSuccess) {
+      set_error(std::string("edigpu_comm_create: ncclCommInitRank failed: ") + r->GetErrorString(rc));
+      delete c;
+      return 1;
+    }
+  }
+  *out = c;
+  return 0;
+}
+
+int edigpu_comm_create_shm(edigpu_comm* out, int32_t rank, int32_t world, const char* name, int64_t slot_bytes) {
+  if (!out || !name || world < 1 || rank < 0 || rank >= world || slot_bytes < 64) {
+    set_error("edigpu_comm_create_shm: bad argument");
+    return 1;
+  }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    set_error("edigpu_comm_create_shm: no usable HIP device; this library has no CPU fallback");
+    return 1;
+  }
+  auto* c = new edigpu_comm_s();
+  c->rank = rank;
+  c->world = world;
+  c->kind = 1;
+  c->shm_name = name[0] == '/' ? name : std::string("/") + name;
+  slot_bytes = (slot_bytes + 63) / 64 * 64;
+  c->shm_bytes = 4096 + (size_t)world * (size_t)slot_bytes;
+  int fd = -1;
+  if (rank == 0) {
+    shm_unlink(c->shm_name.c_str());
+    fd = shm_open(c->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd >= 0 && ftruncate(fd, (off_t)c->shm_bytes) != 0) {
+      close(fd);
+      fd = -1;
+    }
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (fd < 0 && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(60)) {
+      fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
+      struct stat sb;
+      if (fd >= 0 && (fstat(fd, &sb) != 0 || (size_t)sb.st_size < c->shm_bytes)) {
+        close(fd);
+        fd = -1;
+      }
+      if (fd < 0) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    }
+  }
+  if (fd < 0) {
+    set_error("edigpu_comm_create_shm: cannot open the shared-memory segment " + c->shm_name);
+    delete c;
+    return 1;
+  }
+  c->shm = mmap(nullptr, c->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (c->shm == MAP_FAILED) {
+    set_error("edigpu_comm_create_shm: mmap failed");
+    c->shm = nullptr;
+    delete c;
+    return 1;
+  }
+  c->hdr = reinterpret_cast<ShmHeader*>(c->shm);
+  c->slots = reinterpret_cast<char*>(c->shm) + 4096;
+  if (rank == 0) {
+    c->hdr->arrived.store(0);
+    c->hdr->generation.store(0);
+    c->hdr->world = world;
+    c->hdr->slot_bytes = slot_bytes;
+    c->hdr->ready.store(1, std::memory_order_release);
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (c->hdr->ready.load(std::memory_order_acquire) != 1) {
+      std::this_thread::yield();
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+        set_error("edigpu_comm_create_shm: rank 0 never initialised the segment");
+        munmap(c->shm, c->shm_bytes);
+        delete c;
+        return 1;
+      }
+    }
+  }
+  if (comm_common(c) || shm_barrier(c)) {
+    munmap(c->shm, c->shm_bytes);
+    delete c;
+    return 1;
+  }
+  *out = c;
+  return 0;
+}
+
+int edigpu_comm_info(edigpu_comm c, int32_t* rank, int32_t* world, int32_t* kind) {
+  if (!c) {
+    set_error("edigpu_comm_info: NULL communicator");
+    return 1;
+  }
+  if (rank) *rank = c->rank;
+  if (world) *world = c->world;
+  if (kind) *kind = c->kind;
+  return 0;
+}
+
+int edigpu_comm_destroy(edigpu_comm c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  for (double** p : {&c->vin, &c->vout, &c->tmp, &c->vfull, &c->send, &c->recv, &c->hvc, &c->back, &c->hist, &c->work, &c->scr})
+    if (*p) (void)hipFree(*p);
+  if (c->nccl && rccl()) (void)rccl()->CommDestroy(c->nccl);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->shm) {
+    munmap(c->shm, c->shm_bytes);
+    if (c->rank == 0) shm_unlink(c->shm_name.c_str());
+  }
+  delete c;
+  return 0;
+}
+
+// (Nloc, v, Hv) on shards with host vectors: the contract of spMatVec_mpi_* / directMatVec_MPI_*
+static int apply_sharded(edigpu_handle s, edigpu_comm c, int64_t nloc, const double* v, double* hv, int cplx) {
+  if (!s || !c || (nloc > 0 && (!v || !hv))) {
+    set_error("edigpu_apply_sharded: NULL argument");
+    return 1;
+  }
+  if ((s->is_complex != 0) != (cplx != 0)) {
+    set_error("edigpu_apply_sharded: real/complex mismatch between handle and entry point");
+    return 1;
+  }
+  ShardGeom g;
+  if (shard_geometry(s, c, g)) return 1;
+  if (nloc != g.nloc) {
+    set_error("edigpu_apply_sharded: Nloc does not match this rank's shard (edigpu_shard_plan)");
+    return 1;
+  }
+  EDIGPU_HIP(hipSetDevice(s->device));
+  if (comm_workspace(c, g, 1)) return 1;
+  hipStream_t st = s->stream;
+  const int64_t n = g.nloc * g.w, chunk = g.chunk * g.w;
+  EDIGPU_HIP(hipMemsetAsync(c->vin, 0, (size_t)std::max<int64_t>(chunk, 1) * sizeof(double), st));
+  if (n > 0) EDIGPU_HIP(hipMemcpyAsync(c->vin, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+  if (sharded_hv(s, c, g, false, st)) return 1;
+  if (g.transposed && edigpu_transpose_unpack_add(s->dim_up, g.count, g.q, c->world, g.pcol, g.halo, c->back, c->tmp, st))
+    return 1;
+  if (n > 0) EDIGPU_HIP(hipMemcpyAsync(hv, c->tmp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  EDIGPU_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int edigpu_apply_sharded_d(edigpu_handle h, edigpu_comm c, int64_t nloc, const double* v_shard_host, double* hv_shard_host) {
+  return apply_sharded(h, c, nloc, v_shard_host, hv_shard_host, 0);
+}
+
+int edigpu_apply_sharded_z(edigpu_handle h, edigpu_comm c, int64_t nloc, const double* v_shard_host, double* hv_shard_host) {
+  return apply_sharded(h, c, nloc, v_shard_host, hv_shard_host, 1);
+}
+
+int edigpu_lanczos_tridiag_sharded(edigpu_handle h, edigpu_comm c, const double* vin_shard, int nlanc, double* alanc,
+                                   double* blanc, double threshold, int* niter_done, double* norm2) {
+  if (!h || !c || !alanc || !blanc || nlanc < 1) {
+    set_error("edigpu_lanczos_tridiag_sharded: bad argument");
+    return 1;
+  }
+  return sharded_tridiag(h, c, vin_shard, nlanc, alanc, blanc, threshold, niter_done, norm2);
+}
+
+int edigpu_lanczos_bench_sharded(edigpu_handle s, edigpu_comm c, int warmup, int steps, double* ms_per_step,
+                                 int64_t* exchange_bytes) {
+  if (!s || !c || steps < 1 || warmup < 0 || !ms_per_step) {
+    set_error("edigpu_lanczos_bench_sharded: bad argument");
+    return 1;
+  }
+  ShardGeom g;
+  if (shard_geometry(s, c, g)) return 1;
+  EDIGPU_HIP(hipSetDevice(s->device));
+  const int total = warmup + steps;
+  if (comm_workspace(c, g, total)) return 1;
+  hipStream_t st = s->stream;
+  EDIGPU_HIP(hipMemsetAsync(c->hist, 0, (size_t)c->hist_cap * sizeof(double), st));
+  // seeded random start vector of this shard
+  const int64_t n = g.nloc * g.w, chunk = g.chunk * g.w;
+  EDIGPU_HIP(hipMemsetAsync(c->tmp, 0, (size_t)std::max<int64_t>(chunk, 1) * sizeof(double), st));
+  if (n > 0 && lz_fill_random(c->tmp, n, 12345ull + (uint64_t)c->rank, st)) return 1;
+  if (load_seed(c, g, c->tmp, st)) return 1;
+  for (int it = 0; it < warmup; it++)
+    if (sharded_step(s, c, g, it, st)) return 1;
+  if (comm_all_reduce(c, c->scr + 2, 1, st)) return 1;  // barrier
+  EDIGPU_HIP(hipStreamSynchronize(st));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int it = warmup; it < total; it++)
+    if (sharded_step(s, c, g, it, st)) return 1;
+  EDIGPU_HIP(hipStreamSynchronize(st));
+  if (comm_all_reduce(c, c->scr + 2, 1, st)) return 1;
+  EDIGPU_HIP(hipStreamSynchronize(st));
+  const auto t1 = std::chrono::steady_clock::now();
+  *ms_per_step = std::chrono::duration<double, std::milli>(t1 - t0).count() / steps;
+  if (exchange_bytes)
+    *exchange_bytes = g.transposed ? 2 * 8 * (int64_t)(c->world - 1) * g.q * g.pw
+                                   : 8 * g.chunk * g.w * (int64_t)(c->world - 1);
+  return 0;
+}
+
+}  // extern "C"

@@ -75,6 +75,7 @@ int lz_beta(const double* vin, double* vout, int64_t n, double* partial, double*
 int lz_axpy_coef(double* acc, const double* vin, int64_t n, double coef, const double* scal,
                  int iter, hipStream_t st);
 int lz_fill_random(double* v, int64_t n, uint64_t seed, hipStream_t st);
+int measure_membw(int64_t bytes, double out[3]);
 // stand-alone vector kernels with explicit device scalars (sharded loop)
 int vec_rotate(int64_t n, double* vin, double* vout, const double* beta2, hipStream_t st);
 int vec_add_dot(int64_t n, const double* vin, double* vout, const double* tmp, double* out, double* work, hipStream_t st);

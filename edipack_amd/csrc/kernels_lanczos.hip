@@ -559,4 +559,59 @@ int vec_scale(int64_t n, double* v, const double* nrm2, hipStream_t st) {
   return 0;
 }
 
+// ---- streaming ceilings of this device (bench.py reports them next to the kernel's achieved rate) ----
+__global__ void __launch_bounds__(512) k_bw_read(const double2* __restrict__ p, int64_t n, double* __restrict__ out) {
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 512) s += p[i].x + p[i].y;
+  if (s == 1.2345e300) out[0] = s;
+}
+__global__ void __launch_bounds__(512) k_bw_copy(const double2* __restrict__ p, double2* __restrict__ q, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 512) q[i] = p[i];
+}
+__global__ void __launch_bounds__(512) k_bw_triad(const double2* __restrict__ a, const double2* __restrict__ b,
+                                                  double2* __restrict__ c, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 512 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 512) {
+    const double2 x = a[i], y = b[i];
+    c[i] = make_double2(x.x + 3.0 * y.x, x.y + 3.0 * y.y);
+  }
+}
+
+// out[0..2] = read, copy (read + write), triad (2 reads + 1 write) in GB/s on three buffers of `bytes` each
+int measure_membw(int64_t bytes, double out[3]) {
+  const int64_t n = bytes / 16;
+  double2 *a = nullptr, *b = nullptr, *c = nullptr;
+  double* sink = nullptr;
+  EDIGPU_HIP(hipMalloc((void**)&a, (size_t)n * 16));
+  EDIGPU_HIP(hipMalloc((void**)&b, (size_t)n * 16));
+  EDIGPU_HIP(hipMalloc((void**)&c, (size_t)n * 16));
+  EDIGPU_HIP(hipMalloc((void**)&sink, 8));
+  EDIGPU_HIP(hipMemset(a, 0, (size_t)n * 16));
+  EDIGPU_HIP(hipMemset(b, 0, (size_t)n * 16));
+  hipEvent_t e0, e1;
+  EDIGPU_HIP(hipEventCreate(&e0));
+  EDIGPU_HIP(hipEventCreate(&e1));
+  const dim3 g(2048), blk(512);
+  const int reps = 10;
+  for (int w = 0; w < 3; w++) {
+    for (int r = 0; r < reps + 2; r++) {
+      if (r == 2) EDIGPU_HIP(hipEventRecord(e0, 0));
+      if (w == 0) hipLaunchKernelGGL(k_bw_read, g, blk, 0, 0, a, n, sink);
+      if (w == 1) hipLaunchKernelGGL(k_bw_copy, g, blk, 0, 0, a, c, n);
+      if (w == 2) hipLaunchKernelGGL(k_bw_triad, g, blk, 0, 0, a, b, c, n);
+    }
+    EDIGPU_HIP(hipEventRecord(e1, 0));
+    EDIGPU_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    EDIGPU_HIP(hipEventElapsedTime(&ms, e0, e1));
+    out[w] = (double)(w + 1) * (double)n * 16.0 * reps / ((double)ms * 1e6);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  (void)hipFree(c);
+  (void)hipFree(sink);
+  return 0;
+}
+
 }  // namespace edigpu

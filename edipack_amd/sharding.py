@@ -548,3 +548,110 @@ def gpu_sharded_hamiltonian(model, workload_sector, world: int, rank: int, direc
 
     lz = ShardedLanczos(plan, apply_local, apply_remote, dtype=dtype, device="cuda", vec_ops=NativeVecOps())
     return plan, h, lz
+
+
+# -----------------------------------------------------------------------------------------------
+# the N > 1 path inside libedigpu.so (csrc/edigpu_shard.hip): communicator + sharded recurrence in C
+# -----------------------------------------------------------------------------------------------
+class LibraryComm:
+    """edigpu_comm: RCCL over xGMI (``unique_id`` = the 128 bytes of edigpu_comm_unique_id made on rank 0 and handed
+    to every rank by the host) or, with ``shm_name``, the host-staged shared-memory transport for ranks that share
+    a GPU.  The Fortran host gets the same object through fortran/edigpu_shim.f90 (gpu_comm_create)."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes | None = None, shm_name: str | None = None,
+                 slot_bytes: int = 1 << 26):
+        import ctypes as C
+        from . import capi
+        self._capi, self.rank, self.world = capi, rank, world
+        self._c = C.c_void_p()
+        if shm_name is not None:
+            capi.check(capi.lib().edigpu_comm_create_shm(C.byref(self._c), rank, world, shm_name.encode(), slot_bytes),
+                       "edigpu_comm_create_shm")
+        else:
+            buf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+            capi.check(capi.lib().edigpu_comm_create(C.byref(self._c), rank, world, buf), "edigpu_comm_create")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import capi
+        buf = C.create_string_buffer(128)
+        capi.check(capi.lib().edigpu_comm_unique_id(buf), "edigpu_comm_unique_id")
+        return buf.raw
+
+    def plan(self, units: int):
+        """(first, count, q) of this rank's shard of `units` (edigpu_shard_plan)."""
+        import ctypes as C
+        f, n, q = C.c_int64(), C.c_int64(), C.c_int64()
+        self._capi.check(self._capi.lib().edigpu_shard_plan(units, self.world, self.rank, C.byref(f), C.byref(n),
+                                                            C.byref(q)), "edigpu_shard_plan")
+        return f.value, n.value, q.value
+
+    def apply(self, h, v_shard):
+        """spMatVec_mpi_*: (Nloc, v, Hv) on this rank's shard, host arrays."""
+        import numpy as np
+        v = np.ascontiguousarray(v_shard, dtype=h.dtype)
+        hv = np.empty_like(v)
+        fn = self._capi.lib().edigpu_apply_sharded_z if h.is_complex else self._capi.lib().edigpu_apply_sharded_d
+        self._capi.check(fn(h._h, self._c, v.shape[0], self._capi.pd(v.view(np.float64)),
+                            self._capi.pd(hv.view(np.float64))), "edigpu_apply_sharded")
+        return hv
+
+    def tridiag(self, h, v_shard, nlanc: int, threshold: float = 1e-12):
+        """sp_lanc_tridiag(MpiComm, ...) -> (alanc, blanc, niter, norm2); v_shard: host array of this rank's slice."""
+        import ctypes as C
+        import numpy as np
+        v = np.ascontiguousarray(v_shard, dtype=h.dtype)
+        a, b = np.zeros(nlanc), np.zeros(nlanc)
+        nd, n2 = C.c_int(0), C.c_double(0.0)
+        ptr = v.ctypes.data_as(C.c_void_p) if v.size else None
+        self._capi.check(self._capi.lib().edigpu_lanczos_tridiag_sharded(
+            h._h, self._c, ptr, nlanc, self._capi.pd(a), self._capi.pd(b), threshold, C.byref(nd), C.byref(n2)),
+            "edigpu_lanczos_tridiag_sharded")
+        return a, b, nd.value, n2.value
+
+    def bench(self, h, warmup: int, steps: int):
+        """(ms per sharded Lanczos step, bytes this rank sends per product)."""
+        import ctypes as C
+        ms, xb = C.c_double(0.0), C.c_int64(0)
+        self._capi.check(self._capi.lib().edigpu_lanczos_bench_sharded(h._h, self._c, warmup, steps, C.byref(ms),
+                                                                       C.byref(xb)), "edigpu_lanczos_bench_sharded")
+        return ms.value, xb.value
+
+    def destroy(self):
+        if self._c:
+            self._capi.lib().edigpu_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def library_sharded_sector(model, sector, comm: LibraryComm, direct: bool = False, exchange: str = "auto"):
+    """This rank's handle for the in-library N > 1 calls: normal mode -> the whole sector (transposed exchange) unless
+    exchange == "allgather"; everything else -> this rank's row shard.  Returns (handle, first unit, unit count)."""
+    import ctypes as C
+    from . import capi
+    from .hamiltonian import SectorHamiltonian
+    L, cm = capi.lib(), model.to_c()
+    if model.ed_mode == "normal":
+        nup, ndw = sector
+        d_dw = C.c_int64()
+        capi.check(L.edigpu_sector_dim(C.byref(cm), 0, ndw, C.byref(d_dw)))
+        first, count, _ = comm.plan(d_dw.value)
+        if exchange != "allgather":
+            h = SectorHamiltonian.normal_from_model(model, nup, ndw)
+            try:
+                h.transpose_halo()
+                return h, first, count
+            except capi.EdigpuError:      # explicit spH0nd, phonons: all-gather form
+                h.destroy()
+        return SectorHamiltonian.normal_from_model(model, nup, ndw, dw_first=first, dw_count=count), first, count
+    dim = C.c_int64()
+    capi.check(L.edigpu_sector_dim(C.byref(cm), int(sector), 0, C.byref(dim)))
+    first, count, _ = comm.plan(dim.value)
+    build = SectorHamiltonian.direct_from_model if direct else SectorHamiltonian.flat_from_model
+    return build(model, int(sector), row_first=first, row_count=count), first, count

@@ -391,6 +391,65 @@ int edigpu_vec_rotate_lazy(int64_t n, double *vin_dev, double *vout_dev, const d
 int edigpu_vec_add_dot2(int64_t n, const double *vin_dev, double *vout_dev, const double *tmp_dev, double *out2_dev,
                         double *work_dev, void *stream);
 
+/* ----------------------------------------------------------------------- */
+/* N > 1 inside the library: communicator, sharded product, sharded Lanczos    */
+/* ----------------------------------------------------------------------- */
+/*
+ * One process (MPI rank) per GPU.  The communicator takes the place of MpiComm in the reference's distributed
+ * products and in SciFortran's MPI Lanczos driver: it is RCCL over xGMI (edigpu_comm_create; the unique id is made
+ * on rank 0 with edigpu_comm_unique_id and broadcast by the host, e.g. MPI_Bcast of 128 bytes), or a host-staged
+ * transport through POSIX shared memory for ranks of one node that share a GPU (edigpu_comm_create_shm: tests of the
+ * N > 1 data flow on a one-GPU box, hosts without RCCL).  RCCL is loaded at run time (dlopen: the copy the process
+ * already mapped, else /opt/rocm's).
+ *
+ * Shards (edigpu_shard_plan): rank r owns units [r q, min((r+1) q, units)), q = ceil(units / world); units = DimDw
+ * down rows (normal mode) or Dim rows (superc / nonsu2).  The reference puts the remainder on the first / last
+ * ranks instead (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:129-142, ED_SUPERC/ED_HAMILTONIAN_SUPERC.f90:82-88); the choice is
+ * not observable in the results.
+ *
+ * Handles: normal mode with the transposed exchange -- every rank builds the WHOLE sector (edigpu_normal_build with
+ * dw_count < 0: only O(DimUp + DimDw) tables) and the calls below run two all-to-alls per product, the first beside
+ * the row half of H*v (spMatVec_mpi_normal_main, ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:765-929); every other
+ * case -- hand-over arrays, superc / nonsu2 stored or on the fly -- each rank builds ITS shard (first / count of
+ * edigpu_shard_plan) and the calls run one all-gather of the vector beside the shard-local block
+ * (spMatVec_mpi_superc_main, ED_SUPERC/ED_HAMILTONIAN_SUPERC_STORED_HxV.f90:366-432; spMatVec_mpi_nonsu2_main,
+ * ED_NONSU2/ED_HAMILTONIAN_NONSU2_STORED_HxV.f90:213-267; directMatVec_MPI_*).  All ranks call collectively.
+ */
+typedef struct edigpu_comm_s *edigpu_comm;
+#define EDIGPU_UNIQUE_ID_BYTES 128
+int edigpu_shard_plan(int64_t units, int32_t world, int32_t rank, int64_t *first, int64_t *count, int64_t *q);
+int edigpu_comm_unique_id(void *id128);
+/* id128 may be NULL when world == 1 (no RCCL communicator is made then) */
+int edigpu_comm_create(edigpu_comm *c, int32_t rank, int32_t world, const void *id128);
+/* name: POSIX shared-memory name common to the ranks; slot_bytes >= the largest message a rank sends in one collective
+ * (8 * the padded shard length * world for the transposed exchange) */
+int edigpu_comm_create_shm(edigpu_comm *c, int32_t rank, int32_t world, const char *name, int64_t slot_bytes);
+int edigpu_comm_info(edigpu_comm c, int32_t *rank, int32_t *world, int32_t *kind /* 0 RCCL, 1 shared memory */);
+int edigpu_comm_destroy(edigpu_comm c);
+/*
+ * The (Nloc, v, Hv) contract of spMatVec_mpi_* / directMatVec_MPI_* on shards (ED_VARS_GLOBAL.f90:111-132 with
+ * Nloc = vecDim_Hv_sector_*): v_shard_host / hv_shard_host hold this rank's nloc elements; the exchange happens
+ * inside.  Assigned to spHtimesV_p / spHtimesV_cc in a -D_MPI build (fortran/edigpu_shim.f90).
+ */
+int edigpu_apply_sharded_d(edigpu_handle h, edigpu_comm c, int64_t nloc, const double *v_shard_host,
+                           double *hv_shard_host);
+int edigpu_apply_sharded_z(edigpu_handle h, edigpu_comm c, int64_t nloc, const double *v_shard_host,
+                           double *hv_shard_host);
+/*
+ * sp_lanc_tridiag(MpiComm, spHtimesV_p, vvloc, alanc, blanc) with the vectors resident in HBM (call sites
+ * ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:357-365 and the superc / nonsu2 twins): vin_shard (host or device memory) is
+ * this rank's slice of the seed as scatter_vector_MPI leaves it (ED_AUX_FUNX.f90:598-692); it is normalised inside and
+ * *norm2 = <vin|vin> over all ranks (NULL allowed).  Per step the ranks exchange the vector (all-to-all pair or
+ * all-gather, on a side stream) and all-reduce three doubles; nothing else crosses a link and -- with RCCL -- the
+ * host is not synchronised until the coefficients are read back.  Every rank receives the same alanc / blanc.
+ */
+int edigpu_lanczos_tridiag_sharded(edigpu_handle h, edigpu_comm c, const double *vin_shard, int nlanc, double *alanc,
+                                   double *blanc, double threshold, int *niter_done, double *norm2);
+/* bench.py --gpus N: `warmup` + `steps` sharded Lanczos steps on a seeded random vector; wall time per step between
+ * two collectives that act as barriers, and the bytes this rank sends per product */
+int edigpu_lanczos_bench_sharded(edigpu_handle h, edigpu_comm c, int warmup, int steps, double *ms_per_step,
+                                 int64_t *exchange_bytes);
+
 /*
  * Timing helper for bench.py: runs `warmup` untimed and `steps` timed H*v
  * products (device-resident, random unit vector) on the handle's stream and
@@ -408,6 +467,11 @@ int edigpu_time_apply(edigpu_handle h, int warmup, int steps, int lanczos, doubl
  */
 int edigpu_lanczos_bench(edigpu_handle h, int warmup, int steps, double *ms_wall_per_step,
                          double *ms_hv_per_launch);
+
+/* Measurement helper for bench.py: streaming ceilings of the device the calling thread selected -- gbs3[0] read,
+ * [1] copy (bytes read + written), [2] triad (two reads + one write), GB/s on buffers of `bytes` each (use >= 1 GB
+ * to leave the 256 MiB Infinity Cache; SURVEY.md 8d asks for the measured ceiling next to the 8 TB/s spec). */
+int edigpu_membw(int64_t bytes, double *gbs3);
 
 int edigpu_destroy(edigpu_handle h);
 

@@ -23,7 +23,7 @@ def main():
     for f in glob.glob(os.path.join(out, "pmc_*", "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
-            key = ("panel2" if "panel2" in kn else "panel" if "panel" in kn else "rows" if "normal_rows" in kn else
+            key = ("tile" if "dw_tile" in kn else "panel2" if "panel2" in kn else "panel" if "panel" in kn else "rows" if "normal_rows" in kn else
                    "csr" if ("csr_rows" in kn or "sell_rows" in kn) else "direct" if "direct_rows" in kn else None)
             if key:
                 agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -33,23 +33,20 @@ def main():
     for k, d in pmc.items():
         for c, v in sorted(d.items()):
             lines.append(f"{k:6s} {c:24s} {v:.6g}")
-    # HBM-side traffic per H*v = sum over the H*v kernels of (FETCH_SIZE + WRITE_SIZE) KiB
-    # gfx950: FETCH_SIZE reports 1/2 of the bytes of 16-byte-per-lane coalesced streams (MI355X_MICROARCH.md,
-    # HBM section): the row kernel stages V as one contiguous double2 stream -> doubled (98 MB = V once, as it must
-    # be).  The panel kernels read 512..1024-byte row segments at a row stride: taken as is -- measured on config 2,
-    # the two-column kernel (16 B per lane) at the one-column kernel's panel width reports the same FETCH_SIZE,
-    # TCC_REQ and TCC_MISS as the one-column kernel (8 B per lane), and FETCH_SIZE does not move between 512- and
-    # 1024-byte segments (165.6 / 162.3 / 161.7 thousand KiB at widths 64 / 112 / 128), so no halving shows for this
-    # access shape; the value also sits at the physical minimum V + result minus what kernel A left in the L2s.
-    # The CSR / SELL kernels load 8 bytes per lane -> taken as is.
+    # HBM-side traffic per H*v = sum over the H*v kernels of (2 * FETCH_SIZE + WRITE_SIZE) KiB.
+    # gfx950: FETCH_SIZE counts 64 bytes per 128-byte fabric read request (= TCC_EA0_RDREQ * 64), i.e. exactly HALF of
+    # the bytes read, for every access shape of these kernels -- contiguous or 512 / 1024-byte row segments, 8 or 16
+    # bytes per lane -- calibrated on known byte counts in profiles/r02_fetch_calibration.txt
+    # (scripts/calibrate_fetch.sh); WRITE_SIZE is exact there.
     tr = 0.0
     for k, d in pmc.items():
-        f = d.get("FETCH_SIZE", 0.0) * (2.0 if k == "rows" else 1.0)
-        tr += (f + d.get("WRITE_SIZE", 0.0)) * 1024.0
+        tr += (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0
     lines.append("")
-    lines.append(f"HBM/fabric bytes per H*v (FETCH_SIZE+WRITE_SIZE, KiB->B, summed over the H*v kernels): {tr:.4g}")
+    lines.append(f"HBM/fabric bytes per H*v (2*FETCH_SIZE + WRITE_SIZE, KiB->B, summed over the H*v kernels): {tr:.4g}")
     open(os.path.join(out, f"{tag}_{wl}_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
-    json.dump({wl: {"hbm_bytes_per_launch": tr, "per_kernel": pmc}}, open(os.path.join(out, f"{tag}_{wl}_pmc.json"), "w"), indent=1)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from edipack_amd import capi
+    json.dump({wl: {"hbm_bytes_per_launch": tr, "source_hash": capi.kernel_source_hash(), "per_kernel": pmc}}, open(os.path.join(out, f"{tag}_{wl}_pmc.json"), "w"), indent=1)
     print("\n".join(lines))
 
 

@@ -1337,9 +1337,9 @@ def test_transposed_fused_vector_kernels(gpu, world, du, nrows, q, halo):
 
 @pytest.mark.parametrize("workload,exchange", [("cfg3", "transpose"), ("cfg3", "allgather"), ("cfg4", "allgather")])
 def test_bench_multi_path_one_rank_rccl(gpu, workload, exchange):
-    """bench.py's N > 1 code path as a child process with an RCCL world of one rank and the collectives forced
-    (all_to_all_single / all_gather_into_tensor / all_reduce / barrier really go through RCCL): exactly one line on
-    stdout, and it is the JSON line."""
+    """bench.py's N > 1 code path as a child process with an RCCL world of one rank and the collectives forced (the
+    library's grouped send/recv all-to-all, ncclAllGather and ncclAllReduce really go through RCCL): exactly one line
+    on stdout, and it is the JSON line."""
     import json
     import os
     import subprocess
