@@ -110,6 +110,10 @@ SIGNATURES = {
     "edigpu_time_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _pd]),
     "edigpu_lanczos_bench": (C.c_int, [_vp, C.c_int, C.c_int, _pd, _pd]),
     "edigpu_membw": (C.c_int, [_i64, _pd]),
+    "edigpu_dev_alloc": (C.c_int, [_i64, C.POINTER(_vp)]),
+    "edigpu_dev_free": (C.c_int, [_vp]),
+    "edigpu_dev_upload": (C.c_int, [_vp, _vp, _i64]),
+    "edigpu_dev_download": (C.c_int, [_vp, _vp, _i64]),
     "edigpu_shard_plan": (C.c_int, [_i64, C.c_int32, C.c_int32, _pi64, _pi64, _pi64]),
     "edigpu_comm_unique_id": (C.c_int, [_vp]),
     "edigpu_comm_create": (C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int32, _vp]),

@@ -2472,6 +2472,41 @@ int edigpu_time_apply(edigpu_handle s, int warmup, int steps, int lanczos, doubl
   return 0;
 }
 
+int edigpu_dev_alloc(int64_t bytes, void** dev_ptr) {
+  if (!dev_ptr || bytes < 0) {
+    set_error("edigpu_dev_alloc: bad argument");
+    return 1;
+  }
+  if (ensure_device()) return 1;
+  EDIGPU_HIP(hipSetDevice(g_device));
+  *dev_ptr = nullptr;
+  EDIGPU_HIP(hipMalloc(dev_ptr, (size_t)std::max<int64_t>(bytes, 8)));
+  return 0;
+}
+
+int edigpu_dev_free(void* dev_ptr) {
+  if (dev_ptr) EDIGPU_HIP(hipFree(dev_ptr));
+  return 0;
+}
+
+int edigpu_dev_upload(void* dst_dev, const void* src_host, int64_t bytes) {
+  if (bytes < 0 || (bytes > 0 && (!dst_dev || !src_host))) {
+    set_error("edigpu_dev_upload: bad argument");
+    return 1;
+  }
+  if (bytes > 0) EDIGPU_HIP(hipMemcpy(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int edigpu_dev_download(void* dst_host, const void* src_dev, int64_t bytes) {
+  if (bytes < 0 || (bytes > 0 && (!dst_host || !src_dev))) {
+    set_error("edigpu_dev_download: bad argument");
+    return 1;
+  }
+  if (bytes > 0) EDIGPU_HIP(hipMemcpy(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int edigpu_membw(int64_t bytes, double* gbs3) {
   if (!gbs3 || bytes < (1 << 20)) {
     set_error("edigpu_membw: bad argument");

@@ -456,21 +456,33 @@ static int comm_workspace(edigpu_comm_s* c, const ShardGeom& g, int nlanc) {
 
 // tmp <- (H vin) on the local rows.  pre_packed: the send buffer already holds vin (fused rotate).  The exchange runs
 // on the side stream beside the part of the product that needs no remote data.
-static int sharded_hv(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, bool pre_packed, hipStream_t st) {
+static int sharded_hv(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, bool pre_packed, hipStream_t st,
+                      const double** back_out = nullptr) {
   if (g.transposed) {
     if (!pre_packed &&
         edigpu_transpose_pack(s->dim_up, g.count, g.q, c->world, g.pcol, g.halo, c->vin, c->send, st))
       return 1;
-    EDIGPU_HIP(hipEventRecord(c->ev_ready, st));
-    EDIGPU_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
-    if (comm_all_to_all(c, c->send, c->recv, (size_t)(g.q * g.pw), c->side)) return 1;
-    EDIGPU_HIP(hipEventRecord(c->ev_done, c->side));
+    // a world of one exchanges nothing: the column half reads the packed buffer and the caller its result in place
+    const bool alone = c->world == 1 && !force_collectives(c);
+    if (!alone) {
+      EDIGPU_HIP(hipEventRecord(c->ev_ready, st));
+      EDIGPU_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
+      if (comm_all_to_all(c, c->send, c->recv, (size_t)(g.q * g.pw), c->side)) return 1;
+      EDIGPU_HIP(hipEventRecord(c->ev_done, c->side));
+    }
     if (edigpu_normal_apply_rows_dev(s, g.first, g.count, c->vin, c->tmp, st)) return 1;
-    EDIGPU_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
-    if (edigpu_normal_apply_cols_dev(s, g.col_first, g.col_count, g.pw, g.halo, c->recv, c->hvc, st)) return 1;
+    if (!alone) EDIGPU_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
+    if (edigpu_normal_apply_cols_dev(s, g.col_first, g.col_count, g.pw, g.halo, alone ? c->send : c->recv, c->hvc, st))
+      return 1;
+    if (back_out) *back_out = alone ? c->hvc : c->back;
+    if (alone) return 0;
     return comm_all_to_all(c, c->hvc, c->back, (size_t)(g.q * g.pw), st);  // consumed by the caller (unpack)
   }
   const size_t n = (size_t)g.chunk * g.w;
+  if (c->world == 1 && !force_collectives(c)) {  // the chunk is the whole vector
+    if (edigpu_apply_local_dev(s, c->vin, c->tmp, st)) return 1;
+    return edigpu_apply_remote_dev(s, c->vin, c->tmp, st);
+  }
   EDIGPU_HIP(hipEventRecord(c->ev_ready, st));
   EDIGPU_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
   if (comm_all_gather(c, c->vin, c->vfull, n, c->side)) return 1;
@@ -489,10 +501,11 @@ static int sharded_step(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, 
   if (n > 0)
     hipLaunchKernelGGL(ks_rotate3, sh_grid(n, 256 * 16), dim3(kShNT), 0, st, it == 0 ? 1 : 0, n, s->dim_up, g.q, c->world,
                        g.pcol, g.halo, c->vin, c->vout, tp, tpp, g.transposed ? c->send : nullptr);
-  if (sharded_hv(s, c, g, true, st)) return 1;
+  const double* back = nullptr;
+  if (sharded_hv(s, c, g, true, st, &back)) return 1;
   const dim3 gr = sh_grid(std::max<int64_t>(n, 1), kRedBlocks);
   hipLaunchKernelGGL(ks_add_dot3, gr, dim3(kShNT), 0, st, n, s->dim_up, g.q, g.pcol, g.halo, c->vin, c->vout, c->tmp,
-                     g.transposed ? c->back : nullptr, tp, c->work);
+                     g.transposed ? back : nullptr, tp, c->work);
   hipLaunchKernelGGL(ks_sum3, dim3(1), dim3(1024), 0, st, c->work, (int)gr.x, t);
   EDIGPU_HIP(hipGetLastError());
   return comm_all_reduce(c, t, 3, st);
@@ -504,9 +517,10 @@ static int sharded_step_exact(edigpu_sector* s, edigpu_comm_s* c, const ShardGeo
   double* al = c->hist + it;
   double* b2 = c->hist + nlanc + it;
   if (it > 0 && vec_rotate(n, c->vin, c->vout, c->hist + nlanc + it - 1, st)) return 1;
-  if (sharded_hv(s, c, g, false, st)) return 1;
+  const double* back = nullptr;
+  if (sharded_hv(s, c, g, false, st, &back)) return 1;
   if (g.transposed &&
-      edigpu_transpose_unpack_add(s->dim_up, g.count, g.q, c->world, g.pcol, g.halo, c->back, c->tmp, st))
+      edigpu_transpose_unpack_add(s->dim_up, g.count, g.q, c->world, g.pcol, g.halo, back, c->tmp, st))
     return 1;
   if (vec_add_dot(n, c->vin, c->vout, c->tmp, al, c->work, st)) return 1;
   if (comm_all_reduce(c, al, 1, st)) return 1;
@@ -799,8 +813,9 @@ static int apply_sharded(edigpu_handle s, edigpu_comm c, int64_t nloc, const dou
   const int64_t n = g.nloc * g.w, chunk = g.chunk * g.w;
   EDIGPU_HIP(hipMemsetAsync(c->vin, 0, (size_t)std::max<int64_t>(chunk, 1) * sizeof(double), st));
   if (n > 0) EDIGPU_HIP(hipMemcpyAsync(c->vin, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
-  if (sharded_hv(s, c, g, false, st)) return 1;
-  if (g.transposed && edigpu_transpose_unpack_add(s->dim_up, g.count, g.q, c->world, g.pcol, g.halo, c->back, c->tmp, st))
+  const double* back = nullptr;
+  if (sharded_hv(s, c, g, false, st, &back)) return 1;
+  if (g.transposed && edigpu_transpose_unpack_add(s->dim_up, g.count, g.q, c->world, g.pcol, g.halo, back, c->tmp, st))
     return 1;
   if (n > 0) EDIGPU_HIP(hipMemcpyAsync(hv, c->tmp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
   EDIGPU_HIP(hipStreamSynchronize(st));

@@ -20,6 +20,7 @@ module EDIGPU_SHIM
   private
 
   type(c_ptr), save :: gpu_sector = c_null_ptr   !< the live edigpu_handle
+  type(c_ptr), save :: gpu_comm = c_null_ptr     !< the live edigpu_comm (MpiComm's counterpart; N > 1 only)
 
   integer, parameter, public :: EDIGPU_MAXORB = 5, EDIGPU_MAXBATH = 16
   !> breakdown threshold of the tridiagonalisation (sp_lanc_tridiag is called without one: SciFortran's default)
@@ -155,6 +156,149 @@ module EDIGPU_SHIM
        integer(c_int), intent(out) :: niter
        integer(c_int) :: ierr
      end function edigpu_lanczos_tridiag
+     function edigpu_lanczos_tridiag_dev(h, vin_dev, nlanc, alanc, blanc, threshold, niter, norm2) &
+          bind(C, name="edigpu_lanczos_tridiag_dev") result(ierr)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h, vin_dev
+       integer(c_int), value :: nlanc
+       real(c_double), intent(inout) :: alanc(*), blanc(*)
+       real(c_double), value :: threshold
+       integer(c_int), intent(out) :: niter
+       real(c_double), intent(out) :: norm2
+       integer(c_int) :: ierr
+     end function edigpu_lanczos_tridiag_dev
+     function edigpu_lanczos_eigh(h, nitermax, tol, check_every, v0, eval, evec, niter) &
+          bind(C, name="edigpu_lanczos_eigh") result(ierr)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h, v0, evec          ! host or device memory, may be null
+       integer(c_int), value :: nitermax, check_every
+       real(c_double), value :: tol
+       real(c_double), intent(out) :: eval
+       integer(c_int), intent(out) :: niter
+       integer(c_int) :: ierr
+     end function edigpu_lanczos_eigh
+     function edigpu_lanczos_eigh_multi(h, neigen, ncv, tol, maxrestart, v0, evals, evecs, nconv, nmatvec) &
+          bind(C, name="edigpu_lanczos_eigh_multi") result(ierr)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h, v0, evecs          ! host or device memory, may be null
+       integer(c_int), value :: neigen, ncv, maxrestart
+       real(c_double), value :: tol
+       real(c_double), intent(inout) :: evals(*)
+       integer(c_int), intent(out) :: nconv, nmatvec
+       integer(c_int) :: ierr
+     end function edigpu_lanczos_eigh_multi
+     function edigpu_apply_op_normal(src, dst, v_src_dev, v_dst_dev, iorb, ispin, create, stream) &
+          bind(C, name="edigpu_apply_op_normal") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: src, dst, v_src_dev, v_dst_dev, stream
+       integer(c_int), value :: iorb, ispin, create
+       integer(c_int) :: ierr
+     end function edigpu_apply_op_normal
+     function edigpu_apply_op_flat(src, dst, v_src_dev, v_dst_dev, iorb, ispin, create, stream) &
+          bind(C, name="edigpu_apply_op_flat") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: src, dst, v_src_dev, v_dst_dev, stream
+       integer(c_int), value :: iorb, ispin, create
+       integer(c_int) :: ierr
+     end function edigpu_apply_op_flat
+     function edigpu_apply_cops_normal(src, dst, v_src_dev, v_dst_dev, nops, coef, create, iorb, ispin, stream) &
+          bind(C, name="edigpu_apply_cops_normal") result(ierr)
+       import :: c_ptr, c_int, c_int32_t, c_double
+       type(c_ptr), value :: src, dst, v_src_dev, v_dst_dev, stream
+       integer(c_int), value :: nops
+       real(c_double), intent(in) :: coef(*)
+       integer(c_int32_t), intent(in) :: create(*), iorb(*), ispin(*)
+       integer(c_int) :: ierr
+     end function edigpu_apply_cops_normal
+     function edigpu_info(h, info) bind(C, name="edigpu_info") result(ierr)
+       import :: c_ptr, c_int, c_int64_t
+       type(c_ptr), value :: h
+       integer(c_int64_t), intent(out) :: info(10)
+       integer(c_int) :: ierr
+     end function edigpu_info
+     function edigpu_dev_alloc(bytes, p) bind(C, name="edigpu_dev_alloc") result(ierr)
+       import :: c_ptr, c_int, c_int64_t
+       integer(c_int64_t), value :: bytes
+       type(c_ptr), intent(out) :: p
+       integer(c_int) :: ierr
+     end function edigpu_dev_alloc
+     function edigpu_dev_free(p) bind(C, name="edigpu_dev_free") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: p
+       integer(c_int) :: ierr
+     end function edigpu_dev_free
+     function edigpu_dev_upload(dst, src, bytes) bind(C, name="edigpu_dev_upload") result(ierr)
+       import :: c_ptr, c_int, c_int64_t
+       type(c_ptr), value :: dst, src
+       integer(c_int64_t), value :: bytes
+       integer(c_int) :: ierr
+     end function edigpu_dev_upload
+     function edigpu_dev_download(dst, src, bytes) bind(C, name="edigpu_dev_download") result(ierr)
+       import :: c_ptr, c_int, c_int64_t
+       type(c_ptr), value :: dst, src
+       integer(c_int64_t), value :: bytes
+       integer(c_int) :: ierr
+     end function edigpu_dev_download
+     ! ---- N > 1 inside the library (include/edigpu.h, "communicator, sharded product, sharded Lanczos") ----
+     function edigpu_shard_plan(units, world, rank, first, count, q) bind(C, name="edigpu_shard_plan") result(ierr)
+       import :: c_int, c_int32_t, c_int64_t
+       integer(c_int64_t), value :: units
+       integer(c_int32_t), value :: world, rank
+       integer(c_int64_t), intent(out) :: first, count, q
+       integer(c_int) :: ierr
+     end function edigpu_shard_plan
+     function edigpu_comm_unique_id(id) bind(C, name="edigpu_comm_unique_id") result(ierr)
+       import :: c_int, c_char
+       character(kind=c_char), intent(out) :: id(128)
+       integer(c_int) :: ierr
+     end function edigpu_comm_unique_id
+     function edigpu_comm_create(c, rank, world, id) bind(C, name="edigpu_comm_create") result(ierr)
+       import :: c_ptr, c_int, c_int32_t, c_char
+       type(c_ptr) :: c
+       integer(c_int32_t), value :: rank, world
+       character(kind=c_char), intent(in) :: id(128)
+       integer(c_int) :: ierr
+     end function edigpu_comm_create
+     function edigpu_comm_create_shm(c, rank, world, name, slot_bytes) bind(C, name="edigpu_comm_create_shm") result(ierr)
+       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_char
+       type(c_ptr) :: c
+       integer(c_int32_t), value :: rank, world
+       character(kind=c_char), intent(in) :: name(*)
+       integer(c_int64_t), value :: slot_bytes
+       integer(c_int) :: ierr
+     end function edigpu_comm_create_shm
+     function edigpu_comm_destroy(c) bind(C, name="edigpu_comm_destroy") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: c
+       integer(c_int) :: ierr
+     end function edigpu_comm_destroy
+     function edigpu_apply_sharded_d(h, c, nloc, v, hv) bind(C, name="edigpu_apply_sharded_d") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, c_double
+       type(c_ptr), value :: h, c
+       integer(c_int64_t), value :: nloc
+       real(c_double), intent(in) :: v(*)
+       real(c_double), intent(inout) :: hv(*)
+       integer(c_int) :: ierr
+     end function edigpu_apply_sharded_d
+     function edigpu_apply_sharded_z(h, c, nloc, v, hv) bind(C, name="edigpu_apply_sharded_z") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, c_double_complex
+       type(c_ptr), value :: h, c
+       integer(c_int64_t), value :: nloc
+       complex(c_double_complex), intent(in) :: v(*)
+       complex(c_double_complex), intent(inout) :: hv(*)
+       integer(c_int) :: ierr
+     end function edigpu_apply_sharded_z
+     function edigpu_lanczos_tridiag_sharded(h, c, vin, nlanc, alanc, blanc, threshold, niter, norm2) &
+          bind(C, name="edigpu_lanczos_tridiag_sharded") result(ierr)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h, c, vin
+       integer(c_int), value :: nlanc
+       real(c_double), intent(inout) :: alanc(*), blanc(*)
+       real(c_double), value :: threshold
+       integer(c_int), intent(out) :: niter
+       real(c_double), intent(out) :: norm2
+       integer(c_int) :: ierr
+     end function edigpu_lanczos_tridiag_sharded
      function edigpu_destroy(h) bind(C, name="edigpu_destroy") result(ierr)
        import :: c_ptr, c_int
        type(c_ptr), value :: h
@@ -174,6 +318,14 @@ module EDIGPU_SHIM
   public :: spMatVec_gpu_d, spMatVec_gpu_c
   public :: gpu_lanc_tridiag_d, gpu_lanc_tridiag_c
   public :: flatten_rows_count
+  ! "next" rows of SURVEY.md 8(f): the eigensolvers and the device-resident neighbours of the tridiagonalisation
+  public :: gpu_sector_handle, gpu_sector_swap, gpu_sector_dim, gpu_sector_destroy
+  public :: gpu_sp_lanc_eigh_d, gpu_sp_lanc_eigh_c, gpu_sp_eigh_d, gpu_sp_eigh_c
+  public :: gpu_vec_alloc, gpu_vec_free, gpu_vec_upload_d, gpu_vec_download_d, gpu_vec_upload_c, gpu_vec_download_c
+  public :: gpu_sp_lanc_eigh_dev, gpu_apply_op, gpu_apply_cops, gpu_lanc_tridiag_dev
+  ! N > 1: communicator + the MPI twins of the product and of the tridiagonalisation
+  public :: gpu_comm_unique_id, gpu_comm_create, gpu_comm_create_shm, gpu_comm_destroy, gpu_shard_plan
+  public :: spMatVec_mpi_gpu_d, spMatVec_mpi_gpu_c, gpu_lanc_tridiag_mpi_d, gpu_lanc_tridiag_mpi_c
 
 contains
 
@@ -406,6 +558,292 @@ contains
     call gpu_check(edigpu_lanczos_tridiag(gpu_sector, c_loc(vin), int(size(alanc), c_int), &
          alanc, blanc, lanc_threshold, niter), "gpu_lanc_tridiag_c")
   end subroutine gpu_lanc_tridiag_c
+
+  ! ==============================================================================================
+  ! SURVEY.md 8(f) rows f1 / f3 and the N > 1 path, as the Fortran host sees them
+  ! ==============================================================================================
+
+  !> the live sector as an opaque handle / make another handle the live one: the Green's-function loop keeps TWO
+  !! sectors alive (the eigenstate's and the one c / c^+ leads to, ED_NORMAL/ED_GF_NORMAL.f90:141-175) while the
+  !! reference's module globals hold one.  gpu_sector_swap(h) installs h and returns the previous live handle in h.
+  function gpu_sector_handle() result(h)
+    type(c_ptr) :: h
+    h = gpu_sector
+  end function gpu_sector_handle
+
+  subroutine gpu_sector_swap(h)
+    type(c_ptr), intent(inout) :: h
+    type(c_ptr) :: t
+    t = gpu_sector; gpu_sector = h; h = t
+  end subroutine gpu_sector_swap
+
+  !> vecDim_Hv_sector_* of a handle (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:286-313): local rows
+  function gpu_sector_dim(h) result(n)
+    type(c_ptr), intent(in) :: h
+    integer :: n
+    integer(c_int64_t) :: info(10)
+    call gpu_check(edigpu_info(h, info), "gpu_sector_dim")
+    n = int(info(2))
+  end function gpu_sector_dim
+
+  subroutine gpu_sector_destroy(h)
+    type(c_ptr), intent(inout) :: h
+    if (c_associated(h)) call gpu_check(edigpu_destroy(h), "gpu_sector_destroy")
+    h = c_null_ptr
+  end subroutine gpu_sector_destroy
+
+  !> call sp_lanc_eigh(spHtimesV_p, eig_values(1), eig_basis(:,1), Nitermax, iverbose=..., threshold=lanc_tolerance)
+  !! (lanc_method = "lanczos", ED_NORMAL/ED_DIAG_NORMAL.f90:206-214): lowest eigenpair, vectors resident in HBM
+  subroutine gpu_sp_lanc_eigh_d(eval, evec, Nitermax, threshold)
+    real(8), intent(out) :: eval
+    real(8), intent(inout), target :: evec(:)
+    integer, intent(in) :: Nitermax
+    real(8), intent(in), optional :: threshold
+    real(c_double) :: tol
+    integer(c_int) :: niter
+    if (.not. c_associated(gpu_sector)) stop "gpu_sp_lanc_eigh_d: Hsector NOT allocated"
+    tol = 1d-12; if (present(threshold)) tol = max(threshold, 1d-15)
+    call gpu_check(edigpu_lanczos_eigh(gpu_sector, int(Nitermax, c_int), tol, 10_c_int, c_null_ptr, eval, &
+         c_loc(evec), niter), "gpu_sp_lanc_eigh_d")
+  end subroutine gpu_sp_lanc_eigh_d
+
+  subroutine gpu_sp_lanc_eigh_c(eval, evec, Nitermax, threshold)
+    real(8), intent(out) :: eval
+    complex(8), intent(inout), target :: evec(:)
+    integer, intent(in) :: Nitermax
+    real(8), intent(in), optional :: threshold
+    real(c_double) :: tol
+    integer(c_int) :: niter
+    if (.not. c_associated(gpu_sector)) stop "gpu_sp_lanc_eigh_c: Hsector NOT allocated"
+    tol = 1d-12; if (present(threshold)) tol = max(threshold, 1d-15)
+    call gpu_check(edigpu_lanczos_eigh(gpu_sector, int(Nitermax, c_int), tol, 10_c_int, c_null_ptr, eval, &
+         c_loc(evec), niter), "gpu_sp_lanc_eigh_c")
+  end subroutine gpu_sp_lanc_eigh_c
+
+  !> the same with the eigenvector LEFT ON THE DEVICE (evec_dev from gpu_vec_alloc): the state never visits the host
+  !! between the diagonalisation and the Green's-function seeds (row f3)
+  subroutine gpu_sp_lanc_eigh_dev(eval, evec_dev, Nitermax, threshold)
+    real(8), intent(out) :: eval
+    type(c_ptr), intent(in) :: evec_dev
+    integer, intent(in) :: Nitermax
+    real(8), intent(in), optional :: threshold
+    real(c_double) :: tol
+    integer(c_int) :: niter
+    if (.not. c_associated(gpu_sector)) stop "gpu_sp_lanc_eigh_dev: Hsector NOT allocated"
+    tol = 1d-12; if (present(threshold)) tol = max(threshold, 1d-15)
+    call gpu_check(edigpu_lanczos_eigh(gpu_sector, int(Nitermax, c_int), tol, 10_c_int, c_null_ptr, eval, &
+         evec_dev, niter), "gpu_sp_lanc_eigh_dev")
+  end subroutine gpu_sp_lanc_eigh_dev
+
+  !> call sp_eigh(spHtimesV_p, eig_values, eig_basis, Nblock, Nitermax, tol=lanc_tolerance)
+  !! (the default lanc_method = "arpack", ED_NORMAL/ED_DIAG_NORMAL.f90:179-196): the lowest size(eig_values)
+  !! eigenpairs by thick-restart Lanczos on an Nblock-dimensional device-resident basis; Nitermax bounds the
+  !! number of restarts as ARPACK's maxiter does
+  subroutine gpu_sp_eigh_d(eig_values, eig_basis, Nblock, Nitermax, tol)
+    real(8), intent(inout) :: eig_values(:)
+    real(8), intent(inout), target :: eig_basis(:,:)
+    integer, intent(in) :: Nblock, Nitermax
+    real(8), intent(in), optional :: tol
+    real(c_double) :: tol_
+    integer(c_int) :: nconv, nmv
+    if (.not. c_associated(gpu_sector)) stop "gpu_sp_eigh_d: Hsector NOT allocated"
+    tol_ = 1d-12; if (present(tol)) tol_ = max(tol, 1d-14)
+    call gpu_check(edigpu_lanczos_eigh_multi(gpu_sector, int(size(eig_values), c_int), int(Nblock, c_int), tol_, &
+         int(Nitermax, c_int), c_null_ptr, eig_values, c_loc(eig_basis), nconv, nmv), "gpu_sp_eigh_d")
+    if (nconv < size(eig_values)) stop "gpu_sp_eigh_d: not all eigenpairs converged"
+  end subroutine gpu_sp_eigh_d
+
+  subroutine gpu_sp_eigh_c(eig_values, eig_basis, Nblock, Nitermax, tol)
+    real(8), intent(inout) :: eig_values(:)
+    complex(8), intent(inout), target :: eig_basis(:,:)
+    integer, intent(in) :: Nblock, Nitermax
+    real(8), intent(in), optional :: tol
+    real(c_double) :: tol_
+    integer(c_int) :: nconv, nmv
+    if (.not. c_associated(gpu_sector)) stop "gpu_sp_eigh_c: Hsector NOT allocated"
+    tol_ = 1d-12; if (present(tol)) tol_ = max(tol, 1d-14)
+    call gpu_check(edigpu_lanczos_eigh_multi(gpu_sector, int(size(eig_values), c_int), int(Nblock, c_int), tol_, &
+         int(Nitermax, c_int), c_null_ptr, eig_values, c_loc(eig_basis), nconv, nmv), "gpu_sp_eigh_c")
+    if (nconv < size(eig_values)) stop "gpu_sp_eigh_c: not all eigenpairs converged"
+  end subroutine gpu_sp_eigh_c
+
+  !> device vectors of n real(8) (ncomplex = 2 n for complex(8)) elements
+  function gpu_vec_alloc(n) result(p)
+    integer, intent(in) :: n
+    type(c_ptr) :: p
+    call gpu_check(edigpu_dev_alloc(8_c_int64_t * int(n, c_int64_t), p), "gpu_vec_alloc")
+  end function gpu_vec_alloc
+
+  subroutine gpu_vec_free(p)
+    type(c_ptr), intent(inout) :: p
+    call gpu_check(edigpu_dev_free(p), "gpu_vec_free")
+    p = c_null_ptr
+  end subroutine gpu_vec_free
+
+  subroutine gpu_vec_upload_d(p, v)
+    type(c_ptr), intent(in) :: p
+    real(8), intent(in), target :: v(:)
+    call gpu_check(edigpu_dev_upload(p, c_loc(v), 8_c_int64_t * size(v, kind=c_int64_t)), "gpu_vec_upload_d")
+  end subroutine gpu_vec_upload_d
+
+  subroutine gpu_vec_download_d(v, p)
+    real(8), intent(inout), target :: v(:)
+    type(c_ptr), intent(in) :: p
+    call gpu_check(edigpu_dev_download(c_loc(v), p, 8_c_int64_t * size(v, kind=c_int64_t)), "gpu_vec_download_d")
+  end subroutine gpu_vec_download_d
+
+  subroutine gpu_vec_upload_c(p, v)
+    type(c_ptr), intent(in) :: p
+    complex(8), intent(in), target :: v(:)
+    call gpu_check(edigpu_dev_upload(p, c_loc(v), 16_c_int64_t * size(v, kind=c_int64_t)), "gpu_vec_upload_c")
+  end subroutine gpu_vec_upload_c
+
+  subroutine gpu_vec_download_c(v, p)
+    complex(8), intent(inout), target :: v(:)
+    type(c_ptr), intent(in) :: p
+    call gpu_check(edigpu_dev_download(c_loc(v), p, 16_c_int64_t * size(v, kind=c_int64_t)), "gpu_vec_download_c")
+  end subroutine gpu_vec_download_c
+
+  !> vvinit = apply_op_CDG(v_state, iorb, ispin, isector, jsector) / apply_op_C (ED_SECTOR.f90:465-536, called from
+  !! ED_NORMAL/ED_GF_NORMAL.f90:155,167 on the master rank): device vector of sector hsrc -> device vector of sector
+  !! hdst.  iorb, ispin 1-based as in the reference; cdg = .true. for c^+.  Normal-mode handles from gpu_build_normal,
+  !! superc / nonsu2 handles from gpu_build_flat.
+  subroutine gpu_apply_op(hsrc, hdst, v_src_dev, v_dst_dev, iorb, ispin, cdg, flat)
+    type(c_ptr), intent(in) :: hsrc, hdst, v_src_dev, v_dst_dev
+    integer, intent(in) :: iorb, ispin
+    logical, intent(in) :: cdg
+    logical, intent(in), optional :: flat
+    integer(c_int) :: cr
+    logical :: flat_
+    cr = 0; if (cdg) cr = 1
+    flat_ = .false.; if (present(flat)) flat_ = flat
+    if (flat_) then
+       call gpu_check(edigpu_apply_op_flat(hsrc, hdst, v_src_dev, v_dst_dev, int(iorb-1, c_int), int(ispin-1, c_int), &
+            cr, c_null_ptr), "gpu_apply_op(flat)")
+    else
+       call gpu_check(edigpu_apply_op_normal(hsrc, hdst, v_src_dev, v_dst_dev, int(iorb-1, c_int), int(ispin-1, c_int), &
+            cr, c_null_ptr), "gpu_apply_op")
+    end if
+  end subroutine gpu_apply_op
+
+  !> vvinit = apply_Cops(v_state, coefs, Os, orbs, spins, isector, jsector) (ED_SECTOR.f90:839-960; the mixed seeds
+  !! of the off-diagonal Green's functions, ED_NORMAL/ED_GF_NORMAL.f90:216-261): Os(i) = +1 for c^+, -1 for c
+  subroutine gpu_apply_cops(hsrc, hdst, v_src_dev, v_dst_dev, coefs, Os, orbs, spins)
+    type(c_ptr), intent(in) :: hsrc, hdst, v_src_dev, v_dst_dev
+    real(8), intent(in) :: coefs(:)
+    integer, intent(in) :: Os(:), orbs(:), spins(:)
+    integer(c_int32_t) :: o(size(Os)), io(size(Os)), is(size(Os))
+    o = int(Os, c_int32_t); io = int(orbs - 1, c_int32_t); is = int(spins - 1, c_int32_t)
+    call gpu_check(edigpu_apply_cops_normal(hsrc, hdst, v_src_dev, v_dst_dev, int(size(Os), c_int), coefs, o, io, is, &
+         c_null_ptr), "gpu_apply_cops")
+  end subroutine gpu_apply_cops
+
+  !> tridiag_Hv_sector_*(jsector, vvinit, alfa_, beta_, norm2) with the seed already on the device: the live sector
+  !! is the one the seed belongs to; norm2 = <vvinit|vvinit> as the reference returns it
+  subroutine gpu_lanc_tridiag_dev(vin_dev, alanc, blanc, norm2)
+    type(c_ptr), intent(in) :: vin_dev
+    real(8), intent(inout) :: alanc(:), blanc(:)
+    real(8), intent(out) :: norm2
+    integer(c_int) :: niter
+    if (.not. c_associated(gpu_sector)) stop "gpu_lanc_tridiag_dev: Hsector NOT allocated"
+    call gpu_check(edigpu_lanczos_tridiag_dev(gpu_sector, vin_dev, int(size(alanc), c_int), alanc, blanc, &
+         lanc_threshold, niter, norm2), "gpu_lanc_tridiag_dev")
+  end subroutine gpu_lanc_tridiag_dev
+
+  ! ---- N > 1: one MPI rank per GPU -------------------------------------------------------------
+
+  !> rank 0 makes the 128-byte RCCL id; the host broadcasts it (call MPI_Bcast(id, 128, MPI_BYTE, 0, MpiComm, ierr))
+  subroutine gpu_comm_unique_id(id)
+    character(kind=c_char), intent(out) :: id(128)
+    call gpu_check(edigpu_comm_unique_id(id), "gpu_comm_unique_id")
+  end subroutine gpu_comm_unique_id
+
+  !> MpiComm's counterpart: RCCL over xGMI, rank = get_Rank_MPI(MpiComm), world = get_Size_MPI(MpiComm)
+  !! (where the reference builds its communicator: ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:99-125)
+  subroutine gpu_comm_create(rank, world, id)
+    integer, intent(in) :: rank, world
+    character(kind=c_char), intent(in) :: id(128)
+    if (c_associated(gpu_comm)) stop "gpu_comm_create: a communicator is already live"
+    call gpu_check(edigpu_comm_create(gpu_comm, int(rank, c_int32_t), int(world, c_int32_t), id), "gpu_comm_create")
+  end subroutine gpu_comm_create
+
+  !> host-staged transport through POSIX shared memory: ranks of one node that share a GPU (tests, hosts without RCCL)
+  subroutine gpu_comm_create_shm(rank, world, name, slot_bytes)
+    integer, intent(in) :: rank, world
+    character(len=*), intent(in) :: name
+    integer(c_int64_t), intent(in) :: slot_bytes
+    character(kind=c_char) :: cname(len_trim(name)+1)
+    integer :: i
+    if (c_associated(gpu_comm)) stop "gpu_comm_create_shm: a communicator is already live"
+    do i = 1, len_trim(name)
+       cname(i) = name(i:i)
+    end do
+    cname(len_trim(name)+1) = c_null_char
+    call gpu_check(edigpu_comm_create_shm(gpu_comm, int(rank, c_int32_t), int(world, c_int32_t), cname, slot_bytes), &
+         "gpu_comm_create_shm")
+  end subroutine gpu_comm_create_shm
+
+  subroutine gpu_comm_destroy()
+    if (c_associated(gpu_comm)) call gpu_check(edigpu_comm_destroy(gpu_comm), "gpu_comm_destroy")
+    gpu_comm = c_null_ptr
+  end subroutine gpu_comm_destroy
+
+  !> this rank's share of `units` (DimDw in normal mode, Dim in superc / nonsu2): first is 0-based
+  subroutine gpu_shard_plan(units, rank, world, first, count)
+    integer, intent(in) :: units, rank, world
+    integer, intent(out) :: first, count
+    integer(c_int64_t) :: f, n, q
+    call gpu_check(edigpu_shard_plan(int(units, c_int64_t), int(world, c_int32_t), int(rank, c_int32_t), f, n, q), &
+         "gpu_shard_plan")
+    first = int(f); count = int(n)
+  end subroutine gpu_shard_plan
+
+  !> spMatVec_mpi_normal_main / spMatVec_mpi_superc_main / ... (dd_sparse_HxV interface on SHARDS, Nloc =
+  !! vecDim_Hv_sector_*): the exchange happens inside the library.  spHtimesV_p => spMatVec_mpi_gpu_d
+  subroutine spMatVec_mpi_gpu_d(Nloc, v, Hv)
+    integer :: Nloc
+    real(8), dimension(Nloc) :: v, Hv
+    if (.not. c_associated(gpu_sector)) stop "spMatVec_mpi_gpu_d: Hsector NOT allocated"
+    if (.not. c_associated(gpu_comm)) stop "spMatVec_mpi_gpu_d: no communicator"
+    call gpu_check(edigpu_apply_sharded_d(gpu_sector, gpu_comm, int(Nloc, c_int64_t), v, Hv), "spMatVec_mpi_gpu_d")
+  end subroutine spMatVec_mpi_gpu_d
+
+  subroutine spMatVec_mpi_gpu_c(Nloc, v, Hv)
+    integer :: Nloc
+    complex(8), dimension(Nloc) :: v, Hv
+    if (.not. c_associated(gpu_sector)) stop "spMatVec_mpi_gpu_c: Hsector NOT allocated"
+    if (.not. c_associated(gpu_comm)) stop "spMatVec_mpi_gpu_c: no communicator"
+    call gpu_check(edigpu_apply_sharded_z(gpu_sector, gpu_comm, int(Nloc, c_int64_t), v, Hv), "spMatVec_mpi_gpu_c")
+  end subroutine spMatVec_mpi_gpu_c
+
+  !> call sp_lanc_tridiag(MpiComm, spHtimesV_p, vvloc, alanc, blanc) (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:357-365):
+  !! vvloc = this rank's slice as scatter_vector_MPI leaves it; norm2 over all ranks (the reference computes it on
+  !! the master before scattering, :344-349)
+  subroutine gpu_lanc_tridiag_mpi_d(vvloc, alanc, blanc, norm2)
+    real(8), intent(in), target :: vvloc(:)
+    real(8), intent(inout) :: alanc(:), blanc(:)
+    real(8), intent(out), optional :: norm2
+    integer(c_int) :: niter
+    real(c_double) :: n2
+    if (.not. c_associated(gpu_sector)) stop "gpu_lanc_tridiag_mpi_d: Hsector NOT allocated"
+    if (.not. c_associated(gpu_comm)) stop "gpu_lanc_tridiag_mpi_d: no communicator"
+    call gpu_check(edigpu_lanczos_tridiag_sharded(gpu_sector, gpu_comm, c_loc(vvloc), int(size(alanc), c_int), &
+         alanc, blanc, lanc_threshold, niter, n2), "gpu_lanc_tridiag_mpi_d")
+    if (present(norm2)) norm2 = n2
+  end subroutine gpu_lanc_tridiag_mpi_d
+
+  subroutine gpu_lanc_tridiag_mpi_c(vvloc, alanc, blanc, norm2)
+    complex(8), intent(in), target :: vvloc(:)
+    real(8), intent(inout) :: alanc(:), blanc(:)
+    real(8), intent(out), optional :: norm2
+    integer(c_int) :: niter
+    real(c_double) :: n2
+    if (.not. c_associated(gpu_sector)) stop "gpu_lanc_tridiag_mpi_c: Hsector NOT allocated"
+    if (.not. c_associated(gpu_comm)) stop "gpu_lanc_tridiag_mpi_c: no communicator"
+    call gpu_check(edigpu_lanczos_tridiag_sharded(gpu_sector, gpu_comm, c_loc(vvloc), int(size(alanc), c_int), &
+         alanc, blanc, lanc_threshold, niter, n2), "gpu_lanc_tridiag_mpi_c")
+    if (present(norm2)) norm2 = n2
+  end subroutine gpu_lanc_tridiag_mpi_c
 
   !> delete_Hv_sector_* counterpart (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:212-279)
   subroutine gpu_delete_sector()

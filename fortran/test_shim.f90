@@ -28,9 +28,28 @@ program test_shim
   real(8), allocatable :: up_val(:), dw_val(:), nd_val(:)
   real(8) :: alanc(8), blanc(8), err
   integer :: i, j, iup, idw, k, nfail
+  character(len=64) :: arg1, arg2, arg3, arg4
 
   nfail = 0
   call gpu_init(0)
+  ! `test_shim mpi <rank> <world> <name>`: one rank of a Fortran + "MPI" host whose ranks share this GPU (the
+  ! communicator is the library's shared-memory transport; tests/test_fortran_shim.py starts the ranks)
+  if (command_argument_count() >= 4) then
+     call get_command_argument(1, arg1); call get_command_argument(2, arg2)
+     call get_command_argument(3, arg3); call get_command_argument(4, arg4)
+     if (trim(arg1) == "mpi") then
+        read(arg2, *) i
+        read(arg3, *) j
+        call test_mpi_rank(i, j, trim(arg4), nfail)
+        if (nfail == 0) then
+           write(*,"(A,I2)") "FORTRAN SHIM MPI OK rank", i
+        else
+           write(*,"(A,I3)") "FORTRAN SHIM MPI FAILED checks:", nfail
+           stop 1
+        end if
+        stop
+     end if
+  end if
 
   ! ---- a small symmetric Kronecker problem ----
   hup = 0d0; hdw = 0d0
@@ -80,6 +99,12 @@ program test_shim
 
   ! ---- library-built sector from the model globals (no ed_buildh_* on the host) ----
   call test_model_build(nfail)
+
+  ! ---- SURVEY.md 8(f) rows f1 / f3 from the Fortran host: eigensolvers, device-resident c^+ and tridiagonalisation ----
+  call test_next_rows(nfail)
+
+  ! ---- the N > 1 entry points with a world of one (RCCL communicator) ----
+  call test_comm_world_of_one(nfail)
 
   if (nfail == 0) then
      write(*,"(A)") "FORTRAN SHIM OK"
@@ -187,5 +212,138 @@ contains
     if (e > 1d-13) nfail = nfail + 1
     call gpu_delete_sector()
   end subroutine test_model_build
+
+  !> Norb = 1, Nbath = 3 Anderson model (Ns = 4) with fixed parameters
+  subroutine anderson_model(m)
+    type(edigpu_model_t), intent(out) :: m
+    real(8) :: ebath(1,1,3), vbath(1,1,3), zero2(1,1)
+    complex(8) :: hloc(1,1,1,1)
+    m%ed_mode = 0; m%bath_type = 0; m%norb = 1; m%nbath = 3; m%nspin = 1; m%hfmode = 0; m%xmu = 0d0
+    zero2 = 0d0
+    call gpu_model_set_kanamori(m, [2.0d0], zero2, zero2, zero2, zero2)
+    hloc = cmplx(-0.9d0, 0d0, 8)
+    call gpu_model_set_hloc(m, hloc)
+    ebath(1,1,:) = [-0.8d0, 0.1d0, 0.9d0]; vbath(1,1,:) = [0.3d0, 0.45d0, 0.25d0]
+    call gpu_model_set_bath(m, ebath, vbath)
+  end subroutine anderson_model
+
+  subroutine test_next_rows(nfail)
+    integer, intent(inout) :: nfail
+    type(edigpu_model_t) :: m
+    type(c_ptr) :: hgs, hexc, vgs_dev, seed_dev
+    real(8), allocatable :: evec(:), hv(:), seed(:), hseed(:), basis(:,:)
+    real(8) :: e0, evals(3), al(12), bl(12), norm2, e
+    integer :: n, n2
+    call anderson_model(m)
+    call gpu_build_normal(m, 2, 2, 0, -1)              ! sector (2,2): 6 x 6
+    n = gpu_sector_dim(gpu_sector_handle())
+    allocate(evec(n), hv(n), basis(n,3))
+    ! row f1: sp_lanc_eigh and sp_eigh replacements
+    call gpu_sp_lanc_eigh_d(e0, evec, 200, 1d-14)
+    spHtimesV_p => spMatVec_gpu_d
+    call spHtimesV_p(n, evec, hv)
+    e = maxval(abs(hv - e0*evec))
+    write(*,"(A,F14.9,A,ES10.2)") "gpu_sp_lanc_eigh_d: E0 =", e0, "  residual =", e
+    if (e > 1d-9 .or. abs(dot_product(evec, evec) - 1d0) > 1d-12) nfail = nfail + 1
+    call gpu_sp_eigh_d(evals, basis, 20, 300, 1d-12)
+    e = abs(evals(1) - e0)
+    call spHtimesV_p(n, basis(:,2), hv)
+    e = max(e, maxval(abs(hv - evals(2)*basis(:,2))))
+    write(*,"(A,3F12.7,A,ES10.2)") "gpu_sp_eigh_d: evals =", evals, "  err =", e
+    if (e > 1d-9 .or. evals(2) < evals(1) .or. evals(3) < evals(2)) nfail = nfail + 1
+    ! row f3: ground state left on the device -> c^+_up -> tridiagonalisation, nothing but alpha/beta/norm2 comes back
+    vgs_dev = gpu_vec_alloc(n)
+    call gpu_sp_lanc_eigh_dev(e0, vgs_dev, 200, 1d-14)
+    hgs = c_null_ptr
+    call gpu_sector_swap(hgs)                           ! hgs = the (2,2) sector, no live sector now
+    call gpu_build_normal(m, 3, 2, 0, -1)               ! the sector c^+_up leads to
+    hexc = gpu_sector_handle()
+    n2 = gpu_sector_dim(hexc)
+    seed_dev = gpu_vec_alloc(n2)
+    call gpu_apply_op(hgs, hexc, vgs_dev, seed_dev, 1, 1, .true.)
+    call gpu_lanc_tridiag_dev(seed_dev, al, bl, norm2)
+    allocate(seed(n2), hseed(n2))
+    call gpu_vec_download_d(seed, seed_dev)
+    call spHtimesV_p(n2, seed, hseed)
+    e = abs(norm2 - dot_product(seed, seed)) + abs(al(1) - dot_product(seed, hseed)/dot_product(seed, seed))
+    write(*,"(A,F12.8,A,ES10.2)") "device-resident c^+|gs> -> tridiag: norm2 =", norm2, "  err =", e
+    if (e > 1d-11 .or. norm2 <= 0d0 .or. norm2 >= 1d0) nfail = nfail + 1
+    ! apply_Cops with one term must reproduce apply_op
+    call gpu_apply_cops(hgs, hexc, vgs_dev, seed_dev, [1d0], [1], [1], [1])
+    call gpu_vec_download_d(hseed, seed_dev)
+    if (maxval(abs(hseed - seed)) > 1d-15) nfail = nfail + 1
+    call gpu_vec_free(seed_dev); call gpu_vec_free(vgs_dev)
+    call gpu_sector_destroy(hgs)
+    call gpu_delete_sector()
+  end subroutine test_next_rows
+
+  subroutine test_comm_world_of_one(nfail)
+    integer, intent(inout) :: nfail
+    type(edigpu_model_t) :: m
+    character(kind=c_char) :: id(128)
+    real(8), allocatable :: x(:), y(:), yref(:)
+    real(8) :: a1(10), b1(10), a2(10), b2(10), n2, e
+    integer :: n, first, count, ii
+    call anderson_model(m)
+    call gpu_build_normal(m, 2, 2, 0, -1)
+    n = gpu_sector_dim(gpu_sector_handle())
+    allocate(x(n), y(n), yref(n))
+    do ii = 1, n
+       x(ii) = cos(0.7d0*ii) + 0.1d0*ii
+    end do
+    call gpu_comm_unique_id(id)
+    call gpu_comm_create(0, 1, id)
+    call gpu_shard_plan(6, 0, 1, first, count)
+    if (first /= 0 .or. count /= 6) nfail = nfail + 1
+    spHtimesV_p => spMatVec_gpu_d
+    call spHtimesV_p(n, x, yref)
+    spHtimesV_p => spMatVec_mpi_gpu_d
+    call spHtimesV_p(n, x, y)
+    e = maxval(abs(y - yref))/maxval(abs(yref))
+    call gpu_lanc_tridiag_d(x, a1, b1)
+    call gpu_lanc_tridiag_mpi_d(x, a2, b2, n2)
+    e = max(e, maxval(abs(a1 - a2)), maxval(abs(b1 - b2)), abs(n2 - dot_product(x, x))/n2)
+    write(*,"(A,ES10.2)") "world-of-one RCCL communicator, spMatVec_mpi_gpu_d + gpu_lanc_tridiag_mpi_d: err =", e
+    if (e > 1d-11) nfail = nfail + 1
+    call gpu_comm_destroy()
+    call gpu_delete_sector()
+  end subroutine test_comm_world_of_one
+
+  !> one rank of `world`: whole-sector handle (transposed exchange), the product and the tridiagonalisation on this
+  !! rank's down rows against the single-process results computed first with the same handle
+  subroutine test_mpi_rank(rank, world, name, nfail)
+    integer, intent(in) :: rank, world
+    character(len=*), intent(in) :: name
+    integer, intent(inout) :: nfail
+    type(edigpu_model_t) :: m
+    real(8), allocatable :: x(:), y(:), yref(:)
+    real(8) :: a1(10), b1(10), a2(10), b2(10), n2, e
+    integer :: n, first, count, ii, lo, hi, dimup
+    call anderson_model(m)
+    call gpu_build_normal(m, 2, 2, 0, -1)               ! DimUp = DimDw = 6
+    dimup = 6
+    n = gpu_sector_dim(gpu_sector_handle())
+    allocate(x(n), yref(n))
+    do ii = 1, n
+       x(ii) = cos(0.7d0*ii) + 0.1d0*ii
+    end do
+    spHtimesV_p => spMatVec_gpu_d
+    call spHtimesV_p(n, x, yref)
+    call gpu_lanc_tridiag_d(x, a1, b1)
+    call gpu_comm_create_shm(rank, world, name, 1048576_c_int64_t)
+    call gpu_shard_plan(6, rank, world, first, count)
+    lo = first*dimup + 1; hi = (first + count)*dimup
+    allocate(y(max(1, hi - lo + 1)))
+    spHtimesV_p => spMatVec_mpi_gpu_d
+    call spHtimesV_p(hi - lo + 1, x(lo:hi), y)
+    e = 0d0
+    if (hi >= lo) e = maxval(abs(y(1:hi-lo+1) - yref(lo:hi)))/maxval(abs(yref))
+    call gpu_lanc_tridiag_mpi_d(x(lo:hi), a2, b2, n2)
+    e = max(e, maxval(abs(a1 - a2)), maxval(abs(b1 - b2)), abs(n2 - dot_product(x, x))/n2)
+    write(*,"(A,I2,A,I2,A,ES10.2)") "rank", rank, " of", world, ": sharded product + tridiagonalisation err =", e
+    if (e > 1d-11) nfail = nfail + 1
+    call gpu_comm_destroy()
+    call gpu_delete_sector()
+  end subroutine test_mpi_rank
 
 end program test_shim

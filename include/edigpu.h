@@ -468,6 +468,16 @@ int edigpu_time_apply(edigpu_handle h, int warmup, int steps, int lanczos, doubl
 int edigpu_lanczos_bench(edigpu_handle h, int warmup, int steps, double *ms_wall_per_step,
                          double *ms_hv_per_launch);
 
+/*
+ * Device buffers for hosts without a HIP binding of their own (the Fortran host keeps eigenvectors and Green's-function
+ * seeds resident between edigpu_lanczos_eigh*, edigpu_apply_op_* and edigpu_lanczos_tridiag_dev this way; PyTorch
+ * hosts use their own tensors).  Synchronous copies on the device selected by edigpu_init.
+ */
+int edigpu_dev_alloc(int64_t bytes, void **dev_ptr);
+int edigpu_dev_free(void *dev_ptr);
+int edigpu_dev_upload(void *dst_dev, const void *src_host, int64_t bytes);
+int edigpu_dev_download(void *dst_host, const void *src_dev, int64_t bytes);
+
 /* Measurement helper for bench.py: streaming ceilings of the device the calling thread selected -- gbs3[0] read,
  * [1] copy (bytes read + written), [2] triad (two reads + one write), GB/s on buffers of `bytes` each (use >= 1 GB
  * to leave the 256 MiB Infinity Cache; SURVEY.md 8d asks for the measured ceiling next to the 8 TB/s spec). */

@@ -30,3 +30,19 @@ def test_fortran_host_through_shim(gpu):
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=120)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "FORTRAN SHIM OK" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(FLANG), reason="flang not present")
+@pytest.mark.parametrize("world", [2, 3])
+def test_fortran_mpi_ranks_through_shim(gpu, world):
+    """The -D_MPI side of the boundary: `world` Fortran processes (one per MPI rank) share the GPU, create the library's
+    communicator (shared-memory transport) through the shim and call spMatVec_mpi_gpu_d / gpu_lanc_tridiag_mpi_d on
+    their shards -- the (Nloc, v, Hv) contract of spMatVec_mpi_normal_main and sp_lanc_tridiag(MpiComm, ...)."""
+    name = f"edigpu_f90_{os.getpid()}_{world}"
+    procs = [subprocess.Popen([EXE, "mpi", str(r), str(world), name], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(world)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        print(o)
+        assert p.returncode == 0 and "FORTRAN SHIM MPI OK" in o, o
