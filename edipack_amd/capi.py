@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("EDIGPU_LIB", os.path.join(HERE, "lib", "libedigpu.so"
 HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "edigpu.h")
 
 MAXORB = 5
+MAXSUNDRY = 64
 MAXBATH = 16
 
 
@@ -44,6 +45,12 @@ class EdigpuModel(C.Structure):
         ("nph", C.c_int32), ("pad_", C.c_int32),
         ("w0_ph", C.c_double), ("a_ph", C.c_double),
         ("g_ph", C.c_double * (MAXORB * MAXORB)),
+        ("spin_field", C.c_double * (MAXORB * 3)),
+        ("exc_field", C.c_double * 4),
+        ("nsundry", C.c_int32),
+        ("pad2_", C.c_int32),
+        ("sundry_op", C.c_int32 * (MAXSUNDRY * 8)),
+        ("sundry_u", C.c_double * MAXSUNDRY),
     ]
 
 
@@ -60,6 +67,7 @@ _pint = C.POINTER(C.c_int)
 SIGNATURES = {
     "edigpu_last_error": (C.c_char_p, []),
     "edigpu_version": (C.c_int, []),
+    "edigpu_model_sizeof": (C.c_int64, []),
     "edigpu_device_count": (C.c_int, [_pint]),
     "edigpu_init": (C.c_int, [C.c_int]),
     "edigpu_normal_create": (C.c_int, [C.POINTER(_vp), _i64, _i64, _i64, _i64, _pd, _pi64, _pi32, _pd,
@@ -110,6 +118,7 @@ SIGNATURES = {
     "edigpu_time_apply": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _pd]),
     "edigpu_lanczos_bench": (C.c_int, [_vp, C.c_int, C.c_int, _pd, _pd]),
     "edigpu_membw": (C.c_int, [_i64, _pd]),
+    "edigpu_sector_map": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _pi32, _pi64]),
     "edigpu_dev_alloc": (C.c_int, [_i64, C.POINTER(_vp)]),
     "edigpu_dev_free": (C.c_int, [_vp]),
     "edigpu_dev_upload": (C.c_int, [_vp, _vp, _i64]),

@@ -1042,6 +1042,7 @@ extern "C" {
 const char* edigpu_last_error(void) { return g_err.c_str(); }
 
 int edigpu_version(void) { return 100; }
+int64_t edigpu_model_sizeof(void) { return (int64_t)sizeof(edigpu_model); }
 
 int edigpu_device_count(int* count) {
   int n = 0;
@@ -1553,6 +1554,28 @@ int edigpu_sector_dim(const edigpu_model* model, int q1, int q2, int64_t* dim) {
     set_error(e);
     return 1;
   }
+  return 0;
+}
+
+int edigpu_sector_map(const edigpu_model* model, int q1, int q2, int which, int32_t* map, int64_t* n) {
+  if (!model || !n) {
+    set_error("edigpu_sector_map: NULL argument");
+    return 1;
+  }
+  std::vector<int32_t> st;
+  std::string e = sector_map(*model, q1, q2, which, st);
+  if (!e.empty()) {
+    set_error(e);
+    return 1;
+  }
+  if (map) {
+    if (*n < (int64_t)st.size()) {
+      set_error("edigpu_sector_map: output buffer too small");
+      return 1;
+    }
+    std::copy(st.begin(), st.end(), map);
+  }
+  *n = (int64_t)st.size();
   return 0;
 }
 

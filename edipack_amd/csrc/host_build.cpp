@@ -119,8 +119,12 @@ OneBody one_body_normal(const edigpu_model& m, int spin) {
     for (int b = 0; b < norb; b++) {
       if (a == b) continue;
       ob.a[a * ns + b] += ix.hloc(s, s, a, b).real();
+      // exciton field: (exc(1) +/- exc(4)) c+_a c_b, stored/H_up.f90:87-104, H_dw.f90
+      ob.a[a * ns + b] += m.exc_field[0] + (spin == 0 ? 1.0 : -1.0) * m.exc_field[3];
     }
     double e = ix.hloc(s, s, a, a).real() - m.xmu;
+    // spin_field(a,3) (n_up - n_dw): stored/H_local.f90:38-42
+    e += (spin == 0 ? 1.0 : -1.0) * m.spin_field[a * 3 + 2];
     if (m.hfmode) {
       e -= 0.5 * ix.uloc(a);
       for (int b = 0; b < norb; b++) {
@@ -211,6 +215,9 @@ edigpu_model imag_part_model(const edigpu_model& m, bool& any) {
   std::fill(std::begin(r.be), std::end(r.be), 0.0);
   std::fill(std::begin(r.bv), std::end(r.bv), 0.0);
   std::fill(std::begin(r.g_ph), std::end(r.g_ph), 0.0);
+  std::fill(std::begin(r.spin_field), std::end(r.spin_field), 0.0);
+  std::fill(std::begin(r.exc_field), std::end(r.exc_field), 0.0);
+  r.nsundry = 0;
   // (re, im) -> (im, 0) off the orbital diagonal, 0 on it (a Hermitian matrix has a real diagonal)
   const size_t nh = sizeof(r.hloc) / sizeof(double) / 2;
   for (size_t i = 0; i < nh; i++) {
@@ -377,7 +384,43 @@ std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_fir
       if (ix.jx(a, b) != 0.0) any_jx = true;
       if (ix.jp(a, b) != 0.0) any_jp = true;
     }
-  out.has_nd = norb > 1 && (any_jx || any_jp);
+  // coulomb_sundry lines as per-species operator strings in application order (c_l, cd_j, c_k, cd_i), each operator
+  // acting on the word of its own spin with that word's sign only (stored/H_sundry.f90:36-98), so every line is a
+  // product (O_dw (x) O_up) like the exchange and pair-hopping terms
+  struct SpeciesOp { int pos; bool create; };
+  struct Sundry { std::vector<SpeciesOp> up, dw; double u; };
+  std::vector<Sundry> sundry;
+  if (m.nsundry < 0 || m.nsundry > EDIGPU_MAXSUNDRY) return "edigpu_normal_build: nsundry out of range";
+  for (int il = 0; il < m.nsundry; il++) {
+    const int32_t* op = &m.sundry_op[il * 8];
+    Sundry sl;
+    sl.u = m.sundry_u[il];
+    const int order[4] = {3, 1, 2, 0};  // l, j, k, i
+    int balance[2] = {0, 0};
+    for (int k = 0; k < 4; k++) {
+      const int w = order[k], orb = op[2 * w], sp = op[2 * w + 1];
+      if (orb < 1 || orb > norb || sp < 1 || sp > 2) return "edigpu_normal_build: coulomb_sundry orbital / spin out of range";
+      const bool create = w < 2;
+      balance[sp - 1] += create ? 1 : -1;
+      (sp == 1 ? sl.up : sl.dw).push_back({orb - 1, create});
+    }
+    if (balance[0] != 0 || balance[1] != 0)
+      return "edigpu_normal_build: in normal mode coulomb_sundry operators that change the total spin are forbidden";
+    if (sl.u != 0.0) sundry.push_back(sl);
+  }
+  // a string on one word: false when it annihilates the state, else the new word and the sign
+  auto apply_ops = [](const std::vector<SpeciesOp>& ops, uint32_t st, uint32_t& res, int& neg) {
+    neg = 0;
+    for (const SpeciesOp& o : ops) {
+      const uint32_t b = 1u << o.pos;
+      if (o.create ? (st & b) != 0 : (st & b) == 0) return false;
+      neg ^= popc(st & (b - 1u)) & 1;
+      st ^= b;
+    }
+    res = st;
+    return true;
+  };
+  out.has_nd = (norb > 1 && (any_jx || any_jp)) || !sundry.empty();
   out.nd = HostCsr();
   if (out.has_nd) {
     // factored form: one (Pdw (x) Pup) pair per (kind, a, b)
@@ -410,6 +453,22 @@ std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_fir
           fac.nterms++;
         }
       }
+    auto partner_ops = [&](const CombBasis& bs, const std::vector<SpeciesOp>& ops, std::vector<uint32_t>& dst) {
+      for (int64_t i = 0; i < bs.size(); i++) {
+        uint32_t res;
+        int neg;
+        if (apply_ops(ops, (uint32_t)bs.states[i], res, neg))
+          dst.push_back((uint32_t)bs.rank(res) | (neg ? 0x80000000u : 0u));
+        else
+          dst.push_back(0xFFFFFFFFu);
+      }
+    };
+    for (const Sundry& sl : sundry) {
+      fac.coef.push_back(sl.u);
+      partner_ops(out.bup, sl.up, fac.jup);
+      partner_ops(out.bdw, sl.dw, fac.jdw);
+      fac.nterms++;
+    }
     struct Term { uint32_t xu, xd; double val; };
     std::vector<std::vector<Term>> terms((size_t)1 << (2 * norb));
     for (uint32_t iu = 0; iu <= impmask; iu++)
@@ -427,6 +486,12 @@ std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_fir
             if (any_jp && (iu & bb) && !(iu & ba) && (id & bb) && !(id & ba) && ix.jp(a, b) != 0.0)
               tl.push_back({ba | bb, ba | bb, ix.jp(a, b) * sg});
           }
+        for (const Sundry& sl : sundry) {
+          uint32_t ru, rd;
+          int nu, nd;
+          if (apply_ops(sl.up, iu, ru, nu) && apply_ops(sl.dw, id, rd, nd))
+            tl.push_back({iu ^ ru, id ^ rd, (nu ^ nd) ? -sl.u : sl.u});
+        }
       }
     // nnz(Hnd) of the local rows from the impurity-pattern histograms (O(DimUp + DimDw))
     {
@@ -536,6 +601,27 @@ struct OpTerm {           // coef * op[n-1] ... op[1] op[0]  (op[0] acts first)
 };
 
 }  // namespace
+
+// Sector map as build_sector leaves it (ED_SECTOR.f90:165-373): which = 0 / 1: H(1)%map (up) / H(2)%map (down) of a
+// normal-mode sector (q1, q2) = (Nup, Ndw); superc / nonsu2: the single map of sector q1 (Sz / Ntot), which ignored.
+std::string sector_map(const edigpu_model& m, int q1, int q2, int which, std::vector<int32_t>& out) {
+  std::string e = check_model(m);
+  if (!e.empty()) return e;
+  const int ns = model_ns(m);
+  if (m.ed_mode == 0) {
+    if (q1 < 0 || q1 > ns || q2 < 0 || q2 > ns || which < 0 || which > 1) return "edigpu_sector_map: bad sector";
+    CombBasis b;
+    b.init(ns, which == 0 ? q1 : q2);
+    out = b.states;
+    return "";
+  }
+  if (m.ed_mode == 1 ? (q1 < -ns || q1 > ns) : (q1 < 0 || q1 > 2 * ns)) return "edigpu_sector_map: bad sector";
+  if (2 * ns > 31) return "edigpu_sector_map: 2 Ns > 31 bits";
+  SpinBasis sb;
+  sb.init(ns, m.ed_mode, q1);
+  out = sb.states;
+  return "";
+}
 
 // Operator strings and diagonal data of the superc / nonsu2 Hamiltonians over the 2*Ns spin-orbital
 // levels (up: 0..Ns-1, down: Ns..2Ns-1); shared by the stored (CSR) and the direct (on-the-fly) builders.
@@ -680,12 +766,23 @@ static void flat_physics(const edigpu_model& m, std::vector<OpTerm>& terms, std:
 
 }
 
+static std::string refuse_normal_only_fields(const edigpu_model& m, const char* who) {
+  // spin_field, exc_field and coulomb_sundry are built for ed_mode = normal only (include/edigpu.h)
+  bool any = m.nsundry != 0;
+  for (double x : m.spin_field) any = any || x != 0.0;
+  for (double x : m.exc_field) any = any || x != 0.0;
+  if (any) return std::string(who) + ": spin_field / exc_field / coulomb_sundry are not built in this mode";
+  return "";
+}
+
 std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
                        HostFlat& out) {
   std::string e = check_model(m);
   if (!e.empty()) return e;
   if (m.ed_mode != 1 && m.ed_mode != 2) return "edigpu_flat_build: model.ed_mode must be superc or nonsu2";
   if (m.ed_mode == 2 && m.nspin != 2) return "edigpu_flat_build: nonsu2 needs nspin=2";
+  e = refuse_normal_only_fields(m, "edigpu_flat_build");
+  if (!e.empty()) return e;
   Idx ix(m);
   const int ns = model_ns(m), norb = m.norb;
   if (2 * ns > 30) return "edigpu_flat_build: 2*Ns > 30 bits (the reference's integer range)";
@@ -823,6 +920,7 @@ std::string build_orbs(const edigpu_model& m, const int* nups, const int* ndws, 
     auto nd = [&](int a) { return (double)((bits >> (norb + a)) & 1u); };
     for (int a = 0; a < norb; a++) {
       x += ix.hloc(0, 0, a, a).real() * nu(a) + ix.hloc(sd, sd, a, a).real() * nd(a) - m.xmu * (nu(a) + nd(a));
+      x += m.spin_field[a * 3 + 2] * (nu(a) - nd(a));  // stored/Orbs/H_local.f90:19-24
       x += ix.uloc(a) * nu(a) * nd(a);
       for (int b = a + 1; b < norb; b++) {
         x += ix.ust(a, b) * (nu(a) * nd(b) + nu(b) * nd(a));
@@ -867,6 +965,8 @@ std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, i
   if (!e.empty()) return e;
   if (m.ed_mode != 1 && m.ed_mode != 2) return "edigpu_direct_build: model.ed_mode must be superc or nonsu2";
   if (m.ed_mode == 2 && m.nspin != 2) return "edigpu_direct_build: nonsu2 needs nspin=2";
+  e = refuse_normal_only_fields(m, "edigpu_direct_build");
+  if (!e.empty()) return e;
   Idx ix(m);
   const int ns = model_ns(m), norb = m.norb;
   if (2 * ns > 30) return "edigpu_direct_build: 2*Ns > 30 bits (the reference's integer range)";

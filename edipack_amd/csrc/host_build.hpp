@@ -133,5 +133,6 @@ edigpu_model imag_part_model(const edigpu_model& m, bool& any);
 bool eph_offdiagonal(const edigpu_model& m);
 edigpu_model eph_operator_model(const edigpu_model& m);
 std::string sector_dim(const edigpu_model& m, int q1, int q2, int64_t& dim);
+std::string sector_map(const edigpu_model& m, int q1, int q2, int which, std::vector<int32_t>& out);
 
 }  // namespace edigpu

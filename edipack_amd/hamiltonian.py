@@ -64,6 +64,12 @@ class ImpurityModel:
     w0_ph: float = 0.0
     a_ph: float = 0.0
     g_ph: np.ndarray | None = None
+    # normal mode only: spin_field[iorb, xyz] (SPIN_FIELD_X/Y/Z; z is read), exc_field[4] (EXC_FIELD; (1), (4) are
+    # read), coulomb_sundry lines as (U, (orb_i, spin_i), (orb_j, spin_j), (orb_k, spin_k), (orb_l, spin_l)) for
+    # U cd_i cd_j c_k c_l with 0-based orbitals and spin 0 up / 1 down (ED_NORMAL/stored/H_sundry.f90)
+    spin_field: np.ndarray | None = None
+    exc_field: np.ndarray | None = None
+    sundry: list | None = None
 
     @property
     def ns(self) -> int:
@@ -102,6 +108,20 @@ class ImpurityModel:
         if self.g_ph is not None:
             np.ctypeslib.as_array(m.g_ph).reshape(capi.MAXORB, capi.MAXORB)[:no, :no] = \
                 np.asarray(self.g_ph, dtype=float).reshape(no, no)
+        if self.spin_field is not None:
+            np.ctypeslib.as_array(m.spin_field).reshape(capi.MAXORB, 3)[:no, :] = \
+                np.asarray(self.spin_field, dtype=float).reshape(no, 3)
+        if self.exc_field is not None:
+            np.ctypeslib.as_array(m.exc_field)[:] = np.asarray(self.exc_field, dtype=float).reshape(4)
+        if self.sundry:
+            if len(self.sundry) > capi.MAXSUNDRY:
+                raise capi.EdigpuError("ImpurityModel: more than EDIGPU_MAXSUNDRY coulomb_sundry lines")
+            m.nsundry = len(self.sundry)
+            for il, (u, *ops) in enumerate(self.sundry):
+                m.sundry_u[il] = float(u)
+                for k, (orb, spin) in enumerate(ops):
+                    m.sundry_op[il * 8 + 2 * k] = int(orb) + 1
+                    m.sundry_op[il * 8 + 2 * k + 1] = int(spin) + 1
         if self.bath_type in ("replica", "general"):
             if self.hb is None or self.bv is None:
                 raise capi.EdigpuError("ImpurityModel: replica/general baths need hb and bv")
@@ -118,6 +138,17 @@ class ImpurityModel:
             np.ctypeslib.as_array(getattr(m, name)).reshape(2, capi.MAXORB, capi.MAXBATH)[
                 : a.shape[0], : a.shape[1], : a.shape[2]] = a
         return m
+
+
+def sector_map(model: "ImpurityModel", q1: int, q2: int = 0, which: int = 0) -> np.ndarray:
+    """build_sector's map (ED_SECTOR.f90:165-373) as int32: normal mode -> up (which=0) / down (which=1) map of the
+    sector (q1, q2) = (Nup, Ndw); superc / nonsu2 -> the map of sector q1."""
+    cm = model.to_c()
+    n = C.c_int64(0)
+    capi.check(capi.lib().edigpu_sector_map(C.byref(cm), q1, q2, which, None, C.byref(n)), "edigpu_sector_map")
+    out = np.zeros(n.value, np.int32)
+    capi.check(capi.lib().edigpu_sector_map(C.byref(cm), q1, q2, which, capi.pi32(out), C.byref(n)), "edigpu_sector_map")
+    return out
 
 
 def _csr_args(rowptr, col, val, cplx=False):

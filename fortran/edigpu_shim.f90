@@ -22,7 +22,7 @@ module EDIGPU_SHIM
   type(c_ptr), save :: gpu_sector = c_null_ptr   !< the live edigpu_handle
   type(c_ptr), save :: gpu_comm = c_null_ptr     !< the live edigpu_comm (MpiComm's counterpart; N > 1 only)
 
-  integer, parameter, public :: EDIGPU_MAXORB = 5, EDIGPU_MAXBATH = 16
+  integer, parameter, public :: EDIGPU_MAXORB = 5, EDIGPU_MAXBATH = 16, EDIGPU_MAXSUNDRY = 64
   !> breakdown threshold of the tridiagonalisation (sp_lanc_tridiag is called without one: SciFortran's default)
   real(c_double), public :: lanc_threshold = 1.0e-12_c_double
 
@@ -51,6 +51,13 @@ module EDIGPU_SHIM
      integer(c_int32_t) :: pad_ = 0
      real(c_double) :: w0_ph = 0d0, a_ph = 0d0
      real(c_double) :: g_ph(EDIGPU_MAXORB, EDIGPU_MAXORB) = 0d0   !< g_ph(jorb,iorb) = C [iorb][jorb]
+     real(c_double) :: spin_field(3, EDIGPU_MAXORB) = 0d0         !< spin_field(xyz,iorb) = transpose(spin_field)
+     real(c_double) :: exc_field(4) = 0d0
+     integer(c_int32_t) :: nsundry = 0      !< size(coulomb_sundry)
+     integer(c_int32_t) :: pad2_ = 0
+     !> sundry_op(:,l) = [cd_i(1:2), cd_j(1:2), c_k(1:2), c_l(1:2)] of coulomb_sundry(l) (orbital, spin; 1-based)
+     integer(c_int32_t) :: sundry_op(8, EDIGPU_MAXSUNDRY) = 0
+     real(c_double) :: sundry_u(EDIGPU_MAXSUNDRY) = 0d0           !< coulomb_sundry(l)%U
   end type edigpu_model_t
 
   interface
@@ -58,6 +65,10 @@ module EDIGPU_SHIM
        import :: c_ptr
        type(c_ptr) :: msg
      end function edigpu_last_error
+     function edigpu_model_sizeof() bind(C, name="edigpu_model_sizeof") result(n)
+       import :: c_int64_t
+       integer(c_int64_t) :: n
+     end function edigpu_model_sizeof
      function edigpu_init(device) bind(C, name="edigpu_init") result(ierr)
        import :: c_int
        integer(c_int), value :: device
@@ -355,6 +366,12 @@ contains
   !> once per rank, e.g. from ed_solve (ED_MAIN.f90:164): device = local MPI rank
   subroutine gpu_init(device)
     integer, intent(in) :: device
+    type(edigpu_model_t) :: probe
+    ! the Fortran mirror of struct edigpu_model must be the library's (include/edigpu.h)
+    if (int(c_sizeof(probe), c_int64_t) /= edigpu_model_sizeof()) then
+       write(0, *) "edigpu_shim: edigpu_model_t has ", c_sizeof(probe), " bytes, libedigpu expects ", edigpu_model_sizeof()
+       stop 2
+    end if
     call gpu_check(edigpu_init(int(device, c_int)), "gpu_init")
   end subroutine gpu_init
 

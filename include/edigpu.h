@@ -39,6 +39,7 @@ extern "C" {
 #endif
 
 #define EDIGPU_MAXORB 5
+#define EDIGPU_MAXSUNDRY 64
 #define EDIGPU_MAXBATH 16
 
 typedef struct edigpu_sector *edigpu_handle;
@@ -48,6 +49,9 @@ typedef struct edigpu_sector *edigpu_handle;
 /* ----------------------------------------------------------------------- */
 const char *edigpu_last_error(void);
 int edigpu_version(void);
+/* sizeof(edigpu_model) as this library was compiled: a binding checks its own mirror of the struct against it
+ * (ctypes: sizeof(EdigpuModel); Fortran: c_sizeof(edigpu_model_t)) before the first build call. */
+int64_t edigpu_model_sizeof(void);
 /* number of visible HIP devices (0 and an error if the runtime is unusable) */
 int edigpu_device_count(int *count);
 /* select the device used by handles created afterwards from this thread
@@ -140,6 +144,21 @@ typedef struct edigpu_model {
   int32_t pad_;
   double w0_ph, a_ph;
   double g_ph[EDIGPU_MAXORB * EDIGPU_MAXORB];
+  /* Normal mode only (the flat builders refuse a model that sets them):
+   * spin_field[iorb][x,y,z] (ED_INPUT_VARS.f90 SPIN_FIELD_X/Y/Z): the z component enters H_local as
+   *   sum_a spin_field(a,3) (n_a,up - n_a,dw)  (ED_NORMAL/stored/H_local.f90:38-42); x, y are not read in this mode;
+   * exc_field[4] (EXC_FIELD): (1) and (4) add (exc(1) +/- exc(4)) c+_a,s c_b,s, a != b, + for up / - for down
+   *   (ED_NORMAL/stored/H_up.f90:87-104, H_dw.f90); (2), (3) are not read in this mode;
+   * coulomb_sundry (ED_VARS_GLOBAL.f90 coulomb_sundry(:), read from the umatrix file): nsundry lines
+   *   sundry_u[l] cd_i cd_j c_k c_l with sundry_op[l][8] = (orb_i, spin_i, orb_j, spin_j, orb_k, spin_k, orb_l,
+   *   spin_l), orbitals 1-based, spin 1 = up / 2 = down, applied right to left as c_l, cd_j, c_k, cd_i on the word of
+   *   their spin (ED_NORMAL/stored/H_sundry.f90:1-111).  Lines that change N_up or N_dw are refused. */
+  double spin_field[EDIGPU_MAXORB * 3];
+  double exc_field[4];
+  int32_t nsundry;
+  int32_t pad2_;
+  int32_t sundry_op[EDIGPU_MAXSUNDRY * 8];
+  double sundry_u[EDIGPU_MAXSUNDRY];
 } edigpu_model;
 
 /* normal mode sector (N_up, N_dw); the shard owns down-indices [dw_first, dw_first+dw_count)
@@ -195,6 +214,12 @@ int edigpu_orbs_create(edigpu_handle *h, int naxes, const int64_t *dims, const d
 
 /* sector dimensions (get_normal/superc/nonsu2_sector_dimension, ED_SETUP.f90:998-1033) */
 int edigpu_sector_dim(const edigpu_model *model, int q1, int q2, int64_t *dim);
+
+/* The sector map build_sector leaves in Hsector%H(k)%map (ED_SECTOR.f90:165-373), bit-exact: normal mode (q1, q2) =
+ * (Nup, Ndw), which = 0 the up map (DimUp ascending integers with Nup bits set), 1 the down map; superc (q1 = Sz) /
+ * nonsu2 (q1 = Ntot): the one map of states iup + idw 2^Ns (idw outer, iup inner), q2 and which ignored.  Host-only
+ * (no device needed).  *n: in = capacity of map (ignored when map == NULL), out = number of states. */
+int edigpu_sector_map(const edigpu_model *model, int q1, int q2, int which, int32_t *map, int64_t *n);
 
 /* ----------------------------------------------------------------------- */
 /* queries                                                                    */

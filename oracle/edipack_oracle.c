@@ -388,7 +388,8 @@ orc_hnormal *orc_buildh_normal_main(const orc_model *m, int nup_tot, int ndw_tot
   orc_build_sector_normal(ns, nup_tot, ndw_tot, h->mapup, h->mapdw);
   int64_t DimUp = h->dimup;
   h->hd = xcalloc(h->dim, sizeof(double));
-  h->has_nd = nonloc_condition(m);
+  /* either_condition = nonloc_condition .OR. sundry_condition (ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:56-58) */
+  h->has_nd = nonloc_condition(m) || m->nsundry > 0;
 
   int any_sfz = 0;
   for (int io = 0; io < norb; io++)
@@ -494,6 +495,34 @@ orc_hnormal *orc_buildh_normal_main(const orc_model *m, int nup_tot, int ndw_tot
               int64_t j = jup + (jdw - 1) * DimUp;
               coo_push(&coo, i - 1, j - 1, htmp, 0.0);
             }
+    }
+    /* ---- stored/H_sundry.f90:1-111: generic two-body terms U cd_i cd_j c_k c_l, applied right to left as
+     * c_l, cd_j, c_k, cd_i on the up / down word of their spin (no cross-spin sign) ---- */
+    for (int64_t i = 1; m->nsundry > 0 && i <= h->dim; i++) {
+      int64_t iup = i % DimUp;
+      if (iup == 0) iup = DimUp;
+      int64_t idw = (i - 1) / DimUp + 1;
+      int32_t mup = h->mapup[iup - 1], mdw = h->mapdw[idw - 1];
+      for (int il = 0; il < m->nsundry; il++) {
+        const int *op = m->sundry_op[il];
+        const int orbvec_dag[2] = {op[0], op[2]}, spinvec_dag[2] = {op[1], op[3]};
+        const int orbvec[2] = {op[4], op[6]}, spinvec[2] = {op[5], op[7]};
+        int32_t pu = mup, pd = mdw, t;
+        double sg[4];
+        int err; /* orc_c / orc_cdg: non-zero = the operator annihilates the state (the reference's ierr / Jcondition) */
+        /* last annihilation, last creation, first annihilation, first creation */
+        if (spinvec[1] == 1) { err = orc_c(orbvec[1], pu, &t, &sg[0]); pu = t; } else { err = orc_c(orbvec[1], pd, &t, &sg[0]); pd = t; }
+        if (err) continue;
+        if (spinvec_dag[1] == 1) { err = orc_cdg(orbvec_dag[1], pu, &t, &sg[1]); pu = t; } else { err = orc_cdg(orbvec_dag[1], pd, &t, &sg[1]); pd = t; }
+        if (err) continue;
+        if (spinvec[0] == 1) { err = orc_c(orbvec[0], pu, &t, &sg[2]); pu = t; } else { err = orc_c(orbvec[0], pd, &t, &sg[2]); pd = t; }
+        if (err) continue;
+        if (spinvec_dag[0] == 1) { err = orc_cdg(orbvec_dag[0], pu, &t, &sg[3]); pu = t; } else { err = orc_cdg(orbvec_dag[0], pd, &t, &sg[3]); pd = t; }
+        if (err) continue;
+        int64_t jdw = orc_binary_search(h->mapdw, h->dimdw, pd), jup = orc_binary_search(h->mapup, h->dimup, pu);
+        if (jup == 0 || jdw == 0) continue; /* the reference STOPs ("impossible operator"): a spin-changing line */
+        coo_push(&coo, i - 1, jup + (jdw - 1) * DimUp - 1, m->sundry_u[il] * sg[0] * sg[1] * sg[2] * sg[3], 0.0);
+      }
     }
     coo_to_csr(&coo, h->dim, h->dim, &h->nd);
     coo_free(&coo);

@@ -29,6 +29,7 @@ extern "C" {
 
 /* Model parameters: the module-global state of the reference that the
  * Hamiltonian builders read (ED_INPUT_VARS / ED_VARS_GLOBAL / dmft_bath). */
+#define ORC_MAXSUNDRY 64
 typedef struct {
   int ed_mode;   /* 0 normal, 1 superc, 2 nonsu2                (ED_INPUT_VARS ED_MODE)   */
   int bath_type; /* 0 normal, 1 hybrid, 2 replica, 3 general    (ED_INPUT_VARS BATH_TYPE) */
@@ -65,6 +66,11 @@ typedef struct {
   int nph;
   double w0_ph, a_ph;
   double g_ph[ORC_MAXORB][ORC_MAXORB];
+  /* coulomb_sundry(:) (ED_VARS_GLOBAL.f90:299, filled by ED_PARSE_UMATRIX): U cd_i cd_j c_k c_l, per line
+   * [cd_i orb, cd_i spin, cd_j orb, cd_j spin, c_k orb, c_k spin, c_l orb, c_l spin], orbitals 1-based, spin 1 up / 2 down */
+  int nsundry;
+  int sundry_op[ORC_MAXSUNDRY][8];
+  double sundry_u[ORC_MAXSUNDRY];
 } orc_model;
 
 /* CSR matrix in the reference's row order (insertion order inside a row,

@@ -46,6 +46,9 @@ def build(force: bool = False) -> str:
 _D = C.c_double
 
 
+MAXSUNDRY = 64
+
+
 class OrcModel(C.Structure):
     _fields_ = [
         ("ed_mode", C.c_int), ("bath_type", C.c_int),
@@ -77,6 +80,9 @@ class OrcModel(C.Structure):
         ("nph", C.c_int),
         ("w0_ph", _D), ("a_ph", _D),
         ("g_ph", (_D * MAXORB) * MAXORB),
+        ("nsundry", C.c_int),
+        ("sundry_op", (C.c_int * 8) * MAXSUNDRY),
+        ("sundry_u", _D * MAXSUNDRY),
     ]
 
 
@@ -122,6 +128,12 @@ class Model:
     w0_ph: float = 0.0
     a_ph: float = 0.0
     g_ph: np.ndarray | None = None
+    # spin_field[iorb, xyz] (SPIN_FIELD_X/Y/Z), exc_field[4] (EXC_FIELD), coulomb_sundry: list of
+    # (U, (orb_i, spin_i), (orb_j, spin_j), (orb_k, spin_k), (orb_l, spin_l)) for U cd_i cd_j c_k c_l, 0-based orbitals,
+    # spin 0 up / 1 down
+    spin_field: np.ndarray | None = None
+    exc_field: np.ndarray | None = None
+    sundry: list | None = None
 
     @property
     def ns(self) -> int:
@@ -168,6 +180,18 @@ def to_struct(m: Model) -> OrcModel:
     if m.g_ph is not None:
         _np_view(s, "g_ph")[:no, :no] = np.asarray(m.g_ph, dtype=float).reshape(no, no)
     assert no <= MAXORB and m.nbath <= MAXBATH
+    if m.spin_field is not None:
+        _np_view(s, "spin_field")[:no, :] = np.asarray(m.spin_field, dtype=float).reshape(no, 3)
+    if m.exc_field is not None:
+        _np_view(s, "exc_field")[:] = np.asarray(m.exc_field, dtype=float)
+    if m.sundry:
+        assert len(m.sundry) <= MAXSUNDRY
+        s.nsundry = len(m.sundry)
+        for il, (u, *ops) in enumerate(m.sundry):
+            s.sundry_u[il] = float(u)
+            for k, (orb, spin) in enumerate(ops):
+                s.sundry_op[il][2 * k] = int(orb) + 1
+                s.sundry_op[il][2 * k + 1] = int(spin) + 1
     _np_view(s, "uloc")[:no] = np.asarray(m.uloc, dtype=float)[:no]
     # ED_PARSE_UMATRIX.f90:136-142 (ed_use_kanamori): off-diagonal constants
     off = 1.0 - np.eye(no)

@@ -1,0 +1,72 @@
+// Test-only C shim over the host builders of libedigpu (csrc/host_build.cpp): dense images of a normal-mode sector
+// from (a) the explicit arrays (hd, Hup, Hdw, Hnd CSR) and (b) the factored tables the kernels consume (eux / ed /
+// impd, partner tables jup / jdw / coef), so that the CPU suite can compare the builders with the oracle without a
+// GPU.  Compiled with g++ by tests/test_host_builders.py; never part of the product.
+#include <cstring>
+#include <string>
+#include <vector>
+#include "host_build.hpp"
+using namespace edigpu;
+
+static std::string g_err;
+
+extern "C" const char* host_image_error() { return g_err.c_str(); }
+
+// out: dim x dim row-major, zeroed here.  form 0 = explicit arrays, 1 = factored tables.
+extern "C" int host_normal_dense(const edigpu_model* m, int nup, int ndw, int form, double* out, int64_t dim) {
+  HostNormal hn;
+  g_err = build_normal(*m, nup, ndw, 0, -1, hn, form == 0);
+  if (!g_err.empty()) return 1;
+  const int64_t du = hn.dim_up, dd = hn.dim_dw;
+  if (du * dd != dim) { g_err = "host_normal_dense: dim mismatch"; return 2; }
+  std::memset(out, 0, sizeof(double) * dim * dim);
+  auto at = [&](int64_t i, int64_t j) -> double& { return out[i * dim + j]; };
+  for (int64_t idw = 0; idw < dd; idw++)
+    for (int64_t iup = 0; iup < du; iup++) {
+      const int64_t i = iup + idw * du;
+      if (form == 0) at(i, i) += hn.hd[i];
+      else at(i, i) += hn.fac.eux[(size_t)hn.fac.impd[idw] * du + iup] + hn.fac.ed[idw];
+      for (int64_t k = hn.up.rowptr[iup]; k < hn.up.rowptr[iup + 1]; k++) at(i, hn.up.col[k] + idw * du) += hn.up.val[k];
+      for (int64_t k = hn.dw.rowptr[idw]; k < hn.dw.rowptr[idw + 1]; k++) at(i, iup + hn.dw.col[k] * du) += hn.dw.val[k];
+      if (!hn.has_nd) continue;
+      if (form == 0) {
+        for (int64_t k = hn.nd.rowptr[i]; k < hn.nd.rowptr[i + 1]; k++) at(i, hn.nd.col[k]) += hn.nd.val[k];
+      } else {
+        for (int t = 0; t < hn.fac.nterms; t++) {
+          const uint32_t pu = hn.fac.jup[(size_t)t * du + iup], pd = hn.fac.jdw[(size_t)t * dd + idw];
+          if (pu == 0xFFFFFFFFu || pd == 0xFFFFFFFFu) continue;
+          const double sg = ((pu ^ pd) & 0x80000000u) ? -1.0 : 1.0;
+          at(i, (int64_t)(pu & 0x7FFFFFFFu) + (int64_t)(pd & 0x7FFFFFFFu) * du) += sg * hn.fac.coef[t];
+        }
+      }
+    }
+  if (form == 1 && hn.has_nd) {
+    int64_t n = 0;
+    for (int64_t i = 0; i < dim; i++)
+      for (int t = 0; t < hn.fac.nterms; t++)
+        n += hn.fac.jup[(size_t)t * du + i % du] != 0xFFFFFFFFu && hn.fac.jdw[(size_t)t * dd + i / du] != 0xFFFFFFFFu;
+    if (n != hn.nd_nnz) { g_err = "host_normal_dense: nd_nnz disagrees with the factored tables"; return 3; }
+  }
+  return 0;
+}
+
+// dense image of a superc / nonsu2 sector from the stored CSR (re, im interleaved), or the refusal message
+extern "C" int host_flat_dense(const edigpu_model* m, int sector, double* out, int64_t dim) {
+  HostFlat hf;
+  g_err = build_flat(*m, sector, 0, -1, hf);
+  if (!g_err.empty()) return 1;
+  if (hf.dim != dim) { g_err = "host_flat_dense: dim mismatch"; return 2; }
+  std::memset(out, 0, sizeof(double) * 2 * dim * dim);
+  for (int64_t i = 0; i < dim; i++)
+    for (int64_t k = hf.h.rowptr[i]; k < hf.h.rowptr[i + 1]; k++) {
+      out[2 * (i * dim + hf.h.col[k])] += hf.h.val[2 * k];
+      out[2 * (i * dim + hf.h.col[k]) + 1] += hf.h.val[2 * k + 1];
+    }
+  return 0;
+}
+
+extern "C" int host_direct_refuses(const edigpu_model* m, int sector) {
+  HostDirect hd;
+  g_err = build_direct(*m, sector, 0, -1, hd);
+  return g_err.empty() ? 0 : 1;
+}

@@ -28,9 +28,11 @@ def test_library_exports_every_declared_symbol(built):
 
 def test_model_struct_layout_matches_header(built):
     """sizeof(edigpu_model) computed from the header's array extents == ctypes layout."""
-    mo, mb = capi.MAXORB, capi.MAXBATH
+    mo, mb, ms = capi.MAXORB, capi.MAXBATH, capi.MAXSUNDRY
     n_int, n_dbl = 6, 1 + mo + 4 * mo * mo + 2 * 2 * mo * mo * 2 + mo + 4 * 2 * mo * mb + 2 * 2 * mo * mo * mb * 2 + 1 + 2 + mo * mo
+    n_int, n_dbl = n_int + 2 + 8 * ms, n_dbl + 3 * mo + 4 + ms      # spin_field, exc_field, coulomb_sundry
     assert C.sizeof(capi.EdigpuModel) == n_int * 4 + n_dbl * 8
+    assert C.sizeof(capi.EdigpuModel) == capi.lib().edigpu_model_sizeof()
 
 
 def test_error_reporting_without_compute(built):
@@ -61,3 +63,23 @@ def test_product_does_not_import_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
                 assert "edipack_oracle" not in txt, f
+
+
+def test_sector_maps_are_bit_exact(built):
+    """Index data bit-exact: the library's sector maps against the oracle's restatement of
+    build_sector (ED_SECTOR.f90:165-373) for every sector of small normal / superc / nonsu2 models.  Host-only."""
+    import numpy as np
+    from edipack_amd.hamiltonian import sector_map
+    from oracle import oracle as O
+    from tests.common import make_models
+    for mode, bath, norb, nbath in (("normal", "normal", 2, 2), ("normal", "hybrid", 3, 4), ("superc", "hybrid", 2, 3),
+                                    ("nonsu2", "normal", 1, 4)):
+        om, pm = make_models(mode, bath, norb, nbath, seed=1)
+        for sec in O.sectors(om):
+            if mode == "normal":
+                ho = O.HNormal(om, *sec)
+                assert np.array_equal(sector_map(pm, sec[0], sec[1], 0), ho.mapup.astype(np.int32))
+                assert np.array_equal(sector_map(pm, sec[0], sec[1], 1), ho.mapdw.astype(np.int32))
+            else:
+                ho = O.HFlat(om, sec)
+                assert np.array_equal(sector_map(pm, sec), ho.map.astype(np.int32)), (mode, sec)

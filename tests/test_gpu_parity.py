@@ -1643,3 +1643,94 @@ def test_orbs_row_shards(gpu, norb, nbath, nups, ndws, nshard):
     assert rel_err(np.concatenate(out), ref) < TOL
     with pytest.raises(RuntimeError, match="row range"):
         SectorHamiltonian.orbs_from_model(pm, nups, ndws, row_first=ho.dim - 1, row_count=5)
+
+
+# --------------------------------------------------------------------------------------------
+# terms of ED_NORMAL/stored/ that only some inputs switch on: coulomb_sundry (H_sundry.f90), spin_field z
+# (H_local.f90:38-42), exc_field(1),(4) (H_up.f90:87-104, H_dw.f90)
+# --------------------------------------------------------------------------------------------
+_SUNDRY3 = [
+    (0.40, (0, 0), (1, 1), (2, 1), (1, 0)), (0.40, (1, 0), (2, 1), (1, 1), (0, 0)),     # mixed-spin correlated hop
+    (0.25, (0, 0), (2, 0), (2, 0), (1, 0)), (0.25, (1, 0), (2, 0), (2, 0), (0, 0)),     # same spin, density assisted
+    (-0.30, (0, 1), (1, 1), (1, 1), (0, 1)),                                            # n_0dw n_1dw (diagonal of Hnd)
+    (0.15, (2, 0), (0, 1), (1, 1), (1, 0)), (0.15, (1, 0), (1, 1), (0, 1), (2, 0)),
+]
+_SUNDRY2 = [(0.35, (0, 0), (1, 1), (0, 1), (1, 0)), (0.35, (1, 0), (0, 1), (1, 1), (0, 0)),
+            (0.2, (0, 0), (0, 1), (0, 1), (0, 0))]
+
+
+@pytest.mark.parametrize("bath,norb,nbath,sec,jxp,extra", [
+    ("hybrid", 3, 3, (3, 3), 0.0, dict(sundry=_SUNDRY3)),                      # 7 factored terms, no Jx / Jp
+    ("hybrid", 3, 2, (2, 3), 0.25, dict(sundry=_SUNDRY3)),                     # 12 + 7 terms > 16: explicit image
+    ("normal", 2, 2, (3, 2), 0.25, dict(sundry=_SUNDRY2)),
+    ("normal", 1, 4, (2, 3), 0.0, dict(sundry=[(0.6, (0, 0), (0, 1), (0, 1), (0, 0))])),   # one orbital: Hnd diagonal only
+    ("normal", 2, 2, (2, 2), 0.25, dict(spin_field=np.array([[0.3, 0.1, 0.2], [0.0, 0.0, -0.15]]))),
+    ("hybrid", 3, 2, (2, 2), 0.25, dict(exc_field=np.array([0.12, 0.5, 0.5, 0.07]))),
+    ("replica", 2, 2, (3, 3), 0.25, dict(exc_field=np.array([0.1, 0.0, 0.0, -0.2]), sundry=_SUNDRY2,
+                                         spin_field=np.array([[0, 0, 0.1], [0, 0, 0.2]]))),
+    ("hybrid", 3, 7, (5, 5), 0.25, dict(sundry=_SUNDRY3[:4], exc_field=np.array([0.05, 0, 0, 0.02]),
+                                        spin_field=np.array([[0, 0, 0.1], [0, 0, -0.1], [0, 0, 0.05]]))),   # Ns=10, 63504
+])
+@pytest.mark.parametrize("explicit", [False, True])
+def test_normal_sundry_and_fields_match_oracle(gpu, monkeypatch, bath, norb, nbath, sec, jxp, extra, explicit):
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    if explicit:
+        monkeypatch.setenv("EDIGPU_NORMAL_EXPLICIT", "1")
+    om, pm = make_models("normal", bath, norb, nbath, seed=33, jxp=jxp, **extra)
+    ho = O.HNormal(om, *sec)
+    hg = SectorHamiltonian.normal_from_model(pm, *sec)
+    rng = np.random.default_rng(77)
+    v = rng.standard_normal(ho.dim)
+    assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
+    if ho.dim <= 4000:
+        hd, up, dw, nd = hg.export_normal()
+        assert rel_err(hd, ho.hd) < 1e-13
+        assert np.allclose(csr_to_dense(*up, ho.dimup), csr_to_dense(*ho.up, ho.dimup), rtol=0, atol=1e-14)
+        assert np.allclose(csr_to_dense(*dw, ho.dimdw), csr_to_dense(*ho.dw, ho.dimdw), rtol=0, atol=1e-14)
+        if ho.has_nd:
+            assert np.allclose(csr_to_dense(*nd, ho.dim), csr_to_dense(*ho.nd, ho.dim), rtol=0, atol=1e-14)
+    ao, bo, _ = ho.lanc_tridiag(v, 20)
+    ag, bg, _ = hg.lanczos_tridiag(v, 20)
+    assert rel_err(ag[:15], ao[:15]) < 1e-9 and rel_err(bg[:15], bo[:15]) < 1e-9
+    hg.destroy()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_normal_sundry_shards(gpu, world):
+    """dw-shards of a sector with coulomb_sundry lines (Hnd partner rows on other shards, diagonal Hnd entries):
+    the all-gather form -- local rows of the full-vector product -- against the oracle."""
+    import torch
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("normal", "hybrid", 3, 3, seed=35, jxp=0.25, sundry=_SUNDRY3[:4])
+    ho = O.HNormal(om, 3, 3)
+    v = np.random.default_rng(5).standard_normal(ho.dim)
+    ref = ho.matvec(v)
+    dd = ho.dimdw
+    q = -(-dd // world)
+    vd = torch.from_numpy(v).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    out = []
+    for r in range(world):
+        first, cnt = min(r * q, dd), max(0, min(q, dd - r * q))
+        h = SectorHamiltonian.normal_from_model(pm, 3, 3, dw_first=first, dw_count=cnt)
+        hv = torch.empty(h.nloc, dtype=torch.float64, device="cuda")
+        h.apply_local_dev(vd[h.row_first:].data_ptr(), hv.data_ptr(), st)
+        h.apply_remote_dev(vd.data_ptr(), hv.data_ptr(), st)
+        torch.cuda.synchronize()
+        out.append(hv.cpu().numpy())
+        h.destroy()
+    got = np.concatenate(out)
+    assert got.shape == ref.shape and rel_err(got, ref) < TOL
+
+
+def test_flat_modes_refuse_normal_only_fields(gpu):
+    from edipack_amd import capi
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    for mode, sec in (("superc", 0), ("nonsu2", 3)):
+        _, pm = make_models(mode, "normal", 2, 1, seed=1, sundry=_SUNDRY2)
+        with pytest.raises(capi.EdigpuError, match="not built in this mode"):
+            SectorHamiltonian.flat_from_model(pm, sec)
+        with pytest.raises(capi.EdigpuError, match="not built in this mode"):
+            SectorHamiltonian.direct_from_model(pm, sec)

@@ -1,0 +1,112 @@
+"""The host builders of libedigpu (csrc/host_build.cpp) against the oracle, on the CPU: the sector images the kernels
+consume (explicit arrays and factored tables) as dense matrices vs the oracle's dense H of the same seeded model.
+Covers the terms of ED_NORMAL/stored/ that only some inputs switch on: coulomb_sundry (H_sundry.f90), spin_field z
+(H_local.f90:38-42), exc_field(1),(4) (H_up.f90:87-104, H_dw.f90).  tests/host_image.cpp is the test-only shim."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from edipack_amd import capi
+from oracle import oracle as O
+from tests.common import make_models
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# U cd_i cd_j c_k c_l lines (0-based orbital, spin 0 up / 1 down), Hermitian-conjugate pairs so that H stays symmetric
+SUNDRY3 = [
+    (0.40, (0, 0), (1, 1), (2, 1), (1, 0)), (0.40, (1, 0), (2, 1), (1, 1), (0, 0)),     # mixed-spin correlated hop
+    (0.25, (0, 0), (2, 0), (2, 0), (1, 0)), (0.25, (1, 0), (2, 0), (2, 0), (0, 0)),     # same-spin, density assisted
+    (-0.30, (0, 1), (1, 1), (1, 1), (0, 1)),                                            # n_0dw n_1dw (diagonal)
+    (0.15, (2, 0), (0, 1), (1, 1), (1, 0)), (0.15, (1, 0), (1, 1), (0, 1), (2, 0)),
+]
+SUNDRY2 = [(0.35, (0, 0), (1, 1), (0, 1), (1, 0)), (0.35, (1, 0), (0, 1), (1, 1), (0, 0)),
+           (0.2, (0, 0), (0, 1), (0, 1), (0, 0))]
+
+
+@pytest.fixture(scope="module")
+def shim(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    so = str(tmp_path_factory.mktemp("host_image") / "host_image.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "edipack_amd", "csrc"), "-o", so,
+                           os.path.join(ROOT, "tests", "host_image.cpp"),
+                           os.path.join(ROOT, "edipack_amd", "csrc", "host_build.cpp")])
+    lib = C.CDLL(so)
+    lib.host_image_error.restype = C.c_char_p
+    return lib
+
+
+def _host_dense(lib, pm, nup, ndw, form, dim):
+    out = np.zeros((dim, dim))
+    m = pm.to_c()
+    rc = lib.host_normal_dense(C.byref(m), nup, ndw, form, out.ctypes.data_as(C.c_void_p), C.c_int64(dim))
+    assert rc == 0, lib.host_image_error().decode()
+    return out
+
+
+CASES = [
+    # bath, norb, nbath, sector, extra
+    ("hybrid", 3, 3, (3, 3), dict(sundry=SUNDRY3)),
+    ("hybrid", 3, 2, (2, 3), dict(sundry=SUNDRY3, jxp=0.0)),
+    ("normal", 2, 2, (3, 2), dict(sundry=SUNDRY2)),
+    ("normal", 2, 2, (2, 2), dict(spin_field=np.array([[0.3, 0.1, 0.2], [0.0, 0.0, -0.15]]))),
+    ("hybrid", 3, 2, (2, 2), dict(exc_field=np.array([0.12, 0.5, 0.5, 0.07]))),
+    ("replica", 2, 2, (3, 3), dict(exc_field=np.array([0.1, 0.0, 0.0, -0.2]), sundry=SUNDRY2,
+                                   spin_field=np.array([[0, 0, 0.1], [0, 0, 0.2]]))),
+    ("normal", 1, 4, (2, 3), dict(sundry=[(0.6, (0, 0), (0, 1), (0, 1), (0, 0))])),
+    ("hybrid", 3, 3, (3, 3), dict()),
+]
+
+
+@pytest.mark.parametrize("bath,norb,nbath,sec,extra", CASES)
+def test_normal_builder_images_equal_oracle(shim, bath, norb, nbath, sec, extra):
+    extra = dict(extra)
+    jxp = extra.pop("jxp", 0.25)
+    om, pm = make_models("normal", bath, norb, nbath, seed=3, jxp=jxp, **extra)
+    h = O.HNormal(om, *sec)
+    ref = h.dense()
+    assert np.abs(ref - ref.T).max() < 1e-14
+    if extra:
+        om0, _ = make_models("normal", bath, norb, nbath, seed=3, jxp=jxp)
+        assert np.abs(ref - O.HNormal(om0, *sec).dense()).max() > 1e-3   # the switch does something
+    for form in (0, 1):
+        got = _host_dense(shim, pm, sec[0], sec[1], form, h.dim)
+        assert np.abs(got - ref).max() < 1e-13, (form, np.abs(got - ref).max())
+
+
+def test_sundry_lines_that_flip_a_spin_are_refused(shim):
+    """H_sundry.f90:24-34 STOPs on a line that changes N_up - N_dw; the builder returns an error."""
+    _, pm = make_models("normal", "normal", 2, 2, seed=1, sundry=[(0.3, (0, 0), (1, 0), (1, 1), (0, 1))])
+    m = pm.to_c()
+    out = np.zeros((36, 36))
+    rc = shim.host_normal_dense(C.byref(m), 2, 2, 0, out.ctypes.data_as(C.c_void_p), C.c_int64(36))
+    assert rc == 1 and "change the total spin" in shim.host_image_error().decode()
+    _, pm = make_models("normal", "normal", 2, 2, seed=1, sundry=[(0.3, (0, 0), (2, 1), (1, 1), (0, 0))])
+    m = pm.to_c()
+    rc = shim.host_normal_dense(C.byref(m), 2, 2, 0, out.ctypes.data_as(C.c_void_p), C.c_int64(36))
+    assert rc == 1 and "out of range" in shim.host_image_error().decode()
+
+
+@pytest.mark.parametrize("mode", ["superc", "nonsu2"])
+def test_flat_builders_refuse_normal_only_fields(shim, mode):
+    """The superc / nonsu2 builders (and the oracle's) do not restate these terms: they must say so, not drop them."""
+    for extra in (dict(sundry=SUNDRY2), dict(spin_field=np.array([[0, 0, 0.1], [0, 0, 0.0]])),
+                  dict(exc_field=np.array([0.1, 0, 0, 0]))):
+        om, pm = make_models(mode, "normal", 2, 1, seed=1, **extra)
+        m = pm.to_c()
+        sec = 0 if mode == "superc" else 4
+        buf = np.zeros(8)
+        assert shim.host_flat_dense(C.byref(m), sec, buf.ctypes.data_as(C.c_void_p), C.c_int64(1)) == 1
+        assert "not built in this mode" in shim.host_image_error().decode()
+        assert shim.host_direct_refuses(C.byref(m), sec) == 1
+        with pytest.raises(Exception):
+            O.HFlat(om, sec)
+
+
+def test_model_struct_sizes_agree(shim):
+    assert C.sizeof(capi.EdigpuModel) == capi.lib().edigpu_model_sizeof()
