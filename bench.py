@@ -151,7 +151,7 @@ def run_single(args):
     w = WORKLOADS[args.workload]
     capi.init(0)
     t0 = time.perf_counter()
-    h = build_workload(w)
+    h = build_workload(w, handover=args.image == "handover")
     t_build = time.perf_counter() - t0
     bytes_hv, bytes_step = h.algorithmic_bytes()
     ms_step, ms_hv = h.lanczos_bench(args.warmup, args.steps)
@@ -167,6 +167,8 @@ def run_single(args):
         "config": {"workload": f"{w.name}: {w.ed_mode} mode, bath={w.bath_type}, Norb={w.norb}, Nbath={w.nbath}, "
                                f"sector={w.sector}, Dim={h.dim} ({w.note})",
                    "storage": {0: "Kronecker (Hd,Hup,Hdw,Hnd)", 1: "flat CSR", 2: "direct (on-the-fly)"}[h.kind],
+                   "image": args.image + (" (factored=%d, Hnd terms=%d, classes=%d, panel=%d)" % h.image_info()
+                                          if h.kind == 0 else ""),
                    "parallelism": "1 GPU, device-resident Lanczos", "build_s": round(t_build, 3),
                    "hv_only_ms": ms_hv_only, "lanczos_step_GBs": bytes_step / (ms_step * 1e-3) / 1e9},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -283,6 +285,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--image", choices=["library", "handover"], default="library",
+                    help="normal mode: sector built by the library from the model (default) or created from the "
+                         "reference's explicit arrays through edigpu_normal_create (the INTEGRATION.md section 2 patch)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-resident", action="store_true", help="skip the HBM-resident (Ns=16 ladder) H*v measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)

@@ -67,6 +67,7 @@ _pint = C.POINTER(C.c_int)
 SIGNATURES = {
     "edigpu_last_error": (C.c_char_p, []),
     "edigpu_version": (C.c_int, []),
+    "edigpu_image_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "edigpu_model_sizeof": (C.c_int64, []),
     "edigpu_device_count": (C.c_int, [_pint]),
     "edigpu_init": (C.c_int, [C.c_int]),

@@ -1103,8 +1103,30 @@ int edigpu_normal_create(edigpu_handle* h, int64_t dim_up, int64_t dim_dw, int64
   dw.rowptr.assign(dw_rowptr, dw_rowptr + dim_dw + 1);
   dw.col.assign(dw_col, dw_col + dw_rowptr[dim_dw]);
   dw.val.assign(dw_val, dw_val + dw_rowptr[dim_dw]);
+  // The arrays of an impurity model have the structure the library's own builder emits (separable diagonal, Hnd a short
+  // sum of signed partial permutations): recover it and run the factored kernels; anything else keeps the explicit
+  // image.  EDIGPU_HANDOVER_FACTOR=0 (or EDIGPU_NORMAL_EXPLICIT=1) switches the attempt off.
+  HostNormal hn;
+  bool fact = false;
+  {
+    const char* e = getenv("EDIGPU_HANDOVER_FACTOR");
+    if (!(e && atoi(e) == 0) && !env_flag("EDIGPU_NORMAL_EXPLICIT"))
+      fact = factor_handover(dim_up, dim_dw, dw_first, dw_count, hd, nd_rowptr, nd_col, nd_val, 16, hn.fac);
+    if (fact) {  // the arrays as given stay on the host for edigpu_normal_export
+      const int64_t nloc = dim_up * dw_count;
+      hn.hd.assign(hd, hd + nloc);
+      if (nd_rowptr && nd_rowptr[nloc] > 0) {
+        hn.nd.nrow = nloc;
+        hn.nd.ncol = dim_up * dim_dw;
+        hn.nd.rowptr.assign(nd_rowptr, nd_rowptr + nloc + 1);
+        hn.nd.col.assign(nd_col, nd_col + nd_rowptr[nloc]);
+        hn.nd.val.assign(nd_val, nd_val + nd_rowptr[nloc]);
+      }
+    }
+  }
   std::unique_ptr<edigpu_sector> s(new edigpu_sector());
-  if (setup_normal(s.get(), dim_up, dim_dw, dw_first, dw_count, hd, up, dw, nd_rowptr, nd_col, nd_val)) {
+  if (setup_normal(s.get(), dim_up, dim_dw, dw_first, dw_count, hd, up, dw, nd_rowptr, nd_col, nd_val,
+                   fact ? &hn : nullptr)) {
     edigpu_destroy(s.release());
     return 1;
   }
@@ -1576,6 +1598,18 @@ int edigpu_sector_map(const edigpu_model* model, int q1, int q2, int which, int3
     std::copy(st.begin(), st.end(), map);
   }
   *n = (int64_t)st.size();
+  return 0;
+}
+
+int edigpu_image_info(edigpu_handle s, int32_t image[4]) {
+  if (!s || !image || s->kind != 0) {
+    set_error("edigpu_image_info: not a normal-mode handle");
+    return 1;
+  }
+  image[0] = s->factored;
+  image[1] = s->factored ? s->fac_nterms : 0;
+  image[2] = s->factored ? s->fac_nimp : 0;
+  image[3] = s->panel_mode;
   return 0;
 }
 

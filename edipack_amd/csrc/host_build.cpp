@@ -4,7 +4,9 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 
 namespace edigpu {
 
@@ -281,6 +283,86 @@ std::string sector_dim(const edigpu_model& m, int q1, int q2, int64_t& dim) {
   }
 }
 
+
+// Regroup the factored Hnd terms: sum_t c_t (Pdw_t (x) Pup_t) with equal coefficients and pairwise disjoint supports
+// collapses, wherever the terms form a full product set A x B of up-maps and down-maps, into one term
+// (U_{a in A} Pup_a) (x) (U_{b in B} Pdw_b).  With Jx = Jp the four terms of an orbital pair {a, b} (exchange and pair
+// hopping, both directions) are such a set: 12 terms of a 3-orbital model become 3.  Every matrix element is produced
+// by exactly one (term, row) as before, so the product is unchanged; the kernels do a quarter of the partner look-ups.
+static void merge_factored_terms(HostFactored& fac, int64_t du, int64_t dd) {
+  const int nt = fac.nterms;
+  if (nt < 2) return;
+  auto dedupe = [&](const std::vector<uint32_t>& tab, int64_t n, std::vector<int>& id, std::vector<int>& rep) {
+    id.assign(nt, -1);
+    for (int t = 0; t < nt; t++) {
+      for (size_t r = 0; r < rep.size() && id[t] < 0; r++)
+        if (std::equal(tab.begin() + (size_t)t * n, tab.begin() + (size_t)(t + 1) * n, tab.begin() + (size_t)rep[r] * n))
+          id[t] = (int)r;
+      if (id[t] < 0) {
+        id[t] = (int)rep.size();
+        rep.push_back(t);
+      }
+    }
+  };
+  std::vector<int> uid, did, urep, drep;
+  dedupe(fac.jup, du, uid, urep);
+  dedupe(fac.jdw, dd, did, drep);
+  const int nu = (int)urep.size(), nd = (int)drep.size();
+  std::vector<double> c((size_t)nu * nd, 0.0);
+  std::vector<char> has((size_t)nu * nd, 0);
+  for (int t = 0; t < nt; t++) {
+    c[(size_t)uid[t] * nd + did[t]] += fac.coef[t];
+    has[(size_t)uid[t] * nd + did[t]] = 1;
+  }
+  auto disjoint = [](const std::vector<uint32_t>& tab, int64_t n, int a, int b) {
+    for (int64_t i = 0; i < n; i++)
+      if (tab[(size_t)a * n + i] != 0xFFFFFFFFu && tab[(size_t)b * n + i] != 0xFFFFFFFFu) return false;
+    return true;
+  };
+  std::vector<double> coef;
+  std::vector<uint32_t> jup, jdw;
+  int nout = 0;
+  for (int u0 = 0; u0 < nu; u0++)
+    for (int d0 = 0; d0 < nd; d0++) {
+      if (!has[(size_t)u0 * nd + d0]) continue;
+      const double cc = c[(size_t)u0 * nd + d0];
+      std::vector<int> A{u0}, B{d0};
+      for (bool grew = true; grew;) {
+        grew = false;
+        for (int u = 0; u < nu; u++) {
+          if (std::find(A.begin(), A.end(), u) != A.end()) continue;
+          bool ok = true;
+          for (int d : B) ok = ok && has[(size_t)u * nd + d] && c[(size_t)u * nd + d] == cc;
+          for (int a : A) ok = ok && disjoint(fac.jup, du, urep[u], urep[a]);
+          if (ok) A.push_back(u), grew = true;
+        }
+        for (int d = 0; d < nd; d++) {
+          if (std::find(B.begin(), B.end(), d) != B.end()) continue;
+          bool ok = true;
+          for (int u : A) ok = ok && has[(size_t)u * nd + d] && c[(size_t)u * nd + d] == cc;
+          for (int b : B) ok = ok && disjoint(fac.jdw, dd, drep[d], drep[b]);
+          if (ok) B.push_back(d), grew = true;
+        }
+      }
+      for (int u : A)
+        for (int d : B) has[(size_t)u * nd + d] = 0;
+      coef.push_back(cc);
+      jup.resize((size_t)(nout + 1) * du, 0xFFFFFFFFu);
+      jdw.resize((size_t)(nout + 1) * dd, 0xFFFFFFFFu);
+      for (int u : A)
+        for (int64_t i = 0; i < du; i++)
+          if (fac.jup[(size_t)urep[u] * du + i] != 0xFFFFFFFFu) jup[(size_t)nout * du + i] = fac.jup[(size_t)urep[u] * du + i];
+      for (int d : B)
+        for (int64_t i = 0; i < dd; i++)
+          if (fac.jdw[(size_t)drep[d] * dd + i] != 0xFFFFFFFFu) jdw[(size_t)nout * dd + i] = fac.jdw[(size_t)drep[d] * dd + i];
+      nout++;
+    }
+  fac.nterms = nout;
+  fac.coef.swap(coef);
+  fac.jup.swap(jup);
+  fac.jdw.swap(jdw);
+}
+
 std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_first,
                          int64_t dw_count, HostNormal& out, bool explicit_arrays) {
   std::string e = check_model(m);
@@ -469,6 +551,7 @@ std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_fir
       partner_ops(out.bdw, sl.dw, fac.jdw);
       fac.nterms++;
     }
+    if (!getenv("EDIGPU_ND_NO_MERGE")) merge_factored_terms(fac, DimUp, out.dim_dw);
     struct Term { uint32_t xu, xd; double val; };
     std::vector<std::vector<Term>> terms((size_t)1 << (2 * norb));
     for (uint32_t iu = 0; iu <= impmask; iu++)
@@ -1041,6 +1124,208 @@ std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, i
       out.xtab[(id << norb) | iu] = x;
     }
   return "";
+}
+
+}  // namespace edigpu
+
+// --------------------------------------------------------------------------------------
+// Hand-over images (edigpu_normal_create): recover the factored tables from the arrays the reference built
+// --------------------------------------------------------------------------------------
+namespace edigpu {
+
+// spH0d as Hd(iup, idw) = P_c(idw)(iup) + Hd(0, idw): the rows of one class c share the profile P_c(iup) = Hd(iup, r) -
+// Hd(0, r) (in an impurity model: rows with equal impurity occupations of the down word).  Accepted when every local
+// element is reproduced within `tol`.  Tables of rows outside the shard stay zero.
+static bool factor_diagonal(int64_t du, int64_t dd, int64_t dw_first, int64_t dw_count, const double* hd, double tol,
+                            HostFactored& fac) {
+  const int kMaxClasses = 64;
+  std::vector<int64_t> rep;  // class -> local row of its representative
+  fac.ed.assign((size_t)dd, 0.0);
+  fac.impd.assign((size_t)dd, 0);
+  int64_t samples[4] = {du / 5, (2 * du) / 5 + (du > 1), (3 * du) / 4, du - 1};
+  for (int64_t r = 0; r < dw_count; r++) {
+    const double* row = hd + r * du;
+    int cls = -1;
+    for (size_t c = 0; c < rep.size() && cls < 0; c++) {
+      const double* pr = hd + rep[c] * du;
+      bool ok = true;
+      for (int k = 0; k < 4 && ok; k++) {
+        const int64_t i = std::min(samples[k], du - 1);
+        ok = std::fabs((row[i] - row[0]) - (pr[i] - pr[0])) <= tol;
+      }
+      for (int64_t i = 0; i < du && ok; i++) ok = std::fabs((row[i] - row[0]) - (pr[i] - pr[0])) <= tol;
+      if (ok) cls = (int)c;
+    }
+    if (cls < 0) {
+      if ((int)rep.size() == kMaxClasses) return false;
+      cls = (int)rep.size();
+      rep.push_back(r);
+    }
+    fac.ed[(size_t)(dw_first + r)] = row[0];
+    fac.impd[(size_t)(dw_first + r)] = (uint8_t)cls;
+  }
+  fac.nimp = std::max<int>(1, (int)rep.size());
+  fac.eux.assign((size_t)fac.nimp * du, 0.0);
+  for (size_t c = 0; c < rep.size(); c++) {
+    const double* pr = hd + rep[c] * du;
+    for (int64_t i = 0; i < du; i++) fac.eux[c * du + i] = pr[i] - pr[0];
+  }
+  return true;
+}
+
+// spH0nd (local rows, global columns) as sum_t coef_t (Pdw_t (x) Pup_t).  For every (idw -> jdw) pair the entries form
+// an operator on the up index; the distinct ones (up to a sign) are few, each is cut into partial maps of one magnitude
+// and the terms are (operator, map, occurrence of that operator among the pairs of one idw).  The result is checked
+// against the CSR entry by entry (exact: a term contributes +/- coef_t), so a matrix that is not of this form only
+// costs the attempt.
+static bool factor_nonlocal(int64_t du, int64_t dd, int64_t dw_first, int64_t dw_count, const int64_t* rp,
+                            const int32_t* col, const double* val, int max_terms, HostFactored& fac) {
+  struct Ent { int32_t iup, jup; double v; };
+  struct UpOp { std::vector<Ent> e; };
+  std::vector<UpOp> ops;
+  std::unordered_multimap<uint64_t, int> op_index;
+  struct Pair { int32_t jdw; int op; bool neg; };
+  std::vector<std::vector<Pair>> pairs((size_t)dw_count);
+  std::vector<std::pair<int32_t, std::vector<Ent>>> groups;  // of the current dw row
+  for (int64_t r = 0; r < dw_count; r++) {
+    groups.clear();
+    for (int64_t iup = 0; iup < du; iup++) {
+      const int64_t i = iup + r * du;
+      for (int64_t k = rp[i]; k < rp[i + 1]; k++) {
+        const int32_t jdw = (int32_t)(col[k] / du), jup = (int32_t)(col[k] % du);
+        size_t g = 0;
+        while (g < groups.size() && groups[g].first != jdw) g++;
+        if (g == groups.size()) {
+          if (groups.size() >= 64) return false;
+          groups.push_back({jdw, {}});
+        }
+        groups[g].second.push_back({(int32_t)iup, jup, val[k]});
+      }
+    }
+    for (auto& g : groups) {
+      std::vector<Ent>& e = g.second;
+      std::sort(e.begin(), e.end(), [](const Ent& a, const Ent& b) { return a.iup != b.iup ? a.iup < b.iup : a.jup < b.jup; });
+      for (size_t k = 1; k < e.size(); k++)
+        if (e[k].iup == e[k - 1].iup && e[k].jup == e[k - 1].jup) return false;  // duplicate entry
+      if (e.empty() || e[0].v == 0.0) return false;
+      const bool neg = e[0].v < 0.0;
+      uint64_t hsh = 1469598103934665603ull;
+      for (Ent& x : e) {
+        if (neg) x.v = -x.v;
+        uint64_t bits;
+        std::memcpy(&bits, &x.v, 8);
+        for (uint64_t w : {(uint64_t)(uint32_t)x.iup, (uint64_t)(uint32_t)x.jup, bits}) hsh = (hsh ^ w) * 1099511628211ull;
+      }
+      int found = -1;
+      auto range = op_index.equal_range(hsh);
+      for (auto it = range.first; it != range.second && found < 0; ++it) {
+        const std::vector<Ent>& o = ops[it->second].e;
+        if (o.size() == e.size() &&
+            std::equal(o.begin(), o.end(), e.begin(),
+                       [](const Ent& a, const Ent& b) { return a.iup == b.iup && a.jup == b.jup && a.v == b.v; }))
+          found = it->second;
+      }
+      if (found < 0) {
+        if ((int)ops.size() >= max_terms) return false;
+        found = (int)ops.size();
+        ops.push_back({e});
+        op_index.insert({hsh, found});
+      }
+      pairs[r].push_back({g.first, found, neg});
+    }
+  }
+  // partial maps of one magnitude per operator
+  struct Sub { double mag; std::vector<uint32_t> jup; };
+  std::vector<std::vector<Sub>> subs(ops.size());
+  for (size_t o = 0; o < ops.size(); o++) {
+    const std::vector<Ent>& e = ops[o].e;
+    for (size_t k = 0; k < e.size();) {
+      size_t k1 = k;
+      while (k1 < e.size() && e[k1].iup == e[k].iup) k1++;
+      for (size_t q = k; q < k1; q++) {  // the entries of row iup: each goes to a map of its magnitude that is still free here
+        const double mag = std::fabs(e[q].v);
+        size_t sidx = 0;
+        for (; sidx < subs[o].size(); sidx++)
+          if (subs[o][sidx].mag == mag && subs[o][sidx].jup[e[q].iup] == 0xFFFFFFFFu) break;
+        if (sidx == subs[o].size()) {
+          if ((int)subs[o].size() >= max_terms) return false;
+          subs[o].push_back({mag, std::vector<uint32_t>((size_t)du, 0xFFFFFFFFu)});
+        }
+        subs[o][sidx].jup[e[q].iup] = (uint32_t)e[q].jup | (e[q].v < 0.0 ? 0x80000000u : 0u);
+      }
+      k = k1;
+    }
+  }
+  // occurrences of one operator among the pairs of a dw row
+  std::vector<int> nslots(ops.size(), 0);
+  for (int64_t r = 0; r < dw_count; r++) {
+    std::vector<int> cnt(ops.size(), 0);
+    for (const Pair& p : pairs[r]) nslots[p.op] = std::max(nslots[p.op], ++cnt[p.op]);
+  }
+  int nterms = 0;
+  std::vector<std::vector<int>> first_term(ops.size());  // [op][slot] -> first term (one per sub map)
+  for (size_t o = 0; o < ops.size(); o++)
+    for (int sl = 0; sl < nslots[o]; sl++) {
+      first_term[o].push_back(nterms);
+      nterms += (int)subs[o].size();
+    }
+  if (nterms > max_terms) return false;
+  fac.nterms = nterms;
+  fac.coef.assign((size_t)nterms, 0.0);
+  fac.jup.assign((size_t)nterms * du, 0xFFFFFFFFu);
+  fac.jdw.assign((size_t)nterms * dd, 0xFFFFFFFFu);
+  for (size_t o = 0; o < ops.size(); o++)
+    for (int sl = 0; sl < nslots[o]; sl++)
+      for (size_t sb = 0; sb < subs[o].size(); sb++) {
+        const int t = first_term[o][sl] + (int)sb;
+        fac.coef[t] = subs[o][sb].mag;
+        std::copy(subs[o][sb].jup.begin(), subs[o][sb].jup.end(), fac.jup.begin() + (size_t)t * du);
+      }
+  for (int64_t r = 0; r < dw_count; r++) {
+    std::vector<int> cnt(ops.size(), 0);
+    for (const Pair& p : pairs[r]) {
+      const int sl = cnt[p.op]++;
+      for (size_t sb = 0; sb < subs[p.op].size(); sb++)
+        fac.jdw[(size_t)(first_term[p.op][sl] + (int)sb) * dd + dw_first + r] = (uint32_t)p.jdw | (p.neg ? 0x80000000u : 0u);
+    }
+  }
+  // entry-by-entry check
+  std::vector<std::pair<int64_t, double>> want, got;
+  for (int64_t r = 0; r < dw_count; r++)
+    for (int64_t iup = 0; iup < du; iup++) {
+      const int64_t i = iup + r * du;
+      want.clear();
+      got.clear();
+      for (int64_t k = rp[i]; k < rp[i + 1]; k++) want.push_back({col[k], val[k]});
+      for (int t = 0; t < nterms; t++) {
+        const uint32_t pu = fac.jup[(size_t)t * du + iup], pd = fac.jdw[(size_t)t * dd + dw_first + r];
+        if (pu == 0xFFFFFFFFu || pd == 0xFFFFFFFFu) continue;
+        got.push_back({(int64_t)(pu & 0x7FFFFFFFu) + (int64_t)(pd & 0x7FFFFFFFu) * du,
+                       ((pu ^ pd) & 0x80000000u) ? -fac.coef[t] : fac.coef[t]});
+      }
+      if (want.size() != got.size()) return false;
+      std::sort(want.begin(), want.end());
+      std::sort(got.begin(), got.end());
+      if (want != got) return false;
+    }
+  return true;
+}
+
+bool factor_handover(int64_t dim_up, int64_t dim_dw, int64_t dw_first, int64_t dw_count, const double* hd,
+                     const int64_t* nd_rowptr, const int32_t* nd_col, const double* nd_val, int max_terms,
+                     HostFactored& fac) {
+  fac = HostFactored();
+  if (dw_count <= 0 || dim_dw >= ((int64_t)1 << 31) || dim_up >= ((int64_t)1 << 31)) return false;
+  double amax = 0.0;
+  const int64_t nloc = dim_up * dw_count;
+  for (int64_t i = 0; i < nloc; i++) amax = std::max(amax, std::fabs(hd[i]));
+  const double tol = 8.0 * 2.220446049250313e-16 * amax;
+  if (!factor_diagonal(dim_up, dim_dw, dw_first, dw_count, hd, tol, fac)) return false;
+  if (nd_rowptr && nd_rowptr[nloc] > 0 &&
+      !factor_nonlocal(dim_up, dim_dw, dw_first, dw_count, nd_rowptr, nd_col, nd_val, max_terms, fac))
+    return false;
+  fac.valid = true;
+  return true;
 }
 
 }  // namespace edigpu

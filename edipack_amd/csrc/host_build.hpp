@@ -129,6 +129,12 @@ std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int
                        HostFlat& out);
 std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
                          HostDirect& out);
+// Hand-over images: the factored tables recovered from spH0d / spH0nd as the reference built them (local rows of a
+// dw-shard, global columns).  true: fac reproduces the diagonal within 8 ulp of max|Hd| and Hnd entry by entry with at
+// most max_terms terms; false: not of that form (the caller keeps the explicit image).
+bool factor_handover(int64_t dim_up, int64_t dim_dw, int64_t dw_first, int64_t dw_count, const double* hd,
+                     const int64_t* nd_rowptr, const int32_t* nd_col, const double* nd_val, int max_terms,
+                     HostFactored& fac);
 edigpu_model imag_part_model(const edigpu_model& m, bool& any);
 bool eph_offdiagonal(const edigpu_model& m);
 edigpu_model eph_operator_model(const edigpu_model& m);

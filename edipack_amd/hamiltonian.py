@@ -283,6 +283,12 @@ class SectorHamiltonian:
         """vecDim_Hv_sector_* (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:286-313)."""
         return self.nloc
 
+    def image_info(self):
+        """(factored, Hnd terms, diagonal classes, panel variant) of a normal-mode handle's device image."""
+        a = (C.c_int32 * 4)()
+        capi.check(capi.lib().edigpu_image_info(self._h, a), "edigpu_image_info")
+        return tuple(a)
+
     def algorithmic_bytes(self):
         a, b = C.c_double(), C.c_double()
         capi.check(capi.lib().edigpu_algorithmic_bytes(self._h, C.byref(a), C.byref(b)))

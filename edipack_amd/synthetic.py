@@ -47,12 +47,21 @@ WORKLOADS = {
 }
 
 
-def build_workload(w: Workload, **shard):
-    """SectorHamiltonian of a workload (single shard unless dw_first/dw_count or row_first/row_count given)."""
+def build_workload(w: Workload, handover: bool = False, **shard):
+    """SectorHamiltonian of a workload (single shard unless dw_first/dw_count or row_first/row_count given).
+    handover (normal mode): through edigpu_normal_create, i.e. from the explicit arrays (spH0d, spH0ups, spH0dws,
+    spH0nd) as the reference's ed_buildh_normal_main leaves them, instead of from the model."""
     from .hamiltonian import SectorHamiltonian
     m = synthetic_model(w)
     if w.ed_mode == "normal":
-        return SectorHamiltonian.normal_from_model(m, *w.sector, **shard)
+        h = SectorHamiltonian.normal_from_model(m, *w.sector, **shard)
+        if not handover:
+            return h
+        hd, up, dw, nd = h.export_normal()
+        du, dd, first, cnt = h.dim_up, h.dim_dw, h.row_first // h.dim_up, h.nloc // h.dim_up
+        h.destroy()
+        return SectorHamiltonian.normal_from_arrays(du, dd, hd, up, dw, nd if nd[0][-1] > 0 else None,
+                                                    dw_first=first, dw_count=cnt)
     if w.direct:
         return SectorHamiltonian.direct_from_model(m, w.sector, **shard)
     return SectorHamiltonian.flat_from_model(m, w.sector, **shard)

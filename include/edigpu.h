@@ -228,6 +228,11 @@ int edigpu_sector_map(const edigpu_model *model, int q1, int q2, int which, int3
  * [3]=is_complex, [4]=kind (0 normal Kronecker, 1 flat CSR, 2 direct), [5]=DimUp, [6]=DimDw,
  * [7]=nnz(up)+nnz(dw) or nnz(loc), [8]=nnz(nd) or nnz(nonloc), [9]=device id */
 int edigpu_info(edigpu_handle h, int64_t info[10]);
+/* Device image of a normal-mode handle (diagnostics, tests): image[0] = 1 when the kernels run on the factored tables
+ * (separable diagonal + Hnd as a sum of signed partial permutations; library-built sectors, and hand-over sectors
+ * whose arrays edigpu_normal_create could factor), 0 for the explicit image (spH0d + spH0nd as given);
+ * [1] = Hnd terms, [2] = diagonal classes, [3] = panel sweep variant (0 one column per lane, 1 two, 2 LDS-tiled). */
+int edigpu_image_info(edigpu_handle h, int32_t image[4]);
 /* algorithmic bytes of one H*v in the reference's storage format */
 int edigpu_algorithmic_bytes(edigpu_handle h, double *bytes_hv, double *bytes_lanczos_step);
 /* copy the built matrices back to the host (tests: compare with the oracle).

@@ -70,3 +70,27 @@ extern "C" int host_direct_refuses(const edigpu_model* m, int sector) {
   g_err = build_direct(*m, sector, 0, -1, hd);
   return g_err.empty() ? 0 : 1;
 }
+
+// factor_handover on the arrays of one dw-shard: dense image (local rows x global columns, diagonal and Hnd only) from
+// the recovered tables; returns -1 when the arrays are not of the factored form, else the number of terms
+extern "C" int host_handover_dense(int64_t du, int64_t dd, int64_t dw_first, int64_t dw_count, const double* hd,
+                                   const int64_t* nd_rowptr, const int32_t* nd_col, const double* nd_val, double* out,
+                                   int* nclasses) {
+  HostFactored fac;
+  if (!factor_handover(du, dd, dw_first, dw_count, hd, nd_rowptr, nd_col, nd_val, 16, fac)) return -1;
+  const int64_t nloc = du * dw_count, dim = du * dd;
+  std::memset(out, 0, sizeof(double) * nloc * dim);
+  for (int64_t r = 0; r < dw_count; r++)
+    for (int64_t iup = 0; iup < du; iup++) {
+      const int64_t i = iup + r * du, idw = dw_first + r;
+      out[i * dim + (iup + idw * du)] += fac.eux[(size_t)fac.impd[idw] * du + iup] + fac.ed[idw];
+      for (int t = 0; t < fac.nterms; t++) {
+        const uint32_t pu = fac.jup[(size_t)t * du + iup], pd = fac.jdw[(size_t)t * dd + idw];
+        if (pu == 0xFFFFFFFFu || pd == 0xFFFFFFFFu) continue;
+        out[i * dim + (int64_t)(pu & 0x7FFFFFFFu) + (int64_t)(pd & 0x7FFFFFFFu) * du] +=
+            (((pu ^ pd) & 0x80000000u) ? -1.0 : 1.0) * fac.coef[t];
+      }
+    }
+  *nclasses = fac.nimp;
+  return fac.nterms;
+}

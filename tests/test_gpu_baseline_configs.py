@@ -207,3 +207,30 @@ def test_shifted_spectrum_keeps_the_fused_step_accurate(gpu):
         g, g_ref = _cf(a, b, z), _cf(a_ref, b_ref, z)
         assert abs(g - g_ref) < 1e-10 * abs(g_ref), (z, g, g_ref)
 
+
+
+def test_cfg2_handover_image_runs_the_factored_kernels(gpu):
+    """edigpu_normal_create on the explicit arrays of config 2 (what INTEGRATION.md section 2 patches in) recovers the
+    factored tables: same H*v as the library-built sector to rounding, the same tridiagonal, and the arrays come back
+    from edigpu_normal_export bit for bit."""
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from edipack_amd.synthetic import WORKLOADS, synthetic_model
+    w = WORKLOADS["cfg2"]
+    pm = synthetic_model(w)
+    hl = SectorHamiltonian.normal_from_model(pm, *w.sector)
+    hd, up, dw, nd = hl.export_normal()
+    hh = SectorHamiltonian.normal_from_arrays(hl.dim_up, hl.dim_dw, hd, up, dw, nd)
+    fac, nterms, ncls, panel = hh.image_info()
+    assert fac == 1 and 1 <= nterms <= hl.image_info()[1] and ncls == 4 and panel == hl.image_info()[3]
+    v = np.random.default_rng(8).standard_normal(hl.dim)
+    v /= np.linalg.norm(v)
+    a, b = hl.apply(v), hh.apply(v)
+    assert rel_err(b, a) < 1e-14
+    al, bl, _ = hl.lanczos_tridiag(v, 60)
+    ah, bh, _ = hh.lanczos_tridiag(v, 60)
+    assert rel_err(ah[:30], al[:30]) < 1e-10 and rel_err(bh[:30], bl[:30]) < 1e-10
+    for z in (40.0 + 0.1j, -40.0 + 0.1j, 25.0j):
+        assert abs(_cf(ah, bh, z) - _cf(al, bl, z)) / abs(_cf(al, bl, z)) < 1e-10
+    hd2, _, _, nd2 = hh.export_normal()
+    assert np.array_equal(hd2, hd) and all(np.array_equal(x, y) for x, y in zip(nd2, nd))
+    hl.destroy(), hh.destroy()

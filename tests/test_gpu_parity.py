@@ -67,14 +67,23 @@ def test_normal_apply_matches_oracle(gpu, bath, norb, nbath, sec):
     hg.destroy()
 
 
-def test_normal_create_from_reference_arrays(gpu):
+@pytest.mark.parametrize("factor", [True, False])
+def test_normal_create_from_reference_arrays(gpu, monkeypatch, factor):
     """Drop-in boundary: hand over spH0d/spH0ups/spH0dws/spH0nd exactly as the (oracle-restated)
-    reference builds them -- unsorted columns in insertion order."""
+    reference builds them -- unsorted columns in insertion order.  edigpu_normal_create recovers the factored tables
+    from the arrays of an impurity model (factor) or keeps the explicit image (EDIGPU_HANDOVER_FACTOR=0)."""
+    import os
     O = _oracle()
     from edipack_amd.hamiltonian import SectorHamiltonian
+    if not factor:
+        monkeypatch.setenv("EDIGPU_HANDOVER_FACTOR", "0")
     om, _ = make_models("normal", "normal", 2, 3, seed=5)
     ho = O.HNormal(om, 4, 4)
     hg = SectorHamiltonian.normal_from_arrays(ho.dimup, ho.dimdw, ho.hd, ho.up, ho.dw, ho.nd)
+    assert hg.image_info()[0] == int(factor and not os.environ.get("EDIGPU_NORMAL_EXPLICIT"))
+    # what was handed over comes back bit for bit
+    hd, up, dw, nd = hg.export_normal()
+    assert np.array_equal(hd, ho.hd) and all(np.array_equal(a, b) for a, b in zip(nd, ho.nd))
     v = np.random.default_rng(2).standard_normal(ho.dim)
     assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
     # linearity (size-independent property)
@@ -169,12 +178,16 @@ def test_normal_two_phase_equals_fused(gpu):
     assert rel_err(np.concatenate(out), ref) < TOL
 
 
-def test_normal_two_phase_handover_shards(gpu):
+@pytest.mark.parametrize("factor", [True, False])
+def test_normal_two_phase_handover_shards(gpu, monkeypatch, factor):
     """The same two-phase product on the hand-over image (explicit spH0d, spH0nd rows of the shard with global
-    columns as spMatVec_mpi_normal_main holds them): local rows only for Hd / Hnd, H up / H dw replicated."""
+    columns as spMatVec_mpi_normal_main holds them): local rows only for Hd / Hnd, H up / H dw replicated.  With and
+    without the factored tables recovered from the shard's arrays."""
     import torch
     O = _oracle()
     from edipack_amd.hamiltonian import SectorHamiltonian
+    if not factor:
+        monkeypatch.setenv("EDIGPU_HANDOVER_FACTOR", "0")
     om, _ = make_models("normal", "hybrid", 3, 3, seed=9)
     ho = O.HNormal(om, 3, 3)
     v = np.random.default_rng(5).standard_normal(ho.dim)
@@ -1214,16 +1227,25 @@ def test_transposed_exchange_emulated(gpu, bath, norb, nbath, sec, jxp, world):
     h.destroy()
 
 
-def test_transposed_exchange_refusals(gpu):
-    """Hand-over images with explicit spH0nd and phonon sectors are refused (all-gather form instead)."""
+def test_transposed_exchange_refusals(gpu, monkeypatch):
+    """Hand-over images with explicit spH0nd and phonon sectors are refused (all-gather form instead); a hand-over
+    image whose arrays factor is served like a library-built one."""
+    import os
     from edipack_amd.hamiltonian import SectorHamiltonian
     O = _oracle()
     om, pm = make_models("normal", "hybrid", 2, 2, seed=62)
     ho = O.HNormal(om, 3, 3)
+    if not os.environ.get("EDIGPU_NORMAL_EXPLICIT"):
+        hh = SectorHamiltonian.normal_from_arrays(ho.dimup, ho.dimdw, ho.hd, ho.up, ho.dw, ho.nd)
+        hl = SectorHamiltonian.normal_from_model(pm, 3, 3)
+        assert hh.transpose_halo() == hl.transpose_halo()
+        hh.destroy(), hl.destroy()
+    monkeypatch.setenv("EDIGPU_HANDOVER_FACTOR", "0")
     hh = SectorHamiltonian.normal_from_arrays(ho.dimup, ho.dimdw, ho.hd, ho.up, ho.dw, ho.nd)
     with pytest.raises(RuntimeError, match="all-gather"):
         hh.transpose_halo()
     hh.destroy()
+    monkeypatch.delenv("EDIGPU_HANDOVER_FACTOR")
     pm.nph, pm.w0_ph = 2, 0.5
     hp = SectorHamiltonian.normal_from_model(pm, 3, 3)
     with pytest.raises(RuntimeError, match="all-gather"):

@@ -110,3 +110,69 @@ def test_flat_builders_refuse_normal_only_fields(shim, mode):
 
 def test_model_struct_sizes_agree(shim):
     assert C.sizeof(capi.EdigpuModel) == capi.lib().edigpu_model_sizeof()
+
+
+# ---- hand-over images: edigpu_normal_create recovers the factored tables from the reference's arrays ----
+def _handover(shim, ho, first, cnt):
+    du, dd = ho.dimup, ho.dimdw
+    r0, r1 = first * du, (first + cnt) * du
+    ndr, ndc, ndv = ho.nd if ho.has_nd else (np.zeros(ho.dim + 1, np.int64), np.zeros(0, np.int32), np.zeros(0))
+    rp = np.ascontiguousarray(ndr[r0:r1 + 1] - ndr[r0], dtype=np.int64)
+    col = np.ascontiguousarray(ndc[ndr[r0]:ndr[r1]], dtype=np.int32)
+    val = np.ascontiguousarray(ndv[ndr[r0]:ndr[r1]], dtype=np.float64)
+    hd = np.ascontiguousarray(ho.hd[r0:r1])
+    out = np.zeros((r1 - r0, ho.dim))
+    ncls = C.c_int(0)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    nt = shim.host_handover_dense(C.c_int64(du), C.c_int64(dd), C.c_int64(first), C.c_int64(cnt), P(hd), P(rp), P(col),
+                                  P(val), P(out), C.byref(ncls))
+    ref = np.zeros_like(out)
+    ref[np.arange(r1 - r0), np.arange(r0, r1)] = hd
+    for i in range(r1 - r0):
+        for k in range(rp[i], rp[i + 1]):
+            ref[i, col[k]] += val[k]
+    return nt, ncls.value, out, ref
+
+
+@pytest.mark.parametrize("bath,norb,nbath,sec,jxp,extra,nterms,ncls", [
+    ("normal", 2, 2, (3, 3), 0.25, {}, 2, 4),             # Jx = Jp: one term per down move
+    ("hybrid", 3, 2, (2, 3), 0.25, {}, 6, 8),
+    ("hybrid", 3, 2, (3, 2), 0.0, {}, 0, 8),              # no Hnd
+    ("normal", 1, 4, (2, 3), 0.0, {}, 0, 2),
+    ("hybrid", 3, 3, (3, 3), 0.0, dict(sundry=SUNDRY3), None, 8),
+    ("replica", 2, 2, (3, 3), 0.25, dict(spin_field=np.array([[0, 0, 0.1], [0, 0, 0.2]])), 2, 4),
+])
+def test_handover_arrays_factor_exactly(shim, bath, norb, nbath, sec, jxp, extra, nterms, ncls):
+    om, _ = make_models("normal", bath, norb, nbath, seed=12, jxp=jxp, **extra)
+    ho = O.HNormal(om, *sec)
+    for first, cnt in ((0, ho.dimdw), (1, ho.dimdw - 2), (ho.dimdw // 2, 1)):
+        nt, nc, got, ref = _handover(shim, ho, first, cnt)
+        assert nt >= 0, "the arrays of an impurity model must factor"
+        if nterms is not None and cnt == ho.dimdw:
+            assert nt <= nterms and nc <= ncls      # equal operators merge (Jx = Jp: both down moves share one)
+        # Hnd entries are reproduced exactly, the diagonal within 8 ulp of max|Hd|
+        off = ~np.eye(ho.dim, dtype=bool)[first * ho.dimup:(first + cnt) * ho.dimup]
+        assert np.array_equal(got[off], ref[off])
+        assert np.abs(got - ref).max() <= 8 * np.finfo(float).eps * np.abs(ho.hd).max()
+
+
+def test_handover_arrays_that_do_not_factor_fall_back(shim):
+    """A diagonal with no class structure and an Hnd with unrelated entries: the attempt must say no."""
+    om, _ = make_models("normal", "normal", 2, 2, seed=12)
+    ho = O.HNormal(om, 3, 3)
+    rng = np.random.default_rng(0)
+
+    class Fake:
+        pass
+    f = Fake()
+    f.dimup, f.dimdw, f.dim, f.has_nd = ho.dimup, ho.dimdw, ho.dim, True
+    f.hd = rng.standard_normal(ho.dim)                 # every dw row its own profile: > 64 classes? (DimDw = 20: no)
+    f.nd = ho.nd
+    nt, nc, got, ref = _handover(shim, f, 0, ho.dimdw)
+    assert nt >= 0 and nc == ho.dimdw                  # 20 classes: still representable, and exact
+    assert np.abs(got - ref).max() <= 8 * np.finfo(float).eps * np.abs(f.hd).max()
+    # random Hnd values: every (idw -> jdw) pair its own up-operator, more than 16 terms
+    ndr, ndc, ndv = ho.nd
+    f.hd = ho.hd
+    f.nd = (ndr, ndc, rng.standard_normal(ndv.shape))
+    assert _handover(shim, f, 0, ho.dimdw)[0] == -1
