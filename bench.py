@@ -167,7 +167,7 @@ def run_single(args):
         "config": {"workload": f"{w.name}: {w.ed_mode} mode, bath={w.bath_type}, Norb={w.norb}, Nbath={w.nbath}, "
                                f"sector={w.sector}, Dim={h.dim} ({w.note})",
                    "storage": {0: "Kronecker (Hd,Hup,Hdw,Hnd)", 1: "flat CSR", 2: "direct (on-the-fly)"}[h.kind],
-                   "image": args.image + (" (factored=%d, Hnd terms=%d, classes=%d, panel=%d)" % h.image_info()
+                   "image": args.image + (" (factored=%d, Hnd terms=%d, classes=%d, panel=%d, panel-major W=%d)" % h.image_info()[:5]
                                           if h.kind == 0 else ""),
                    "parallelism": "1 GPU, device-resident Lanczos", "build_s": round(t_build, 3),
                    "hv_only_ms": ms_hv_only, "lanczos_step_GBs": bytes_step / (ms_step * 1e-3) / 1e9},

@@ -592,6 +592,80 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
     if (dev_upload(&s->d_tl_val, tv.data(), tv.size())) return 1;
     s->tl_has_nd = with_nd ? 1 : 0;
   }
+  // Panel-major vector layout for the device-resident Lanczos loop (normal_args.hpp): large factored whole
+  // sectors whose rows fit the LDS row kernel.  W columns per panel so that one panel of V (DimDw * W * 8 bytes, whole
+  // cache lines) stays in an XCD's L2 while the sweep walks it.  OPT-IN (EDIGPU_BLOCKED=1): measured on config 2 and the
+  // Ns = 16 ladder it brings the sweep's fetch traffic to 1.1x / 1.9x of V + result (natural layout 1.7x / 5x), but the
+  // sweep is bound by the L2's gather throughput, not by the fabric, and runs 10-60 % slower than the LDS-tiled sweep of
+  // the natural layout.  EDIGPU_BLOCKED_W forces a width (16 / 32 / 64), EDIGPU_BLOCKED_MIN
+  // the smallest sector (rows), EDIGPU_BLOCKED_LDS_KB the staged block.
+  if (s->factored && built && dw_first == 0 && dw_count == dim_dw && s->rows_per_block >= 1 && s->row_split == 1 &&
+      dim_dw <= 65535 && dim_up >= 64) {
+    const char* e;
+    const bool on = (e = getenv("EDIGPU_BLOCKED")) && atoi(e) != 0;
+    const int64_t min_rows = (e = getenv("EDIGPU_BLOCKED_MIN")) ? atoll(e) : ((int64_t)1 << 21);
+    const int64_t l2_bytes = ((e = getenv("EDIGPU_BLOCKED_L2_KB")) ? atoll(e) : 2048) * 1024;
+    int shift = 0;
+    for (int sh : {6, 5, 4})
+      if (!shift && dim_dw * ((int64_t)8 << sh) <= l2_bytes) shift = sh;
+    if ((e = getenv("EDIGPU_BLOCKED_W"))) {
+      const int w = atoi(e);
+      shift = w == 64 ? 6 : w == 32 ? 5 : w == 16 ? 4 : 0;
+    }
+    const HostFactored& f = built->fac;
+    if (on && shift && s->nloc >= min_rows && f.nterms <= 16) {
+      // weight table: +/- every hop amplitude and Hnd coefficient, 0.0 at index 0 (padding entries)
+      std::vector<double> wtab{0.0};
+      auto widx = [&](double w) -> int {
+        for (size_t i = 0; i < wtab.size(); i++)
+          if (wtab[i] == w && std::signbit(wtab[i]) == std::signbit(w)) return (int)i;
+        wtab.push_back(w);
+        return (int)wtab.size() - 1;
+      };
+      // LDS block of the sweep: EDIGPU_BLOCKED_LDS_KB (default 64) of staged segments, a multiple of 32 rows
+      const int64_t lds_kb = (e = getenv("EDIGPU_BLOCKED_LDS_KB")) ? atoll(e) : 64;
+      int64_t R = std::max<int64_t>(32, std::min<int64_t>(lds_kb * 1024 / ((int64_t)8 << shift), 4096) / 32 * 32);
+      std::vector<int4> meta((size_t)dim_dw);
+      std::vector<uint32_t> ent;
+      ent.reserve((size_t)dw.rowptr[dim_dw] + 8 * (size_t)dim_dw);
+      bool fits = true;
+      for (int64_t g = 0; g < dim_dw && fits; g++) {
+        const int64_t cs = g / R * R;  // first row of g's block
+        int4 m = {(int)ent.size(), 0, 0, 0};
+        for (int pass = 0; pass < 2; pass++) {  // hops inside the block (entry = index in the block), then the others
+          int& cnt = pass == 0 ? m.y : m.z;
+          for (int64_t q = dw.rowptr[g]; q < dw.rowptr[g + 1]; q++) {
+            const int64_t c = dw.col[q];
+            const bool inside = c >= cs && c < cs + R;
+            if (inside != (pass == 0)) continue;
+            ent.push_back((uint32_t)(inside ? c - cs : c) | ((uint32_t)widx(dw.val[q]) << 16));
+            cnt++;
+          }
+          for (; cnt % 4; cnt++) ent.push_back((uint32_t)(pass == 0 ? g - cs : g));  // (own row, weight 0)
+        }
+        for (int t = 0; t < f.nterms; t++) {
+          const uint32_t jd = f.jdw[(size_t)t * dim_dw + g];
+          if (jd == 0xFFFFFFFFu) continue;
+          ent.push_back((jd & 0xFFFFu) | ((uint32_t)widx((jd >> 31) ? -f.coef[t] : f.coef[t]) << 16) | ((uint32_t)(t + 1) << 24));
+          m.w++;
+        }
+        while (ent.size() % 4) ent.push_back(0);  // the next row starts on a 16-byte boundary
+        meta[(size_t)g] = m;
+        fits = wtab.size() <= 256;
+      }
+      if (fits) {
+        wtab.resize(256, 0.0);
+        ent.resize(ent.size() + 8, 0);
+        if (dev_upload(&s->d_bl_meta, meta.data(), meta.size())) return 1;
+        if (dev_upload(&s->d_bl_ent, ent.data(), ent.size())) return 1;
+        if (dev_upload(&s->d_bl_wtab, wtab.data(), wtab.size())) return 1;
+        s->blk_shift = shift;
+        s->blk_rows = (int)R;
+        s->blk_ps = dim_dw << shift;
+        s->blk_len = ((dim_up + ((int64_t)1 << shift) - 1) >> shift) * s->blk_ps;
+      }
+    }
+  }
   return finish_handle(s);
 }
 
@@ -823,7 +897,8 @@ static int ensure_workspace(edigpu_sector* s) {
   dev_free(s->d_tmp);
   dev_free(s->d_partial);
   dev_free(s->d_scal);
-  const size_t n = (size_t)std::max<int64_t>(len, 1);
+  // (the panel-major layout of the Lanczos loop pads the last panel: blk_len >= len)
+  const size_t n = (size_t)std::max<int64_t>(std::max(len, s->blk_len), 1);
   EDIGPU_HIP(hipMalloc((void**)&s->d_vin, n * sizeof(double)));
   EDIGPU_HIP(hipMalloc((void**)&s->d_vout, n * sizeof(double)));
   EDIGPU_HIP(hipMalloc((void**)&s->d_tmp, n * sizeof(double)));
@@ -989,7 +1064,7 @@ static bool flat_lanczos_fusable(const edigpu_sector* s) {
 }
 
 static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
-  const int64_t len = s->ws_len;
+  const int64_t len = s->lz_len;
   if (normal_lanczos_fusable(s)) {
     // rotate (and the pending axpy) fused into the row kernel, alpha and <Q|Q> into the panel sweep
     // (kernels_normal.hip); EDIGPU_LANCZOS_EXACTBETA=1 keeps the separate axpy+norm kernel
@@ -1024,12 +1099,38 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
 
 static int lanczos_prepare(edigpu_sector* s, int nlanc, double threshold, hipStream_t st) {
   s->lz_exactbeta = getenv("EDIGPU_LANCZOS_EXACTBETA") != nullptr;
+  // the recurrence of a large factored normal-mode sector runs on panel-major vectors (set-up decides, blk_shift)
+  s->lz_blocked = s->kind == 0 && s->blk_shift > 0 && s->nph == 0 && normal_lanczos_fusable(s);
+  s->lz_len = s->lz_blocked ? s->blk_len : s->ws_len;
   dev_free(s->d_scal);
   const size_t ns = (size_t)SC_AB + 2 * (size_t)nlanc;
   EDIGPU_HIP(hipMalloc((void**)&s->d_scal, ns * sizeof(double)));
   EDIGPU_HIP(hipMemsetAsync(s->d_scal, 0, ns * sizeof(double), st));
   EDIGPU_HIP(hipMemcpyAsync(s->d_scal + SC_THR, &threshold, sizeof(double), hipMemcpyHostToDevice, st));
-  EDIGPU_HIP(hipMemsetAsync(s->d_vout, 0, (size_t)s->ws_len * sizeof(double), st));
+  EDIGPU_HIP(hipMemsetAsync(s->d_vout, 0, (size_t)s->lz_len * sizeof(double), st));
+  return 0;
+}
+
+// start vector of a recurrence into d_vin, in the layout lanczos_prepare chose: src = host or device vector in the
+// natural layout (ws_len doubles), or nullptr for seeded random numbers
+static int lanczos_seed(edigpu_sector* s, const double* src, uint64_t seed, hipStream_t st) {
+  double* dst = s->lz_blocked ? s->d_tmp : s->d_vin;
+  if (src) {
+    EDIGPU_HIP(hipMemcpyAsync(dst, src, (size_t)s->ws_len * sizeof(double), hipMemcpyDefault, st));
+  } else if (lz_fill_random(dst, s->ws_len, seed, st)) {
+    return 1;
+  }
+  if (s->lz_blocked) return vec_to_blocked(s->d_tmp, s->d_vin, s->dim_up, s->dim_dw, s->blk_shift, st);
+  return 0;
+}
+
+// a vector of the current recurrence (device, lz_len doubles) to a host or device buffer in the natural layout
+static int lanczos_fetch(edigpu_sector* s, const double* v, double* dst, hipStream_t st) {
+  if (s->lz_blocked) {
+    if (vec_from_blocked(v, s->d_tmp, s->dim_up, s->dim_dw, s->blk_shift, st)) return 1;
+    v = s->d_tmp;
+  }
+  EDIGPU_HIP(hipMemcpyAsync(dst, v, (size_t)s->ws_len * sizeof(double), hipMemcpyDefault, st));
   return 0;
 }
 
@@ -1601,7 +1702,7 @@ int edigpu_sector_map(const edigpu_model* model, int q1, int q2, int which, int3
   return 0;
 }
 
-int edigpu_image_info(edigpu_handle s, int32_t image[4]) {
+int edigpu_image_info(edigpu_handle s, int32_t image[6]) {
   if (!s || !image || s->kind != 0) {
     set_error("edigpu_image_info: not a normal-mode handle");
     return 1;
@@ -1610,6 +1711,8 @@ int edigpu_image_info(edigpu_handle s, int32_t image[4]) {
   image[1] = s->factored ? s->fac_nterms : 0;
   image[2] = s->factored ? s->fac_nimp : 0;
   image[3] = s->panel_mode;
+  image[4] = s->blk_shift ? (1 << s->blk_shift) : 0;
+  image[5] = 0;
   return 0;
 }
 
@@ -1967,8 +2070,8 @@ static int tridiag_impl(edigpu_handle s, const double* vin, int nlanc, double* a
   if (ensure_workspace(s)) return 1;
   hipStream_t st = s->stream;
   if (lanczos_prepare(s, nlanc, threshold, st)) return 1;
-  EDIGPU_HIP(hipMemcpyAsync(s->d_vin, vin, (size_t)s->ws_len * sizeof(double), hipMemcpyDefault, st));
-  if (lz_norm_begin(s->d_vin, s->ws_len, s->d_partial, s->d_scal, st)) return 1;
+  if (lanczos_seed(s, vin, 0, st)) return 1;
+  if (lz_norm_begin(s->d_vin, s->lz_len, s->d_partial, s->d_scal, st)) return 1;
   for (int it = 0; it < nlanc; it++)
     if (lanczos_step(s, it, nlanc, st)) return 1;
   std::vector<double> sc((size_t)SC_AB + 2 * (size_t)nlanc);
@@ -2134,7 +2237,11 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
   if (check_every <= 0) check_every = 10;
   if ((int64_t)nitermax > s->nloc) nitermax = (int)s->nloc;
   hipStream_t st = s->stream;
-  const int64_t len = s->ws_len;
+  // breakdown guard: a beta below 1e-12 means the Krylov space is exhausted (tiny sectors with nitermax ~ dim); the
+  // recurrence stops there instead of dividing by it
+  constexpr double kBreakdown = 1e-12;
+  if (lanczos_prepare(s, nitermax, kBreakdown, st)) return 1;
+  const int64_t len = s->lz_len;
   const size_t vbytes = (size_t)len * sizeof(double);
   // keep the normalised start vector for the second pass
   double* d_v0 = nullptr;
@@ -2143,15 +2250,7 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
     (void)hipFree(d_v0);
     return 1;
   };
-  // breakdown guard: a beta below 1e-12 means the Krylov space is exhausted (tiny sectors with nitermax ~ dim); the
-  // recurrence stops there instead of dividing by it
-  constexpr double kBreakdown = 1e-12;
-  if (lanczos_prepare(s, nitermax, kBreakdown, st)) return fail();
-  if (v0_host) {
-    if (hipMemcpyAsync(s->d_vin, v0_host, vbytes, hipMemcpyDefault, st) != hipSuccess) return fail();
-  } else if (lz_fill_random(s->d_vin, len, 0x5eed1234ull, st)) {
-    return fail();
-  }
+  if (lanczos_seed(s, v0_host, 0x5eed1234ull, st)) return fail();
   if (lz_norm_begin(s->d_vin, len, s->d_partial, s->d_scal, st)) return fail();
   if (hipMemcpyAsync(d_v0, s->d_vin, vbytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail();
 
@@ -2210,7 +2309,7 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
     }
     // normalise
     if (!rc) rc |= lz_norm_begin(d_acc, len, s->d_partial, s->d_scal, st);
-    if (!rc && hipMemcpyAsync(evec_host, d_acc, vbytes, hipMemcpyDefault, st) != hipSuccess) rc = 1;
+    if (!rc) rc |= lanczos_fetch(s, d_acc, evec_host, st);
     if (hipStreamSynchronize(st) != hipSuccess) rc = 1;
     (void)hipFree(d_acc);
     if (rc) {
@@ -2497,11 +2596,15 @@ int edigpu_time_apply(edigpu_handle s, int warmup, int steps, int lanczos, doubl
   EDIGPU_HIP(hipSetDevice(s->device));
   if (ensure_workspace(s)) return 1;
   hipStream_t st = s->stream;
-  const int64_t len = s->ws_len;
   const int total = warmup + steps;
   if (lanczos_prepare(s, std::max(total, 1), 0.0, st)) return 1;
-  if (lz_fill_random(s->d_vin, len, 12345ull, st)) return 1;
-  if (lz_norm_begin(s->d_vin, len, s->d_partial, s->d_scal, st)) return 1;
+  if (lanczos) {
+    if (lanczos_seed(s, nullptr, 12345ull, st)) return 1;
+    if (lz_norm_begin(s->d_vin, s->lz_len, s->d_partial, s->d_scal, st)) return 1;
+  } else {  // the boundary product (edigpu_apply_dev): vectors in the natural layout
+    if (lz_fill_random(s->d_vin, s->ws_len, 12345ull, st)) return 1;
+    if (lz_norm_begin(s->d_vin, s->ws_len, s->d_partial, s->d_scal, st)) return 1;
+  }
   hipEvent_t e0, e1;
   EDIGPU_HIP(hipEventCreate(&e0));
   EDIGPU_HIP(hipEventCreate(&e1));
@@ -2584,12 +2687,16 @@ int edigpu_lanczos_bench(edigpu_handle s, int warmup, int steps, double* ms_wall
   EDIGPU_HIP(hipSetDevice(s->device));
   if (ensure_workspace(s)) return 1;
   hipStream_t st = s->stream;
-  const int64_t len = s->ws_len;
   const int total = warmup + steps;
   if (lanczos_prepare(s, total, 0.0, st)) return 1;
-  if (lz_fill_random(s->d_vin, len, 12345ull, st)) return 1;
-  if (lz_norm_begin(s->d_vin, len, s->d_partial, s->d_scal, st)) return 1;
+  if (lanczos_seed(s, nullptr, 12345ull, st)) return 1;
+  if (lz_norm_begin(s->d_vin, s->lz_len, s->d_partial, s->d_scal, st)) return 1;
   int rc = 0;
+  // the product as the loop computes it: on the panel-major vectors when the recurrence runs on them
+  auto hv_probe = [&]() -> int {
+    if (s->lz_blocked) return launch_normal_blocked(s, s->d_vin, s->d_tmp, st);
+    return apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st);
+  };
   for (int it = 0; it < warmup && !rc; it++) rc |= lanczos_step(s, it, total, st);
   if (!rc) rc |= (hipStreamSynchronize(st) != hipSuccess);
   const auto t0 = std::chrono::steady_clock::now();
@@ -2599,10 +2706,10 @@ int edigpu_lanczos_bench(edigpu_handle s, int warmup, int steps, double* ms_wall
   // H*v launches alone (the Lanczos vector of the last step as input), HIP events around each
   std::vector<hipEvent_t> ev(2 * (size_t)steps);
   for (auto& e : ev) EDIGPU_HIP(hipEventCreate(&e));
-  for (int k = 0; k < 3 && !rc; k++) rc |= apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st);
+  for (int k = 0; k < 3 && !rc; k++) rc |= hv_probe();
   for (int k = 0; k < steps && !rc; k++) {
     rc |= (hipEventRecord(ev[2 * k], st) != hipSuccess);
-    rc |= apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st);
+    rc |= hv_probe();
     rc |= (hipEventRecord(ev[2 * k + 1], st) != hipSuccess);
   }
   if (!rc) rc |= (hipStreamSynchronize(st) != hipSuccess);
@@ -2638,6 +2745,9 @@ int edigpu_destroy(edigpu_handle s) {
   dev_free(s->d_mx_rowptr);
   dev_free(s->d_tile_chunks);
   dev_free(s->d_tile_lbeg);
+  dev_free(s->d_bl_meta);
+  dev_free(s->d_bl_ent);
+  dev_free(s->d_bl_wtab);
   dev_free(s->d_tl_meta);
   dev_free(s->d_tl_col);
   dev_free(s->d_tl_val);

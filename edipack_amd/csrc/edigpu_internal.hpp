@@ -118,6 +118,16 @@ struct edigpu_sector {
   int32_t* d_tl_col = nullptr;
   double* d_tl_val = nullptr;
   int tl_has_nd = 0;
+  // panel-major vector layout of the fused Lanczos loop (NormalArgs::blk_shift): chosen at set-up for large factored
+  // whole sectors, 0 = not available; lz_blocked: the current recurrence runs on it
+  int blk_shift = 0;
+  int64_t blk_ps = 0, blk_len = 0;
+  int4* d_bl_meta = nullptr;
+  int blk_rows = 0;             // rows of an LDS block of the blocked sweep
+  uint32_t* d_bl_ent = nullptr;
+  double* d_bl_wtab = nullptr;
+  bool lz_blocked = false;
+  int64_t lz_len = 0;           // doubles per vector of the current recurrence (blk_len or ws_len)
   int row_split = 1;  // rows longer than the LDS: number of column parts the row kernel stages them in (SPLIT)
   int col_halo = 0;             // max |partner column - column| over the factored Hnd terms (transposed exchange)
   uint32_t* d_jdw = nullptr;    // nterms * dim_dw

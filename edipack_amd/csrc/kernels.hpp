@@ -75,6 +75,11 @@ int lz_beta(const double* vin, double* vout, int64_t n, double* partial, double*
 int lz_axpy_coef(double* acc, const double* vin, int64_t n, double coef, const double* scal,
                  int iter, hipStream_t st);
 int lz_fill_random(double* v, int64_t n, uint64_t seed, hipStream_t st);
+// natural layout (idw * DimUp + iup) <-> panel-major layout of the Lanczos loop (normal_args.hpp: blk_shift); the
+// padding columns of the last panel are written as zeros
+int vec_to_blocked(const double* src, double* dst, int64_t dim_up, int64_t dim_dw, int shift, hipStream_t st);
+int vec_from_blocked(const double* src, double* dst, int64_t dim_up, int64_t dim_dw, int shift, hipStream_t st);
+int launch_normal_blocked(const edigpu_sector* s, const double* v, double* hv, hipStream_t st);
 int measure_membw(int64_t bytes, double out[3]);
 // stand-alone vector kernels with explicit device scalars (sharded loop)
 int vec_rotate(int64_t n, double* vin, double* vout, const double* beta2, hipStream_t st);

@@ -318,6 +318,41 @@ int lz_axpy_coef(double* acc, const double* vin, int64_t n, double coef, const d
   return 0;
 }
 
+__global__ void __launch_bounds__(256) k_to_blocked(const double* __restrict__ src, double* __restrict__ dst, int64_t dim_up,
+                                                    int64_t dim_dw, int shift, int64_t n) {
+  const int64_t ps = dim_dw << shift;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t panel = i / ps, rem = i - panel * ps;
+    const int64_t row = rem >> shift, col = (panel << shift) + (rem & (((int64_t)1 << shift) - 1));
+    dst[i] = col < dim_up ? src[row * dim_up + col] : 0.0;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_from_blocked(const double* __restrict__ src, double* __restrict__ dst, int64_t dim_up,
+                                                      int64_t dim_dw, int shift, int64_t n) {
+  const int64_t ps = dim_dw << shift;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / dim_up, col = i - row * dim_up;
+    dst[i] = src[(col >> shift) * ps + (row << shift) + (col & (((int64_t)1 << shift) - 1))];
+  }
+}
+
+int vec_to_blocked(const double* src, double* dst, int64_t dim_up, int64_t dim_dw, int shift, hipStream_t st) {
+  const int64_t n = ((dim_up + ((int64_t)1 << shift) - 1) >> shift) * (dim_dw << shift);
+  const unsigned g = (unsigned)std::min<int64_t>((n + 255) / 256, 65536);
+  hipLaunchKernelGGL(k_to_blocked, dim3(g), dim3(256), 0, st, src, dst, dim_up, dim_dw, shift, n);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int vec_from_blocked(const double* src, double* dst, int64_t dim_up, int64_t dim_dw, int shift, hipStream_t st) {
+  const int64_t n = dim_up * dim_dw;
+  const unsigned g = (unsigned)std::min<int64_t>((n + 255) / 256, 65536);
+  hipLaunchKernelGGL(k_from_blocked, dim3(g), dim3(256), 0, st, src, dst, dim_up, dim_dw, shift, n);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 int lz_fill_random(double* v, int64_t n, uint64_t seed, hipStream_t st) {
   hipLaunchKernelGGL(k_fill_random, ew_grid(n), dim3(kLzNT), 0, st, v, n, seed);
   EDIGPU_HIP(hipGetLastError());

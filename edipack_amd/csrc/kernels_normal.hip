@@ -78,6 +78,13 @@ __global__ void __launch_bounds__(NT)
   extern __shared__ double vs[];
 
   const int64_t DimUp = a.dim_up;
+  // element (row, col) of a vector: natural layout, or the panel-major one of the Lanczos loop (normal_args.hpp);
+  // 4 adjacent columns starting at a multiple of 4 are contiguous in both
+  const int bsh = a.blk_shift;
+  const int64_t bps = a.blk_ps;
+  auto vix = [&](int64_t row, int64_t col) -> int64_t {
+    return bsh ? (col >> bsh) * bps + (row << bsh) + (col & (((int64_t)1 << bsh) - 1)) : row * DimUp + col;
+  };
   // staged part of a row: all of it, or the columns [sf, sf + sc) of this launch (SPLIT)
   const int64_t sf = SPLIT ? a.split_first : 0, sc = SPLIT ? a.split_count : DimUp;
   // staged row stride: sc columns + a zero slot at index sc (target of the dead ELL slots), even
@@ -115,9 +122,10 @@ __global__ void __launch_bounds__(NT)
           for (int u = 0; u < 4; u++) {
             const int64_t j = j0 + tid + u * NT;
             const int rr = r < nr ? r : 0;  // clamped: always a valid address
-            t[r][u] = reinterpret_cast<const double2*>(v_src + (r0 + rr) * DimUp + sf)[j < n2 ? j : n2 - 1];
+            const int64_t jc = 2 * (j < n2 ? j : n2 - 1);
+            t[r][u] = *reinterpret_cast<const double2*>(v_src + vix(r0 + rr, sf + jc));
             if (FUSE == 3) {
-              const double2 pp = reinterpret_cast<const double2*>(v_local + (r0 + rr) * DimUp)[j < n2 ? j : n2 - 1];
+              const double2 pp = *reinterpret_cast<const double2*>(v_local + vix(r0 + rr, jc));
               t[r][u].x -= alpha * pp.x;
               t[r][u].y -= alpha * pp.y;
             }
@@ -143,8 +151,8 @@ __global__ void __launch_bounds__(NT)
           for (int u = 0; u < 4; u++) {
             const int64_t j = j0 + tid + u * NT;
             const int rr = r < nr ? r : 0;
-            t[r][u] = v_src[(r0 + rr) * DimUp + sf + (j < sc ? j : sc - 1)];
-            if (FUSE == 3) t[r][u] -= alpha * v_local[(r0 + rr) * DimUp + (j < DimUp ? j : DimUp - 1)];
+            t[r][u] = v_src[vix(r0 + rr, sf + (j < sc ? j : sc - 1))];
+            if (FUSE == 3) t[r][u] -= alpha * v_local[vix(r0 + rr, j < DimUp ? j : DimUp - 1)];
             if (FUSE >= 2) t[r][u] *= ibeta;
           }
 #pragma unroll
@@ -190,7 +198,7 @@ __global__ void __launch_bounds__(NT)
 #pragma unroll
             for (int e = 0; e < kE; e++) x[e] = ok[e] ? vs[r * S + col0 + e] : 0.0;
           } else {
-            load4<VEC>(v_local, (r0 + r) * DimUp + col0, ok, x);
+            load4<VEC>(v_local, vix(r0 + r, col0), ok, x);
           }
 #pragma unroll
           for (int e = 0; e < kE; e++) acc[r][e] = (SPLIT && sf != 0) ? 0.0 : h[e] * x[e];  // the diagonal: first part only
@@ -304,7 +312,7 @@ __global__ void __launch_bounds__(NT)
                 const double x = USE_LDS ? (PACKED ? *reinterpret_cast<const double*>(
                                                          reinterpret_cast<const char*>(vs) + r * rowB + cc[e])
                                                    : vs[r * S + cc[e]])
-                                         : v_local[(r0 + r) * DimUp + cc[e]];
+                                         : v_local[vix(r0 + r, cc[e])];
                 acc[r][e] = fma(ww[e], x, acc[r][e]);
               }
             }
@@ -342,18 +350,18 @@ __global__ void __launch_bounds__(NT)
 #pragma unroll
     for (int r = 0; r < TD; r++)
       if (r < nr) {
-        double* dst = hv + (r0 + r) * DimUp + col0;
+        double* dst = hv + vix(r0 + r, col0);
         if (!LOCAL || (SPLIT && sf != 0)) {
           double old[kE];
-          load4<VEC>(hv, (r0 + r) * DimUp + col0, ok, old);
+          load4<VEC>(hv, vix(r0 + r, col0), ok, old);
 #pragma unroll
           for (int e = 0; e < kE; e++) acc[r][e] += old[e];
         }
         if (FUSE >= 2) {
           // Q <- acc - beta * P_old ; P <- x (the staged, normalised vector)
           double pold[kE];
-          load4<VEC>(v_local, (r0 + r) * DimUp + col0, ok, pold);
-          double* pdst = const_cast<double*>(v_local) + (r0 + r) * DimUp + col0;
+          load4<VEC>(v_local, vix(r0 + r, col0), ok, pold);
+          double* pdst = const_cast<double*>(v_local) + vix(r0 + r, col0);
 #pragma unroll
           for (int e = 0; e < kE; e++) acc[r][e] -= beta * pold[e];
           if (VEC) {
@@ -537,6 +545,12 @@ static void fill_args(const edigpu_sector* s, NormalArgs& a) {
   a.tl_col = s->d_tl_col;
   a.tl_val = s->d_tl_val;
   a.tl_has_nd = s->tl_has_nd;
+  a.blk_shift = 0;  // natural layout unless the caller runs the panel-major Lanczos loop
+  a.blk_ps = 0;
+  a.bl_meta = s->d_bl_meta;
+  a.blk_rows = s->blk_rows;
+  a.bl_ent = s->d_bl_ent;
+  a.bl_wtab = s->d_bl_wtab;
   a.mx_rowptr = s->d_mx_rowptr;
   a.mx_col = s->d_mx_col;
   a.mx_val = s->d_mx_val;
@@ -618,7 +632,12 @@ int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const do
   a.scal = scal;
   a.partial = partial;
   a.partial_cap = partial_cap;
+  if (s->lz_blocked) {  // P, Q in the panel-major layout (lanczos_prepare)
+    a.blk_shift = s->blk_shift;
+    a.blk_ps = s->blk_ps;
+  }
   if (launch_rows(s, a, P, P, Q, first ? 101 : (lazy_axpy ? 103 : 102), st)) return 1;
+  if (s->lz_blocked) return launch_dw_blocked(a, a.nterms > 0, P, Q, st, true, npartial);
   const bool fac_nd = s->factored && a.nterms > 0 && s->d_mx_rowptr != nullptr;
   if (!s->factored && s->has_nd && s->nd.sell) {
     // explicit image (hand-over arrays): panels without the dot, then Q += Hnd v as a SELL pass whose
@@ -627,6 +646,20 @@ int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const do
     return launch_csr_lanczos(s->nd, 0, P, Q, partial, partial_cap, npartial, scal + SC_ALPHA, st);
   }
   return launch_dw_panels(a, true, fac_nd, P, Q, st, true, npartial);
+}
+
+// plain H*v on panel-major vectors (the product of the blocked Lanczos loop without the fused recurrence)
+int launch_normal_blocked(const edigpu_sector* s, const double* v, double* hv, hipStream_t st) {
+  if (s->blk_shift == 0 || s->dw_count == 0) {
+    set_error("launch_normal_blocked: the sector has no panel-major image");
+    return 1;
+  }
+  NormalArgs a;
+  fill_args(s, a);
+  a.blk_shift = s->blk_shift;
+  a.blk_ps = s->blk_ps;
+  if (launch_rows(s, a, v, v, hv, 1, st)) return 1;
+  return launch_dw_blocked(a, a.nterms > 0, v, hv, st, false, nullptr);
 }
 
 }  // namespace edigpu

@@ -641,6 +641,314 @@ __global__ void __launch_bounds__(NT)
   }
 }
 
+
+// ---- the sweep on the panel-major layout (NormalArgs::blk_shift) ----
+// A panel of V is one contiguous array of DimDw segments of W doubles (whole 128-byte lines), sized to stay in the L2 of
+// the XCD that sweeps it, so the fabric sees V and the result once (in the natural layout a segment of row r starts
+// at byte r * DimUp * 8 and straddles lines: a panel narrow enough for the L2 of a long sector occupies twice its size
+// in lines, and narrower panels only RAISED the fetch traffic there -- measured).  But L2 hits are not free either: a
+// sweep that gathers every hop from the L2 moves (hops per row + 2) * 8 bytes per element through it, 34 GB per
+// product on the Ns = 16 ladder, which is the whole 2.1 ms of the natural-layout kernel at the ~16 TB/s the L2
+// delivers.  Narrow panels make tall LDS tiles affordable -- 512 rows x 16 columns are 64 KiB -- and with rows in
+// ascending order of the down word (impurity bits lowest) a contiguous block of 512 rows contains 59 % of its own
+// hop partners (128 rows: 43 %, 32 rows: 28 %): a workgroup stages its block once and takes those gathers from the
+// LDS, only the rest from the L2.
+// A segment is served by L = W / 2 lanes (16 bytes each), a wave works on 64 / L rows at once, each lane group on
+// kBlkJ rows interleaved (4 * kBlkJ independent gathers in flight per lane); the hop lists are 4-byte entries (staged
+// row / global row, weight index, Hnd term) read 16 bytes at a time, the weights come from a 256-entry table in the
+// LDS.  Workgroups with the same blockIdx & 7 (one XCD under the round-robin dispatch) walk a contiguous range of
+// panels, one panel at a time.
+constexpr int kBlkNT = 256;
+constexpr int kBlkJ = 4;
+
+struct BlkArgs {
+  int npanels, panels_per_xcd, nchunks, rows_per_task;
+};
+
+template <int SHIFT, bool DO_ND, bool ALPHA>
+__global__ void __launch_bounds__(kBlkNT)
+    normal_dw_blk_kernel(NormalArgs a, BlkArgs p, const double* __restrict__ v, double* __restrict__ hv) {
+  constexpr int W = 1 << SHIFT, L = W / 2, RW = 64 / L, NW = kBlkNT / 64, RB = NW * RW;
+  extern __shared__ double2 stile[];  // [rows_per_task][L]: the block's own segments of V
+  __shared__ double wtab[256];
+  __shared__ double red[3 * NW];
+  __shared__ uint32_t ju2[DO_ND ? 2 * kMaxNdTerms * L : 1];
+  const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane / L, lg = lane % L;
+  double asum = 0.0, qsum = 0.0, nsum = 0.0;
+  const bool stop = ALPHA && a.scal[SC_STOP] != 0.0;
+  const double sg = ALPHA ? a.scal[SC_ALPHA] : 0.0;
+  wtab[threadIdx.x] = a.bl_wtab[threadIdx.x];  // kBlkNT == 256
+  const int64_t DimDw = a.dim_dw, DimUp = a.dim_up, PS = a.blk_ps;
+  const int pfirst = x * p.panels_per_xcd;
+  int plast = pfirst + p.panels_per_xcd;
+  if (plast > p.npanels) plast = p.npanels;
+  const int ntasks = stop ? 0 : (plast - pfirst) * p.nchunks;
+  const int R = p.rows_per_task;
+  int cur_panel = -1;
+  for (int task = slot; task < ntasks; task += nslots) {
+    const int panel = pfirst + task / p.nchunks, chunk = task % p.nchunks;
+    const double* __restrict__ vp = v + (int64_t)panel * PS;
+    double* __restrict__ hp = hv + (int64_t)panel * PS;
+    const int64_t rb = (int64_t)chunk * R;
+    const int nrows = (int)(DimDw - rb < R ? DimDw - rb : R);
+    __syncthreads();  // the previous task's readers of the tile and of ju2 are done
+    // ---- stage the block: nrows * L contiguous double2 ----
+    {
+      const double2* __restrict__ src = reinterpret_cast<const double2*>(vp + (rb << SHIFT));
+      const int n2 = nrows * L;
+      for (int i0 = 0; i0 < n2; i0 += 4 * kBlkNT) {
+        double2 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u * kBlkNT + threadIdx.x;
+          t[u] = src[i < n2 ? i : n2 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u * kBlkNT + threadIdx.x;
+          if (i < n2) stile[i] = t[u];
+        }
+      }
+    }
+    if (DO_ND && panel != cur_panel) {  // partner columns of this panel's columns, per term and component
+      const int64_t pbase = (int64_t)panel << SHIFT;
+      for (int i = threadIdx.x; i < 2 * a.nterms * L; i += kBlkNT) {
+        const int t2 = i / L, l = i % L;
+        const int64_t col = pbase + 2 * l + (t2 & 1);
+        uint32_t w = 0xFFFFFFFFu;
+        if (col < DimUp) {
+          const uint32_t jt = a.jup[(int64_t)(t2 >> 1) * DimUp + col];
+          if (jt != 0xFFFFFFFFu) {
+            const int64_t rel = (int64_t)(jt & 0x7FFFFFFFu) - pbase;
+            w = (rel >= 0 && rel < W) ? ((jt & 0x80000000u) | (uint32_t)rel)
+                                      : ((jt & 0x80000000u) | 0x40000000u | (jt & 0x3FFFFFFFu));
+          }
+        }
+        ju2[i] = w;
+      }
+      cur_panel = panel;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < R; pass += RB * kBlkJ) {
+      const int lr0 = pass + wave * RW + grp;  // staged index of this lane group's first row
+      if (pass >= nrows) break;                 // uniform
+      double2 acc[kBlkJ];
+      int4 meta[kBlkJ];
+      bool live[kBlkJ];
+#pragma unroll
+      for (int j = 0; j < kBlkJ; j++) {
+        const int lr = lr0 + j * RB;
+        live[j] = lr < nrows;
+        const int64_t rr = rb + (live[j] ? lr : nrows - 1);  // clamped: a valid address, masked at the store
+        acc[j] = *reinterpret_cast<const double2*>(hp + (rr << SHIFT) + 2 * lg);
+        meta[j] = a.bl_meta[rr];
+      }
+      const uint32_t* __restrict__ le[kBlkJ];
+      uint4 e[kBlkJ];
+      // ---- hops that leave the block: L2 gathers, the kBlkJ rows of the lane group interleaved ----
+      int no[kBlkJ], nomax = 0;
+#pragma unroll
+      for (int j = 0; j < kBlkJ; j++) {
+        le[j] = a.bl_ent + meta[j].x + meta[j].y;  // the inter entries follow the intra ones
+        no[j] = live[j] ? meta[j].z : 0;
+        nomax = no[j] > nomax ? no[j] : nomax;
+        e[j] = *reinterpret_cast<const uint4*>(le[j]);  // (no such hops: reads the next entries, weights masked)
+      }
+      for (int b = 0; b < nomax; b += 4) {
+        double2 y[kBlkJ][4];
+#pragma unroll
+        for (int j = 0; j < kBlkJ; j++) {
+          y[j][0] = *reinterpret_cast<const double2*>(vp + ((int64_t)(e[j].x & 0xFFFFu) << SHIFT) + 2 * lg);
+          y[j][1] = *reinterpret_cast<const double2*>(vp + ((int64_t)(e[j].y & 0xFFFFu) << SHIFT) + 2 * lg);
+          y[j][2] = *reinterpret_cast<const double2*>(vp + ((int64_t)(e[j].z & 0xFFFFu) << SHIFT) + 2 * lg);
+          y[j][3] = *reinterpret_cast<const double2*>(vp + ((int64_t)(e[j].w & 0xFFFFu) << SHIFT) + 2 * lg);
+        }
+        uint4 en[kBlkJ];
+#pragma unroll
+        for (int j = 0; j < kBlkJ; j++) {
+          int bn = b + 4 < no[j] ? b + 4 : no[j] - 4;  // clamped: the last batch again (its weights are masked)
+          bn = bn < 0 ? 0 : bn;
+          en[j] = *reinterpret_cast<const uint4*>(le[j] + bn);
+        }
+#pragma unroll
+        for (int j = 0; j < kBlkJ; j++) {
+          const bool on = b < no[j];
+          const double w0 = on ? wtab[(e[j].x >> 16) & 255u] : 0.0, w1 = on ? wtab[(e[j].y >> 16) & 255u] : 0.0,
+                       w2 = on ? wtab[(e[j].z >> 16) & 255u] : 0.0, w3 = on ? wtab[(e[j].w >> 16) & 255u] : 0.0;
+          acc[j].x += w0 * y[j][0].x;
+          acc[j].y += w0 * y[j][0].y;
+          acc[j].x += w1 * y[j][1].x;
+          acc[j].y += w1 * y[j][1].y;
+          acc[j].x += w2 * y[j][2].x;
+          acc[j].y += w2 * y[j][2].y;
+          acc[j].x += w3 * y[j][3].x;
+          acc[j].y += w3 * y[j][3].y;
+          e[j] = en[j];
+        }
+      }
+      // ---- hops inside the block: LDS gathers ----
+#pragma unroll
+      for (int j = 0; j < kBlkJ; j++) {
+        if (!live[j]) continue;
+        const uint32_t* __restrict__ li = a.bl_ent + meta[j].x;
+        for (int b = 0; b < meta[j].y; b += 4) {
+          const uint4 ei = *reinterpret_cast<const uint4*>(li + b);
+          const double2 y0 = stile[(int)(ei.x & 0xFFFFu) * L + lg], y1 = stile[(int)(ei.y & 0xFFFFu) * L + lg],
+                        y2 = stile[(int)(ei.z & 0xFFFFu) * L + lg], y3 = stile[(int)(ei.w & 0xFFFFu) * L + lg];
+          const double w0 = wtab[(ei.x >> 16) & 255u], w1 = wtab[(ei.y >> 16) & 255u], w2 = wtab[(ei.z >> 16) & 255u],
+                       w3 = wtab[(ei.w >> 16) & 255u];
+          acc[j].x += w0 * y0.x;
+          acc[j].y += w0 * y0.y;
+          acc[j].x += w1 * y1.x;
+          acc[j].y += w1 * y1.y;
+          acc[j].x += w2 * y2.x;
+          acc[j].y += w2 * y2.y;
+          acc[j].x += w3 * y3.x;
+          acc[j].y += w3 * y3.y;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kBlkJ; j++) {
+        const int lr = lr0 + j * RB;
+        if (!live[j]) continue;
+        const int64_t r = rb + lr;
+        double2 s = acc[j];
+        if (DO_ND) {
+          const uint32_t* __restrict__ ln = a.bl_ent + meta[j].x + meta[j].y + meta[j].z;
+          for (int q = 0; q < meta[j].w; q++) {
+            const uint32_t ee = ln[q];
+            const int term = (int)(ee >> 24) - 1;
+            const double w = wtab[(ee >> 16) & 255u];
+            const int64_t prow = (int64_t)(ee & 0xFFFFu);
+            const uint32_t j0 = ju2[(2 * term) * L + lg], j1 = ju2[(2 * term + 1) * L + lg];
+            const bool v0 = j0 != 0xFFFFFFFFu, v1 = j1 != 0xFFFFFFFFu;
+            const double w0 = v0 ? ((j0 >> 31) ? -w : w) : 0.0, w1 = v1 ? ((j1 >> 31) ? -w : w) : 0.0;
+            // the partner row's segment (an L2 hit like a hop); the partner columns sit a few lanes away in the group
+            const double2 y = *reinterpret_cast<const double2*>(vp + (prow << SHIFT) + 2 * lg);
+            const int l0 = grp * L + (int)((j0 >> 1) & (L - 1)), l1 = grp * L + (int)((j1 >> 1) & (L - 1));
+            const double s0x = __shfl(y.x, l0, 64), s0y = __shfl(y.y, l0, 64);
+            const double s1x = __shfl(y.x, l1, 64), s1y = __shfl(y.y, l1, 64);
+            double p0 = (j0 & 1u) ? s0y : s0x, p1 = (j1 & 1u) ? s1y : s1x;
+            if (v0 && (j0 & 0x40000000u)) {  // the partner column lies in a neighbouring panel
+              const int64_t jc = (int64_t)(j0 & 0x3FFFFFFFu);
+              p0 = v[(jc >> SHIFT) * PS + (prow << SHIFT) + (jc & (W - 1))];
+            }
+            if (v1 && (j1 & 0x40000000u)) {
+              const int64_t jc = (int64_t)(j1 & 0x3FFFFFFFu);
+              p1 = v[(jc >> SHIFT) * PS + (prow << SHIFT) + (jc & (W - 1))];
+            }
+            s.x += w0 * p0;
+            s.y += w1 * p1;
+          }
+        }
+        *reinterpret_cast<double2*>(hp + (r << SHIFT) + 2 * lg) = s;
+        if (ALPHA) {
+          const double2 o = stile[lr * L + lg];  // the row's own segment of v (zero in the padding columns)
+          const double dx = s.x - sg * o.x, dy = s.y - sg * o.y;
+          asum += o.x * s.x + o.y * s.y;
+          qsum += dx * dx + dy * dy;
+          nsum += o.x * o.x + o.y * o.y;
+        }
+      }
+    }
+  }
+  if (ALPHA) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      asum += __shfl_down(asum, off, 64);
+      qsum += __shfl_down(qsum, off, 64);
+      nsum += __shfl_down(nsum, off, 64);
+    }
+    if (lane == 0) {
+      red[wave] = asum;
+      red[NW + wave] = qsum;
+      red[2 * NW + wave] = nsum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0, q = 0.0, n = 0.0;
+#pragma unroll
+      for (int i = 0; i < NW; i++) {
+        t += red[i];
+        q += red[NW + i];
+        n += red[2 * NW + i];
+      }
+      a.partial[blockIdx.x] = t;
+      a.partial[gridDim.x + blockIdx.x] = q;
+      a.partial[2 * gridDim.x + blockIdx.x] = n;
+    }
+  }
+}
+
+int launch_dw_blocked(const NormalArgs& a, bool do_nd, const double* v, double* hv, hipStream_t st, bool alpha,
+                      int* nblocks) {
+  if (a.blk_shift < 4 || a.blk_shift > 6 || a.blk_rows < 32 || !a.bl_meta || !a.bl_ent || !a.bl_wtab || a.dw_first != 0 ||
+      a.dw_count != a.dim_dw) {
+    set_error("launch_dw_blocked: the sector has no panel-major image");
+    return 1;
+  }
+  if (do_nd && a.nterms > kMaxNdTerms) {
+    set_error("launch_dw_blocked: too many factored Hnd terms");
+    return 1;
+  }
+  BlkArgs p;
+  const int W = 1 << a.blk_shift;
+  p.npanels = (int)((a.dim_up + W - 1) >> a.blk_shift);
+  p.panels_per_xcd = (p.npanels + 7) / 8;
+  p.rows_per_task = a.blk_rows;  // rows of an LDS block: the lists were split by it at set-up
+  p.nchunks = (int)((a.dim_dw + p.rows_per_task - 1) / p.rows_per_task);
+  const size_t lds = (size_t)p.rows_per_task * (W / 2) * sizeof(double2);
+  // a persistent grid: as many workgroups as stay resident (EDIGPU_BLOCKED_WGS caps them per CU), each walking its
+  // XCD's tasks in order, so that an XCD works on one panel (at a boundary: two) at a time
+  static const int cap_per_cu = [] {
+    const char* e = getenv("EDIGPU_BLOCKED_WGS");
+    const int n = e ? atoi(e) : 8;
+    return n >= 1 && n <= 8 ? n : 8;
+  }();
+  const int64_t most = (int64_t)p.panels_per_xcd * p.nchunks * 8;
+#define EDIGPU_LAUNCH_BLK2(SH, ND, AL)                                                                  \
+  do {                                                                                                  \
+    auto kern = normal_dw_blk_kernel<SH, ND, AL>;                                                       \
+    if (ensure_dynamic_lds((const void*)kern, lds)) return 1;                                           \
+    int per_cu = resident_blocks((const void*)kern, kBlkNT, lds);                                       \
+    if (per_cu < 1) return 1;                                                                           \
+    if (per_cu > cap_per_cu) per_cu = cap_per_cu;                                                       \
+    int64_t g = (int64_t)per_cu * device_cu_count();                                                    \
+    g -= g % 8;                                                                                         \
+    if (g > most) g = most;                                                                             \
+    if (g < 8) g = 8;                                                                                   \
+    if (nblocks) *nblocks = (int)g;                                                                     \
+    if (alpha && 3 * g > a.partial_cap) {                                                               \
+      set_error("launch_dw_blocked: partial buffer too small for this grid");                           \
+      return 1;                                                                                         \
+    }                                                                                                   \
+    hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(kBlkNT), lds, st, a, p, v, hv);                    \
+  } while (0)
+#define EDIGPU_LAUNCH_BLK(SH)              \
+  do {                                     \
+    if (do_nd && alpha)                    \
+      EDIGPU_LAUNCH_BLK2(SH, true, true);  \
+    else if (do_nd)                        \
+      EDIGPU_LAUNCH_BLK2(SH, true, false); \
+    else if (alpha)                        \
+      EDIGPU_LAUNCH_BLK2(SH, false, true); \
+    else                                   \
+      EDIGPU_LAUNCH_BLK2(SH, false, false);\
+  } while (0)
+  if (a.blk_shift == 4)
+    EDIGPU_LAUNCH_BLK(4);
+  else if (a.blk_shift == 5)
+    EDIGPU_LAUNCH_BLK(5);
+  else
+    EDIGPU_LAUNCH_BLK(6);
+#undef EDIGPU_LAUNCH_BLK2
+#undef EDIGPU_LAUNCH_BLK
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 static int panel_resident_blocks() {
   // EDIGPU_PANEL_BPP: workgroups per panel (tuning knob); default = what one XCD keeps resident
   static int v = -1;

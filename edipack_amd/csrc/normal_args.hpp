@@ -56,6 +56,18 @@ struct NormalArgs {
   const int32_t* tl_col;
   const double* tl_val;
   int tl_has_nd;  // the lists carry the factored Hnd terms
+  // Panel-major ("blocked") vector layout of the device-resident Lanczos loop: element (idw, iup) lives at
+  // (iup >> blk_shift) * blk_ps + (idw << blk_shift) + (iup & (W - 1)), W = 1 << blk_shift columns per panel, blk_ps =
+  // DimDw * W; the last panel is padded with zeros.  blk_shift = 0: natural layout (idw * DimUp + iup).
+  int blk_shift;
+  int64_t blk_ps;
+  // lists of the blocked sweep (normal_dw_blk_kernel): per row bl_meta = (first entry, hops inside the row's LDS block,
+  // hops leaving it -- both padded to x4 --, Hnd terms); entry = row (16 bit: index inside the block / global row) |
+  // weight index << 16 | (Hnd term + 1) << 24; bl_wtab: 256 weights
+  const int4* bl_meta;
+  const uint32_t* bl_ent;
+  int blk_rows;  // rows of an LDS block of the blocked sweep
+  const double* bl_wtab;
   const int32_t* mx_rowptr;  // merged list: ptr[dw_count+1]
   const int32_t* mx_col;     // partner row (24 bit) | tag << 24
   const double* mx_val;
@@ -65,6 +77,10 @@ struct NormalArgs {
 // alpha: also write the per-workgroup partials of <v|hv> and <hv|hv> (fused Lanczos step).
 int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* v_full, double* hv,
                      hipStream_t st, bool alpha = false, int* nblocks = nullptr);
+
+// the same sweep on vectors in the panel-major layout (a.blk_shift > 0)
+int launch_dw_blocked(const NormalArgs& a, bool do_nd, const double* v, double* hv, hipStream_t st, bool alpha,
+                      int* nblocks);
 
 int launch_dw_panel_cols(const NormalArgs& a, bool do_nd, int64_t col_first, int64_t ncol, int64_t stride, int halo,
                          const double* w, double* hv, hipStream_t st);

@@ -284,8 +284,8 @@ class SectorHamiltonian:
         return self.nloc
 
     def image_info(self):
-        """(factored, Hnd terms, diagonal classes, panel variant) of a normal-mode handle's device image."""
-        a = (C.c_int32 * 4)()
+        """(factored, Hnd terms, diagonal classes, panel variant, panel-major width, 0) of a normal-mode handle."""
+        a = (C.c_int32 * 6)()
         capi.check(capi.lib().edigpu_image_info(self._h, a), "edigpu_image_info")
         return tuple(a)
 

@@ -231,8 +231,10 @@ int edigpu_info(edigpu_handle h, int64_t info[10]);
 /* Device image of a normal-mode handle (diagnostics, tests): image[0] = 1 when the kernels run on the factored tables
  * (separable diagonal + Hnd as a sum of signed partial permutations; library-built sectors, and hand-over sectors
  * whose arrays edigpu_normal_create could factor), 0 for the explicit image (spH0d + spH0nd as given);
- * [1] = Hnd terms, [2] = diagonal classes, [3] = panel sweep variant (0 one column per lane, 1 two, 2 LDS-tiled). */
-int edigpu_image_info(edigpu_handle h, int32_t image[4]);
+ * [1] = Hnd terms, [2] = diagonal classes, [3] = panel sweep variant (0 one column per lane, 1 two, 2 LDS-tiled),
+ * [4] = columns per panel of the panel-major vector layout the device-resident Lanczos loops of this sector run on
+ * (0: natural layout; DESIGN.md "panel-major vectors"), [5] = reserved (0). */
+int edigpu_image_info(edigpu_handle h, int32_t image[6]);
 /* algorithmic bytes of one H*v in the reference's storage format */
 int edigpu_algorithmic_bytes(edigpu_handle h, double *bytes_hv, double *bytes_lanczos_step);
 /* copy the built matrices back to the host (tests: compare with the oracle).

@@ -1756,3 +1756,52 @@ def test_flat_modes_refuse_normal_only_fields(gpu):
             SectorHamiltonian.flat_from_model(pm, sec)
         with pytest.raises(capi.EdigpuError, match="not built in this mode"):
             SectorHamiltonian.direct_from_model(pm, sec)
+
+
+# --------------------------------------------------------------------------------------------
+# panel-major vector layout of the device-resident Lanczos loops (large factored sectors; forced here on small ones)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w", [16, 32, 64])
+@pytest.mark.parametrize("bath,norb,nbath,sec,jxp", [
+    ("normal", 2, 3, (4, 4), 0.25),      # DimUp = 70: a partly filled last panel
+    ("hybrid", 3, 5, (4, 3), 0.25),      # DimUp = 70, DimDw = 56, 3 merged Hnd terms
+    ("normal", 2, 4, (5, 5), 0.0),       # DimUp = 252, no Hnd
+    ("hybrid", 3, 6, (4, 5), 0.25),      # odd DimUp? C(9,4) = 126 x 126
+    ("normal", 1, 8, (4, 5), 0.0),       # one orbital
+])
+def test_panel_major_lanczos_matches_oracle(gpu, monkeypatch, w, bath, norb, nbath, sec, jxp):
+    """The blocked loop (rows kernel on panel-major vectors + normal_dw_blk_kernel) against the oracle's recurrence and
+    against the natural-layout loop of the same handle type: alpha / beta, the Ritz vector that comes back through the
+    layout conversion, and the H*v probe of the bench."""
+    import os
+    if os.environ.get("EDIGPU_NORMAL_EXPLICIT") or os.environ.get("EDIGPU_LANCZOS_UNFUSED"):
+        pytest.skip("the panel-major loop needs the factored image and the fused step")
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("normal", bath, norb, nbath, seed=71, jxp=jxp)
+    ho = O.HNormal(om, *sec)
+    monkeypatch.setenv("EDIGPU_BLOCKED", "1")
+    monkeypatch.setenv("EDIGPU_BLOCKED_MIN", "0")
+    monkeypatch.setenv("EDIGPU_BLOCKED_W", str(w))
+    hb = SectorHamiltonian.normal_from_model(pm, *sec)
+    assert hb.image_info()[4] == w
+    monkeypatch.setenv("EDIGPU_BLOCKED", "0")
+    hn = SectorHamiltonian.normal_from_model(pm, *sec)
+    assert hn.image_info()[4] == 0
+    v = np.random.default_rng(3).standard_normal(ho.dim)
+    n = 40
+    ao, bo, _ = ho.lanc_tridiag(v, n)
+    ab, bb, nb = hb.lanczos_tridiag(v, n)
+    an, bn, nn = hn.lanczos_tridiag(v, n)
+    assert nb == nn == n
+    assert rel_err(ab[:15], ao[:15]) < 1e-10 and rel_err(bb[:15], bo[:15]) < 1e-10
+    assert rel_err(ab[:15], an[:15]) < 1e-11 and rel_err(bb[:15], bn[:15]) < 1e-11
+    for z in (40.0 + 0.1j, -40.0 + 0.1j, 25.0j):
+        assert abs(_cf(ab, bb, z) - _cf(ao, bo, z)) / abs(_cf(ao, bo, z)) < 1e-10
+    # ground state: energy and vector (the vector crosses the layout conversion both ways)
+    eb, xb, _ = hb.lanczos_eigh(nitermax=min(300, ho.dim), tol=1e-13, v0=v)
+    e0 = np.linalg.eigvalsh(ho.dense())[0] if ho.dim <= 5000 else hn.lanczos_eigh(nitermax=300, tol=1e-13, v0=v)[0]
+    assert abs(eb - e0) < 1e-9 * max(1.0, abs(e0))
+    assert rel_err(hb.apply(xb), eb * xb) < 1e-6
+    assert hb.lanczos_bench(2, 3)[1] > 0.0
+    hb.destroy(), hn.destroy()
