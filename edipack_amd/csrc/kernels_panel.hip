@@ -1029,11 +1029,6 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
     if (np < 8) np = 8;
     p.width = (int)((a.dim_up + np - 1) / np);
     p.width += p.width & 1;
-    if (const char* e = getenv("EDIGPU_PANEL_ALIGN")) {  // EXPERIMENT: panel boundaries on multiples of this many columns
-      const int al = atoi(e);
-      if (al > 1) p.width = (p.width + al - 1) / al * al;
-      if (p.width > 128) p.width = 128;
-    }
     p.npanels = (int)((a.dim_up + p.width - 1) / p.width);
   } else {
     plan_panels(p, a.dim_up);

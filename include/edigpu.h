@@ -197,7 +197,8 @@ int edigpu_direct_build(edigpu_handle *h, const edigpu_model *model, int sector,
  * ED_AUX_FUNX.f90) and H = Hd + sum over the 2*Norb axes of one (1+Nbath)-level factor each.
  * Takes the place of build_Hv_sector_normal with ed_total_ud=F -> ed_buildh_normal_orbs
  * (ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:273-496) and spMatVec_normal_orbs (:652-761).
- * Single shard only (the MPI variant :932-1082 is not built).  All apply / Lanczos entry points work on it.
+ * edigpu_orbs_build holds the whole sector; edigpu_orbs_build_rows below is the row shard of the MPI variant
+ * (:932-1082).  All apply / Lanczos entry points work on a whole-sector handle.
  */
 int edigpu_orbs_build(edigpu_handle *h, const edigpu_model *model, const int32_t *nups, const int32_t *ndws);
 /* The same sector as a row shard (rows [row_first, row_first + row_count) of the tensor-ordered vector; row_count < 0:

@@ -3,8 +3,11 @@
 #   gpurun -- 'bash scripts/check_switches.sh'
 for sw in EDIGPU_LANCZOS_UNFUSED EDIGPU_NORMAL_EXPLICIT EDIGPU_FLAT_HOSTBUILD EDIGPU_LANCZOS_EXACTBETA EDIGPU_TRL_TWOPASS \
           EDIGPU_ELL_UNTYPED EDIGPU_CSR_NOSELL EDIGPU_CSR_UNPACKED EDIGPU_DIRECT_TERMORDER EDIGPU_PANEL_VEC2_MIN \
-          "EDIGPU_ROW_SPLIT=2" "EDIGPU_PANEL_VEC2=0" EDIGPU_ND_IN_ROWS; do
+          "EDIGPU_ROW_SPLIT=2" "EDIGPU_PANEL_VEC2=0" EDIGPU_ND_IN_ROWS "EDIGPU_PANEL_TILE=0" "EDIGPU_TILE_ROWS=64" \
+          EDIGPU_TILE_PERSIST "EDIGPU_HANDOVER_FACTOR=0" EDIGPU_ND_NO_MERGE "EDIGPU_BLOCKED=1 EDIGPU_BLOCKED_MIN=0" \
+          "EDIGPU_BLOCKED=1 EDIGPU_BLOCKED_MIN=0 EDIGPU_BLOCKED_W=16 EDIGPU_BLOCKED_LDS_KB=4"; do
   case $sw in *=*) kv=$sw;; *) kv=$sw=1;; esac
-  env $kv timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/sw_${sw%%=*}.log 2>&1
-  echo "$kv: $(tail -1 gpurun_out/sw_${sw%%=*}.log)"
+  tag=$(echo "${kv}" | tr " =" "__")
+  env $kv timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/sw_${tag}.log 2>&1
+  echo "$kv: $(tail -1 gpurun_out/sw_${tag}.log)"
 done
