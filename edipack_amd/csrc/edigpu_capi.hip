@@ -1702,6 +1702,60 @@ int edigpu_sector_map(const edigpu_model* model, int q1, int q2, int which, int3
   return 0;
 }
 
+int edigpu_sector_map_jz(const edigpu_model* model, int ntot, int twojz, int32_t* map, int64_t* n) {
+  if (!model || !n) {
+    set_error("edigpu_sector_map_jz: NULL argument");
+    return 1;
+  }
+  std::vector<int32_t> st;
+  std::string e = sector_map_jz(*model, ntot, twojz, st);
+  if (!e.empty()) {
+    set_error(e);
+    return 1;
+  }
+  if (map) {
+    if (*n < (int64_t)st.size()) {
+      set_error("edigpu_sector_map_jz: output buffer too small");
+      return 1;
+    }
+    std::copy(st.begin(), st.end(), map);
+  }
+  *n = (int64_t)st.size();
+  return 0;
+}
+
+int edigpu_flat_build_jz(edigpu_handle* h, const edigpu_model* model, int ntot, int twojz, int64_t row_first,
+                         int64_t row_count) {
+  if (!h || !model) {
+    set_error("edigpu_flat_build_jz: NULL argument");
+    return 1;
+  }
+  *h = nullptr;
+  if (ensure_device()) return 1;
+  if (model->nph > 0) {
+    set_error("edigpu_flat_build_jz: phonon sectors are not built in the Jz basis");
+    return 1;
+  }
+  HostFlat hf;
+  std::string e = build_flat(*model, ntot, row_first, row_count, hf, true, twojz);
+  if (!e.empty()) {
+    set_error(e);
+    return 1;
+  }
+  if (hf.dim == 0) {
+    set_error("edigpu_flat_build_jz: empty sector");
+    return 1;
+  }
+  // a hand-over-like handle: the stored image only (apply_op / lazy export need the plain sector labels)
+  std::unique_ptr<edigpu_sector> s(new edigpu_sector());
+  if (setup_flat(s.get(), hf.row_count, hf.dim, hf.row_first, hf.h.rowptr.data(), hf.h.col.data(), hf.h.val.data(), 1)) {
+    edigpu_destroy(s.release());
+    return 1;
+  }
+  *h = s.release();
+  return 0;
+}
+
 int edigpu_image_info(edigpu_handle s, int32_t image[6]) {
   if (!s || !image || s->kind != 0) {
     set_error("edigpu_image_info: not a normal-mode handle");
@@ -2077,6 +2131,13 @@ static int tridiag_impl(edigpu_handle s, const double* vin, int nlanc, double* a
   std::vector<double> sc((size_t)SC_AB + 2 * (size_t)nlanc);
   EDIGPU_HIP(hipMemcpyAsync(sc.data(), s->d_scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   EDIGPU_HIP(hipStreamSynchronize(st));
+  if (!(sc[SC_NORM] > 0.0)) {  // zero seed: nothing to tridiagonalise (the reference skips such channels)
+    std::fill(alanc, alanc + nlanc, 0.0);
+    std::fill(blanc, blanc + nlanc, 0.0);
+    if (niter_done) *niter_done = 0;
+    if (norm2) *norm2 = 0.0;
+    return 0;
+  }
   for (int k = 0; k < nlanc; k++) {
     alanc[k] = sc[SC_AB + k];
     blanc[k] = sc[SC_AB + nlanc + k];

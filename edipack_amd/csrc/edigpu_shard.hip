@@ -836,6 +836,10 @@ int edigpu_lanczos_tridiag_sharded(edigpu_handle h, edigpu_comm c, const double*
     set_error("edigpu_lanczos_tridiag_sharded: bad argument");
     return 1;
   }
+  // a world of one rank holding the whole sector: the fused single-GPU recurrence (half the vector traffic of the
+  // exchange form: no send / receive buffers); EDIGPU_FORCE_COLLECTIVES=1 keeps the N > 1 code path (tests)
+  if (c->world == 1 && h->nloc == h->dim && !getenv("EDIGPU_FORCE_COLLECTIVES") && vin_shard)
+    return edigpu_lanczos_tridiag_dev(h, vin_shard, nlanc, alanc, blanc, threshold, niter_done, norm2);
   return sharded_tridiag(h, c, vin_shard, nlanc, alanc, blanc, threshold, niter_done, norm2);
 }
 

@@ -662,7 +662,37 @@ struct SpinBasis {
       }
     }
   }
+  // Jz_basis=T sectors of nonsu2 (ED_SECTOR.f90:289-350): Ntot = q and twoJz = (Nup - Ndw) + twoLz with twoLz = sum over
+  // the levels iorb + Norb * ibath of 2 Lzdiag(iorb) (n_up + n_dw), Lzdiag = [-1, +1, 0] (ED_VARS_GLOBAL.f90:283).  The
+  // states stay in ascending order; ranking is a binary search (the two-table form does not apply: which up words
+  // go with a down word depends on its Lz as well as on its occupation).
+  bool jz = false;
+  void init_jz(int ns_, int norb, int ntot, int twojz) {
+    static const int lzdiag[3] = {-1, +1, 0};
+    ns = ns_;
+    mode = 2;
+    q = ntot;
+    jz = true;
+    const uint32_t nw = 1u << ns;
+    std::vector<int8_t> lz(nw, 0);  // twoLz / 2 of a word
+    for (uint32_t w = 0; w < nw; w++) {
+      int x = 0;
+      for (int p = 0; p < ns; p++)
+        if ((w >> p) & 1u) x += lzdiag[p % norb];
+      lz[w] = (int8_t)x;
+    }
+    states.clear();
+    for (uint32_t d = 0; d < nw; d++)
+      for (uint32_t u = 0; u < nw; u++) {
+        const int nu = popc(u), nd = popc(d);
+        if (nu + nd == ntot && (nu - nd) + 2 * (lz[u] + lz[d]) == twojz) states.push_back((int32_t)(u | (d << ns)));
+      }
+  }
   inline int64_t rank(uint32_t s) const {
+    if (jz) {
+      auto it = std::lower_bound(states.begin(), states.end(), (int32_t)s);
+      return (it != states.end() && *it == (int32_t)s) ? (int64_t)(it - states.begin()) : -1;
+    }
     return (int64_t)off_dw[s >> ns] + rk_up[s & ((1u << ns) - 1u)];
   }
 };
@@ -687,6 +717,17 @@ struct OpTerm {           // coef * op[n-1] ... op[1] op[0]  (op[0] acts first)
 
 // Sector map as build_sector leaves it (ED_SECTOR.f90:165-373): which = 0 / 1: H(1)%map (up) / H(2)%map (down) of a
 // normal-mode sector (q1, q2) = (Nup, Ndw); superc / nonsu2: the single map of sector q1 (Sz / Ntot), which ignored.
+std::string sector_map_jz(const edigpu_model& m, int ntot, int twojz, std::vector<int32_t>& out) {
+  std::string e = check_model(m);
+  if (!e.empty()) return e;
+  const int ns = model_ns(m);
+  if (m.ed_mode != 2 || m.norb != 3 || 2 * ns > 31 || ntot < 0 || ntot > 2 * ns) return "edigpu_sector_map_jz: needs nonsu2, Norb = 3";
+  SpinBasis sb;
+  sb.init_jz(ns, m.norb, ntot, twojz);
+  out = sb.states;
+  return "";
+}
+
 std::string sector_map(const edigpu_model& m, int q1, int q2, int which, std::vector<int32_t>& out) {
   std::string e = check_model(m);
   if (!e.empty()) return e;
@@ -859,7 +900,7 @@ static std::string refuse_normal_only_fields(const edigpu_model& m, const char* 
 }
 
 std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
-                       HostFlat& out) {
+                       HostFlat& out, bool jz_basis, int twojz) {
   std::string e = check_model(m);
   if (!e.empty()) return e;
   if (m.ed_mode != 1 && m.ed_mode != 2) return "edigpu_flat_build: model.ed_mode must be superc or nonsu2";
@@ -870,7 +911,15 @@ std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int
   const int ns = model_ns(m), norb = m.norb;
   if (2 * ns > 30) return "edigpu_flat_build: 2*Ns > 30 bits (the reference's integer range)";
   SpinBasis sb;
-  sb.init(ns, m.ed_mode, sector);
+  if (jz_basis) {
+    if (m.ed_mode != 2 || norb != 3) return "edigpu_flat_build_jz: Jz_basis needs ed_mode = nonsu2 and Norb = 3 (Lzdiag = [-1, +1, 0])";
+    if (!(m.bath_type == 2 || m.bath_type == 3 || m.nbath == 1))
+      return "edigpu_flat_build_jz: Jz_basis labels the levels as iorb + Norb * ibath: replica / general bath (or Nbath = 1)";
+    if (sector < 0 || sector > 2 * ns) return "edigpu_flat_build_jz: bad sector";
+    sb.init_jz(ns, norb, sector, twojz);
+  } else {
+    sb.init(ns, m.ed_mode, sector);
+  }
   out.ns = ns;
   out.dim = (int64_t)sb.states.size();
   if (row_count < 0) {
@@ -923,6 +972,7 @@ std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int
       for (int k = 0; k < t.n && ok; k++) ok = apply_op(w, t.pos[k], t.create[k], sg);
       if (!ok) continue;
       const int32_t j = (int32_t)sb.rank(w);
+      if (j < 0) return "edigpu_flat_build_jz: the model does not conserve Jz (a matrix element leaves the sector)";
       const cplx v = t.coef * sg;
       bool merged = false;
       for (size_t k = 0; k < rc.size(); k++)

@@ -125,8 +125,10 @@ std::string build_orbs(const edigpu_model& m, const int* nups, const int* ndws, 
 // kernels need; the arrays are only materialised for export (edigpu_normal_export).
 std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_first,
                          int64_t dw_count, HostNormal& out, bool explicit_arrays = true);
+// jz_basis: the nonsu2 sector (Ntot = sector, twoJz) of Jz_basis=T (ED_SECTOR.f90:289-350)
 std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
-                       HostFlat& out);
+                       HostFlat& out, bool jz_basis = false, int twojz = 0);
+std::string sector_map_jz(const edigpu_model& m, int ntot, int twojz, std::vector<int32_t>& out);
 std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
                          HostDirect& out);
 // Hand-over images: the factored tables recovered from spH0d / spH0nd as the reference built them (local rows of a

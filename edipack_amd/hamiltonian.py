@@ -151,6 +151,16 @@ def sector_map(model: "ImpurityModel", q1: int, q2: int = 0, which: int = 0) -> 
     return out
 
 
+def sector_map_jz(model: "ImpurityModel", ntot: int, twojz: int) -> np.ndarray:
+    """build_sector's map of the nonsu2 sector (Ntot, twoJz) of JZ_BASIS=T (ED_SECTOR.f90:289-350)."""
+    cm = model.to_c()
+    n = C.c_int64(0)
+    capi.check(capi.lib().edigpu_sector_map_jz(C.byref(cm), ntot, twojz, None, C.byref(n)), "edigpu_sector_map_jz")
+    out = np.zeros(n.value, np.int32)
+    capi.check(capi.lib().edigpu_sector_map_jz(C.byref(cm), ntot, twojz, capi.pi32(out), C.byref(n)), "edigpu_sector_map_jz")
+    return out
+
+
 def _csr_args(rowptr, col, val, cplx=False):
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
     col = np.ascontiguousarray(col, dtype=np.int32)
@@ -196,6 +206,16 @@ class SectorHamiltonian:
         cm = model.to_c()
         capi.check(capi.lib().edigpu_flat_build(C.byref(h), C.byref(cm), sector, row_first, row_count),
                    "edigpu_flat_build")
+        return cls(h)
+
+    @classmethod
+    def flat_jz_from_model(cls, model: ImpurityModel, ntot: int, twojz: int, row_first: int = 0,
+                           row_count: int = -1) -> "SectorHamiltonian":
+        """nonsu2 sector (Ntot, twoJz) of JZ_BASIS=T (build_sector, ED_SECTOR.f90:289-350)."""
+        h = C.c_void_p()
+        cm = model.to_c()
+        capi.check(capi.lib().edigpu_flat_build_jz(C.byref(h), C.byref(cm), ntot, twojz, row_first, row_count),
+                   "edigpu_flat_build_jz")
         return cls(h)
 
     @classmethod

@@ -181,6 +181,19 @@ int edigpu_flat_build(edigpu_handle *h, const edigpu_model *model, int sector, i
                       int64_t row_count);
 
 /*
+ * nonsu2 sector of JZ_BASIS=T (ED_INPUT_VARS.f90:757; build_sector, ED_SECTOR.f90:289-350): the states with Ntot = ntot
+ * and twoJz = (Nup - Ndw) + twoLz, twoLz = sum over the levels iorb + Norb*ibath of 2 Lzdiag(iorb) (n_up + n_dw),
+ * Lzdiag = [-1, +1, 0] (ED_VARS_GLOBAL.f90:283) -- three orbitals, replica / general bath (or Nbath = 1), the level
+ * order that labelling assumes.  The Hamiltonian is the nonsu2 one (ed_buildH_nonsu2_main) on that map; a model whose
+ * terms leave the sector (Jz not conserved: the reference's binary_search would fail) is refused.  The stored image
+ * is built on the host (no on-the-fly / device-built form); apply / Lanczos / eigensolver entry points as for
+ * edigpu_flat_build, shards by rows.  edigpu_sector_map_jz returns the map (as edigpu_sector_map).
+ */
+int edigpu_flat_build_jz(edigpu_handle *h, const edigpu_model *model, int ntot, int twojz, int64_t row_first,
+                         int64_t row_count);
+int edigpu_sector_map_jz(const edigpu_model *model, int ntot, int twojz, int32_t *map, int64_t *n);
+
+/*
  * On-the-fly ("direct", ED_SPARSE_H=F) sector: nothing of H is stored; every H*v regenerates the
  * matrix elements from the sector map, as directMatVec_nonsu2_main / directMatVec_MPI_nonsu2_main
  * (ED_NONSU2/ED_HAMILTONIAN_NONSU2_DIRECT_HxV.f90:22-252) and directMatVec_[MPI_]superc_main

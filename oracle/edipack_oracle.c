@@ -144,6 +144,32 @@ int64_t orc_build_sector_nonsu2(int ns, int ntot, int32_t *map) {
   return dim;
 }
 
+/* nonsu2, Jz_basis=T: ED_SECTOR.f90:289-350.  The sector holds the states with Ntot = ntot and
+ * twoJz = (Nup - Ndw) + twoLz, twoLz = sum over the levels iorb + Norb*ibath (ibath = 0: impurity) of
+ * 2 Lzdiag(iorb) (n_up + n_dw), Lzdiag = [-1, +1, 0] (ED_VARS_GLOBAL.f90:283): three orbitals. */
+int64_t orc_build_sector_nonsu2_jz(int norb, int nbath, int ntot, int twojz, int32_t *map) {
+  static const int lzdiag[3] = {-1, +1, 0};
+  const int ns = norb * (nbath + 1);
+  if (norb != 3) return -1;
+  int64_t dim = 0;
+  for (int32_t idw = 0; idw < ((int32_t)1 << ns); idw++) {
+    int ndw_ = popcnt32((uint32_t)idw);
+    for (int32_t iup = 0; iup < ((int32_t)1 << ns); iup++) {
+      int nup_ = popcnt32((uint32_t)iup);
+      int nt_ = nup_ + ndw_, twosz_ = nup_ - ndw_, twolz_ = 0;
+      for (int ibath = 0; ibath <= nbath; ibath++)
+        for (int iorb = 1; iorb <= norb; iorb++) {
+          int lev = iorb + norb * ibath; /* 1-based level of bdecomp */
+          twolz_ += 2 * lzdiag[iorb - 1] * ((iup >> (lev - 1)) & 1) + 2 * lzdiag[iorb - 1] * ((idw >> (lev - 1)) & 1);
+        }
+      if (nt_ != ntot || twojz != twosz_ + twolz_) continue;
+      if (map) map[dim] = iup + idw * ((int32_t)1 << ns);
+      dim++;
+    }
+  }
+  return dim;
+}
+
 /* ------------------------------------------------------------------ */
 /* sparse container: ED_SPARSE_MATRIX.f90:16-41, :328-360              */
 /* ------------------------------------------------------------------ */

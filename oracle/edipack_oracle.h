@@ -102,6 +102,8 @@ int orc_bath_stride(const orc_model *m, int iorb, int kp); /* 1-based in, 1-base
 int orc_build_sector_normal(int ns, int nup, int ndw, int32_t *mapup, int32_t *mapdw);
 int64_t orc_build_sector_superc(int ns, int sz, int32_t *map);  /* map may be NULL: count only */
 int64_t orc_build_sector_nonsu2(int ns, int ntot, int32_t *map);
+/* Jz_basis=T (ED_SECTOR.f90:289-350): Norb = 3, levels iorb + Norb*ibath; -1 for other Norb */
+int64_t orc_build_sector_nonsu2_jz(int norb, int nbath, int ntot, int twojz, int32_t *map);
 
 /* ED_AUX_FUNX.f90:334-384, :463-480 */
 int orc_c(int pos, int32_t in, int32_t *out, double *sgn);
@@ -147,6 +149,8 @@ typedef struct {
 } orc_hflat;
 orc_hflat *orc_buildh_superc_main(const orc_model *m, int sz);
 orc_hflat *orc_buildh_nonsu2_main(const orc_model *m, int ntot);
+/* the same builder on a Jz_basis=T sector (Ntot, twoJz): build_sector's map is the only difference */
+orc_hflat *orc_buildh_nonsu2_jz(const orc_model *m, int ntot, int twojz);
 void orc_hflat_free(orc_hflat *h);
 /* ED_SUPERC/..._STORED_HxV.f90:312-362, ED_NONSU2/..._STORED_HxV.f90:194-209 */
 void orc_spmatvec_flat_z(const orc_hflat *h, const double *v, double *hv);

@@ -274,6 +274,10 @@ def lib() -> C.CDLL:
     L.orc_buildh_superc_main.argtypes = [C.POINTER(OrcModel), C.c_int]
     L.orc_buildh_nonsu2_main.restype = vp
     L.orc_buildh_nonsu2_main.argtypes = [C.POINTER(OrcModel), C.c_int]
+    L.orc_buildh_nonsu2_jz.restype = vp
+    L.orc_buildh_nonsu2_jz.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int]
+    L.orc_build_sector_nonsu2_jz.restype = C.c_int64
+    L.orc_build_sector_nonsu2_jz.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, i32p]
     L.orc_hflat_free.argtypes = [vp]
     L.orc_hflat_sizes.argtypes = [vp, i64p]
     L.orc_spmatvec_flat_z.argtypes = [vp, dp, dp]
@@ -529,12 +533,14 @@ class HNormalCmplx:
 class HFlat:
     """Oracle-built flat-CSR sector Hamiltonian (superc: sector=Sz, nonsu2: sector=Ntot)."""
 
-    def __init__(self, model: Model, sector: int):
+    def __init__(self, model: Model, sector: int, twojz: int | None = None):
         self._L = lib()
         self.model = model
         self._s = to_struct(model)
         if model.ed_mode == "superc":
             self._h = self._L.orc_buildh_superc_main(C.byref(self._s), sector)
+        elif model.ed_mode == "nonsu2" and twojz is not None:       # Jz_basis=T sector (Ntot, twoJz)
+            self._h = self._L.orc_buildh_nonsu2_jz(C.byref(self._s), sector, twojz)
         elif model.ed_mode == "nonsu2":
             self._h = self._L.orc_buildh_nonsu2_main(C.byref(self._s), sector)
         else:

@@ -156,3 +156,31 @@ def csr_to_dense(rowptr, col, val, ncol):
         for k in range(rowptr[i], rowptr[i + 1]):
             out[i, col[k]] += val[k]
     return out
+
+
+def make_jz_models(nbath: int, seed: int = 0, jx: float = 0.25):
+    """A three-orbital nonsu2 problem that conserves Jz = Lz + Sz with Lzdiag = [-1, +1, 0] (ED_VARS_GLOBAL.f90:283),
+    replica bath (levels iorb + Norb * ibath, the labelling of build_sector's Jz branch): impHloc and the replica
+    matrices are real diagonals plus the two couplings between single-particle states of equal jz -- (orb 1, up) with
+    (orb 3, down), jz = -1/2, and (orb 3, up) with (orb 2, down), jz = +1/2 -- as spin-orbit coupling produces them;
+    Uloc, Ust, Jh and the spin-exchange Jx conserve Jz, the pair hopping Jp does not and is off."""
+    rng = np.random.default_rng(20260704 + seed)
+    norb = 3
+
+    def jz_matrix(scale):
+        h = np.zeros((2, 2, norb, norb), complex)
+        for s_ in range(2):
+            h[s_, s_] = np.diag(rng.uniform(-1, 1, norb) * scale)
+        for (sa, a, sb, b) in ((0, 0, 1, 2), (0, 2, 1, 1)):       # (spin, orbital) pairs of equal jz
+            z = scale * 0.4 * (rng.standard_normal() + 1j * rng.standard_normal())
+            h[sa, sb, a, b] = z
+            h[sb, sa, b, a] = np.conj(z)
+        return h
+    hl = jz_matrix(0.5)
+    hb = np.zeros((2, 2, norb, norb, nbath), complex)
+    for k in range(nbath):
+        hb[..., k] = jz_matrix(1.0)
+    v = np.tile(rng.uniform(0.1, 0.6, nbath), (2, norb, 1))
+    par = dict(ed_mode="nonsu2", bath_type="replica", norb=norb, nbath=nbath, nspin=2, hfmode=True, xmu=0.0,
+               uloc=tuple([2.0] * norb), ust=1.5, jh=0.25, jx=jx, jp=0.0)
+    return _replica_pair("nonsu2", "replica", norb, nbath, 2, hl, hb, v, par)

@@ -94,3 +94,18 @@ extern "C" int host_handover_dense(int64_t du, int64_t dd, int64_t dw_first, int
   *nclasses = fac.nimp;
   return fac.nterms;
 }
+
+// the nonsu2 sector (Ntot, twoJz) of JZ_BASIS=T from the host builder: dense (re, im interleaved), or the refusal
+extern "C" int host_flat_jz_dense(const edigpu_model* m, int ntot, int twojz, double* out, int64_t dim) {
+  HostFlat hf;
+  g_err = build_flat(*m, ntot, 0, -1, hf, true, twojz);
+  if (!g_err.empty()) return 1;
+  if (hf.dim != dim) { g_err = "host_flat_jz_dense: dim mismatch"; return 2; }
+  std::memset(out, 0, sizeof(double) * 2 * dim * dim);
+  for (int64_t i = 0; i < dim; i++)
+    for (int64_t k = hf.h.rowptr[i]; k < hf.h.rowptr[i + 1]; k++) {
+      out[2 * (i * dim + hf.h.col[k])] += hf.h.val[2 * k];
+      out[2 * (i * dim + hf.h.col[k]) + 1] += hf.h.val[2 * k + 1];
+    }
+  return 0;
+}

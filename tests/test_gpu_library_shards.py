@@ -85,9 +85,14 @@ def test_library_shards_share_one_gpu(gpu, world, case):
     assert rel_err(got, ref) < 1e-12
 
 
-def test_library_comm_rccl_world_of_one(gpu):
-    """The RCCL communicator itself (ncclCommInitRank with a unique id, world of one) and the sharded calls on it."""
+@pytest.mark.parametrize("force", [True, False])
+def test_library_comm_rccl_world_of_one(gpu, monkeypatch, force):
+    """The RCCL communicator itself (ncclCommInitRank with a unique id, world of one) and the sharded calls on it:
+    with the collectives forced (the N > 1 code path, RCCL calls included) and as a user gets it (a world of one
+    rank is handed to the fused single-GPU recurrence)."""
     import torch  # noqa: F401
+    if force:
+        monkeypatch.setenv("EDIGPU_FORCE_COLLECTIVES", "1")
     from edipack_amd.sharding import LibraryComm, library_sharded_sector
     uid = LibraryComm.unique_id()
     assert len(uid) == 128

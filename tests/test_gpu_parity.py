@@ -1805,3 +1805,46 @@ def test_panel_major_lanczos_matches_oracle(gpu, monkeypatch, w, bath, norb, nba
     assert rel_err(hb.apply(xb), eb * xb) < 1e-6
     assert hb.lanczos_bench(2, 3)[1] > 0.0
     hb.destroy(), hn.destroy()
+
+
+# --------------------------------------------------------------------------------------------
+# nonsu2 sectors of JZ_BASIS=T (build_sector, ED_SECTOR.f90:289-350)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nbath,ntot,twojz", [(1, 6, 0), (1, 5, 1), (2, 9, 1), (2, 8, -4)])
+def test_jz_sectors_match_oracle(gpu, nbath, ntot, twojz):
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from tests.common import make_jz_models
+    O = _oracle()
+    om, pm = make_jz_models(nbath, seed=9)
+    ho = O.HFlat(om, ntot, twojz=twojz)
+    hg = SectorHamiltonian.flat_jz_from_model(pm, ntot, twojz)
+    assert hg.dim == ho.dim and hg.is_complex
+    rng = np.random.default_rng(4)
+    v = rng.standard_normal(ho.dim) + 1j * rng.standard_normal(ho.dim)
+    assert rel_err(hg.apply(v), ho.matvec(v)) < TOL
+    n = min(30, ho.dim)
+    a, b, nd = hg.lanczos_tridiag(v, n)
+    ao, bo, _ = ho.lanc_tridiag(v, n)
+    k = min(10, n)
+    assert rel_err(a[:k], ao[:k]) < 1e-9 and rel_err(b[:k], bo[:k]) < 1e-9
+    e0, x, _ = hg.lanczos_eigh(nitermax=min(300, ho.dim), tol=1e-13, v0=v)
+    assert abs(e0 - np.linalg.eigvalsh(ho.dense())[0]) < 1e-9
+    # the sector is a block of the Ntot sector: its ground state energy is one of that sector's eigenvalues
+    full = O.HFlat(om, ntot)
+    assert np.abs(np.linalg.eigvalsh(full.dense()) - e0).min() < 1e-9
+    hg.destroy()
+    # row shards (the MPI decomposition): local + remote phases on the gathered vector
+    import torch
+    cut = ho.dim // 3
+    vd = torch.from_numpy(v).cuda()
+    out = []
+    st = torch.cuda.current_stream().cuda_stream
+    for first, cnt in ((0, cut), (cut, ho.dim - cut)):
+        hs = SectorHamiltonian.flat_jz_from_model(pm, ntot, twojz, row_first=first, row_count=cnt)
+        hv = torch.empty(hs.nloc, dtype=torch.complex128, device="cuda")
+        hs.apply_local_dev(vd[first:].data_ptr(), hv.data_ptr(), st)
+        hs.apply_remote_dev(vd.data_ptr(), hv.data_ptr(), st)
+        torch.cuda.synchronize()
+        out.append(hv.cpu().numpy())
+        hs.destroy()
+    assert rel_err(np.concatenate(out), ho.matvec(v)) < TOL

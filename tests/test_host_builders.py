@@ -176,3 +176,40 @@ def test_handover_arrays_that_do_not_factor_fall_back(shim):
     f.hd = ho.hd
     f.nd = (ndr, ndc, rng.standard_normal(ndv.shape))
     assert _handover(shim, f, 0, ho.dimdw)[0] == -1
+
+
+# ---- nonsu2 sectors of JZ_BASIS=T ----
+@pytest.mark.parametrize("nbath,ntot,twojz", [(1, 6, 0), (1, 5, 1), (1, 3, -3), (2, 9, 1), (2, 4, 0)])
+def test_jz_sector_builder_equals_oracle(shim, nbath, ntot, twojz):
+    from edipack_amd.hamiltonian import sector_map_jz
+    from tests.common import make_jz_models
+    om, pm = make_jz_models(nbath, seed=4)
+    ho = O.HFlat(om, ntot, twojz=twojz)
+    assert ho.dim > 0
+    assert np.array_equal(sector_map_jz(pm, ntot, twojz), ho.map)          # bit-exact index data
+    out = np.zeros((ho.dim, ho.dim, 2))
+    m = pm.to_c()
+    rc = shim.host_flat_jz_dense(C.byref(m), ntot, twojz, out.ctypes.data_as(C.c_void_p), C.c_int64(ho.dim))
+    assert rc == 0, shim.host_image_error().decode()
+    got = out[..., 0] + 1j * out[..., 1]
+    assert np.abs(got - ho.dense()).max() < 1e-13
+
+
+def test_jz_sector_builder_refusals(shim):
+    from tests.common import make_jz_models
+    _, pm = make_jz_models(1, seed=4)
+    buf = np.zeros(8)
+    pm.jp = 0.3          # pair hopping moves a pair between orbitals of different Lz: Jz is not conserved
+    m = pm.to_c()
+    n = len(O.HFlat(make_jz_models(1, seed=4)[0], 6, twojz=0).map)
+    big = np.zeros(2 * n * n)
+    assert shim.host_flat_jz_dense(C.byref(m), 6, 0, big.ctypes.data_as(C.c_void_p), C.c_int64(n)) == 1
+    assert "does not conserve Jz" in shim.host_image_error().decode()
+    _, p2 = make_models("nonsu2", "normal", 2, 2, seed=1)                   # two orbitals
+    m = p2.to_c()
+    assert shim.host_flat_jz_dense(C.byref(m), 4, 0, buf.ctypes.data_as(C.c_void_p), C.c_int64(1)) == 1
+    assert "Norb = 3" in shim.host_image_error().decode()
+    _, p3 = make_models("nonsu2", "normal", 3, 2, seed=1)                   # orbital-major bath levels
+    m = p3.to_c()
+    assert shim.host_flat_jz_dense(C.byref(m), 4, 0, buf.ctypes.data_as(C.c_void_p), C.c_int64(1)) == 1
+    assert "iorb + Norb * ibath" in shim.host_image_error().decode()

@@ -364,3 +364,35 @@ def test_oracle_complex_tridiag_reproduces_flat_momenta(name, tol):
 
     for got, gold in flat_momenta(name, tridiag):
         assert np.max(np.abs(got / gold - 1.0)) < tol
+
+
+def test_oracle_jz_sectors_partition_the_ntot_sectors():
+    """JZ_BASIS=T (ED_SECTOR.f90:289-350): the (Ntot, twoJz) maps are disjoint, ascending, and their union is the Ntot
+    map; for a Jz-conserving model the sector Hamiltonians are the diagonal blocks of the Ntot Hamiltonian, so the union
+    of their spectra is its spectrum (the Ntot builder is fixture-pinned)."""
+    from tests.common import make_jz_models
+    om, _ = make_jz_models(1, seed=2)
+    L = O.lib()
+    ns = 6
+    for ntot in (3, 6):
+        full = O.HFlat(om, ntot)
+        maps, evs = [], []
+        for twojz in range(-12, 13):
+            n = L.orc_build_sector_nonsu2_jz(3, 1, ntot, twojz, None)
+            if n <= 0:
+                continue
+            h = O.HFlat(om, ntot, twojz=twojz)
+            assert h.dim == n and np.all(np.diff(h.map) > 0)
+            maps.append(h.map)
+            d = h.dense()
+            assert np.abs(d - d.conj().T).max() < 1e-14
+            # the block of the full matrix on these states
+            idx = np.searchsorted(full.map, h.map)
+            assert np.array_equal(full.map[idx], h.map)
+            assert np.abs(full.dense()[np.ix_(idx, idx)] - d).max() < 1e-14
+            evs.append(np.linalg.eigvalsh(d))
+        allm = np.concatenate(maps)
+        assert len(np.unique(allm)) == len(allm) == full.dim and np.array_equal(np.sort(allm), full.map)
+        assert np.abs(np.sort(np.concatenate(evs)) - np.linalg.eigvalsh(full.dense())).max() < 1e-10
+    # odd twoJz + even Ntot etc.: empty
+    assert L.orc_build_sector_nonsu2_jz(3, 1, 6, 1, None) == 0
