@@ -109,6 +109,15 @@ module EDIGPU_SHIM
        integer(c_int64_t), value :: row_first, row_count
        integer(c_int) :: ierr
      end function edigpu_flat_build
+     function edigpu_flat_build_jz(h, model, ntot, twojz, row_first, row_count) &
+          bind(C, name="edigpu_flat_build_jz") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, edigpu_model_t
+       type(c_ptr) :: h
+       type(edigpu_model_t), intent(in) :: model
+       integer(c_int), value :: ntot, twojz
+       integer(c_int64_t), value :: row_first, row_count
+       integer(c_int) :: ierr
+     end function edigpu_flat_build_jz
      function edigpu_direct_build(h, model, sector, row_first, row_count) &
           bind(C, name="edigpu_direct_build") result(ierr)
        import :: c_ptr, c_int, c_int64_t, edigpu_model_t
@@ -325,7 +334,7 @@ module EDIGPU_SHIM
   public :: gpu_init, gpu_delete_sector
   public :: gpu_set_normal, gpu_set_csr_d, gpu_set_csr_c
   public :: gpu_model_set_kanamori, gpu_model_set_hloc, gpu_model_set_bath
-  public :: gpu_build_normal, gpu_build_normal_cmplx, gpu_build_flat, gpu_build_orbs
+  public :: gpu_build_normal, gpu_build_normal_cmplx, gpu_build_flat, gpu_build_flat_jz, gpu_build_orbs
   public :: spMatVec_gpu_d, spMatVec_gpu_c
   public :: gpu_lanc_tridiag_d, gpu_lanc_tridiag_c
   public :: flatten_rows_count
@@ -500,6 +509,15 @@ contains
             int(row_count, c_int64_t)), "gpu_build_flat")
     end if
   end subroutine gpu_build_flat
+
+  !> build_Hv_sector_nonsu2 with Jz_basis=T: sector (getN(isector), gettwoJz(isector)) (ED_SECTOR.f90:289-350)
+  subroutine gpu_build_flat_jz(m, ntot, twojz, row_first, row_count)
+    type(edigpu_model_t), intent(in) :: m
+    integer, intent(in) :: ntot, twojz, row_first, row_count
+    if (c_associated(gpu_sector)) stop "gpu_build_flat_jz: a sector is already allocated"
+    call gpu_check(edigpu_flat_build_jz(gpu_sector, m, int(ntot, c_int), int(twojz, c_int), int(row_first, c_int64_t), &
+         int(row_count, c_int64_t)), "gpu_build_flat_jz")
+  end subroutine gpu_build_flat_jz
 
   !> build_Hv_sector_normal with ed_total_ud=F: per-orbital (Nups, Ndws)
   subroutine gpu_build_orbs(m, nups, ndws)

@@ -1828,10 +1828,13 @@ def test_jz_sectors_match_oracle(gpu, nbath, ntot, twojz):
     k = min(10, n)
     assert rel_err(a[:k], ao[:k]) < 1e-9 and rel_err(b[:k], bo[:k]) < 1e-9
     e0, x, _ = hg.lanczos_eigh(nitermax=min(300, ho.dim), tol=1e-13, v0=v)
-    assert abs(e0 - np.linalg.eigvalsh(ho.dense())[0]) < 1e-9
-    # the sector is a block of the Ntot sector: its ground state energy is one of that sector's eigenvalues
-    full = O.HFlat(om, ntot)
-    assert np.abs(np.linalg.eigvalsh(full.dense()) - e0).min() < 1e-9
+    assert rel_err(hg.apply(x), e0 * x) < 1e-6
+    if ho.dim <= 3000:
+        assert abs(e0 - np.linalg.eigvalsh(ho.dense())[0]) < 1e-9
+    if nbath == 1:
+        # the sector is a block of the Ntot sector: its ground state energy is one of that sector's eigenvalues
+        full = O.HFlat(om, ntot)
+        assert np.abs(np.linalg.eigvalsh(full.dense()) - e0).min() < 1e-9
     hg.destroy()
     # row shards (the MPI decomposition): local + remote phases on the gathered vector
     import torch
