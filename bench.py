@@ -179,7 +179,7 @@ def run_single(args):
                      "traffic_frac": (traffic / (ms_hv * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "measured_ceiling_GBs": {"read": rd, "copy": cp, "triad": tr,
                                               "note": "streaming kernels on 1 GiB buffers, this device, this run"},
-                     "kernel": {0: "normal_rows_kernel + normal_dw_panel2_kernel (normal_dw_panel_kernel for odd DimUp / small sectors)", 1: "sell_rows_packed_kernel (SELL-64 + value dictionary; csr_rows_kernel fallback)",
+                     "kernel": {0: "normal_rows_kernel + normal_dw_tile_kernel (sectors of >= 2M rows; normal_dw_panel_kernel below, normal_dw_blk_kernel on panel-major vectors)", 1: "sell_rows_packed_kernel (SELL-64 + value dictionary; csr_rows_kernel fallback)",
                                 2: "direct_rows_kernel"}[h.kind],
                      "algorithmic_bytes_per_launch": bytes_hv, "ms_per_launch": ms_hv},
     }
