@@ -592,28 +592,32 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
     if (dev_upload(&s->d_tl_val, tv.data(), tv.size())) return 1;
     s->tl_has_nd = with_nd ? 1 : 0;
   }
-  // Panel-major vector layout for the device-resident Lanczos loop (normal_args.hpp): large factored whole
-  // sectors whose rows fit the LDS row kernel.  W columns per panel so that one panel of V (DimDw * W * 8 bytes, whole
-  // cache lines) stays in an XCD's L2 while the sweep walks it.  OPT-IN (EDIGPU_BLOCKED=1): measured on config 2 and the
-  // Ns = 16 ladder it brings the sweep's fetch traffic to 1.1x / 1.9x of V + result (natural layout 1.7x / 5x), but the
-  // sweep is bound by the L2's gather throughput, not by the fabric, and runs 10-60 % slower than the LDS-tiled sweep of
-  // the natural layout.  EDIGPU_BLOCKED_W forces a width (16 / 32 / 64), EDIGPU_BLOCKED_MIN
-  // the smallest sector (rows), EDIGPU_BLOCKED_LDS_KB the staged block.
+  // Panel-major vector layout for the device-resident Lanczos loop (normal_args.hpp): large
+  // factored whole sectors whose rows fit the LDS row kernel.  Default: 128-column panels (1 KiB line-aligned segments)
+  // swept by the LDS-tiled kernel -- measured 6 % (config 2), 14 % (Ns = 15) and 8 % (Ns = 16) faster per product than
+  // the same kernel on the natural layout, whose segments start at arbitrary 8-byte offsets.  EDIGPU_BLOCKED=0 keeps the
+  // natural layout; EDIGPU_BLOCKED_W=16 / 32 / 64 selects the narrow-panel sweep (normal_dw_blk_kernel: panels that
+  // stay in one L2, fetch traffic 1.1-1.9x of V + result instead of 1.8-5x, but bound by the L2's gather throughput and
+  // 10-60 % slower: an experiment that is kept, tested, off); EDIGPU_BLOCKED_MIN the smallest sector (rows),
+  // EDIGPU_BLOCKED_LDS_KB the staged block of the narrow sweep.
   if (s->factored && built && dw_first == 0 && dw_count == dim_dw && s->rows_per_block >= 1 && s->row_split == 1 &&
       dim_dw <= 65535 && dim_up >= 64) {
     const char* e;
-    const bool on = (e = getenv("EDIGPU_BLOCKED")) && atoi(e) != 0;
+    const bool on = !(e = getenv("EDIGPU_BLOCKED")) || atoi(e) != 0;
     const int64_t min_rows = (e = getenv("EDIGPU_BLOCKED_MIN")) ? atoll(e) : ((int64_t)1 << 21);
-    const int64_t l2_bytes = ((e = getenv("EDIGPU_BLOCKED_L2_KB")) ? atoll(e) : 2048) * 1024;
-    int shift = 0;
-    for (int sh : {6, 5, 4})
-      if (!shift && dim_dw * ((int64_t)8 << sh) <= l2_bytes) shift = sh;
+    int shift = 7;
     if ((e = getenv("EDIGPU_BLOCKED_W"))) {
       const int w = atoi(e);
-      shift = w == 64 ? 6 : w == 32 ? 5 : w == 16 ? 4 : 0;
+      shift = w == 128 ? 7 : w == 64 ? 6 : w == 32 ? 5 : w == 16 ? 4 : 0;
     }
     const HostFactored& f = built->fac;
-    if (on && shift && s->nloc >= min_rows && f.nterms <= 16) {
+    if (on && shift == 7 && s->nloc >= min_rows && s->panel_mode == 2 && (f.nterms == 0 || s->tl_has_nd)) {
+      // 128-column panels: the tiled sweep and its lists as they are, on line-aligned contiguous panels
+      s->blk_shift = 7;
+      s->blk_rows = s->tile_rows;
+      s->blk_ps = dim_dw << 7;
+      s->blk_len = ((dim_up + 127) >> 7) * s->blk_ps;
+    } else if (on && shift && shift < 7 && s->nloc >= min_rows && f.nterms <= 16) {
       // weight table: +/- every hop amplitude and Hnd coefficient, 0.0 at index 0 (padding entries)
       std::vector<double> wtab{0.0};
       auto widx = [&](double w) -> int {

@@ -415,7 +415,9 @@ constexpr int kTileRowsPerWave = 4;
 constexpr int kTileMaxRows = kTileRowsPerWave * 16;  // 1024-thread workgroups; 512-thread ones take half as many
 constexpr int kTileBatch = 4;      // list entries per batch (a row's two hop lists are padded to whole batches)
 
-template <int NT, bool DO_ND, bool ALPHA, bool EDGE>
+// BLK: vectors in the panel-major layout with 128-column panels (NormalArgs::blk_shift == 7): a panel is one
+// contiguous array of DimDw segments of 1024 bytes, the segment of row r starts at r * 128
+template <int NT, bool DO_ND, bool ALPHA, bool EDGE, bool BLK = false>
 __global__ void __launch_bounds__(NT)
     normal_dw_tile_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full, double* __restrict__ hv) {
   __shared__ double red[3 * (NT / 64)];
@@ -448,6 +450,10 @@ __global__ void __launch_bounds__(NT)
     const int rb = a.tile_chunks[chunk], nrows = a.tile_chunks[chunk + 1] - rb;
     const int lb = a.tile_lbeg[chunk], ln = a.tile_lbeg[chunk + 1] - lb;
     const int64_t pbase = (int64_t)panel * p.width;
+    // BLK: row stride 128 inside the panel's own array, every lane owns a (possibly zero-padded) column pair
+    const int64_t RS = BLK ? 128 : DimUp;
+    const double* __restrict__ vb = BLK ? v_full + (int64_t)panel * a.blk_ps : v_full;
+    double* __restrict__ hb = BLK ? hv + (int64_t)panel * a.blk_ps : hv;
     auto col_of = [&](int l, bool& okl, bool& pairl) -> int64_t {
       const int64_t cl = pbase + 2 * l;
       okl = 2 * l < p.width && cl < DimUp;
@@ -456,8 +462,12 @@ __global__ void __launch_bounds__(NT)
       return ccl;
     };
     bool ok, pair;
-    const int64_t cc = col_of(lane, ok, pair);
-    const int64_t c = pbase + 2 * lane;
+    int64_t cc = col_of(lane, ok, pair);
+    int64_t c = pbase + 2 * lane;
+    if (BLK) {
+      cc = c = 2 * lane;
+      ok = pair = true;  // the padding columns hold zeros and receive zeros
+    }
     auto ld2 = [&](const double* q) -> double2 {
       if (!EDGE) return *reinterpret_cast<const double2*>(q);
       if (pair) {
@@ -488,13 +498,13 @@ __global__ void __launch_bounds__(NT)
       for (int j = 0; j < kTileRowsPerWave; j++) {
         const int r = wave + j * NW;
         const int rr = r < nrows ? r : nrows - 1;  // clamped: a valid address
-        acc[j] = ld2(&hv[(int64_t)(rb + rr) * DimUp + cc]);
+        acc[j] = ld2(&hb[(int64_t)(rb + rr) * RS + cc]);
       }
 #pragma unroll
       for (int j = 0; j < kTileRowsPerWave; j++) {
         const int r = wave + j * NW;
         const int rr = r < nrows ? r : nrows - 1;
-        own[j] = ld2(&v_full[(g0 + rr) * DimUp + cc]);
+        own[j] = ld2(&vb[(g0 + rr) * RS + cc]);
       }
       for (int i = threadIdx.x; i < ln; i += NT) {
         lcol[i] = a.tl_col[lb + i];
@@ -525,6 +535,11 @@ __global__ void __launch_bounds__(NT)
         bool okl, pairl;
         const int64_t ccl = col_of(l, okl, pairl);
         const int64_t src = (int64_t)(t2 >> 1) * DimUp + ccl;
+        if (BLK) {  // the lane's own columns, whether they exist or are padding
+          const int64_t cb = pbase + 2 * l + (t2 & 1);
+          ju2[i] = cb < DimUp ? encode(a.jup[(int64_t)(t2 >> 1) * DimUp + cb]) : 0xFFFFFFFFu;
+          continue;
+        }
         ju2[i] = (t2 & 1) ? (pairl ? encode(a.jup[src + 1]) : 0xFFFFFFFFu) : encode(a.jup[src]);
       }
       cur_panel = panel;
@@ -540,10 +555,10 @@ __global__ void __launch_bounds__(NT)
         const int4 cw = *reinterpret_cast<const int4*>(lcol + jb);
         const double2 wa = *reinterpret_cast<const double2*>(lval + jb);
         const double2 wb = *reinterpret_cast<const double2*>(lval + jb + 2);
-        const double2 y0 = ld2(&v_full[(int64_t)__builtin_amdgcn_readfirstlane(cw.x) * DimUp + cc]);
-        const double2 y1 = ld2(&v_full[(int64_t)__builtin_amdgcn_readfirstlane(cw.y) * DimUp + cc]);
-        const double2 y2 = ld2(&v_full[(int64_t)__builtin_amdgcn_readfirstlane(cw.z) * DimUp + cc]);
-        const double2 y3 = ld2(&v_full[(int64_t)__builtin_amdgcn_readfirstlane(cw.w) * DimUp + cc]);
+        const double2 y0 = ld2(&vb[(int64_t)__builtin_amdgcn_readfirstlane(cw.x) * RS + cc]);
+        const double2 y1 = ld2(&vb[(int64_t)__builtin_amdgcn_readfirstlane(cw.y) * RS + cc]);
+        const double2 y2 = ld2(&vb[(int64_t)__builtin_amdgcn_readfirstlane(cw.z) * RS + cc]);
+        const double2 y3 = ld2(&vb[(int64_t)__builtin_amdgcn_readfirstlane(cw.w) * RS + cc]);
         s.x += wa.x * y0.x;
         s.y += wa.x * y0.y;
         s.x += wa.y * y1.x;
@@ -581,13 +596,17 @@ __global__ void __launch_bounds__(NT)
           const bool v0 = j0 != 0xFFFFFFFFu, v1 = j1 != 0xFFFFFFFFu;
           const double w0 = v0 ? ((j0 >> 31) ? -w : w) : 0.0, w1 = v1 ? ((j1 >> 31) ? -w : w) : 0.0;
           // the partner row's segment, coalesced like a down hop; the partner columns sit a few lanes away
-          const double2 y = ld2(&v_full[prow * DimUp + cc]);
+          const double2 y = ld2(&vb[prow * RS + cc]);
           const int l0 = (int)((j0 >> 1) & 63u), l1 = (int)((j1 >> 1) & 63u);
           const double s0x = __shfl(y.x, l0, 64), s0y = __shfl(y.y, l0, 64);
           const double s1x = __shfl(y.x, l1, 64), s1y = __shfl(y.y, l1, 64);
           double p0 = (j0 & 1u) ? s0y : s0x, p1 = (j1 & 1u) ? s1y : s1x;
-          if (v0 && (j0 & 0x40000000u)) p0 = v_full[prow * DimUp + (int64_t)(j0 & 0x3FFFFFFFu)];  // panel edge
-          if (v1 && (j1 & 0x40000000u)) p1 = v_full[prow * DimUp + (int64_t)(j1 & 0x3FFFFFFFu)];
+          auto edge = [&](uint32_t jw) -> double {  // a partner column in a neighbouring panel
+            const int64_t jc = (int64_t)(jw & 0x3FFFFFFFu);
+            return BLK ? v_full[(jc >> 7) * a.blk_ps + prow * 128 + (jc & 127)] : v_full[prow * DimUp + jc];
+          };
+          if (v0 && (j0 & 0x40000000u)) p0 = edge(j0);
+          if (v1 && (j1 & 0x40000000u)) p1 = edge(j1);
           s.x += w0 * p0;
           s.y += w1 * p1;
         }
@@ -600,7 +619,7 @@ __global__ void __launch_bounds__(NT)
       if (r < nrows) {  // wave-uniform
         acc[j] = row_sum(r, acc[j]);
         if (ok) {
-          st2(&hv[(int64_t)(rb + r) * DimUp + c], acc[j]);
+          st2(&hb[(int64_t)(rb + r) * RS + c], acc[j]);
           if (ALPHA) {
             const double2 o = tile[r * kTileSeg + lane];  // the row's own segment of v
             const double dx = acc[j].x - sg * o.x, dy = acc[j].y - sg * o.y;
@@ -882,8 +901,66 @@ __global__ void __launch_bounds__(kBlkNT)
   }
 }
 
+// 128-column panels of the panel-major layout: the LDS-tiled sweep of the natural layout (normal_dw_tile_kernel, its
+// chunk plan and lists) on contiguous, line-aligned panels
+static int launch_dw_blocked_tiles(const NormalArgs& a, bool do_nd, const double* v, double* hv, hipStream_t st, bool alpha,
+                                   int* nblocks) {
+  if (!a.tile_chunks || !a.tl_meta || a.tile_rows > kTileMaxRows || (do_nd && !a.tl_has_nd) || a.dw_first != 0 ||
+      a.dw_count != a.dim_dw) {
+    set_error("launch_dw_blocked: 128-column panels need the tiled sweep's row lists");
+    return 1;
+  }
+  PanelArgs p;
+  p.width = 128;
+  p.npanels = (int)((a.dim_up + 127) / 128);
+  p.col_first = 0;
+  p.ncol = a.dim_up;
+  p.stride = a.dim_up;
+  p.halo = 0;
+  p.rows_per_block = 0;
+  p.tile_rows = a.tile_rows;
+  p.blocks_per_panel = a.tile_nchunks;
+  p.list_cap = a.tile_list_cap;
+  const int panel_groups = (p.npanels + 7) / 8;
+  const int64_t g = (int64_t)panel_groups * p.blocks_per_panel * 8;
+  if (nblocks) *nblocks = (int)g;
+  if (alpha && 3 * g > a.partial_cap) {
+    set_error("launch_dw_blocked: partial buffer too small for this grid");
+    return 1;
+  }
+  const size_t lds = (size_t)p.tile_rows * kTileSeg * sizeof(double2) + (size_t)p.list_cap * (sizeof(double) + sizeof(int32_t)) +
+                     (size_t)p.tile_rows * sizeof(int4) + (do_nd ? (size_t)2 * a.nterms * 64 * sizeof(uint32_t) : 0);
+  const bool big = p.tile_rows > kTileRowsPerWave * (kPanelNT / 64);
+#define EDIGPU_LAUNCH_BT(NTV, ND, AL)                                                   \
+  do {                                                                                  \
+    auto kern = normal_dw_tile_kernel<NTV, ND, AL, false, true>;                        \
+    if (ensure_dynamic_lds((const void*)kern, lds)) return 1;                           \
+    hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NTV), lds, st, a, p, v, hv);       \
+  } while (0)
+#define EDIGPU_LAUNCH_BT2(ND, AL)          \
+  do {                                     \
+    if (big)                               \
+      EDIGPU_LAUNCH_BT(1024, ND, AL);      \
+    else                                   \
+      EDIGPU_LAUNCH_BT(kPanelNT, ND, AL);  \
+  } while (0)
+  if (do_nd && alpha)
+    EDIGPU_LAUNCH_BT2(true, true);
+  else if (do_nd)
+    EDIGPU_LAUNCH_BT2(true, false);
+  else if (alpha)
+    EDIGPU_LAUNCH_BT2(false, true);
+  else
+    EDIGPU_LAUNCH_BT2(false, false);
+#undef EDIGPU_LAUNCH_BT2
+#undef EDIGPU_LAUNCH_BT
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_dw_blocked(const NormalArgs& a, bool do_nd, const double* v, double* hv, hipStream_t st, bool alpha,
                       int* nblocks) {
+  if (a.blk_shift == 7) return launch_dw_blocked_tiles(a, do_nd, v, hv, st, alpha, nblocks);
   if (a.blk_shift < 4 || a.blk_shift > 6 || a.blk_rows < 32 || !a.bl_meta || !a.bl_ent || !a.bl_wtab || a.dw_first != 0 ||
       a.dw_count != a.dim_dw) {
     set_error("launch_dw_blocked: the sector has no panel-major image");

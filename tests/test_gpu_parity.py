@@ -1761,7 +1761,7 @@ def test_flat_modes_refuse_normal_only_fields(gpu):
 # --------------------------------------------------------------------------------------------
 # panel-major vector layout of the device-resident Lanczos loops (large factored sectors; forced here on small ones)
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("w", [16, 32, 64])
+@pytest.mark.parametrize("w", [16, 32, 64, 128])
 @pytest.mark.parametrize("bath,norb,nbath,sec,jxp", [
     ("normal", 2, 3, (4, 4), 0.25),      # DimUp = 70: a partly filled last panel
     ("hybrid", 3, 5, (4, 3), 0.25),      # DimUp = 70, DimDw = 56, 3 merged Hnd terms
@@ -1783,6 +1783,8 @@ def test_panel_major_lanczos_matches_oracle(gpu, monkeypatch, w, bath, norb, nba
     monkeypatch.setenv("EDIGPU_BLOCKED", "1")
     monkeypatch.setenv("EDIGPU_BLOCKED_MIN", "0")
     monkeypatch.setenv("EDIGPU_BLOCKED_W", str(w))
+    if w == 128:      # the tiled sweep on 128-column panels: needs the tiled sweep's lists (large-sector variant)
+        monkeypatch.setenv("EDIGPU_PANEL_VEC2_MIN", "0")
     hb = SectorHamiltonian.normal_from_model(pm, *sec)
     assert hb.image_info()[4] == w
     monkeypatch.setenv("EDIGPU_BLOCKED", "0")
