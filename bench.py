@@ -57,10 +57,15 @@ def _hbm_resident(steps: int):
     h = build_workload(w)
     try:
         bytes_hv, _ = h.algorithmic_bytes()
-        ms = h.time_apply(2, max(5, min(steps, 20)), lanczos=False)
+        n = max(5, min(steps, 20))
+        ms = h.time_apply(2, n, lanczos=2)            # the product as the Lanczos loops compute it (as roofline.*)
+        ms_boundary = h.time_apply(2, n, lanczos=0)   # edigpu_apply_dev: vectors in the reference's layout
+        tr = _traffic_from_profiles(w.name)
         return {"workload": f"{w.name}: 3 orbitals, hybrid bath, Ns=16, sector {w.sector}, Dim={h.dim}",
                 "ms_hv": ms, "achieved": bytes_hv / (ms * 1e-3) / 1e9, "unit": "GB/s",
-                "frac": bytes_hv / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_hv}
+                "frac": bytes_hv / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_hv,
+                "ms_hv_reference_layout": ms_boundary, "traffic": tr,
+                "traffic_frac": (tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None}
     finally:
         h.destroy()
 
@@ -155,7 +160,7 @@ def run_single(args):
     t_build = time.perf_counter() - t0
     bytes_hv, bytes_step = h.algorithmic_bytes()
     ms_step, ms_hv = h.lanczos_bench(args.warmup, args.steps)
-    ms_hv_only = h.time_apply(max(2, args.warmup), args.steps, lanczos=False)
+    ms_hv_only = h.time_apply(max(2, args.warmup), args.steps, lanczos=False)   # boundary product, reference layout
     achieved = bytes_hv / (ms_hv * 1e-3) / 1e9
     traffic = _traffic_from_profiles(w.name)
     rd, cp, tr = capi.membw(1 << 30)

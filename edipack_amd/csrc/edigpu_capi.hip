@@ -2663,7 +2663,7 @@ int edigpu_time_apply(edigpu_handle s, int warmup, int steps, int lanczos, doubl
   hipStream_t st = s->stream;
   const int total = warmup + steps;
   if (lanczos_prepare(s, std::max(total, 1), 0.0, st)) return 1;
-  if (lanczos) {
+  if (lanczos) {  // 1: Lanczos steps; 2: the plain product as the loop computes it (panel-major vectors where it uses them)
     if (lanczos_seed(s, nullptr, 12345ull, st)) return 1;
     if (lz_norm_begin(s->d_vin, s->lz_len, s->d_partial, s->d_scal, st)) return 1;
   } else {  // the boundary product (edigpu_apply_dev): vectors in the natural layout
@@ -2676,7 +2676,9 @@ int edigpu_time_apply(edigpu_handle s, int warmup, int steps, int lanczos, doubl
   int rc = 0;
   for (int it = 0; it < total && !rc; it++) {
     if (it == warmup) rc |= (hipEventRecord(e0, st) != hipSuccess);
-    if (lanczos) {
+    if (lanczos == 2) {
+      rc |= s->lz_blocked ? launch_normal_blocked(s, s->d_vin, s->d_tmp, st) : apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st);
+    } else if (lanczos) {
       rc |= lanczos_step(s, it, total, st);
     } else {
       // fixed source vector -> fixed destination: the plain SpMV measurement

@@ -453,7 +453,9 @@ class SectorHamiltonian:
             capi.pd(vec.view(np.float64)) if want_vector else None, C.byref(nd)), "edigpu_lanczos_eigh")
         return ev.value, vec, nd.value
 
-    def time_apply(self, warmup: int, steps: int, lanczos: bool = False) -> float:
+    def time_apply(self, warmup: int, steps: int, lanczos: int = 0) -> float:
+        """ms per step: lanczos = 0 the boundary product (edigpu_apply_dev), 1 full Lanczos steps, 2 the plain product
+        as the device-resident loops compute it (panel-major vectors where they are used)."""
         ms = C.c_double()
         capi.check(capi.lib().edigpu_time_apply(self._h, warmup, steps, int(lanczos), C.byref(ms)),
                    "edigpu_time_apply")

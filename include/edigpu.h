@@ -499,8 +499,9 @@ int edigpu_lanczos_bench_sharded(edigpu_handle h, edigpu_comm c, int warmup, int
 /*
  * Timing helper for bench.py: runs `warmup` untimed and `steps` timed H*v
  * products (device-resident, random unit vector) on the handle's stream and
- * returns the average duration of one H*v measured with HIP events on that
- * stream, plus (if lanczos!=0) the same for full Lanczos steps.
+ * returns the average duration of one step measured with HIP events on that stream.  lanczos = 0: the boundary
+ * product (edigpu_apply_dev: vectors in the reference's layout); 1: full Lanczos steps; 2: the plain product as the
+ * device-resident Lanczos loops compute it (on panel-major vectors for the sectors that use them).
  */
 int edigpu_time_apply(edigpu_handle h, int warmup, int steps, int lanczos, double *ms_per_step);
 
