@@ -626,8 +626,9 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
         wtab.push_back(w);
         return (int)wtab.size() - 1;
       };
-      // LDS block of the sweep: EDIGPU_BLOCKED_LDS_KB (default 64) of staged segments, a multiple of 32 rows
-      const int64_t lds_kb = (e = getenv("EDIGPU_BLOCKED_LDS_KB")) ? atoll(e) : 64;
+      // LDS block of the sweep: EDIGPU_BLOCKED_LDS_KB (default 32) of staged segments, a multiple of 32 rows; the
+      // block's list entries are staged next to them
+      const int64_t lds_kb = (e = getenv("EDIGPU_BLOCKED_LDS_KB")) ? atoll(e) : 32;
       int64_t R = std::max<int64_t>(32, std::min<int64_t>(lds_kb * 1024 / ((int64_t)8 << shift), 4096) / 32 * 32);
       std::vector<int4> meta((size_t)dim_dw);
       std::vector<uint32_t> ent;
@@ -657,9 +658,22 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
         meta[(size_t)g] = m;
         fits = wtab.size() <= 256;
       }
+      std::vector<int32_t> lend;
+      int list_cap = 4;
+      for (int64_t cs = 0; cs < dim_dw && fits; cs += R) {
+        const int64_t last = std::min<int64_t>(cs + R, dim_dw) - 1;
+        const int4& ml = meta[(size_t)last];
+        const int end = (ml.x + ml.y + ml.z + ml.w + 3) / 4 * 4;
+        lend.push_back(end);
+        list_cap = std::max(list_cap, end - meta[(size_t)cs].x);
+      }
+      // the whole block (segments + lists + row meta) must fit a workgroup's LDS
+      fits = fits && (size_t)R * ((size_t)8 << shift) + (size_t)list_cap * 4 + (size_t)R * 16 + 8192 <= 150 * 1024;
       if (fits) {
         wtab.resize(256, 0.0);
         ent.resize(ent.size() + 8, 0);
+        if (dev_upload(&s->d_bl_lend, lend.data(), lend.size())) return 1;
+        s->blk_list_cap = list_cap;
         if (dev_upload(&s->d_bl_meta, meta.data(), meta.size())) return 1;
         if (dev_upload(&s->d_bl_ent, ent.data(), ent.size())) return 1;
         if (dev_upload(&s->d_bl_wtab, wtab.data(), wtab.size())) return 1;
@@ -2813,6 +2827,7 @@ int edigpu_destroy(edigpu_handle s) {
   dev_free(s->d_tile_chunks);
   dev_free(s->d_tile_lbeg);
   dev_free(s->d_bl_meta);
+  dev_free(s->d_bl_lend);
   dev_free(s->d_bl_ent);
   dev_free(s->d_bl_wtab);
   dev_free(s->d_tl_meta);

@@ -124,6 +124,8 @@ struct edigpu_sector {
   int64_t blk_ps = 0, blk_len = 0;
   int4* d_bl_meta = nullptr;
   int blk_rows = 0;             // rows of an LDS block of the blocked sweep
+  int blk_list_cap = 0;
+  int32_t* d_bl_lend = nullptr;
   uint32_t* d_bl_ent = nullptr;
   double* d_bl_wtab = nullptr;
   bool lz_blocked = false;

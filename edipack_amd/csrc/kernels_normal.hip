@@ -549,6 +549,8 @@ static void fill_args(const edigpu_sector* s, NormalArgs& a) {
   a.blk_ps = 0;
   a.bl_meta = s->d_bl_meta;
   a.blk_rows = s->blk_rows;
+  a.blk_list_cap = s->blk_list_cap;
+  a.bl_lend = s->d_bl_lend;
   a.bl_ent = s->d_bl_ent;
   a.bl_wtab = s->d_bl_wtab;
   a.mx_rowptr = s->d_mx_rowptr;

@@ -677,43 +677,47 @@ __global__ void __launch_bounds__(NT)
 // row / global row, weight index, Hnd term) read 16 bytes at a time, the weights come from a 256-entry table in the
 // LDS.  Workgroups with the same blockIdx & 7 (one XCD under the round-robin dispatch) walk a contiguous range of
 // panels, one panel at a time.
-constexpr int kBlkNT = 256;
-constexpr int kBlkJ = 4;
+constexpr int kBlkNT = 512;
+constexpr int kBlkJ = 2;
 
 struct BlkArgs {
-  int npanels, panels_per_xcd, nchunks, rows_per_task;
+  int npanels, panels_per_xcd, nchunks, rows_per_task, list_cap;
 };
 
 template <int SHIFT, bool DO_ND, bool ALPHA>
 __global__ void __launch_bounds__(kBlkNT)
     normal_dw_blk_kernel(NormalArgs a, BlkArgs p, const double* __restrict__ v, double* __restrict__ hv) {
   constexpr int W = 1 << SHIFT, L = W / 2, RW = 64 / L, NW = kBlkNT / 64, RB = NW * RW;
-  extern __shared__ double2 stile[];  // [rows_per_task][L]: the block's own segments of V
+  // dynamic LDS: the block's own segments of V [rows_per_task][L] double2 | its list entries [list_cap] | row meta
+  extern __shared__ double2 stile[];
   __shared__ double wtab[256];
   __shared__ double red[3 * NW];
   __shared__ uint32_t ju2[DO_ND ? 2 * kMaxNdTerms * L : 1];
+  const int R = p.rows_per_task;
+  uint32_t* lent = reinterpret_cast<uint32_t*>(stile + (size_t)R * L);
+  int4* lmeta = reinterpret_cast<int4*>(lent + p.list_cap);
   const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane / L, lg = lane % L;
   double asum = 0.0, qsum = 0.0, nsum = 0.0;
   const bool stop = ALPHA && a.scal[SC_STOP] != 0.0;
   const double sg = ALPHA ? a.scal[SC_ALPHA] : 0.0;
-  wtab[threadIdx.x] = a.bl_wtab[threadIdx.x];  // kBlkNT == 256
+  if (threadIdx.x < 256) wtab[threadIdx.x] = a.bl_wtab[threadIdx.x];
   const int64_t DimDw = a.dim_dw, DimUp = a.dim_up, PS = a.blk_ps;
   const int pfirst = x * p.panels_per_xcd;
   int plast = pfirst + p.panels_per_xcd;
   if (plast > p.npanels) plast = p.npanels;
   const int ntasks = stop ? 0 : (plast - pfirst) * p.nchunks;
-  const int R = p.rows_per_task;
-  int cur_panel = -1;
+  int cur_panel = -1, cur_chunk = -1;
   for (int task = slot; task < ntasks; task += nslots) {
+    // chunk-major inside a panel group would re-stage lists less often, but the L2 wants one panel at a time
     const int panel = pfirst + task / p.nchunks, chunk = task % p.nchunks;
     const double* __restrict__ vp = v + (int64_t)panel * PS;
     double* __restrict__ hp = hv + (int64_t)panel * PS;
     const int64_t rb = (int64_t)chunk * R;
     const int nrows = (int)(DimDw - rb < R ? DimDw - rb : R);
-    __syncthreads();  // the previous task's readers of the tile and of ju2 are done
-    // ---- stage the block: nrows * L contiguous double2 ----
+    __syncthreads();  // the previous task's readers of the tile, the lists and ju2 are done
+    // ---- stage the block: nrows * L contiguous double2, and (when the chunk changed) its lists ----
     {
       const double2* __restrict__ src = reinterpret_cast<const double2*>(vp + (rb << SHIFT));
       const int n2 = nrows * L;
@@ -729,6 +733,19 @@ __global__ void __launch_bounds__(kBlkNT)
           const int i = i0 + u * kBlkNT + threadIdx.x;
           if (i < n2) stile[i] = t[u];
         }
+      }
+      if (chunk != cur_chunk) {
+        const int lbeg = a.bl_meta[rb].x;  // multiple of 4
+        const int lend = a.bl_lend[chunk];  // one past the chunk's last entry, multiple of 4
+        const uint4* __restrict__ ls = reinterpret_cast<const uint4*>(a.bl_ent + lbeg);
+        uint4* ld = reinterpret_cast<uint4*>(lent);
+        for (int i = threadIdx.x; i < (lend - lbeg) / 4; i += kBlkNT) ld[i] = ls[i];
+        for (int i = threadIdx.x; i < nrows; i += kBlkNT) {
+          int4 m = a.bl_meta[rb + i];
+          m.x -= lbeg;
+          lmeta[i] = m;
+        }
+        cur_chunk = chunk;
       }
     }
     if (DO_ND && panel != cur_panel) {  // partner columns of this panel's columns, per term and component
@@ -747,12 +764,11 @@ __global__ void __launch_bounds__(kBlkNT)
         }
         ju2[i] = w;
       }
-      cur_panel = panel;
     }
+    cur_panel = panel;
     __syncthreads();
-    for (int pass = 0; pass < R; pass += RB * kBlkJ) {
+    for (int pass = 0; pass < nrows; pass += RB * kBlkJ) {
       const int lr0 = pass + wave * RW + grp;  // staged index of this lane group's first row
-      if (pass >= nrows) break;                 // uniform
       double2 acc[kBlkJ];
       int4 meta[kBlkJ];
       bool live[kBlkJ];
@@ -760,40 +776,33 @@ __global__ void __launch_bounds__(kBlkNT)
       for (int j = 0; j < kBlkJ; j++) {
         const int lr = lr0 + j * RB;
         live[j] = lr < nrows;
-        const int64_t rr = rb + (live[j] ? lr : nrows - 1);  // clamped: a valid address, masked at the store
-        acc[j] = *reinterpret_cast<const double2*>(hp + (rr << SHIFT) + 2 * lg);
-        meta[j] = a.bl_meta[rr];
+        const int lc = live[j] ? lr : nrows - 1;  // clamped: a valid address, masked at the store
+        acc[j] = *reinterpret_cast<const double2*>(hp + ((rb + lc) << SHIFT) + 2 * lg);
+        meta[j] = lmeta[lc];
       }
-      const uint32_t* __restrict__ le[kBlkJ];
-      uint4 e[kBlkJ];
-      // ---- hops that leave the block: L2 gathers, the kBlkJ rows of the lane group interleaved ----
-      int no[kBlkJ], nomax = 0;
+      // ---- hops that leave the block: L2 gathers, 4 * kBlkJ in flight per lane; entries come from the LDS ----
+      int nomax = 0;
 #pragma unroll
       for (int j = 0; j < kBlkJ; j++) {
-        le[j] = a.bl_ent + meta[j].x + meta[j].y;  // the inter entries follow the intra ones
-        no[j] = live[j] ? meta[j].z : 0;
-        nomax = no[j] > nomax ? no[j] : nomax;
-        e[j] = *reinterpret_cast<const uint4*>(le[j]);  // (no such hops: reads the next entries, weights masked)
+        if (!live[j]) meta[j].z = 0;
+        nomax = meta[j].z > nomax ? meta[j].z : nomax;
       }
       for (int b = 0; b < nomax; b += 4) {
+        uint4 e[kBlkJ];
         double2 y[kBlkJ][4];
 #pragma unroll
         for (int j = 0; j < kBlkJ; j++) {
+          int bj = b < meta[j].z ? b : meta[j].z - 4;  // clamped: the last batch again, weights masked below
+          bj = bj < 0 ? 0 : bj;
+          e[j] = *reinterpret_cast<const uint4*>(lent + meta[j].x + meta[j].y + bj);
           y[j][0] = *reinterpret_cast<const double2*>(vp + ((int64_t)(e[j].x & 0xFFFFu) << SHIFT) + 2 * lg);
           y[j][1] = *reinterpret_cast<const double2*>(vp + ((int64_t)(e[j].y & 0xFFFFu) << SHIFT) + 2 * lg);
           y[j][2] = *reinterpret_cast<const double2*>(vp + ((int64_t)(e[j].z & 0xFFFFu) << SHIFT) + 2 * lg);
           y[j][3] = *reinterpret_cast<const double2*>(vp + ((int64_t)(e[j].w & 0xFFFFu) << SHIFT) + 2 * lg);
         }
-        uint4 en[kBlkJ];
 #pragma unroll
         for (int j = 0; j < kBlkJ; j++) {
-          int bn = b + 4 < no[j] ? b + 4 : no[j] - 4;  // clamped: the last batch again (its weights are masked)
-          bn = bn < 0 ? 0 : bn;
-          en[j] = *reinterpret_cast<const uint4*>(le[j] + bn);
-        }
-#pragma unroll
-        for (int j = 0; j < kBlkJ; j++) {
-          const bool on = b < no[j];
+          const bool on = b < meta[j].z;
           const double w0 = on ? wtab[(e[j].x >> 16) & 255u] : 0.0, w1 = on ? wtab[(e[j].y >> 16) & 255u] : 0.0,
                        w2 = on ? wtab[(e[j].z >> 16) & 255u] : 0.0, w3 = on ? wtab[(e[j].w >> 16) & 255u] : 0.0;
           acc[j].x += w0 * y[j][0].x;
@@ -804,14 +813,13 @@ __global__ void __launch_bounds__(kBlkNT)
           acc[j].y += w2 * y[j][2].y;
           acc[j].x += w3 * y[j][3].x;
           acc[j].y += w3 * y[j][3].y;
-          e[j] = en[j];
         }
       }
-      // ---- hops inside the block: LDS gathers ----
+      // ---- hops inside the block: entries and data from the LDS ----
 #pragma unroll
       for (int j = 0; j < kBlkJ; j++) {
         if (!live[j]) continue;
-        const uint32_t* __restrict__ li = a.bl_ent + meta[j].x;
+        const uint32_t* li = lent + meta[j].x;
         for (int b = 0; b < meta[j].y; b += 4) {
           const uint4 ei = *reinterpret_cast<const uint4*>(li + b);
           const double2 y0 = stile[(int)(ei.x & 0xFFFFu) * L + lg], y1 = stile[(int)(ei.y & 0xFFFFu) * L + lg],
@@ -835,7 +843,7 @@ __global__ void __launch_bounds__(kBlkNT)
         const int64_t r = rb + lr;
         double2 s = acc[j];
         if (DO_ND) {
-          const uint32_t* __restrict__ ln = a.bl_ent + meta[j].x + meta[j].y + meta[j].z;
+          const uint32_t* ln = lent + meta[j].x + meta[j].y + meta[j].z;
           for (int q = 0; q < meta[j].w; q++) {
             const uint32_t ee = ln[q];
             const int term = (int)(ee >> 24) - 1;
@@ -961,7 +969,7 @@ static int launch_dw_blocked_tiles(const NormalArgs& a, bool do_nd, const double
 int launch_dw_blocked(const NormalArgs& a, bool do_nd, const double* v, double* hv, hipStream_t st, bool alpha,
                       int* nblocks) {
   if (a.blk_shift == 7) return launch_dw_blocked_tiles(a, do_nd, v, hv, st, alpha, nblocks);
-  if (a.blk_shift < 4 || a.blk_shift > 6 || a.blk_rows < 32 || !a.bl_meta || !a.bl_ent || !a.bl_wtab || a.dw_first != 0 ||
+  if (a.blk_shift < 4 || a.blk_shift > 6 || a.blk_rows < 32 || !a.bl_meta || !a.bl_ent || !a.bl_wtab || !a.bl_lend || a.blk_list_cap < 4 || a.dw_first != 0 ||
       a.dw_count != a.dim_dw) {
     set_error("launch_dw_blocked: the sector has no panel-major image");
     return 1;
@@ -976,7 +984,9 @@ int launch_dw_blocked(const NormalArgs& a, bool do_nd, const double* v, double* 
   p.panels_per_xcd = (p.npanels + 7) / 8;
   p.rows_per_task = a.blk_rows;  // rows of an LDS block: the lists were split by it at set-up
   p.nchunks = (int)((a.dim_dw + p.rows_per_task - 1) / p.rows_per_task);
-  const size_t lds = (size_t)p.rows_per_task * (W / 2) * sizeof(double2);
+  p.list_cap = a.blk_list_cap;
+  const size_t lds = (size_t)p.rows_per_task * (W / 2) * sizeof(double2) + (size_t)p.list_cap * sizeof(uint32_t) +
+                     (size_t)p.rows_per_task * sizeof(int4);
   // a persistent grid: as many workgroups as stay resident (EDIGPU_BLOCKED_WGS caps them per CU), each walking its
   // XCD's tasks in order, so that an XCD works on one panel (at a boundary: two) at a time
   static const int cap_per_cu = [] {

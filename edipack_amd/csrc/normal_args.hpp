@@ -66,7 +66,9 @@ struct NormalArgs {
   // weight index << 16 | (Hnd term + 1) << 24; bl_wtab: 256 weights
   const int4* bl_meta;
   const uint32_t* bl_ent;
-  int blk_rows;  // rows of an LDS block of the blocked sweep
+  int blk_rows;          // rows of an LDS block of the blocked sweep
+  int blk_list_cap;      // list entries of the fullest block (multiple of 4)
+  const int32_t* bl_lend;  // per block: one past its last list entry
   const double* bl_wtab;
   const int32_t* mx_rowptr;  // merged list: ptr[dw_count+1]
   const int32_t* mx_col;     // partner row (24 bit) | tag << 24

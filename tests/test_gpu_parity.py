@@ -1774,8 +1774,10 @@ def test_panel_major_lanczos_matches_oracle(gpu, monkeypatch, w, bath, norb, nba
     against the natural-layout loop of the same handle type: alpha / beta, the Ritz vector that comes back through the
     layout conversion, and the H*v probe of the bench."""
     import os
-    if os.environ.get("EDIGPU_NORMAL_EXPLICIT") or os.environ.get("EDIGPU_LANCZOS_UNFUSED"):
-        pytest.skip("the panel-major loop needs the factored image and the fused step")
+    if os.environ.get("EDIGPU_NORMAL_EXPLICIT") or os.environ.get("EDIGPU_LANCZOS_UNFUSED") or os.environ.get("EDIGPU_ROW_SPLIT"):
+        pytest.skip("the panel-major loop needs the factored image, the fused step and whole rows in the LDS")
+    if w == 128 and (os.environ.get("EDIGPU_PANEL_VEC2") == "0" or os.environ.get("EDIGPU_PANEL_TILE") == "0"):
+        pytest.skip("128-column panels are swept by the tiled kernel, which this switch turns off")
     O = _oracle()
     from edipack_amd.hamiltonian import SectorHamiltonian
     om, pm = make_models("normal", bath, norb, nbath, seed=71, jxp=jxp)
