@@ -209,12 +209,14 @@ def test_shifted_spectrum_keeps_the_fused_step_accurate(gpu):
 
 
 
-def test_cfg2_handover_image_runs_the_factored_kernels(gpu):
+def test_cfg2_handover_image_runs_the_factored_kernels(gpu, monkeypatch):
     """edigpu_normal_create on the explicit arrays of config 2 (what INTEGRATION.md section 2 patches in) recovers the
     factored tables: same H*v as the library-built sector to rounding, the same tridiagonal, and the arrays come back
     from edigpu_normal_export bit for bit."""
     from edipack_amd.hamiltonian import SectorHamiltonian
     from edipack_amd.synthetic import WORKLOADS, synthetic_model
+    for k in ("EDIGPU_HANDOVER_FACTOR", "EDIGPU_NORMAL_EXPLICIT", "EDIGPU_ND_NO_MERGE"):
+        monkeypatch.delenv(k, raising=False)
     w = WORKLOADS["cfg2"]
     pm = synthetic_model(w)
     hl = SectorHamiltonian.normal_from_model(pm, *w.sector)

@@ -75,8 +75,7 @@ def test_normal_create_from_reference_arrays(gpu, monkeypatch, factor):
     import os
     O = _oracle()
     from edipack_amd.hamiltonian import SectorHamiltonian
-    if not factor:
-        monkeypatch.setenv("EDIGPU_HANDOVER_FACTOR", "0")
+    monkeypatch.setenv("EDIGPU_HANDOVER_FACTOR", "1" if factor else "0")
     om, _ = make_models("normal", "normal", 2, 3, seed=5)
     ho = O.HNormal(om, 4, 4)
     hg = SectorHamiltonian.normal_from_arrays(ho.dimup, ho.dimdw, ho.hd, ho.up, ho.dw, ho.nd)
@@ -186,8 +185,7 @@ def test_normal_two_phase_handover_shards(gpu, monkeypatch, factor):
     import torch
     O = _oracle()
     from edipack_amd.hamiltonian import SectorHamiltonian
-    if not factor:
-        monkeypatch.setenv("EDIGPU_HANDOVER_FACTOR", "0")
+    monkeypatch.setenv("EDIGPU_HANDOVER_FACTOR", "1" if factor else "0")
     om, _ = make_models("normal", "hybrid", 3, 3, seed=9)
     ho = O.HNormal(om, 3, 3)
     v = np.random.default_rng(5).standard_normal(ho.dim)
@@ -1236,6 +1234,7 @@ def test_transposed_exchange_refusals(gpu, monkeypatch):
     om, pm = make_models("normal", "hybrid", 2, 2, seed=62)
     ho = O.HNormal(om, 3, 3)
     if not os.environ.get("EDIGPU_NORMAL_EXPLICIT"):
+        monkeypatch.setenv("EDIGPU_HANDOVER_FACTOR", "1")
         hh = SectorHamiltonian.normal_from_arrays(ho.dimup, ho.dimdw, ho.hd, ho.up, ho.dw, ho.nd)
         hl = SectorHamiltonian.normal_from_model(pm, 3, 3)
         assert hh.transpose_halo() == hl.transpose_halo()
