@@ -792,13 +792,17 @@ __global__ void __launch_bounds__(kBlkNT)
         double2 y[kBlkJ][4];
 #pragma unroll
         for (int j = 0; j < kBlkJ; j++) {
-          int bj = b < meta[j].z ? b : meta[j].z - 4;  // clamped: the last batch again, weights masked below
-          bj = bj < 0 ? 0 : bj;
-          e[j] = *reinterpret_cast<const uint4*>(lent + meta[j].x + meta[j].y + bj);
-          y[j][0] = *reinterpret_cast<const double2*>(vp + ((int64_t)(e[j].x & 0xFFFFu) << SHIFT) + 2 * lg);
-          y[j][1] = *reinterpret_cast<const double2*>(vp + ((int64_t)(e[j].y & 0xFFFFu) << SHIFT) + 2 * lg);
-          y[j][2] = *reinterpret_cast<const double2*>(vp + ((int64_t)(e[j].z & 0xFFFFu) << SHIFT) + 2 * lg);
-          y[j][3] = *reinterpret_cast<const double2*>(vp + ((int64_t)(e[j].w & 0xFFFFu) << SHIFT) + 2 * lg);
+          // a lane group whose list is exhausted keeps issuing loads with the others: of its own row, weight 0 (never
+          // of whatever follows its list in the LDS)
+          const bool on = b < meta[j].z;
+          e[j] = *reinterpret_cast<const uint4*>(lent + meta[j].x + meta[j].y + (on ? b : 0));
+          const uint32_t own = (uint32_t)(rb + (live[j] ? lr0 + j * RB : nrows - 1));
+          const uint32_t r0 = on ? (e[j].x & 0xFFFFu) : own, r1 = on ? (e[j].y & 0xFFFFu) : own,
+                         r2 = on ? (e[j].z & 0xFFFFu) : own, r3 = on ? (e[j].w & 0xFFFFu) : own;
+          y[j][0] = *reinterpret_cast<const double2*>(vp + ((int64_t)r0 << SHIFT) + 2 * lg);
+          y[j][1] = *reinterpret_cast<const double2*>(vp + ((int64_t)r1 << SHIFT) + 2 * lg);
+          y[j][2] = *reinterpret_cast<const double2*>(vp + ((int64_t)r2 << SHIFT) + 2 * lg);
+          y[j][3] = *reinterpret_cast<const double2*>(vp + ((int64_t)r3 << SHIFT) + 2 * lg);
         }
 #pragma unroll
         for (int j = 0; j < kBlkJ; j++) {
