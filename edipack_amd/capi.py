@@ -122,6 +122,11 @@ SIGNATURES = {
     "edigpu_lanczos_bench": (C.c_int, [_vp, C.c_int, C.c_int, _pd, _pd]),
     "edigpu_membw": (C.c_int, [_i64, _pd]),
     "edigpu_sector_map": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _pi32, _pi64]),
+    "edigpu_cache_create": (C.c_int, [C.POINTER(_vp), _i64]),
+    "edigpu_cache_get": (C.c_int, [_vp, C.POINTER(EdigpuModel), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "edigpu_cache_stats": (C.c_int, [_vp, _pi64]),
+    "edigpu_cache_clear": (C.c_int, [_vp]),
+    "edigpu_cache_destroy": (C.c_int, [_vp]),
     "edigpu_dev_alloc": (C.c_int, [_i64, C.POINTER(_vp)]),
     "edigpu_dev_free": (C.c_int, [_vp]),
     "edigpu_dev_upload": (C.c_int, [_vp, _vp, _i64]),

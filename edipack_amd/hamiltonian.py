@@ -171,8 +171,9 @@ def _csr_args(rowptr, col, val, cplx=False):
 class SectorHamiltonian:
     """One sector Hamiltonian resident on the GPU (an ``edigpu_handle``)."""
 
-    def __init__(self, handle: C.c_void_p):
+    def __init__(self, handle: C.c_void_p, owned: bool = True):
         self._h = handle
+        self._owned = owned        # False: the handle belongs to a SectorCache
         info = (C.c_int64 * 10)()
         capi.check(capi.lib().edigpu_info(self._h, info), "edigpu_info")
         (self.dim, self.nloc, self.row_first, cplx, self.kind, self.dim_up, self.dim_dw,
@@ -470,7 +471,8 @@ class SectorHamiltonian:
 
     def destroy(self) -> None:
         if self._h:
-            capi.lib().edigpu_destroy(self._h)
+            if self._owned:
+                capi.lib().edigpu_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -565,3 +567,34 @@ def tridiag_Hv_sector(build, vvinit: np.ndarray, nlanc: int | None = None, lanc_
     finally:
         delete_Hv_sector()
     return alanc, blanc, norm2
+
+
+class SectorCache:
+    """Per-solve cache of sector handles (``edigpu_cache_*``): what replaces the reference's rebuild
+    of the sector Hamiltonian in every ``tridiag_Hv_sector_*`` call.  ``get`` returns a SectorHamiltonian that borrows
+    the cached handle (its ``destroy`` is a no-op); the two most recently returned ones are never evicted."""
+    KINDS = {"normal": 0, "stored": 1, "direct": 2, "normal_cmplx": 3}
+
+    def __init__(self, max_device_bytes: int = 8 << 30):
+        self._c = C.c_void_p()
+        capi.check(capi.lib().edigpu_cache_create(C.byref(self._c), int(max_device_bytes)), "edigpu_cache_create")
+
+    def get(self, model: ImpurityModel, kind: str, q1: int, q2: int = 0) -> SectorHamiltonian:
+        h = C.c_void_p()
+        cm = model.to_c()
+        capi.check(capi.lib().edigpu_cache_get(self._c, C.byref(cm), self.KINDS[kind], q1, q2, C.byref(h)),
+                   "edigpu_cache_get")
+        return SectorHamiltonian(h, owned=False)
+
+    def stats(self) -> dict:
+        a = (C.c_int64 * 5)()
+        capi.check(capi.lib().edigpu_cache_stats(self._c, a), "edigpu_cache_stats")
+        return dict(zip(("hits", "misses", "evictions", "bytes", "entries"), [int(x) for x in a]))
+
+    def clear(self) -> None:
+        capi.check(capi.lib().edigpu_cache_clear(self._c), "edigpu_cache_clear")
+
+    def destroy(self) -> None:
+        if self._c:
+            capi.lib().edigpu_cache_destroy(self._c)
+            self._c = None

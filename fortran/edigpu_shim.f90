@@ -21,6 +21,8 @@ module EDIGPU_SHIM
 
   type(c_ptr), save :: gpu_sector = c_null_ptr   !< the live edigpu_handle
   type(c_ptr), save :: gpu_comm = c_null_ptr     !< the live edigpu_comm (MpiComm's counterpart; N > 1 only)
+  type(c_ptr), save :: gpu_cache = c_null_ptr    !< the per-solve cache of sector handles (gpu_cache_create)
+  logical, save :: gpu_sector_borrowed = .false. !< the live handle belongs to gpu_cache: gpu_delete_sector keeps it
 
   integer, parameter, public :: EDIGPU_MAXORB = 5, EDIGPU_MAXBATH = 16, EDIGPU_MAXSUNDRY = 64
   !> breakdown threshold of the tridiagonalisation (sp_lanc_tridiag is called without one: SciFortran's default)
@@ -267,6 +269,36 @@ module EDIGPU_SHIM
        integer(c_int64_t), intent(out) :: first, count, q
        integer(c_int) :: ierr
      end function edigpu_shard_plan
+     function edigpu_cache_create(c, max_device_bytes) bind(C, name="edigpu_cache_create") result(ierr)
+       import :: c_ptr, c_int, c_int64_t
+       type(c_ptr) :: c
+       integer(c_int64_t), value :: max_device_bytes
+       integer(c_int) :: ierr
+     end function edigpu_cache_create
+     function edigpu_cache_get(c, model, kind, q1, q2, h) bind(C, name="edigpu_cache_get") result(ierr)
+       import :: c_ptr, c_int, edigpu_model_t
+       type(c_ptr), value :: c
+       type(edigpu_model_t), intent(in) :: model
+       integer(c_int), value :: kind, q1, q2
+       type(c_ptr) :: h
+       integer(c_int) :: ierr
+     end function edigpu_cache_get
+     function edigpu_cache_stats(c, stats) bind(C, name="edigpu_cache_stats") result(ierr)
+       import :: c_ptr, c_int, c_int64_t
+       type(c_ptr), value :: c
+       integer(c_int64_t) :: stats(5)
+       integer(c_int) :: ierr
+     end function edigpu_cache_stats
+     function edigpu_cache_clear(c) bind(C, name="edigpu_cache_clear") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: c
+       integer(c_int) :: ierr
+     end function edigpu_cache_clear
+     function edigpu_cache_destroy(c) bind(C, name="edigpu_cache_destroy") result(ierr)
+       import :: c_ptr, c_int
+       type(c_ptr), value :: c
+       integer(c_int) :: ierr
+     end function edigpu_cache_destroy
      function edigpu_comm_unique_id(id) bind(C, name="edigpu_comm_unique_id") result(ierr)
        import :: c_int, c_char
        character(kind=c_char), intent(out) :: id(128)
@@ -340,6 +372,7 @@ module EDIGPU_SHIM
   public :: flatten_rows_count
   ! "next" rows of SURVEY.md 8(f): the eigensolvers and the device-resident neighbours of the tridiagonalisation
   public :: gpu_sector_handle, gpu_sector_swap, gpu_sector_dim, gpu_sector_destroy
+  public :: gpu_cache_create, gpu_cache_clear, gpu_cache_destroy, gpu_cache_stats, gpu_build_cached
   public :: gpu_sp_lanc_eigh_d, gpu_sp_lanc_eigh_c, gpu_sp_eigh_d, gpu_sp_eigh_c
   public :: gpu_vec_alloc, gpu_vec_free, gpu_vec_upload_d, gpu_vec_download_d, gpu_vec_upload_c, gpu_vec_download_c
   public :: gpu_sp_lanc_eigh_dev, gpu_apply_op, gpu_apply_cops, gpu_lanc_tridiag_dev
@@ -883,9 +916,49 @@ contains
   !> delete_Hv_sector_* counterpart (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:212-279)
   subroutine gpu_delete_sector()
     if (c_associated(gpu_sector)) then
-       call gpu_check(edigpu_destroy(gpu_sector), "gpu_delete_sector")
+       if (.not. gpu_sector_borrowed) call gpu_check(edigpu_destroy(gpu_sector), "gpu_delete_sector")
        gpu_sector = c_null_ptr
+       gpu_sector_borrowed = .false.
     end if
   end subroutine gpu_delete_sector
+
+  !> per-solve cache of sector handles (row f2): the reference builds the sector Hamiltonian anew in every
+  !! tridiag_Hv_sector_* (build_Hv_sector_* ... delete_Hv_sector_*); with the cache a repeated request for the same
+  !! (model, sector) returns the handle that is already on the device.  max_mb: device-memory budget.
+  subroutine gpu_cache_create(max_mb)
+    integer, intent(in) :: max_mb
+    if (c_associated(gpu_cache)) return
+    call gpu_check(edigpu_cache_create(gpu_cache, int(max_mb, c_int64_t) * 1048576_c_int64_t), "gpu_cache_create")
+  end subroutine gpu_cache_create
+
+  !> in place of gpu_build_normal / gpu_build_flat / gpu_build_normal_cmplx inside build_Hv_sector_*: kind 0 normal
+  !! (q1, q2 = Nup, Ndw), 1 stored superc / nonsu2 (q1 = Sz / Ntot), 2 on-the-fly, 3 normal with complex algebra.  The live
+  !! handle then belongs to the cache: delete_Hv_sector_* (gpu_delete_sector) only lets go of it.
+  subroutine gpu_build_cached(m, kind, q1, q2)
+    type(edigpu_model_t), intent(in) :: m
+    integer, intent(in) :: kind, q1, q2
+    if (.not. c_associated(gpu_cache)) stop "gpu_build_cached: call gpu_cache_create first"
+    if (c_associated(gpu_sector)) stop "gpu_build_cached: a sector is already allocated"
+    call gpu_check(edigpu_cache_get(gpu_cache, m, int(kind, c_int), int(q1, c_int), int(q2, c_int), gpu_sector), &
+         "gpu_build_cached")
+    gpu_sector_borrowed = .true.
+  end subroutine gpu_build_cached
+
+  subroutine gpu_cache_stats(hits, misses, evictions)
+    integer, intent(out) :: hits, misses, evictions
+    integer(c_int64_t) :: st(5)
+    call gpu_check(edigpu_cache_stats(gpu_cache, st), "gpu_cache_stats")
+    hits = int(st(1)); misses = int(st(2)); evictions = int(st(3))
+  end subroutine gpu_cache_stats
+
+  !> a new bath (the next DMFT iteration) makes every cached sector stale: drop them
+  subroutine gpu_cache_clear()
+    if (c_associated(gpu_cache)) call gpu_check(edigpu_cache_clear(gpu_cache), "gpu_cache_clear")
+  end subroutine gpu_cache_clear
+
+  subroutine gpu_cache_destroy()
+    if (c_associated(gpu_cache)) call gpu_check(edigpu_cache_destroy(gpu_cache), "gpu_cache_destroy")
+    gpu_cache = c_null_ptr
+  end subroutine gpu_cache_destroy
 
 end module EDIGPU_SHIM

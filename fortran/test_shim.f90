@@ -105,6 +105,7 @@ program test_shim
 
   ! ---- the N > 1 entry points with a world of one (RCCL communicator) ----
   call test_comm_world_of_one(nfail)
+  call test_sector_cache(nfail)
 
   if (nfail == 0) then
      write(*,"(A)") "FORTRAN SHIM OK"
@@ -308,6 +309,43 @@ contains
     call gpu_comm_destroy()
     call gpu_delete_sector()
   end subroutine test_comm_world_of_one
+
+  !> the per-solve sector cache in the shape of the Green's-function loop: build_Hv_sector(jsector) ... delete_Hv_sector
+  !! for the same few sectors again and again; a repeated request must return the handle that is already there
+  subroutine test_sector_cache(nfail)
+    integer, intent(inout) :: nfail
+    type(edigpu_model_t) :: m
+    type(c_ptr) :: h1, h2
+    real(8) :: a1(6), b1(6), a2(6), b2(6)
+    real(8), allocatable :: x(:)
+    integer :: hits, misses, evictions, n, ii, k
+    call anderson_model(m)
+    call gpu_cache_create(256)
+    do k = 1, 3
+       call gpu_build_cached(m, 0, 2, 2)
+       if (k == 1) h1 = gpu_sector_handle()
+       h2 = gpu_sector_handle()
+       n = gpu_sector_dim(h2)
+       if (.not. allocated(x)) then
+          allocate(x(n))
+          do ii = 1, n
+             x(ii) = sin(0.3d0*ii) + 0.05d0*ii
+          end do
+       end if
+       if (k == 1) call gpu_lanc_tridiag_d(x, a1, b1)
+       if (k == 3) call gpu_lanc_tridiag_d(x, a2, b2)
+       call gpu_delete_sector()                 ! lets go of the borrowed handle, the cache keeps it
+       call gpu_build_cached(m, 0, 3, 2)        ! the sector c^+ leads to
+       call gpu_delete_sector()
+    end do
+    call gpu_cache_stats(hits, misses, evictions)
+    write(*,"(A,3I4)") "sector cache (hits, misses, evictions):", hits, misses, evictions
+    if (.not. c_associated(h1, h2)) nfail = nfail + 1
+    if (hits /= 4 .or. misses /= 2 .or. evictions /= 0) nfail = nfail + 1
+    if (maxval(abs(a1 - a2)) > 0d0 .or. maxval(abs(b1 - b2)) > 0d0) nfail = nfail + 1
+    call gpu_cache_clear()
+    call gpu_cache_destroy()
+  end subroutine test_sector_cache
 
   !> one rank of `world`: whole-sector handle (transposed exchange), the product and the tridiagonalisation on this
   !! rank's down rows against the single-process results computed first with the same handle

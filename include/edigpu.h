@@ -496,6 +496,28 @@ int edigpu_lanczos_tridiag_sharded(edigpu_handle h, edigpu_comm c, const double 
 int edigpu_lanczos_bench_sharded(edigpu_handle h, edigpu_comm c, int warmup, int steps, double *ms_per_step,
                                  int64_t *exchange_bytes);
 
+/* ----------------------------------------------------------------------- */
+/* Per-solve cache of sector handles                     */
+/* ----------------------------------------------------------------------- */
+/*
+ * The reference rebuilds the sector Hamiltonian in every tridiag_Hv_sector_* call (build_Hv_sector_* ...
+ * delete_Hv_sector_*, ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:351-368): one build per Green's-function channel and state.
+ * edigpu_cache_get returns the handle of (model, kind, sector) -- building it on a miss with edigpu_normal_build
+ * (kind 0: q1, q2 = Nup, Ndw), edigpu_flat_build (1: q1 = Sz / Ntot), edigpu_direct_build (2) or edigpu_normal_build_z
+ * (3), whole sectors -- and keeps it on the device for the next request.  The handle belongs to the cache: do not
+ * edigpu_destroy it.  Entries are evicted least recently used once their device memory (measured at build time + the
+ * Lanczos workspace) exceeds max_device_bytes; the two most recently returned handles are never evicted (the
+ * Green's-function loop holds the eigenstate's sector and the target sector at once).  The key includes every byte of
+ * the model: a new bath is a new key; edigpu_cache_clear drops everything (e.g. at the start of a DMFT iteration).
+ * stats = hits, misses, evictions, device bytes in use, entries.  Thread-safe.
+ */
+typedef struct edigpu_cache_s *edigpu_cache;
+int edigpu_cache_create(edigpu_cache *c, int64_t max_device_bytes);
+int edigpu_cache_get(edigpu_cache c, const edigpu_model *model, int kind, int q1, int q2, edigpu_handle *h);
+int edigpu_cache_stats(edigpu_cache c, int64_t stats[5]);
+int edigpu_cache_clear(edigpu_cache c);
+int edigpu_cache_destroy(edigpu_cache c);
+
 /*
  * Timing helper for bench.py: runs `warmup` untimed and `steps` timed H*v
  * products (device-resident, random unit vector) on the handle's stream and

@@ -1854,3 +1854,47 @@ def test_jz_sectors_match_oracle(gpu, nbath, ntot, twojz):
         out.append(hv.cpu().numpy())
         hs.destroy()
     assert rel_err(np.concatenate(out), ho.matvec(v)) < TOL
+
+
+# --------------------------------------------------------------------------------------------
+# per-solve cache of sector handles
+# --------------------------------------------------------------------------------------------
+def test_sector_cache(gpu):
+    """A repeated request returns the handle that is already on the device; another model or sector is a miss; the
+    budget evicts least recently used entries but never the two most recent ones; cached handles compute what fresh
+    ones do."""
+    from edipack_amd.hamiltonian import SectorCache, SectorHamiltonian
+    O = _oracle()
+    om, pm = make_models("normal", "hybrid", 3, 3, seed=81)
+    om2, pm2 = make_models("normal", "hybrid", 3, 3, seed=82)
+    cache = SectorCache(max_device_bytes=1 << 30)
+    h1 = cache.get(pm, "normal", 3, 3)
+    h2 = cache.get(pm, "normal", 3, 3)
+    assert h1._h.value == h2._h.value and cache.stats()["hits"] == 1 and cache.stats()["misses"] == 1
+    v = np.random.default_rng(1).standard_normal(h1.dim)
+    assert rel_err(h1.apply(v), O.HNormal(om, 3, 3).matvec(v)) < TOL
+    h3 = cache.get(pm2, "normal", 3, 3)                       # another bath: another key
+    assert h3._h.value != h1._h.value and rel_err(h3.apply(v), O.HNormal(om2, 3, 3).matvec(v)) < TOL
+    h1.destroy()                                              # borrowed: a no-op for the cache
+    assert cache.get(pm, "normal", 3, 3)._h.value == h2._h.value
+    _, ps = make_models("superc", "hybrid", 2, 3, seed=83)
+    hs = cache.get(ps, "stored", 0)
+    hd = cache.get(ps, "direct", 0)
+    w = np.random.default_rng(2).standard_normal(hs.dim) + 0j
+    assert rel_err(hs.apply(w), hd.apply(w)) < TOL
+    st = cache.stats()
+    assert st["entries"] == 4 and st["evictions"] == 0 and st["bytes"] > 0
+    cache.destroy()
+    # a budget of nothing: every new entry evicts the coldest one, the two most recent stay usable
+    small = SectorCache(max_device_bytes=0)
+    a = small.get(pm, "normal", 3, 3)
+    b = small.get(pm, "normal", 3, 4)
+    c = small.get(pm, "normal", 4, 3)
+    assert small.stats()["entries"] == 2 and small.stats()["evictions"] == 1
+    vb = np.random.default_rng(3).standard_normal(b.dim)
+    vc = np.random.default_rng(3).standard_normal(c.dim)
+    assert rel_err(b.apply(vb), O.HNormal(om, 3, 4).matvec(vb)) < TOL
+    assert rel_err(c.apply(vc), O.HNormal(om, 4, 3).matvec(vc)) < TOL
+    small.clear()
+    assert small.stats()["entries"] == 0
+    small.destroy()
