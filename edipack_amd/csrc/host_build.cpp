@@ -1144,6 +1144,23 @@ std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, i
     d.cim = t.coef.imag();
     out.terms.push_back(d);
   }
+  // Order the terms by where they lead: a term takes state s to s + delta with delta = sum(+2^b over the levels it
+  // fills) - sum(2^b over the levels it empties), and ranks grow with the state.  A lane pops its applicable terms in
+  // list order, so with ascending delta the lanes of a wave (consecutive rows) walk their partners in ascending
+  // column order together -- what the column-sorted rows of the stored SELL image give that kernel.
+  // EDIGPU_DIRECT_NOSORT=1 keeps the order of the operator list.
+  if (!getenv("EDIGPU_DIRECT_NOSORT")) {
+    auto delta = [](const DirectTerm& t) {
+      int64_t d = 0;
+      for (int b = 0; b < 32; b++) {
+        if ((t.need_clear >> b) & 1u) d += (int64_t)1 << b;
+        if ((t.need_set >> b) & 1u) d -= (int64_t)1 << b;
+      }
+      return d;
+    };
+    std::stable_sort(out.terms.begin(), out.terms.end(),
+                     [&](const DirectTerm& x, const DirectTerm& y) { return delta(x) < delta(y); });
+  }
   // (an earlier version merged every hop with its reverse into one "pair" term; with the two-instruction
   // applicability test of the kernels a plain term list is faster -- see kernels_direct.hip)
   // diagonal: byte-wise sums of the one-body energies + impurity interaction table

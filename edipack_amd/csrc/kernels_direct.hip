@@ -28,8 +28,10 @@ constexpr int kDirNT = 1024;  // 2 workgroups/CU with the 2 x 2^Ns-entry rank ta
 // collects the applicability of 32 terms in a bit mask and then pops its own set bits, two per round: every
 // gather instruction has all lanes active and two are in flight per lane -- about 4x fewer dependent gather
 // rounds per row.  The per-term data then differ from lane to lane and come from an LDS copy of the term list.
+// (two workgroups of 16 waves per CU need 8 waves per SIMD, i.e. at most 64 VGPRs: the fused-step variant would take 68
+// and run at half the occupancy -- 1.70 against 1.39 ms on config 5 -- without the second launch bound)
 template <bool LDS_TABLES, bool LZ, bool COMPACT>
-__global__ void __launch_bounds__(kDirNT)
+__global__ void __launch_bounds__(kDirNT, 8)
     direct_rows_kernel(int64_t nrow, int64_t row_first, int ns, int norb, int nterms,
                        const int32_t* __restrict__ states, const int32_t* __restrict__ off_dw,
                        const int32_t* __restrict__ rk_up, const DirectTerm* __restrict__ terms,

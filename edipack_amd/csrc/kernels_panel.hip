@@ -418,6 +418,8 @@ constexpr int kTileBatch = 4;      // list entries per batch (a row's two hop li
 // BLK: vectors in the panel-major layout with 128-column panels (NormalArgs::blk_shift == 7): a panel is one
 // contiguous array of DimDw segments of 1024 bytes, the segment of row r starts at r * 128
 template <int NT, bool DO_ND, bool ALPHA, bool EDGE, bool BLK = false>
+// (forcing 64 VGPRs -- a fourth 512-thread workgroup per CU -- spills ten registers in the Hnd variants and measured
+// 3-5 % slower than three workgroups per CU at 66-76 VGPRs)
 __global__ void __launch_bounds__(NT)
     normal_dw_tile_kernel(NormalArgs a, PanelArgs p, const double* __restrict__ v_full, double* __restrict__ hv) {
   __shared__ double red[3 * (NT / 64)];
