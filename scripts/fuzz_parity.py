@@ -57,7 +57,30 @@ def main():
                 hl = np.asarray(m.hloc, complex).copy()
                 hl[0, 0] = hl[0, 0] + 1j * t
                 m.hloc = hl
-        tag = (trial, mode, bath, norb, nbath, nph, cmplx)
+        # the terms only some inputs switch on (normal mode, real algebra): random coulomb_sundry lines with their
+        # Hermitian conjugates, spin_field z, exc_field (1), (4)
+        extra = mode == "normal" and nph == 0 and not cmplx and rng.random() < 0.4
+        if extra:
+            lines = []
+            for _ in range(int(rng.integers(1, 4))):
+                while True:
+                    ops = [(int(rng.integers(0, norb)), int(rng.integers(0, 2))) for _ in range(4)]
+                    bal = [0, 0]
+                    for k_, (_, sp) in enumerate(ops):
+                        bal[sp] += 1 if k_ < 2 else -1
+                    if bal == [0, 0]:
+                        break
+                u = float(rng.uniform(-0.5, 0.5))
+                lines.append((u, ops[0], ops[1], ops[2], ops[3]))
+                # Hermitian conjugate of cd_i cd_j c_k c_l applied as c_l, cd_j, c_k, cd_i (per-spin-word signs): the
+                # reversed string c^+_l c^+_k ... is again of the form (cd_l' cd_k' ...) with (i, j, k, l) -> (l, k, j, i)
+                lines.append((u, ops[3], ops[2], ops[1], ops[0]))
+            sf = np.zeros((norb, 3))
+            sf[:, 2] = rng.uniform(-0.3, 0.3, norb)
+            ef = np.array([rng.uniform(-0.2, 0.2), 0.0, 0.0, rng.uniform(-0.2, 0.2)])
+            for m in (om, pm):
+                m.sundry, m.spin_field, m.exc_field = lines, sf, ef
+        tag = (trial, mode, bath, norb, nbath, nph, cmplx, extra)
         if mode == "normal":
             sec = (int(rng.integers(0, ns + 1)), int(rng.integers(0, ns + 1)))
             if cmplx:
@@ -66,6 +89,10 @@ def main():
             else:
                 ho, hs = O.HNormal(om, *sec), [SectorHamiltonian.normal_from_model(pm, *sec)]
                 v = rng.standard_normal(ho.dim)
+                if nph == 0 and 0 < ho.dim <= 60000:
+                    # the hand-over boundary on the oracle's (= the reference's) arrays: factored when they allow it
+                    hs.append(SectorHamiltonian.normal_from_arrays(ho.dimup, ho.dimdw, ho.hd, ho.up, ho.dw,
+                                                                   ho.nd if ho.has_nd else None))
         else:
             sec = int(rng.integers(-ns, ns + 1)) if mode == "superc" else int(rng.integers(0, 2 * ns + 1))
             ho = O.HFlat(om, sec)
