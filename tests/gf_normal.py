@@ -44,7 +44,7 @@ def apply_c_up(h_from, h_to, vec, iorb, create):
 
 def sigma_momenta_normal(om, tridiag, beta=1000.0, lmats=4096, ngfiter=200, gs_threshold=1e-9, nmom=4):
     """-> array [norb, nmom] as Sigma_momenta.check stores it (orbital-major)."""
-    assert om.ed_mode == "normal" and om.bath_type in ("normal", "hybrid")
+    assert om.ed_mode == "normal" and om.bath_type in ("normal", "hybrid", "replica", "general")
     secs = []
     for sec in O.sectors(om):
         h = O.HNormal(om, *sec)
@@ -91,7 +91,7 @@ def sigma_momenta_normal(om, tridiag, beta=1000.0, lmats=4096, ngfiter=200, gs_t
     gm = np.zeros((lmats, no, no), complex)
     for a in range(no):
         gm[:, a, a] = g_of([a])
-    if om.bath_type == "hybrid":     # off-diagonal G only exists with a shared bath (ed_solve_offdiag_gf)
+    if om.bath_type != "normal":     # off-diagonal G only exists with a shared bath (ed_solve_offdiag_gf)
         for a in range(no):
             for b in range(a + 1, no):
                 # (c_a + c_b) channel: G_ab = (G_mix - G_aa - G_bb)/2 (real symmetric), ED_GF_NORMAL.f90:96-110
@@ -99,7 +99,18 @@ def sigma_momenta_normal(om, tridiag, beta=1000.0, lmats=4096, ngfiter=200, gs_t
                 gm[:, a, b] = gab
                 gm[:, b, a] = gab
     g0inv = np.zeros((lmats, no, no), complex)
-    for a in range(no):
+    if om.bath_type in ("replica", "general"):
+        # delta_bath_array, ED_BATH/ED_BATH_FUNCTIONS: Delta(z) = sum_k V_k (z - H_k)^-1 V_k^T with the replica matrices
+        # H_k = hb[0, 0, :, :, k]; replica: one amplitude per bath element, general: one per orbital (vg)
+        delta = np.zeros((lmats, no, no), complex)
+        for k in range(om.nbath):
+            hk = np.asarray(om.hb)[0, 0, :, :, k]
+            vk = np.full(no, om.vr[k]) if om.bath_type == "replica" else np.asarray(om.vg)[:no, k]
+            inv = np.linalg.inv(z[:, None, None] * np.eye(no)[None] - hk[None])
+            delta += vk[None, :, None] * inv * vk[None, None, :]
+        hl = np.asarray(om.hloc)[0, 0].real
+        g0inv = (z[:, None, None] + om.xmu) * np.eye(no)[None] - hl[None] - delta
+    for a in range(no if om.bath_type in ("normal", "hybrid") else 0):
         for b in range(no):
             ea = om.be[0, 0 if om.bath_type == "hybrid" else a, :]
             if om.bath_type == "normal" and a != b:

@@ -493,6 +493,30 @@ def test_golden_sigma_momenta_through_gpu_tridiag(gpu, name):
     assert np.max(np.abs(m - g) / np.abs(g)) < 1e-10   # north_star: Green's functions within 1e-10 relative
 
 
+@pytest.mark.parametrize("name", ["REPLICA_NORMAL", "GENERAL_NORMAL"])
+def test_golden_replica_sigma_momenta_through_gpu_tridiag(gpu, name):
+    """The same for the replica / general directories (sectors with inter-orbital bath hops, mixed channels), every
+    sector taken from the per-solve cache -- the Green's-function loop asks for the same few sectors again and again."""
+    from edipack_amd.hamiltonian import SectorCache
+    from tests.common import replica_golden_models
+    from tests.gf_normal import sigma_momenta_normal
+    from tests.test_oracle_golden import GOLD
+    g = GOLD[name]
+    om, pm = replica_golden_models(g["input"])
+    cache = SectorCache(1 << 30)
+
+    def tridiag(sec, v, nl):
+        a, b, _ = cache.get(pm, "normal", *sec).lanczos_tridiag(v, nl)
+        return a, b
+
+    m = sigma_momenta_normal(om, tridiag, beta=g["input"]["BETA"], ngfiter=int(g["input"]["LANC_NGFITER"]))
+    gold = np.array(g["Sigma_momenta"]).reshape(m.shape)
+    assert np.max(np.abs(m - gold) / np.abs(gold)) < 1e-10
+    st = cache.stats()
+    assert st["hits"] > st["misses"] > 0
+    cache.destroy()
+
+
 def test_apply_op_and_device_seeded_tridiag(gpu):
     """edigpu_apply_op_normal (c / c^+ device to device, both spins) against the test-side restatement of
     apply_op_C/CDG, and edigpu_lanczos_tridiag_dev (seed and norm2 on the device side) against the

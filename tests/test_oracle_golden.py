@@ -84,6 +84,24 @@ def test_oracle_tridiag_reproduces_sigma_momenta(name):
     assert np.max(np.abs(m - g) / np.abs(g)) < 1e-11
 
 
+@pytest.mark.parametrize("name", ["REPLICA_NORMAL", "GENERAL_NORMAL"])
+def test_oracle_tridiag_reproduces_replica_sigma_momenta(name):
+    """Sigma_momenta.check of the replica / general normal-mode directories: diagonal and mixed channels (the bath
+    couples the orbitals), G0 from the replica matrices -- the tridiagonalisation of sectors built with inter-orbital
+    bath hops, pinned like the normal / hybrid ones."""
+    from tests.gf_normal import sigma_momenta_normal
+    g = GOLD[name]
+    om, _ = replica_golden_models(g["input"])
+
+    def tridiag(sec, v, nl):
+        a, b, _ = O.HNormal(om, *sec).lanc_tridiag(v.copy(), nl)
+        return a, b
+
+    m = sigma_momenta_normal(om, tridiag, beta=g["input"]["BETA"], ngfiter=int(g["input"]["LANC_NGFITER"]))
+    gold = np.array(g["Sigma_momenta"]).reshape(m.shape)
+    assert np.max(np.abs(m - gold) / np.abs(gold)) < 1e-10
+
+
 @pytest.mark.parametrize("name", REPLICA_DIRS)
 def test_oracle_reproduces_replica_general_fixture(name):
     g = GOLD[name]
