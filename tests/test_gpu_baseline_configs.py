@@ -236,3 +236,39 @@ def test_cfg2_handover_image_runs_the_factored_kernels(gpu, monkeypatch):
     hd2, _, _, nd2 = hh.export_normal()
     assert np.array_equal(hd2, hd) and all(np.array_equal(x, y) for x, y in zip(nd2, nd))
     hl.destroy(), hh.destroy()
+
+
+@pytest.mark.parametrize("workload", ["cfg3_ns15", "cfg3_ns16"])
+def test_hbm_resident_ladder_panel_major_vs_natural(gpu, monkeypatch, workload):
+    """The sectors the roofline fraction is quoted on (41 M and 166 M rows, HBM-resident): the default loop on
+    panel-major vectors against the same recurrence on the reference's layout (EDIGPU_BLOCKED=0) -- two different
+    sweeps (tiled kernel with and without the BLK addressing, conversions on the way in), same coefficients -- and the
+    boundary product's linearity at that size."""
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from edipack_amd.synthetic import WORKLOADS, synthetic_model
+    for k in ("EDIGPU_BLOCKED", "EDIGPU_BLOCKED_W", "EDIGPU_BLOCKED_MIN"):
+        monkeypatch.delenv(k, raising=False)
+    w = WORKLOADS[workload]
+    pm = synthetic_model(w)
+    hb = SectorHamiltonian.normal_from_model(pm, *w.sector)
+    assert hb.image_info()[4] == 128
+    rng = np.random.default_rng(11)
+    v = rng.standard_normal(hb.dim)
+    v /= np.linalg.norm(v)
+    ab, bb, nb = hb.lanczos_tridiag(v, 40)
+    x = rng.standard_normal(hb.dim)
+    hv, hx = hb.apply(v), hb.apply(x)
+    assert rel_err(hb.apply(2.0 * v - 3.0 * x), 2.0 * hv - 3.0 * hx) < 1e-12
+    assert abs(np.dot(x, hv) - np.dot(hx, v)) < 1e-10 * np.linalg.norm(hv) * np.linalg.norm(x)     # symmetric H
+    assert abs(np.dot(v, hv) - ab[0]) < 1e-10 * max(1.0, abs(ab[0]))                                # alpha_1 = <v|H|v>
+    hb.destroy()
+    del hv, hx, x
+    monkeypatch.setenv("EDIGPU_BLOCKED", "0")
+    hn = SectorHamiltonian.normal_from_model(pm, *w.sector)
+    assert hn.image_info()[4] == 0
+    an, bn, nn = hn.lanczos_tridiag(v, 40)
+    hn.destroy()
+    assert nb == nn == 40
+    assert rel_err(ab[:25], an[:25]) < 1e-10 and rel_err(bb[:25], bn[:25]) < 1e-10
+    for z in (60.0 + 0.1j, -60.0 + 0.1j, 40.0j):
+        assert abs(_cf(ab, bb, z) - _cf(an, bn, z)) / abs(_cf(an, bn, z)) < 1e-10
