@@ -1108,11 +1108,23 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
     }
     return lz_finalize_alpha_beta(s->d_vin, s->d_vout, len, s->d_partial, np, s->d_scal, iter, nlanc, st);
   }
-  if (iter > 0 && lz_rotate(s->d_vin, s->d_vout, len, s->d_scal, st)) return 1;
+  // no fused product (ed_total_ud = F, phonon branches, complex normal mode, rows staged in column parts, shards): the
+  // product goes to its own buffer; the one-reduction recurrence around it -- lazy rotate with the pending axpy, Q += H P
+  // with the three sums, one finalize -- moves 8 vector passes per step where the literal form moves 11.  The three-sum
+  // beta (k_finalize_ab) is what makes this safe: with beta^2 = <w|w> - alpha^2 the same loop made the lowest Ritz value
+  // jitter at 6e-14 |H| (round 1, removed then).  EDIGPU_LANCZOS_EXACTBETA=1 / EDIGPU_LANCZOS_UNFUSED=1: the literal form.
+  static const bool literal = getenv("EDIGPU_LANCZOS_UNFUSED") != nullptr;
+  if (literal || s->lz_exactbeta) {
+    if (iter > 0 && lz_rotate(s->d_vin, s->d_vout, len, s->d_scal, st)) return 1;
+    if (apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st)) return 1;
+    if (lz_alpha(s->d_vin, s->d_vout, s->d_tmp, len, s->d_partial, s->d_scal, iter, nlanc, st)) return 1;
+    return lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, iter, nlanc, st);
+  }
+  int np = 0;
+  if (iter > 0 && lz_rotate_lazy(s->d_vin, s->d_vout, len, s->d_scal, st)) return 1;
   if (apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st)) return 1;
-  if (lz_alpha(s->d_vin, s->d_vout, s->d_tmp, len, s->d_partial, s->d_scal, iter, nlanc, st)) return 1;
-  if (lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, iter, nlanc, st)) return 1;
-  return 0;
+  if (lz_add_dot3(s->d_vin, s->d_vout, s->d_tmp, len, s->d_scal, s->d_partial, &np, st)) return 1;
+  return lz_finalize_alpha_beta(s->d_vin, s->d_vout, len, s->d_partial, np, s->d_scal, iter, nlanc, st);
 }
 
 static int lanczos_prepare(edigpu_sector* s, int nlanc, double threshold, hipStream_t st) {

@@ -74,6 +74,8 @@ int lz_beta(const double* vin, double* vout, int64_t n, double* partial, double*
             int nlanc, hipStream_t st);
 int lz_axpy_coef(double* acc, const double* vin, int64_t n, double coef, const double* scal,
                  int iter, hipStream_t st);
+int lz_add_dot3(const double* P, double* Q, const double* tmp, int64_t n, const double* scal, double* partial, int* np,
+                hipStream_t st);
 int lz_fill_random(double* v, int64_t n, uint64_t seed, hipStream_t st);
 // natural layout (idw * DimUp + iup) <-> panel-major layout of the Lanczos loop (normal_args.hpp: blk_shift); the
 // padding columns of the last panel are written as zeros

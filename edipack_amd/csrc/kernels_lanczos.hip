@@ -206,6 +206,61 @@ int lz_rotate_lazy(double* P, double* Q, int64_t n, const double* scal, hipStrea
   return 0;
 }
 
+// Q += tmp (the product H P that was written to its own buffer) with the three sums of the one-reduction recurrence:
+// <P|Q>, sum (Q - sg P)^2 about sg = the previous alpha, <P|P> (k_finalize_ab).  For the sectors whose product has no
+// fused epilogue (ed_total_ud = F, phonon branches, complex normal mode, rows staged in column parts).
+__global__ void __launch_bounds__(kLzNT)
+    k_add_dot3(const double* __restrict__ P, double* __restrict__ Q, const double* __restrict__ tmp, int64_t n,
+               const double* __restrict__ scal, double* __restrict__ partial) {
+  __shared__ double red[3 * (kLzNT / 64)];
+  double a = 0.0, q = 0.0, nn = 0.0;
+  if (scal[SC_STOP] == 0.0) {
+    const double sg = scal[SC_ALPHA];
+    for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT) {
+      const double p = P[i], w = Q[i] + tmp[i];
+      Q[i] = w;
+      const double d = w - sg * p;
+      a += p * w;
+      q += d * d;
+      nn += p * p;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off, 64);
+    q += __shfl_down(q, off, 64);
+    nn += __shfl_down(nn, off, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[wave] = a;
+    red[kLzNT / 64 + wave] = q;
+    red[2 * (kLzNT / 64) + wave] = nn;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0.0, tq = 0.0, tn = 0.0;
+#pragma unroll
+    for (int i = 0; i < kLzNT / 64; i++) {
+      ta += red[i];
+      tq += red[kLzNT / 64 + i];
+      tn += red[2 * (kLzNT / 64) + i];
+    }
+    partial[blockIdx.x] = ta;
+    partial[gridDim.x + blockIdx.x] = tq;
+    partial[2 * gridDim.x + blockIdx.x] = tn;
+  }
+}
+
+int lz_add_dot3(const double* P, double* Q, const double* tmp, int64_t n, const double* scal, double* partial,
+                int* np, hipStream_t st) {
+  dim3 g = red_grid(n);
+  hipLaunchKernelGGL(k_add_dot3, g, dim3(kLzNT), 0, st, P, Q, tmp, n, scal, partial);
+  EDIGPU_HIP(hipGetLastError());
+  *np = (int)g.x;
+  return 0;
+}
+
 int lz_rotate(double* vin, double* vout, int64_t n, const double* scal, hipStream_t st) {
   hipLaunchKernelGGL(k_rotate, ew_grid(n), dim3(kLzNT), 0, st, vin, vout, n, scal);
   EDIGPU_HIP(hipGetLastError());
