@@ -936,6 +936,8 @@ static int apply_any(edigpu_sector* s, const double* v_local, const double* v_fu
       set_error("complex normal-mode sectors are single-shard: use the fused product");
       return 1;
     }
+    // one real product on the doubled up index (interleaved complex = real vectors of that sector)
+    if (s->sub_d) return apply_any(s->sub_d, v_full, v_full, hv, 3, st);
     const int64_t n = s->dim;
     double *xr = s->d_cz, *xi = xr + n, *yr = xi + n, *yi = yr + n, *t1 = yi + n, *t2 = t1 + n;
     if (launch_deinterleave(n, v_full, xr, xi, st)) return 1;
@@ -1421,7 +1423,25 @@ int edigpu_normal_build_z(edigpu_handle* h, const edigpu_model* model, int nup, 
   s->built_by_library = true;
   s->sub_s = hs;
   s->sub_a = ha;
-  if (hipMalloc((void**)&s->d_cz, (size_t)6 * (size_t)std::max<int64_t>(s->dim, 1) * sizeof(double)) != hipSuccess) {
+  // The complex operator as one real sector on the doubled up index: one pass over 2 Dim elements instead of four
+  // real products and two layout passes.  EDIGPU_CMPLX_FOURPRODUCTS=1, or more than 16 factored terms (complex replica
+  // matrices with many imaginary inter-orbital hops), keep the composite above.
+  if (!env_flag("EDIGPU_CMPLX_FOURPRODUCTS") && !env_flag("EDIGPU_NORMAL_EXPLICIT")) {
+    HostNormal hd2;
+    const std::string e2 = build_normal_doubled(*model, nup, ndw, hd2, 16);
+    if (e2.empty()) {
+      std::unique_ptr<edigpu_sector> sd(new edigpu_sector());
+      if (setup_normal(sd.get(), hd2.dim_up, hd2.dim_dw, 0, hd2.dim_dw, nullptr, hd2.up, hd2.dw, nullptr, nullptr, nullptr,
+                       &hd2)) {
+        edigpu_destroy(sd.release());
+        edigpu_destroy(s.release());
+        return 1;
+      }
+      s->sub_d = sd.release();
+    }
+  }
+  if (!s->sub_d &&  // planar work vectors of the four-product composite
+      hipMalloc((void**)&s->d_cz, (size_t)6 * (size_t)std::max<int64_t>(s->dim, 1) * sizeof(double)) != hipSuccess) {
     set_error("edigpu_normal_build_z: out of device memory");
     edigpu_destroy(s.release());
     return 1;
@@ -2150,6 +2170,9 @@ static int tridiag_impl(edigpu_handle s, const double* vin, int nlanc, double* a
     return 1;
   }
   if (single_shard(s, "edigpu_lanczos_tridiag")) return 1;
+  // _CMPLX_NORMAL held as one real sector on the doubled up index: complex Lanczos on H = real Lanczos on that sector
+  // with the interleaved vector read as real (alpha = <v|H|v> is real, beta a norm), so the fused real loop does it
+  if (s->kind == 4 && s->sub_d) return tridiag_impl(s->sub_d, vin, nlanc, alanc, blanc, threshold, niter_done, norm2);
   EDIGPU_HIP(hipSetDevice(s->device));
   if (ensure_workspace(s)) return 1;
   hipStream_t st = s->stream;
@@ -2323,6 +2346,8 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
     return 1;
   }
   if (single_shard(s, "edigpu_lanczos_eigh")) return 1;
+  if (s->kind == 4 && s->sub_d)  // see tridiag_impl: the Ritz vector comes back interleaved, i.e. complex
+    return edigpu_lanczos_eigh(s->sub_d, nitermax, tol, check_every, v0_host, eval, evec_host, niter_done);
   EDIGPU_HIP(hipSetDevice(s->device));
   if (ensure_workspace(s)) return 1;
   if (check_every <= 0) check_every = 10;
@@ -2684,6 +2709,7 @@ int edigpu_time_apply(edigpu_handle s, int warmup, int steps, int lanczos, doubl
     return 1;
   }
   if (single_shard(s, "edigpu_time_apply")) return 1;
+  if (s->kind == 4 && s->sub_d && lanczos) return edigpu_time_apply(s->sub_d, warmup, steps, lanczos, ms_per_step);
   EDIGPU_HIP(hipSetDevice(s->device));
   if (ensure_workspace(s)) return 1;
   hipStream_t st = s->stream;
@@ -2777,6 +2803,7 @@ int edigpu_lanczos_bench(edigpu_handle s, int warmup, int steps, double* ms_wall
     return 1;
   }
   if (single_shard(s, "edigpu_lanczos_bench")) return 1;
+  if (s->kind == 4 && s->sub_d) return edigpu_lanczos_bench(s->sub_d, warmup, steps, ms_wall_per_step, ms_hv_per_launch);
   EDIGPU_HIP(hipSetDevice(s->device));
   if (ensure_workspace(s)) return 1;
   hipStream_t st = s->stream;
@@ -2831,6 +2858,7 @@ int edigpu_destroy(edigpu_handle s) {
   }
   if (s->sub_s) edigpu_destroy(s->sub_s);
   if (s->sub_a) edigpu_destroy(s->sub_a);
+  if (s->sub_d) edigpu_destroy(s->sub_d);
   dev_free(s->d_cz);
   dev_free(s->d_hd);
   dev_free(s->d_gu);

@@ -108,6 +108,9 @@ struct edigpu_sector {
   // kind 4 (_CMPLX_NORMAL): H = S + iA as two real normal-mode handles + planar work vectors (6 * dim doubles)
   edigpu_sector* sub_s = nullptr;
   edigpu_sector* sub_a = nullptr;
+  // kind 4, preferred: the same operator as ONE real sector on the doubled up index 2 iup + (re | im)
+  // (host_build.cpp: build_normal_doubled); the interleaved complex vectors are its real vectors
+  edigpu_sector* sub_d = nullptr;
   double* d_cz = nullptr;
   int panel_mode = 0;           // panel sweep variant (NormalArgs::panel_mode), fixed at set-up
   int tile_nchunks = 0, tile_rows = 0;

@@ -138,6 +138,8 @@ bool factor_handover(int64_t dim_up, int64_t dim_dw, int64_t dw_first, int64_t d
                      const int64_t* nd_rowptr, const int32_t* nd_col, const double* nd_val, int max_terms,
                      HostFactored& fac);
 edigpu_model imag_part_model(const edigpu_model& m, bool& any);
+// the complex (_CMPLX_NORMAL) sector as one real sector on the doubled up index 2 iup + (re | im); "" on success
+std::string build_normal_doubled(const edigpu_model& m, int nup, int ndw, HostNormal& out, int max_terms);
 bool eph_offdiagonal(const edigpu_model& m);
 edigpu_model eph_operator_model(const edigpu_model& m);
 std::string sector_dim(const edigpu_model& m, int q1, int q2, int64_t& dim);

@@ -170,9 +170,13 @@ int edigpu_normal_build(edigpu_handle *h, const edigpu_model *model, int nup, in
  * spH0ups / spH0dws and the vectors of ed_mode=normal are complex(8) and the imaginary parts of impHloc(1,1,a,b)
  * and of the replica / general bath matrices enter the hops (ED_NORMAL/stored/H_up.f90:8-50, H_dw.f90).  The handle
  * is complex (edigpu_apply_z, interleaved re/im vectors, real alpha / beta) and holds the whole sector.  Inside,
- * H = S + iA runs as four products of the real-valued kernels on planar work vectors (S: the real parts = the
- * ordinary build; A: the antisymmetric hop matrices of the imaginary parts) -- about 4.5x the cost of a real
- * product; a native complex kernel is not built for this compile-time variant.  No phonons. */
+ * H = S + iA (S: the real parts = the ordinary build; A: the antisymmetric hop matrices of the imaginary parts) is held
+ * as ONE real sector on the doubled up index 2 iup + (re | im) -- the interleaved complex vectors are its real
+ * vectors, H' = S (x) 1 + A (x) [[0,-1],[1,0]] -- so the kernels, the panel-major layout and the fused recurrence of
+ * the real sectors do the complex product in one pass over 2 Dim elements (measured 1.9-2.6x a real product, complex
+ * Lanczos step 2.0-2.4x).  More than 16 factored terms (complex replica matrices with many imaginary inter-orbital
+ * hops) or EDIGPU_CMPLX_FOURPRODUCTS=1: four products of the two real handles on planar work vectors (3.4-4.9x).
+ * No phonons. */
 int edigpu_normal_build_z(edigpu_handle *h, const edigpu_model *model, int nup, int ndw);
 /* superc sector Sz / nonsu2 sector Ntot; the shard owns rows [row_first, row_first+row_count)
  * (row_count < 0: all).  Equivalent to build_Hv_sector_superc / _nonsu2

@@ -109,3 +109,31 @@ extern "C" int host_flat_jz_dense(const edigpu_model* m, int ntot, int twojz, do
     }
   return 0;
 }
+
+// the _CMPLX_NORMAL sector as one real sector on the doubled up index (build_normal_doubled): its dense REAL image of
+// size (2 dim) x (2 dim) from the factored tables, rows / columns ordered (idw, iup, re|im) -- i.e. the interleaved
+// complex layout read as real
+extern "C" int host_normal_doubled_dense(const edigpu_model* m, int nup, int ndw, double* out, int64_t dim2, int* nterms) {
+  HostNormal hn;
+  g_err = build_normal_doubled(*m, nup, ndw, hn, 16);
+  if (!g_err.empty()) return 1;
+  const int64_t du = hn.dim_up, dd = hn.dim_dw;
+  if (du * dd != dim2) { g_err = "host_normal_doubled_dense: dim mismatch"; return 2; }
+  std::memset(out, 0, sizeof(double) * dim2 * dim2);
+  auto at = [&](int64_t i, int64_t j) -> double& { return out[i * dim2 + j]; };
+  for (int64_t idw = 0; idw < dd; idw++)
+    for (int64_t iup = 0; iup < du; iup++) {
+      const int64_t i = iup + idw * du;
+      at(i, i) += hn.fac.eux[(size_t)hn.fac.impd[idw] * du + iup] + hn.fac.ed[idw];
+      for (int64_t k = hn.up.rowptr[iup]; k < hn.up.rowptr[iup + 1]; k++) at(i, hn.up.col[k] + idw * du) += hn.up.val[k];
+      for (int64_t k = hn.dw.rowptr[idw]; k < hn.dw.rowptr[idw + 1]; k++) at(i, iup + hn.dw.col[k] * du) += hn.dw.val[k];
+      for (int t = 0; t < hn.fac.nterms; t++) {
+        const uint32_t pu = hn.fac.jup[(size_t)t * du + iup], pd = hn.fac.jdw[(size_t)t * dd + idw];
+        if (pu == 0xFFFFFFFFu || pd == 0xFFFFFFFFu) continue;
+        at(i, (int64_t)(pu & 0x7FFFFFFFu) + (int64_t)(pd & 0x7FFFFFFFu) * du) +=
+            (((pu ^ pd) & 0x80000000u) ? -1.0 : 1.0) * hn.fac.coef[t];
+      }
+    }
+  *nterms = hn.fac.nterms;
+  return 0;
+}

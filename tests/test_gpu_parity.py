@@ -1435,9 +1435,14 @@ def _complexify(om, pm, seed):
     ("replica", 2, 2, (3, 3)),     # complex bath matrices
     ("general", 2, 3, (4, 4)),
 ])
-def test_cmplx_normal_matches_oracle(gpu, bath, norb, nbath, sec):
+@pytest.mark.parametrize("form", ["doubled", "fourproducts"])
+def test_cmplx_normal_matches_oracle(gpu, monkeypatch, bath, norb, nbath, sec, form):
+    """form: the complex operator as one real sector on the doubled up index (default), or as four products of the two
+    real handles S, A (EDIGPU_CMPLX_FOURPRODUCTS=1, also the fall-back for more than 16 factored terms)."""
     O = _oracle()
     from edipack_amd.hamiltonian import SectorHamiltonian
+    if form == "fourproducts":
+        monkeypatch.setenv("EDIGPU_CMPLX_FOURPRODUCTS", "1")
     om, pm = make_models("normal", bath, norb, nbath, seed=95)
     _complexify(om, pm, 96)
     ho = O.HNormalCmplx(om, *sec)

@@ -213,3 +213,36 @@ def test_jz_sector_builder_refusals(shim):
     m = p3.to_c()
     assert shim.host_flat_jz_dense(C.byref(m), 4, 0, buf.ctypes.data_as(C.c_void_p), C.c_int64(1)) == 1
     assert "iorb + Norb * ibath" in shim.host_image_error().decode()
+
+
+# ---- _CMPLX_NORMAL as one real sector on the doubled up index ----
+@pytest.mark.parametrize("bath,norb,nbath,sec", [
+    ("normal", 2, 2, (3, 2)),
+    ("hybrid", 3, 3, (3, 4)),      # Hnd terms of S + three imaginary down-hop terms
+    ("replica", 2, 2, (3, 3)),     # complex bath matrices: imaginary hops between bath levels as well
+    ("general", 2, 3, (4, 4)),
+    ("normal", 1, 3, (2, 2)),      # one orbital: nothing imaginary, H' = S (x) 1
+])
+def test_cmplx_normal_doubled_real_image_equals_oracle(shim, bath, norb, nbath, sec):
+    """build_normal_doubled: H = S + iA read as the real operator [[S, -A], [A, S]] on interleaved (re, im) components
+    must be the oracle's complex matrix, entry by entry."""
+    from tests.test_gpu_parity import _complexify
+    om, pm = make_models("normal", bath, norb, nbath, seed=95)
+    _complexify(om, pm, 96)
+    ho = O.HNormalCmplx(om, *sec)
+    hc = ho.dense()
+    n = ho.dim
+    out = np.zeros((2 * n, 2 * n))
+    nt = C.c_int(0)
+    m = pm.to_c()
+    rc = shim.host_normal_doubled_dense(C.byref(m), sec[0], sec[1], out.ctypes.data_as(C.c_void_p), C.c_int64(2 * n),
+                                        C.byref(nt))
+    assert rc == 0, shim.host_image_error().decode()
+    # interleaved layout: real index 2 i + c for complex index i
+    ref = np.zeros((2 * n, 2 * n))
+    ref[0::2, 0::2] = hc.real
+    ref[1::2, 1::2] = hc.real
+    ref[0::2, 1::2] = -hc.imag
+    ref[1::2, 0::2] = hc.imag
+    assert np.abs(out - ref).max() < 1e-13 and np.abs(out - out.T).max() < 1e-13
+    assert nt.value <= 16
