@@ -801,6 +801,9 @@ static int apply_sharded(edigpu_handle s, edigpu_comm c, int64_t nloc, const dou
     set_error("edigpu_apply_sharded: real/complex mismatch between handle and entry point");
     return 1;
   }
+  // _CMPLX_NORMAL held as one real sector on the doubled up index: its down rows shard like any real sector's (each row
+  // 2 DimUp doubles = DimUp complex elements), so the transposed exchange serves complex sectors as well
+  if (s->kind == 4 && s->sub_d) return apply_sharded(s->sub_d, c, 2 * nloc, v, hv, 0);
   ShardGeom g;
   if (shard_geometry(s, c, g)) return 1;
   if (nloc != g.nloc) {
@@ -838,6 +841,7 @@ int edigpu_lanczos_tridiag_sharded(edigpu_handle h, edigpu_comm c, const double*
   }
   // a world of one rank holding the whole sector: the fused single-GPU recurrence (half the vector traffic of the
   // exchange form: no send / receive buffers); EDIGPU_FORCE_COLLECTIVES=1 keeps the N > 1 code path (tests)
+  if (h->kind == 4 && h->sub_d) h = h->sub_d;  // complex normal sector = its doubled real sector (see apply_sharded)
   if (c->world == 1 && h->nloc == h->dim && !getenv("EDIGPU_FORCE_COLLECTIVES") && vin_shard)
     return edigpu_lanczos_tridiag_dev(h, vin_shard, nlanc, alanc, blanc, threshold, niter_done, norm2);
   return sharded_tridiag(h, c, vin_shard, nlanc, alanc, blanc, threshold, niter_done, norm2);
@@ -849,6 +853,7 @@ int edigpu_lanczos_bench_sharded(edigpu_handle s, edigpu_comm c, int warmup, int
     set_error("edigpu_lanczos_bench_sharded: bad argument");
     return 1;
   }
+  if (s->kind == 4 && s->sub_d) s = s->sub_d;
   ShardGeom g;
   if (shard_geometry(s, c, g)) return 1;
   EDIGPU_HIP(hipSetDevice(s->device));

@@ -630,7 +630,8 @@ class LibraryComm:
             pass
 
 
-def library_sharded_sector(model, sector, comm: LibraryComm, direct: bool = False, exchange: str = "auto"):
+def library_sharded_sector(model, sector, comm: LibraryComm, direct: bool = False, exchange: str = "auto",
+                           cmplx: bool = False):
     """This rank's handle for the in-library N > 1 calls: normal mode -> the whole sector (transposed exchange) unless
     exchange == "allgather"; everything else -> this rank's row shard.  Returns (handle, first unit, unit count)."""
     import ctypes as C
@@ -642,6 +643,8 @@ def library_sharded_sector(model, sector, comm: LibraryComm, direct: bool = Fals
         d_dw = C.c_int64()
         capi.check(L.edigpu_sector_dim(C.byref(cm), 0, ndw, C.byref(d_dw)))
         first, count, _ = comm.plan(d_dw.value)
+        if cmplx:       # _CMPLX_NORMAL: whole sector, served through its doubled real sector (transposed exchange)
+            return SectorHamiltonian.normal_cmplx_from_model(model, nup, ndw), first, count
         if exchange != "allgather":
             h = SectorHamiltonian.normal_from_model(model, nup, ndw)
             try:

@@ -480,6 +480,8 @@ int edigpu_comm_destroy(edigpu_comm c);
  * The (Nloc, v, Hv) contract of spMatVec_mpi_* / directMatVec_MPI_* on shards (ED_VARS_GLOBAL.f90:111-132 with
  * Nloc = vecDim_Hv_sector_*): v_shard_host / hv_shard_host hold this rank's nloc elements; the exchange happens
  * inside.  Assigned to spHtimesV_p / spHtimesV_cc in a -D_MPI build (fortran/edigpu_shim.f90).
+ * A complex normal-mode handle (edigpu_normal_build_z, whole sector on every rank) is served through its doubled real
+ * sector with the transposed exchange: nloc = this rank's down rows * DimUp complex elements.
  */
 int edigpu_apply_sharded_d(edigpu_handle h, edigpu_comm c, int64_t nloc, const double *v_shard_host,
                            double *hv_shard_host);

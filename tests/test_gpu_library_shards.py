@@ -23,16 +23,22 @@ CASES = [
     ("normal", "normal", 2, 3, (4, 4), False, "allgather"),  # down-row shards, all-gather form
     ("superc", "hybrid", 2, 3, 0, False, "auto"),            # stored flat CSR, loc / non-loc blocks
     ("nonsu2", "hybrid", 2, 3, 5, True, "auto"),             # on-the-fly kernel: gather first
+    ("normal", "hybrid", 3, 2, (3, 2), False, "cmplx"),      # _CMPLX_NORMAL through its doubled real sector
 ]
 
 
-def _reference(mode, bath, norb, nbath, sector, seed=31):
+def _reference(mode, bath, norb, nbath, sector, seed=31, cmplx=False):
     from oracle import oracle as O
     om, pm = make_models(mode, bath, norb, nbath, seed=seed)
-    ho = O.HNormal(om, *sector) if mode == "normal" else O.HFlat(om, sector)
+    if cmplx:
+        from tests.test_gpu_parity import _complexify
+        _complexify(om, pm, seed + 1)
+        ho = O.HNormalCmplx(om, *sector)
+    else:
+        ho = O.HNormal(om, *sector) if mode == "normal" else O.HFlat(om, sector)
     rng = np.random.default_rng(17)
     v = rng.standard_normal(ho.dim)
-    if mode != "normal":
+    if mode != "normal" or cmplx:
         v = v + 1j * rng.standard_normal(ho.dim)
     return ho, pm, v
 
@@ -44,9 +50,10 @@ def _rank_main(rank, world, name, case, q):
         from edipack_amd.sharding import LibraryComm, library_sharded_sector
         capi.init(0)
         mode, bath, norb, nbath, sector, direct, exchange = case
-        ho, pm, v = _reference(mode, bath, norb, nbath, sector)
+        ho, pm, v = _reference(mode, bath, norb, nbath, sector, cmplx=exchange == "cmplx")
         comm = LibraryComm(rank, world, shm_name=name, slot_bytes=1 << 22)
-        h, first, count = library_sharded_sector(pm, sector, comm, direct=direct, exchange=exchange)
+        h, first, count = library_sharded_sector(pm, sector, comm, direct=direct, exchange=exchange,
+                                                 cmplx=exchange == "cmplx")
         ul = ho.dimup if mode == "normal" else 1
         sl = slice(first * ul, (first + count) * ul)
         hv = comm.apply(h, v[sl])
@@ -63,7 +70,7 @@ def _rank_main(rank, world, name, case, q):
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_library_shards_share_one_gpu(gpu, world, case):
     mode, bath, norb, nbath, sector, direct, exchange = case
-    ho, _, v = _reference(mode, bath, norb, nbath, sector)
+    ho, _, v = _reference(mode, bath, norb, nbath, sector, cmplx=exchange == "cmplx")
     ref = ho.matvec(v)
     a_ref, b_ref, _ = ho.lanc_tridiag(v, 20)
     ctx = mp.get_context("spawn")
