@@ -1083,8 +1083,11 @@ static bool flat_lanczos_fusable(const edigpu_sector* s) {
   return s->kind == 1 && csr_lanczos_fusable(s->loc) && s->nonloc.nnz == 0;
 }
 
+// iter < 0: a later step (not the first) whose index the finalize kernel takes from the device-side counter -- the form
+// that can be captured once and replayed (lanczos_run)
 static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
   const int64_t len = s->lz_len;
+  const bool later = iter != 0;
   if (normal_lanczos_fusable(s)) {
     // rotate (and the pending axpy) fused into the row kernel, alpha and <Q|Q> into the panel sweep
     // (kernels_normal.hip); EDIGPU_LANCZOS_EXACTBETA=1 keeps the separate axpy+norm kernel
@@ -1102,7 +1105,7 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
     // flat / direct sectors held whole on this GPU: rotate with the pending axpy, then Q += H*v with
     // the alpha and <Q|Q> partials in the product's epilogue (no tmp vector, no separate dot kernels)
     int np = 0;
-    if (iter > 0 && lz_rotate_lazy(s->d_vin, s->d_vout, len, s->d_scal, st)) return 1;
+    if (later && lz_rotate_lazy(s->d_vin, s->d_vout, len, s->d_scal, st)) return 1;
     if (s->kind == 2) {
       if (launch_direct_lanczos(s, s->d_vin, s->d_vout, s->d_partial, s->partial_cap, &np, s->d_scal + SC_ALPHA, st)) return 1;
     } else if (launch_csr_lanczos(s->loc, s->is_complex, s->d_vin, s->d_vout, s->d_partial, s->partial_cap, &np, s->d_scal + SC_ALPHA, st)) {
@@ -1123,7 +1126,7 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
     return lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, iter, nlanc, st);
   }
   int np = 0;
-  if (iter > 0 && lz_rotate_lazy(s->d_vin, s->d_vout, len, s->d_scal, st)) return 1;
+  if (later && lz_rotate_lazy(s->d_vin, s->d_vout, len, s->d_scal, st)) return 1;
   if (apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st)) return 1;
   if (lz_add_dot3(s->d_vin, s->d_vout, s->d_tmp, len, s->d_scal, s->d_partial, &np, st)) return 1;
   return lz_finalize_alpha_beta(s->d_vin, s->d_vout, len, s->d_partial, np, s->d_scal, iter, nlanc, st);
@@ -1134,9 +1137,13 @@ static int lanczos_prepare(edigpu_sector* s, int nlanc, double threshold, hipStr
   // the recurrence of a large factored normal-mode sector runs on panel-major vectors (set-up decides, blk_shift)
   s->lz_blocked = s->kind == 0 && s->blk_shift > 0 && s->nph == 0 && normal_lanczos_fusable(s);
   s->lz_len = s->lz_blocked ? s->blk_len : s->ws_len;
-  dev_free(s->d_scal);
   const size_t ns = (size_t)SC_AB + 2 * (size_t)nlanc;
-  EDIGPU_HIP(hipMalloc((void**)&s->d_scal, ns * sizeof(double)));
+  if (!s->d_scal || s->scal_cap < ns) {  // (kept across runs: a captured graph holds its address)
+    dev_free(s->d_scal);
+    s->scal_cap = 0;
+    EDIGPU_HIP(hipMalloc((void**)&s->d_scal, ns * sizeof(double)));
+    s->scal_cap = ns;
+  }
   EDIGPU_HIP(hipMemsetAsync(s->d_scal, 0, ns * sizeof(double), st));
   EDIGPU_HIP(hipMemcpyAsync(s->d_scal + SC_THR, &threshold, sizeof(double), hipMemcpyHostToDevice, st));
   EDIGPU_HIP(hipMemsetAsync(s->d_vout, 0, (size_t)s->lz_len * sizeof(double), st));
@@ -1153,6 +1160,65 @@ static int lanczos_seed(edigpu_sector* s, const double* src, uint64_t seed, hipS
     return 1;
   }
   if (s->lz_blocked) return vec_to_blocked(s->d_tmp, s->d_vin, s->dim_up, s->dim_dw, s->blk_shift, st);
+  return 0;
+}
+
+// Steps [from, to) of the current recurrence.  EDIGPU_LANCZOS_GRAPH=1: the later steps of a small sector -- identical
+// launches once the step index lives on the device (k_finalize_ab, iter < 0) -- are captured once as a hipGraph of
+// kGraphSteps steps and replayed; the executable stays with the handle for the next run of the same length.
+// OPT-IN because it buys nothing here: measured on configs 1 / 3 / 4 (10.9 / 20.3 / 23.8 us per step with the graph,
+// 11.4 / 20.4 / 23.1 without), i.e. the three dependent kernels of a step are bound by their own dispatch-to-completion
+// latency on the device, not by host-side launch cost; fusing the finalize into the sweep's last workgroup is what would
+// shorten a small sector's step.  EDIGPU_LANCZOS_GRAPH_MAX sets the largest sector (rows) that uses the graph.
+static int lanczos_run(edigpu_sector* s, int from, int to, int nlanc, hipStream_t st) {
+  constexpr int kGraphSteps = 8;
+  static const bool graph_on = getenv("EDIGPU_LANCZOS_GRAPH") && atoi(getenv("EDIGPU_LANCZOS_GRAPH")) != 0;
+  static const int64_t graph_max = getenv("EDIGPU_LANCZOS_GRAPH_MAX") ? atoll(getenv("EDIGPU_LANCZOS_GRAPH_MAX")) : ((int64_t)1 << 21);
+  static const bool literal = getenv("EDIGPU_LANCZOS_UNFUSED") != nullptr;
+  int it = from;
+  if (it == 0 && it < to) {
+    if (lanczos_step(s, 0, nlanc, st)) return 1;
+    it = 1;
+  }
+  const bool eligible = graph_on && !literal && !s->lz_exactbeta && !s->lz_graph_failed && s->nloc <= graph_max &&
+                        s->nph == 0 && s->kind != 4 && to - it >= kGraphSteps + (s->lz_graph ? 0 : 1);
+  if (eligible) {
+    if (s->lz_graph && (s->lz_graph_nlanc != nlanc || s->lz_graph_scal != s->d_scal || s->lz_graph_blocked != s->lz_blocked)) {
+      (void)hipGraphExecDestroy(s->lz_graph);
+      s->lz_graph = nullptr;
+    }
+    if (!s->lz_graph) {
+      // one uncaptured later step first: whatever the launchers set up lazily (function attributes, occupancy
+      // queries) happens outside the capture
+      if (lanczos_step(s, it, nlanc, st)) return 1;
+      it++;
+      hipGraph_t g = nullptr;
+      bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      for (int k = 0; ok && k < kGraphSteps; k++) ok = lanczos_step(s, -1, nlanc, st) == 0;
+      if (hipStreamEndCapture(st, &g) != hipSuccess) ok = false;
+      if (ok && g && hipGraphInstantiate(&s->lz_graph, g, nullptr, nullptr, 0) != hipSuccess) {
+        s->lz_graph = nullptr;
+        ok = false;
+      }
+      if (g) (void)hipGraphDestroy(g);
+      if (!ok) {
+        (void)hipGetLastError();
+        s->lz_graph = nullptr;
+        s->lz_graph_failed = true;  // plain launches from here on (the capture enqueued nothing)
+      } else {
+        s->lz_graph_k = kGraphSteps;
+        s->lz_graph_nlanc = nlanc;
+        s->lz_graph_scal = s->d_scal;
+        s->lz_graph_blocked = s->lz_blocked;
+      }
+    }
+    while (s->lz_graph && to - it >= s->lz_graph_k) {
+      EDIGPU_HIP(hipGraphLaunch(s->lz_graph, st));
+      it += s->lz_graph_k;
+    }
+  }
+  for (; it < to; it++)
+    if (lanczos_step(s, it, nlanc, st)) return 1;
   return 0;
 }
 
@@ -2179,8 +2245,7 @@ static int tridiag_impl(edigpu_handle s, const double* vin, int nlanc, double* a
   if (lanczos_prepare(s, nlanc, threshold, st)) return 1;
   if (lanczos_seed(s, vin, 0, st)) return 1;
   if (lz_norm_begin(s->d_vin, s->lz_len, s->d_partial, s->d_scal, st)) return 1;
-  for (int it = 0; it < nlanc; it++)
-    if (lanczos_step(s, it, nlanc, st)) return 1;
+  if (lanczos_run(s, 0, nlanc, nlanc, st)) return 1;
   std::vector<double> sc((size_t)SC_AB + 2 * (size_t)nlanc);
   EDIGPU_HIP(hipMemcpyAsync(sc.data(), s->d_scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, st));
   EDIGPU_HIP(hipStreamSynchronize(st));
@@ -2374,9 +2439,12 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
   double e_old = 0.0;
   int ndone = 0;
   bool have = false, conv = false;
-  for (int it = 0; it < nitermax && !conv; it++) {
-    if (lanczos_step(s, it, nitermax, st)) return fail();
-    if ((it + 1) % check_every == 0 || it + 1 == nitermax) {
+  for (int it0 = 0; it0 < nitermax && !conv;) {
+    // the steps up to the next convergence check in one go (replayed from a graph on launch-bound sectors)
+    const int it1 = std::min(nitermax, (it0 / check_every + 1) * check_every);
+    if (lanczos_run(s, it0, it1, nitermax, st)) return fail();
+    it0 = it1;
+    {
       if (hipMemcpyAsync(sc.data(), s->d_scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess)
         return fail();
       if (hipStreamSynchronize(st) != hipSuccess) return fail();
@@ -2817,10 +2885,11 @@ int edigpu_lanczos_bench(edigpu_handle s, int warmup, int steps, double* ms_wall
     if (s->lz_blocked) return launch_normal_blocked(s, s->d_vin, s->d_tmp, st);
     return apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st);
   };
-  for (int it = 0; it < warmup && !rc; it++) rc |= lanczos_step(s, it, total, st);
+  // (a launch-bound sector replays its steps from a captured graph, as edigpu_lanczos_tridiag does: lanczos_run)
+  rc |= lanczos_run(s, 0, warmup, total, st);
   if (!rc) rc |= (hipStreamSynchronize(st) != hipSuccess);
   const auto t0 = std::chrono::steady_clock::now();
-  for (int k = 0; k < steps && !rc; k++) rc |= lanczos_step(s, warmup + k, total, st);
+  if (!rc) rc |= lanczos_run(s, warmup, total, total, st);
   if (!rc) rc |= (hipStreamSynchronize(st) != hipSuccess);
   const auto t1 = std::chrono::steady_clock::now();
   // H*v launches alone (the Lanczos vector of the last step as input), HIP events around each
@@ -2866,6 +2935,7 @@ int edigpu_destroy(edigpu_handle s) {
   dev_free(s->d_mx_rowptr);
   dev_free(s->d_tile_chunks);
   dev_free(s->d_tile_lbeg);
+  if (s->lz_graph) (void)hipGraphExecDestroy(s->lz_graph);
   dev_free(s->d_bl_meta);
   dev_free(s->d_bl_lend);
   dev_free(s->d_bl_ent);

@@ -176,5 +176,12 @@ struct edigpu_sector {
   double* d_partial = nullptr;  // reduction partials
   double* d_scal = nullptr;     // alpha/beta/flags on device
   bool lz_exactbeta = false;    // EDIGPU_LANCZOS_EXACTBETA at the start of the current recurrence
+  // launch-bound sectors replay the steps of a recurrence from a captured hipGraph (lanczos_run): the executable and
+  // what it was captured for
+  hipGraphExec_t lz_graph = nullptr;
+  int lz_graph_k = 0, lz_graph_nlanc = 0;
+  const void* lz_graph_scal = nullptr;
+  bool lz_graph_blocked = false, lz_graph_failed = false;
+  size_t scal_cap = 0;          // doubles allocated in d_scal
   int64_t ws_len = 0;           // in doubles per vector
 };

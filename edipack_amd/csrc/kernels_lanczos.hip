@@ -289,6 +289,9 @@ __global__ void __launch_bounds__(1024)
   __shared__ double sa[1024], sq[1024], sn[1024];
   __shared__ int exact;
   if (scal[SC_STOP] != 0.0) return;
+  // iter < 0: the step index comes from the device-side counter (steps replayed from a captured graph are
+  // identical launches: nothing about them may depend on a host-side loop variable)
+  if (iter < 0) iter = (int)scal[SC_NDONE];
   double a = 0.0, q = 0.0, nn = 0.0;
   for (int i = threadIdx.x; i < np; i += 1024) {
     a += partial[i];
