@@ -1093,8 +1093,11 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
     // (kernels_normal.hip); EDIGPU_LANCZOS_EXACTBETA=1 keeps the separate axpy+norm kernel
     const bool exactbeta = s->lz_exactbeta;  // read once per run in lanczos_prepare
     int np = 0;
-    if (launch_normal_lanczos(s, s->d_vin, s->d_vout, s->d_scal, s->d_partial, s->partial_cap, iter == 0, !exactbeta, st, &np))
+    bool finalized = false;
+    if (launch_normal_lanczos(s, s->d_vin, s->d_vout, s->d_scal, s->d_partial, s->partial_cap, iter == 0, !exactbeta, st, &np,
+                              nlanc, &finalized))
       return 1;
+    if (finalized) return 0;  // the sweep's last workgroup wrote alpha, beta and the stop flag
     if (exactbeta) {
       if (lz_finalize_alpha(s->d_partial, np, s->d_scal, iter, nlanc, st)) return 1;
       return lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, iter, nlanc, st);
@@ -1145,6 +1148,8 @@ static int lanczos_prepare(edigpu_sector* s, int nlanc, double threshold, hipStr
     s->scal_cap = ns;
   }
   EDIGPU_HIP(hipMemsetAsync(s->d_scal, 0, ns * sizeof(double), st));
+  if (!s->d_lzcnt) EDIGPU_HIP(hipMalloc((void**)&s->d_lzcnt, 64));
+  EDIGPU_HIP(hipMemsetAsync(s->d_lzcnt, 0, 64, st));
   EDIGPU_HIP(hipMemcpyAsync(s->d_scal + SC_THR, &threshold, sizeof(double), hipMemcpyHostToDevice, st));
   EDIGPU_HIP(hipMemsetAsync(s->d_vout, 0, (size_t)s->lz_len * sizeof(double), st));
   return 0;
@@ -2936,6 +2941,7 @@ int edigpu_destroy(edigpu_handle s) {
   dev_free(s->d_tile_chunks);
   dev_free(s->d_tile_lbeg);
   if (s->lz_graph) (void)hipGraphExecDestroy(s->lz_graph);
+  dev_free(s->d_lzcnt);
   dev_free(s->d_bl_meta);
   dev_free(s->d_bl_lend);
   dev_free(s->d_bl_ent);

@@ -183,5 +183,6 @@ struct edigpu_sector {
   const void* lz_graph_scal = nullptr;
   bool lz_graph_blocked = false, lz_graph_failed = false;
   size_t scal_cap = 0;          // doubles allocated in d_scal
+  unsigned int* d_lzcnt = nullptr;  // arrival counter of the in-kernel finalize (lz_finalize.hpp)
   int64_t ws_len = 0;           // in doubles per vector
 };

@@ -40,8 +40,10 @@ int launch_transpose_unpack_add(int64_t dim_up, int64_t nrows, int64_t q, int wo
                                 const double* recv, double* hv_rows, hipStream_t st);
 // fused Lanczos step (normal, single shard): P = Lanczos vector, Q = work vector, see kernels_normal.hip
 bool normal_lanczos_fusable(const edigpu_sector* s);
+// nlanc / finalized: when the sweep finalizes the step in its last workgroup (*finalized = true) no finalize kernel must follow
 int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const double* scal,
-                          double* partial, int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial);
+                          double* partial, int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial,
+                          int nlanc = 0, bool* finalized = nullptr);
 // alpha = sum(partial[0:np]), beta = sqrt(sum(partial[np:2np]) - alpha^2) with an exact fallback pass
 int lz_finalize_alpha_beta(const double* P, const double* Q, int64_t n, double* partial, int np,
                            double* scal, int iter, int nlanc, hipStream_t st);

@@ -12,6 +12,7 @@
 // Reductions are deterministic: a fixed grid writes one partial per workgroup
 // (wave shuffle + LDS), a single-workgroup kernel adds the partials in order.
 #include "kernels.hpp"
+#include "lz_finalize.hpp"
 
 namespace edigpu {
 
@@ -286,65 +287,9 @@ int lz_alpha(const double* vin, double* vout, const double* tmp, int64_t n, doub
 __global__ void __launch_bounds__(1024)
     k_finalize_ab(const double* __restrict__ partial, int np, const double* __restrict__ P,
                   const double* __restrict__ Q, int64_t n, double* __restrict__ scal, int iter, int nlanc) {
-  __shared__ double sa[1024], sq[1024], sn[1024];
-  __shared__ int exact;
+  __shared__ double sh[3 * 1024];
   if (scal[SC_STOP] != 0.0) return;
-  // iter < 0: the step index comes from the device-side counter (steps replayed from a captured graph are
-  // identical launches: nothing about them may depend on a host-side loop variable)
-  if (iter < 0) iter = (int)scal[SC_NDONE];
-  double a = 0.0, q = 0.0, nn = 0.0;
-  for (int i = threadIdx.x; i < np; i += 1024) {
-    a += partial[i];
-    q += partial[np + i];
-    nn += partial[2 * np + i];
-  }
-  sa[threadIdx.x] = a;
-  sq[threadIdx.x] = q;
-  sn[threadIdx.x] = nn;
-  __syncthreads();
-  for (int off = 512; off > 0; off >>= 1) {
-    if (threadIdx.x < off) {
-      sa[threadIdx.x] += sa[threadIdx.x + off];
-      sq[threadIdx.x] += sq[threadIdx.x + off];
-      sn[threadIdx.x] += sn[threadIdx.x + off];
-    }
-    __syncthreads();
-  }
-  const double alpha = sa[0], qq = sq[0], vv = sn[0], sg = scal[SC_ALPHA];
-  // |Q - alpha v|^2 from the three sums, exactly (no |v| = 1 assumed: with it the deviation eta of |v|^2 from one is
-  // fed back through 2 (alpha - sg) sg eta / beta^2 and grows by that factor per step once the spectrum is shifted
-  // -- measured: 1e-12 -> 1e-2 in twelve steps at |alpha| = 800, beta = 3)
-  const double d = alpha - sg;
-  double b2 = qq - 2.0 * d * (alpha - sg * vv) + d * d * vv;
-  if (threadIdx.x == 0) exact = b2 < 1e-3 * qq;
-  __syncthreads();
-  if (exact) {  // uniform
-    double s = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
-      const double w = Q[i] - alpha * P[i];
-      s += w * w;
-    }
-    __syncthreads();
-    sa[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-      if (threadIdx.x < off) sa[threadIdx.x] += sa[threadIdx.x + off];
-      __syncthreads();
-    }
-    b2 = sa[0];
-  }
-  if (threadIdx.x == 0) {
-    scal[SC_ALPHA] = alpha;
-    scal[SC_AB + iter] = alpha;
-    scal[SC_NDONE] = (double)(iter + 1);
-    scal[SC_EXACT] = 0.0;
-    const double b = sqrt(b2 > 0.0 ? b2 : 0.0);
-    scal[SC_BETA] = b;
-    if (!(fabs(b) > 0.0) || fabs(b) < scal[SC_THR])  // see k_finalize
-      scal[SC_STOP] = 1.0;
-    else if (iter + 1 < nlanc)
-      scal[SC_AB + nlanc + iter + 1] = b;
-  }
+  lz_finalize_ab_device<1024>(partial, np, P, Q, n, scal, iter, nlanc, sh);
 }
 
 int lz_finalize_alpha_beta(const double* P, const double* Q, int64_t n, double* partial, int np,

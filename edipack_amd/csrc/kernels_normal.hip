@@ -559,6 +559,9 @@ static void fill_args(const edigpu_sector* s, NormalArgs& a) {
   a.scal = nullptr;
   a.partial = nullptr;
   a.partial_cap = 0;
+  a.lz_counter = nullptr;
+  a.lz_nlanc = 0;
+  a.lz_len = 0;
   a.split_first = 0;
   a.split_count = s->dim_up;
 }
@@ -628,12 +631,26 @@ bool normal_lanczos_fusable(const edigpu_sector* s) {
 }
 
 int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const double* scal,
-                          double* partial, int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial) {
+                          double* partial, int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial,
+                          int nlanc, bool* finalized) {
   NormalArgs a;
   fill_args(s, a);
   a.scal = scal;
   a.partial = partial;
   a.partial_cap = partial_cap;
+  // EDIGPU_LANCZOS_INKERNEL_FINALIZE=1: the sweep's last workgroup finalizes the step itself (lz_finalize.hpp) instead of
+  // a separate 5 us kernel.  OPT-IN, because it is much slower on this part: the release fence every workgroup needs
+  // before it counts itself as arrived writes back its XCD's whole L2 (buffer_wbl2), i.e. the result vector the sweep
+  // has just produced -- measured 306 against 162 us per step on config 2, 24.5 against 20.2 on config 3.
+  static const bool inkernel = getenv("EDIGPU_LANCZOS_INKERNEL_FINALIZE") && atoi(getenv("EDIGPU_LANCZOS_INKERNEL_FINALIZE")) != 0;
+  const bool explicit_nd = !s->factored && s->has_nd && s->nd.sell;
+  if (finalized) *finalized = false;
+  if (inkernel && lazy_axpy && !explicit_nd && s->d_lzcnt && finalized) {
+    a.lz_counter = s->d_lzcnt;
+    a.lz_nlanc = nlanc;
+    a.lz_len = s->lz_len;
+    *finalized = true;
+  }
   if (s->lz_blocked) {  // P, Q in the panel-major layout (lanczos_prepare)
     a.blk_shift = s->blk_shift;
     a.blk_ps = s->blk_ps;

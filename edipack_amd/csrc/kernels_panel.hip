@@ -20,10 +20,12 @@
 // row, lists staged in LDS: half as many gather instructions) measured 1.8x SLOWER (175 us).  What does pay is
 // two columns per lane with a FULL wave per row (normal_dw_panel2_kernel below: 1024-byte segments, 16-byte
 // gathers, panels twice as wide): 95 -> 81 us.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
+#include "lz_finalize.hpp"
 #include "normal_args.hpp"
 
 namespace edigpu {
@@ -51,6 +53,7 @@ __global__ void __launch_bounds__(kPanelNT)
   __shared__ double red[3 * (kPanelNT / 64)];
   const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
   const int panel = (k / p.blocks_per_panel) * 8 + x;
+  __shared__ double lzsh[ALPHA ? 3 * kPanelNT + 2 : 1];  // in-kernel finalize of the fused step (lz_finalize.hpp)
   if (ALPHA) {
     if (panel >= p.npanels || a.scal[SC_STOP] != 0.0) {
       if (threadIdx.x == 0) {
@@ -58,6 +61,9 @@ __global__ void __launch_bounds__(kPanelNT)
         a.partial[gridDim.x + blockIdx.x] = 0.0;
         a.partial[2 * gridDim.x + blockIdx.x] = 0.0;
       }
+      // (a workgroup of the grid's padding still counts as arrived)
+      if (a.lz_counter)
+        lz_finalize_if_last<kPanelNT>(a.lz_counter, a.partial, v_full, hv, a.lz_len, const_cast<double*>(a.scal), a.lz_nlanc, lzsh);
       return;
     }
   }
@@ -204,6 +210,8 @@ __global__ void __launch_bounds__(kPanelNT)
       a.partial[gridDim.x + blockIdx.x] = q;
       a.partial[2 * gridDim.x + blockIdx.x] = n;
     }
+    if (a.lz_counter)
+      lz_finalize_if_last<kPanelNT>(a.lz_counter, a.partial, v_full, hv, a.lz_len, const_cast<double*>(a.scal), a.lz_nlanc, lzsh);
   }
 }
 
@@ -225,6 +233,7 @@ __global__ void __launch_bounds__(kPanelNT)
   extern __shared__ uint32_t ju2[];  // [2 * nterms][kPanelNT]: partner columns of the lane's two columns
   const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
   const int panel = (k / p.blocks_per_panel) * 8 + x;
+  __shared__ double lzsh[ALPHA ? 3 * kPanelNT + 2 : 1];  // in-kernel finalize of the fused step (lz_finalize.hpp)
   if (ALPHA) {
     if (panel >= p.npanels || a.scal[SC_STOP] != 0.0) {
       if (threadIdx.x == 0) {
@@ -232,6 +241,9 @@ __global__ void __launch_bounds__(kPanelNT)
         a.partial[gridDim.x + blockIdx.x] = 0.0;
         a.partial[2 * gridDim.x + blockIdx.x] = 0.0;
       }
+      // (a workgroup of the grid's padding still counts as arrived)
+      if (a.lz_counter)
+        lz_finalize_if_last<kPanelNT>(a.lz_counter, a.partial, v_full, hv, a.lz_len, const_cast<double*>(a.scal), a.lz_nlanc, lzsh);
       return;
     }
   }
@@ -385,6 +397,8 @@ __global__ void __launch_bounds__(kPanelNT)
       a.partial[gridDim.x + blockIdx.x] = q;
       a.partial[2 * gridDim.x + blockIdx.x] = n;
     }
+    if (a.lz_counter)
+      lz_finalize_if_last<kPanelNT>(a.lz_counter, a.partial, v_full, hv, a.lz_len, const_cast<double*>(a.scal), a.lz_nlanc, lzsh);
   }
 }
 
@@ -659,6 +673,10 @@ __global__ void __launch_bounds__(NT)
       a.partial[gridDim.x + blockIdx.x] = q;
       a.partial[2 * gridDim.x + blockIdx.x] = n;
     }
+    // the staged tile is no longer needed: its LDS serves the in-kernel finalize (the launcher sizes it for that)
+    if (a.lz_counter)
+      lz_finalize_if_last<NT>(a.lz_counter, a.partial, v_full, hv, a.lz_len, const_cast<double*>(a.scal), a.lz_nlanc,
+                              reinterpret_cast<double*>(tile));
   }
 }
 
@@ -695,6 +713,7 @@ __global__ void __launch_bounds__(kBlkNT)
   __shared__ double wtab[256];
   __shared__ double red[3 * NW];
   __shared__ uint32_t ju2[DO_ND ? 2 * kMaxNdTerms * L : 1];
+  __shared__ double lzsh[ALPHA ? 3 * kBlkNT + 2 : 1];  // in-kernel finalize of the fused step (lz_finalize.hpp)
   const int R = p.rows_per_task;
   uint32_t* lent = reinterpret_cast<uint32_t*>(stile + (size_t)R * L);
   int4* lmeta = reinterpret_cast<int4*>(lent + p.list_cap);
@@ -912,6 +931,8 @@ __global__ void __launch_bounds__(kBlkNT)
       a.partial[gridDim.x + blockIdx.x] = q;
       a.partial[2 * gridDim.x + blockIdx.x] = n;
     }
+    if (a.lz_counter)
+      lz_finalize_if_last<kBlkNT>(a.lz_counter, a.partial, v, hv, a.lz_len, const_cast<double*>(a.scal), a.lz_nlanc, lzsh);
   }
 }
 
@@ -942,8 +963,9 @@ static int launch_dw_blocked_tiles(const NormalArgs& a, bool do_nd, const double
     set_error("launch_dw_blocked: partial buffer too small for this grid");
     return 1;
   }
-  const size_t lds = (size_t)p.tile_rows * kTileSeg * sizeof(double2) + (size_t)p.list_cap * (sizeof(double) + sizeof(int32_t)) +
-                     (size_t)p.tile_rows * sizeof(int4) + (do_nd ? (size_t)2 * a.nterms * 64 * sizeof(uint32_t) : 0);
+  size_t lds = (size_t)p.tile_rows * kTileSeg * sizeof(double2) + (size_t)p.list_cap * (sizeof(double) + sizeof(int32_t)) +
+               (size_t)p.tile_rows * sizeof(int4) + (do_nd ? (size_t)2 * a.nterms * 64 * sizeof(uint32_t) : 0);
+  if (alpha) lds = std::max<size_t>(lds, 3 * 1024 * sizeof(double) + 16);  // the in-kernel finalize reuses the tile's LDS
   const bool big = p.tile_rows > kTileRowsPerWave * (kPanelNT / 64);
 #define EDIGPU_LAUNCH_BT(NTV, ND, AL)                                                   \
   do {                                                                                  \
@@ -1150,8 +1172,9 @@ int launch_dw_panels(const NormalArgs& a, bool do_dw, bool do_nd, const double* 
   }
   if (tiled) {
     p.list_cap = a.tile_list_cap;
-    const size_t lds = (size_t)p.tile_rows * kTileSeg * sizeof(double2) + (size_t)p.list_cap * (sizeof(double) + sizeof(int32_t)) +
-                       (size_t)p.tile_rows * sizeof(int4) + (do_nd ? (size_t)2 * a.nterms * 64 * sizeof(uint32_t) : 0);
+    size_t lds = (size_t)p.tile_rows * kTileSeg * sizeof(double2) + (size_t)p.list_cap * (sizeof(double) + sizeof(int32_t)) +
+                 (size_t)p.tile_rows * sizeof(int4) + (do_nd ? (size_t)2 * a.nterms * 64 * sizeof(uint32_t) : 0);
+    if (alpha) lds = std::max<size_t>(lds, 3 * 1024 * sizeof(double) + 16);  // the in-kernel finalize reuses the tile's LDS
     // persistent grid: as many workgroups as stay resident (a multiple of 8: one stream of tasks per XCD), never
     // more than there are tasks
     const int64_t ntasks = (int64_t)panel_groups * bpp * 8;

@@ -42,6 +42,11 @@ struct NormalArgs {
   const double* scal;
   double* partial;
   int64_t partial_cap;  // doubles in `partial`; the panel launch checks its grid against it before enqueueing
+  // finalize of the fused step inside the sweep (lz_finalize.hpp): arrival counter (zero at launch; nullptr = a separate
+  // finalize kernel follows), recurrence length, doubles per vector
+  unsigned int* lz_counter;
+  int lz_nlanc;
+  int64_t lz_len;
   // panel sweep variant chosen when the sector was set up (environment switches are read there):
   // 0 one column per lane, 1 two columns per lane, 2 two columns + LDS-staged row chunks (tile_chunks: nchunks + 1
   // local row offsets, tile_rows: the longest chunk)
