@@ -639,9 +639,11 @@ int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const do
   a.partial = partial;
   a.partial_cap = partial_cap;
   // EDIGPU_LANCZOS_INKERNEL_FINALIZE=1: the sweep's last workgroup finalizes the step itself (lz_finalize.hpp) instead of
-  // a separate 5 us kernel.  OPT-IN, because it is much slower on this part: the release fence every workgroup needs
-  // before it counts itself as arrived writes back its XCD's whole L2 (buffer_wbl2), i.e. the result vector the sweep
-  // has just produced -- measured 306 against 162 us per step on config 2, 24.5 against 20.2 on config 3.
+  // a separate 5 us kernel.  OPT-IN: it buys nothing.  With a release fence per workgroup (which writes back the XCD's
+  // whole L2 on this part) it measured 306 against 162 us per step on config 2; in the fence-free form (device-scope
+  // stores / loads for the partials) 167.8 against 162.3 (config 2), 20.9 against 20.1 (config 3), 10.8 against 11.4
+  // (config 1): the reduction of a few thousand partials by one workgroup takes as long at the tail of the sweep as it
+  // does in its own kernel.
   static const bool inkernel = getenv("EDIGPU_LANCZOS_INKERNEL_FINALIZE") && atoi(getenv("EDIGPU_LANCZOS_INKERNEL_FINALIZE")) != 0;
   const bool explicit_nd = !s->factored && s->has_nd && s->nd.sell;
   if (finalized) *finalized = false;

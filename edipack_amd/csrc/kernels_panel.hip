@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(kPanelNT)
       }
       // (a workgroup of the grid's padding still counts as arrived)
       if (a.lz_counter)
-        lz_finalize_if_last<kPanelNT>(a.lz_counter, a.partial, v_full, hv, a.lz_len, const_cast<double*>(a.scal), a.lz_nlanc, lzsh);
+        lz_finalize_if_last<kPanelNT>(a.lz_counter, a.partial, 0.0, 0.0, 0.0, v_full, hv, a.lz_len, const_cast<double*>(a.scal),
+                                      a.lz_nlanc, lzsh);
       return;
     }
   }
@@ -198,20 +199,23 @@ __global__ void __launch_bounds__(kPanelNT)
       red[2 * (kPanelNT / 64) + wave] = nsum;
     }
     __syncthreads();
+    double t = 0.0, q = 0.0, n = 0.0;
     if (threadIdx.x == 0) {
-      double t = 0.0, q = 0.0, n = 0.0;
 #pragma unroll
       for (int i = 0; i < kPanelNT / 64; i++) {
         t += red[i];
         q += red[kPanelNT / 64 + i];
         n += red[2 * (kPanelNT / 64) + i];
       }
-      a.partial[blockIdx.x] = t;
-      a.partial[gridDim.x + blockIdx.x] = q;
-      a.partial[2 * gridDim.x + blockIdx.x] = n;
+      if (!a.lz_counter) {
+        a.partial[blockIdx.x] = t;
+        a.partial[gridDim.x + blockIdx.x] = q;
+        a.partial[2 * gridDim.x + blockIdx.x] = n;
+      }
     }
     if (a.lz_counter)
-      lz_finalize_if_last<kPanelNT>(a.lz_counter, a.partial, v_full, hv, a.lz_len, const_cast<double*>(a.scal), a.lz_nlanc, lzsh);
+      lz_finalize_if_last<kPanelNT>(a.lz_counter, a.partial, t, q, n, v_full, hv, a.lz_len, const_cast<double*>(a.scal),
+                                    a.lz_nlanc, lzsh);
   }
 }
 
@@ -243,7 +247,8 @@ __global__ void __launch_bounds__(kPanelNT)
       }
       // (a workgroup of the grid's padding still counts as arrived)
       if (a.lz_counter)
-        lz_finalize_if_last<kPanelNT>(a.lz_counter, a.partial, v_full, hv, a.lz_len, const_cast<double*>(a.scal), a.lz_nlanc, lzsh);
+        lz_finalize_if_last<kPanelNT>(a.lz_counter, a.partial, 0.0, 0.0, 0.0, v_full, hv, a.lz_len, const_cast<double*>(a.scal),
+                                      a.lz_nlanc, lzsh);
       return;
     }
   }
@@ -385,20 +390,23 @@ __global__ void __launch_bounds__(kPanelNT)
       red[2 * (kPanelNT / 64) + wave] = nsum;
     }
     __syncthreads();
+    double t = 0.0, q = 0.0, n = 0.0;
     if (threadIdx.x == 0) {
-      double t = 0.0, q = 0.0, n = 0.0;
 #pragma unroll
       for (int i = 0; i < kPanelNT / 64; i++) {
         t += red[i];
         q += red[kPanelNT / 64 + i];
         n += red[2 * (kPanelNT / 64) + i];
       }
-      a.partial[blockIdx.x] = t;
-      a.partial[gridDim.x + blockIdx.x] = q;
-      a.partial[2 * gridDim.x + blockIdx.x] = n;
+      if (!a.lz_counter) {
+        a.partial[blockIdx.x] = t;
+        a.partial[gridDim.x + blockIdx.x] = q;
+        a.partial[2 * gridDim.x + blockIdx.x] = n;
+      }
     }
     if (a.lz_counter)
-      lz_finalize_if_last<kPanelNT>(a.lz_counter, a.partial, v_full, hv, a.lz_len, const_cast<double*>(a.scal), a.lz_nlanc, lzsh);
+      lz_finalize_if_last<kPanelNT>(a.lz_counter, a.partial, t, q, n, v_full, hv, a.lz_len, const_cast<double*>(a.scal),
+                                    a.lz_nlanc, lzsh);
   }
 }
 
@@ -661,21 +669,23 @@ __global__ void __launch_bounds__(NT)
       red[2 * (NT / 64) + wave] = nsum;
     }
     __syncthreads();
+    double t = 0.0, q = 0.0, n = 0.0;
     if (threadIdx.x == 0) {
-      double t = 0.0, q = 0.0, n = 0.0;
 #pragma unroll
       for (int i = 0; i < NT / 64; i++) {
         t += red[i];
         q += red[NT / 64 + i];
         n += red[2 * (NT / 64) + i];
       }
-      a.partial[blockIdx.x] = t;
-      a.partial[gridDim.x + blockIdx.x] = q;
-      a.partial[2 * gridDim.x + blockIdx.x] = n;
+      if (!a.lz_counter) {
+        a.partial[blockIdx.x] = t;
+        a.partial[gridDim.x + blockIdx.x] = q;
+        a.partial[2 * gridDim.x + blockIdx.x] = n;
+      }
     }
     // the staged tile is no longer needed: its LDS serves the in-kernel finalize (the launcher sizes it for that)
     if (a.lz_counter)
-      lz_finalize_if_last<NT>(a.lz_counter, a.partial, v_full, hv, a.lz_len, const_cast<double*>(a.scal), a.lz_nlanc,
+      lz_finalize_if_last<NT>(a.lz_counter, a.partial, t, q, n, v_full, hv, a.lz_len, const_cast<double*>(a.scal), a.lz_nlanc,
                               reinterpret_cast<double*>(tile));
   }
 }
@@ -919,20 +929,23 @@ __global__ void __launch_bounds__(kBlkNT)
       red[2 * NW + wave] = nsum;
     }
     __syncthreads();
+    double t = 0.0, q = 0.0, n = 0.0;
     if (threadIdx.x == 0) {
-      double t = 0.0, q = 0.0, n = 0.0;
 #pragma unroll
       for (int i = 0; i < NW; i++) {
         t += red[i];
         q += red[NW + i];
         n += red[2 * NW + i];
       }
-      a.partial[blockIdx.x] = t;
-      a.partial[gridDim.x + blockIdx.x] = q;
-      a.partial[2 * gridDim.x + blockIdx.x] = n;
+      if (!a.lz_counter) {
+        a.partial[blockIdx.x] = t;
+        a.partial[gridDim.x + blockIdx.x] = q;
+        a.partial[2 * gridDim.x + blockIdx.x] = n;
+      }
     }
     if (a.lz_counter)
-      lz_finalize_if_last<kBlkNT>(a.lz_counter, a.partial, v, hv, a.lz_len, const_cast<double*>(a.scal), a.lz_nlanc, lzsh);
+      lz_finalize_if_last<kBlkNT>(a.lz_counter, a.partial, t, q, n, v, hv, a.lz_len, const_cast<double*>(a.scal), a.lz_nlanc,
+                                  lzsh);
   }
 }
 

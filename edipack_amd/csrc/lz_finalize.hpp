@@ -15,8 +15,10 @@ namespace edigpu {
 // beta^2 = |Q - alpha P|^2 = qq - 2 d (alpha - sg vv) + d^2 vv, d = alpha - sg -- exact for any sg, so a spectrum far
 // from zero does not cancel; when the difference still loses more than ~3 digits (near-invariant subspace, rare) the
 // workgroup recomputes |Q - alpha P|^2 by sweeping the two vectors.  iter < 0: the step index is scal[SC_NDONE].
-template <int NT>
-__device__ inline void lz_finalize_ab_device(const double* __restrict__ partial, int np, const double* __restrict__ P,
+// COHERENT: the partials were written by other workgroups of the SAME launch with device-scope stores; read them with
+// device-scope loads (they bypass whatever this XCD's L2 still holds of the previous step's partials)
+template <int NT, bool COHERENT = false>
+__device__ inline void lz_finalize_ab_device(const double* partial, int np, const double* __restrict__ P,
                                              const double* __restrict__ Q, int64_t n, double* __restrict__ scal, int iter,
                                              int nlanc, double* sh) {
   double* sa = sh;
@@ -25,9 +27,15 @@ __device__ inline void lz_finalize_ab_device(const double* __restrict__ partial,
   if (iter < 0) iter = (int)scal[SC_NDONE];
   double a = 0.0, q = 0.0, nn = 0.0;
   for (int i = threadIdx.x; i < np; i += NT) {
-    a += partial[i];
-    q += partial[np + i];
-    nn += partial[2 * np + i];
+    if (COHERENT) {
+      a += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      q += __hip_atomic_load(partial + np + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      nn += __hip_atomic_load(partial + 2 * np + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      a += partial[i];
+      q += partial[np + i];
+      nn += partial[2 * np + i];
+    }
   }
   sa[threadIdx.x] = a;
   sq[threadIdx.x] = q;
@@ -47,6 +55,7 @@ __device__ inline void lz_finalize_ab_device(const double* __restrict__ partial,
   const bool exact = b2 < 1e-3 * qq;  // the same value in every thread
   __syncthreads();
   if (exact) {
+    if (COHERENT) __threadfence();  // (rare) the sweep's result vector, written by the other workgroups of this launch
     double s = 0.0;
     for (int64_t i = threadIdx.x; i < n; i += NT) {
       const double w = Q[i] - alpha * P[i];
@@ -75,27 +84,31 @@ __device__ inline void lz_finalize_ab_device(const double* __restrict__ partial,
   }
 }
 
-// Last-workgroup epilogue of a sweep that has just written its three partials (thread 0 of every workgroup): the
-// workgroup that arrives last at the counter finalizes the step, so that no separate kernel has to be launched.  All
-// threads of the workgroup call this; returns after the finalize (if this workgroup did it).  counter must be zero at
-// launch; the finalizing workgroup resets it.  sh: 3 * NT doubles + one int, free for use at this point.
+// Last-workgroup epilogue of a sweep (thread 0 of every workgroup holds its three sums): the workgroup that arrives
+// last at the counter finalizes the step, so that no separate kernel has to be launched.  All threads of the workgroup
+// call this.  No fences: a release fence per workgroup writes back its XCD's whole L2 on this part (measured 2x slower
+// than the separate kernel); instead the three partials are written with device-scope stores (write-through), the wave
+// waits for them to complete, and only then counts itself with a device-scope atomic; the last workgroup reads the
+// partials with device-scope loads.  counter must be zero at launch; the finalizing workgroup resets it.  sh: 3 * NT
+// doubles + one int, free for use at this point.
 template <int NT>
-__device__ inline void lz_finalize_if_last(unsigned int* counter, const double* partial, const double* P, const double* Q,
-                                           int64_t n, double* scal, int nlanc, double* sh) {
+__device__ inline void lz_finalize_if_last(unsigned int* counter, double* partial, double t, double q, double n_,
+                                           const double* P, const double* Q, int64_t n, double* scal, int nlanc, double* sh) {
   int* flag = reinterpret_cast<int*>(sh + 3 * NT);
   if (scal[SC_STOP] != 0.0) return;  // recurrence already terminated (uniform; nobody counts)
-  __syncthreads();  // this workgroup's partials are written (thread 0) and sh is free
+  __syncthreads();                   // sh is free
   if (threadIdx.x == 0) {
-    __threadfence();  // release: the partials are visible device-wide before the arrival is counted
-    const unsigned int prev = atomicAdd(counter, 1u);
+    __hip_atomic_store(partial + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(partial + gridDim.x + blockIdx.x, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(partial + 2 * gridDim.x + blockIdx.x, n_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);   // the stores have completed before this workgroup counts as arrived
+    const unsigned int prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *flag = prev == gridDim.x - 1u;
-    if (*flag) __threadfence();  // acquire: the other workgroups' partials
   }
   __syncthreads();
   if (!*flag) return;
-  __threadfence();
-  lz_finalize_ab_device<NT>(partial, (int)gridDim.x, P, Q, n, scal, -1, nlanc, sh);
-  if (threadIdx.x == 0) *counter = 0u;
+  lz_finalize_ab_device<NT, true>(partial, (int)gridDim.x, P, Q, n, scal, -1, nlanc, sh);
+  if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace edigpu
