@@ -2444,22 +2444,61 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
   double e_old = 0.0;
   int ndone = 0;
   bool have = false, conv = false;
+  // With a vector asked for, the Lanczos vectors are kept as they are produced (blocks of kKeep vectors, allocated
+  // while the device has room: 288 GB hold thousands of config-2 vectors) and the Ritz vector is assembled from them --
+  // one extra copy per step instead of a second pass that regenerates every v_k with as many products again.
+  // EDIGPU_EIGH_TWOPASS=1, or an allocation that fails, falls back to the second pass.
+  constexpr int kKeep = 16;
+  std::vector<double*> kept;  // block b holds v_(b kKeep) .. v_(b kKeep + kKeep - 1)
+  bool keep = evec_host != nullptr && !getenv("EDIGPU_EIGH_TWOPASS");
+  auto drop_kept = [&]() {
+    for (double* b : kept) (void)hipFree(b);
+    kept.clear();
+    keep = false;
+  };
+  auto fail_all = [&]() {
+    drop_kept();
+    return fail();
+  };
   for (int it0 = 0; it0 < nitermax && !conv;) {
     // the steps up to the next convergence check in one go (replayed from a graph on launch-bound sectors)
     const int it1 = std::min(nitermax, (it0 / check_every + 1) * check_every);
-    if (lanczos_run(s, it0, it1, nitermax, st)) return fail();
+    if (keep) {
+      for (int it = it0; it < it1 && keep; it++) {
+        if (it % kKeep == 0) {
+          size_t fr = 0, tot = 0;
+          double* b = nullptr;
+          // leave a quarter of the device free for whatever else lives there
+          if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < tot / 4 + (size_t)kKeep * vbytes ||
+              hipMalloc((void**)&b, (size_t)kKeep * vbytes) != hipSuccess) {
+            (void)hipGetLastError();
+            drop_kept();
+            break;
+          }
+          kept.push_back(b);
+        }
+        if (lanczos_step(s, it, nitermax, st)) return fail_all();
+        if (hipMemcpyAsync(kept[(size_t)(it / kKeep)] + (size_t)(it % kKeep) * (size_t)len, s->d_vin, vbytes,
+                           hipMemcpyDeviceToDevice, st) != hipSuccess)
+          return fail_all();
+        it0 = it + 1;
+      }
+      if (it0 < it1 && lanczos_run(s, it0, it1, nitermax, st)) return fail_all();  // (room ran out part way)
+    } else if (lanczos_run(s, it0, it1, nitermax, st)) {
+      return fail_all();
+    }
     it0 = it1;
     {
       if (hipMemcpyAsync(sc.data(), s->d_scal, sc.size() * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess)
-        return fail();
-      if (hipStreamSynchronize(st) != hipSuccess) return fail();
+        return fail_all();
+      if (hipStreamSynchronize(st) != hipSuccess) return fail_all();
       ndone = (int)sc[SC_NDONE];
       if (ndone == 0) break;
       d.assign(sc.begin() + SC_AB, sc.begin() + SC_AB + ndone);
       e.assign(sc.begin() + SC_AB + nitermax, sc.begin() + SC_AB + nitermax + ndone);
       if (tql2(ndone, d, e, z)) {
         set_error("edigpu_lanczos_eigh: tridiagonal QL did not converge");
-        return fail();
+        return fail_all();
       }
       const double e_new = *std::min_element(d.begin(), d.end());
       if (have && fabs(e_new - e_old) < tol) conv = true;
@@ -2470,7 +2509,7 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
   }
   if (ndone == 0) {
     set_error("edigpu_lanczos_eigh: zero start vector");
-    return fail();
+    return fail_all();
   }
   *eval = e_old;
   if (niter_done) *niter_done = ndone;
@@ -2482,19 +2521,24 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
     double* d_acc = nullptr;
     if (hipMalloc((void**)&d_acc, vbytes) != hipSuccess) {
       set_error("edigpu_lanczos_eigh: out of device memory");
-      return fail();
+      return fail_all();
     }
     (void)hipMemsetAsync(d_acc, 0, vbytes, st);
-    (void)hipMemcpyAsync(s->d_vin, d_v0, vbytes, hipMemcpyDeviceToDevice, st);
-    if (lanczos_prepare(s, ndone, kBreakdown, st)) {
-      (void)hipFree(d_acc);
-      return fail();
-    }
     int rc = 0;
-    for (int it = 0; it < ndone && !rc; it++) {
-      // same kernels, same order as the first pass => bitwise the same Lanczos vectors
-      rc |= lanczos_step(s, it, ndone, st);
-      rc |= lz_axpy_coef(d_acc, s->d_vin, len, y[it], s->d_scal, -1, st);
+    if (keep && (int)kept.size() * kKeep >= ndone) {
+      for (int it = 0; it < ndone && !rc; it++)
+        rc |= lz_axpy_coef(d_acc, kept[(size_t)(it / kKeep)] + (size_t)(it % kKeep) * (size_t)len, len, y[it], s->d_scal, -1, st);
+    } else {
+      (void)hipMemcpyAsync(s->d_vin, d_v0, vbytes, hipMemcpyDeviceToDevice, st);
+      if (lanczos_prepare(s, ndone, kBreakdown, st)) {
+        (void)hipFree(d_acc);
+        return fail_all();
+      }
+      for (int it = 0; it < ndone && !rc; it++) {
+        // same kernels, same order as the first pass => bitwise the same Lanczos vectors
+        rc |= lanczos_step(s, it, ndone, st);
+        rc |= lz_axpy_coef(d_acc, s->d_vin, len, y[it], s->d_scal, -1, st);
+      }
     }
     // normalise
     if (!rc) rc |= lz_norm_begin(d_acc, len, s->d_partial, s->d_scal, st);
@@ -2503,9 +2547,10 @@ int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_eve
     (void)hipFree(d_acc);
     if (rc) {
       if (g_err.empty()) set_error("edigpu_lanczos_eigh: second pass failed");
-      return fail();
+      return fail_all();
     }
   }
+  drop_kept();
   (void)hipFree(d_v0);
   return 0;
 }

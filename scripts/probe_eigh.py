@@ -30,6 +30,16 @@ def main():
     t0 = time.perf_counter()
     e0, _, nit = h.lanczos_eigh(nitermax=300, tol=args.tol, want_vector=False)
     out["eigh"] = {"e0": e0, "iterations": nit, "seconds": round(time.perf_counter() - t0, 4)}
+    # the same with the Ritz vector left on the device (the form the Green's-function step consumes)
+    import ctypes as C
+    vec = C.c_void_p()
+    capi.check(capi.lib().edigpu_dev_alloc(8 * h.dim * (2 if h.is_complex else 1), C.byref(vec)))
+    ev, nd = C.c_double(), C.c_int(0)
+    t0 = time.perf_counter()
+    capi.check(capi.lib().edigpu_lanczos_eigh(h._h, 300, args.tol, 10, None, C.byref(ev),
+                                                 C.cast(vec, C.POINTER(C.c_double)), C.byref(nd)))
+    out["eigh_with_vector"] = {"e0": ev.value, "iterations": nd.value, "seconds": round(time.perf_counter() - t0, 4)}
+    capi.check(capi.lib().edigpu_dev_free(vec))
     for ne in (1, 2, 4):
         t0 = time.perf_counter()
         ev, _, nconv, nmv = h.lanczos_eigh_multi(ne, ncv=args.ncv, tol=args.tol, want_vectors=False)
