@@ -4,6 +4,7 @@ in profiles/r02_bench_*.json, so that the text always quotes the committed evide
 import json
 import os
 import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
@@ -19,7 +20,9 @@ def sp(x):
     return f"{x:,.0f}".replace(",", " ")
 
 
+CHECK = "--check" in sys.argv     # report instead of rewriting; exit 1 when the text does not quote the bench lines
 s = open("DESIGN.md").read()
+s_before = s
 out = []
 for ln in s.split("\n"):
     hit = next((wl for wl, nm in NAMES.items() if ln.startswith(f"| {nm} |")), None)
@@ -44,8 +47,13 @@ s = re.sub(r"\*\*6 \d\d\d Lanczos iterations/s\*\*", f"**{sp(d['value'])} Lanczo
 s = re.sub(r"6 \d\d\d it/s is 8\d % of it\.", f"{sp(d['value'])} it/s is {100 * d['value'] / 7100:.0f} % of it.", s)
 s = re.sub(r"the same rate \(6 \d\d\d it/s;", f"the same rate ({sp(dh['value'])} it/s;", s)
 s = re.sub(r"`profiles/r02_bench_cfg2_handover.json`\): 6 \d\d\d it/s", f"`profiles/r02_bench_cfg2_handover.json`): {sp(dh['value'])} it/s", s)
-open("DESIGN.md", "w").write(s)
 t = open("INTEGRATION.md").read()
+t_before = t
 t = re.sub(r"Config 2 through this patch: 6 \d\d\d Lanczos it/s", f"Config 2 through this patch: {sp(dh['value'])} Lanczos it/s", t)
+if CHECK:
+    stale = [n for n, a, b in (("DESIGN.md", s_before, s), ("INTEGRATION.md", t_before, t)) if a != b]
+    print("stale:", stale)
+    sys.exit(1 if stale else 0)
+open("DESIGN.md", "w").write(s)
 open("INTEGRATION.md", "w").write(t)
 print("cfg2", d["value"], "handover", dh["value"], "ns17", d17["value"])
