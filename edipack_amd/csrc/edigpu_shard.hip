@@ -378,6 +378,8 @@ struct ShardGeom {
   int w = 1;                // doubles per element
   int64_t units = 0, unit_len = 1, q = 0, first = 0, count = 0;
   int64_t nloc = 0, chunk = 0;  // elements of this rank's shard / of the padded chunk
+  int nblk = 1;                 // phonon blocks per vector (Nph + 1): the local vector is nblk blocks of blk elements
+  int64_t blk = 0;
   // transposed exchange
   int halo = 0;
   int64_t pcol = 0, col_first = 0, col_count = 0, pw = 0, xlen = 0;
@@ -385,7 +387,8 @@ struct ShardGeom {
 
 static int shard_geometry(const edigpu_sector* s, const edigpu_comm_s* c, ShardGeom& g) {
   g.w = s->is_complex ? 2 : 1;
-  g.transposed = s->kind == 0 && s->nloc == s->dim && normal_transposable(s);
+  g.transposed = s->kind == 0 && s->nloc == s->dim && normal_transposable_el(s);
+  g.nblk = s->kind == 0 && s->nph > 0 ? s->nph + 1 : 1;
   if (s->kind == 0) {
     g.units = s->dim_dw;
     g.unit_len = s->dim_up;
@@ -396,8 +399,9 @@ static int shard_geometry(const edigpu_sector* s, const edigpu_comm_s* c, ShardG
   g.q = (g.units + c->world - 1) / c->world;
   g.first = std::min<int64_t>((int64_t)c->rank * g.q, g.units);
   g.count = std::max<int64_t>(0, std::min<int64_t>(g.q, g.units - g.first));
-  g.nloc = g.count * g.unit_len;
-  g.chunk = g.q * g.unit_len;
+  g.blk = g.count * g.unit_len;
+  g.nloc = g.blk * g.nblk;
+  g.chunk = g.q * g.unit_len * g.nblk;
   if (g.transposed) {
     g.halo = s->col_halo;
     g.pcol = (s->dim_up + c->world - 1) / c->world;
@@ -407,6 +411,13 @@ static int shard_geometry(const edigpu_sector* s, const edigpu_comm_s* c, ShardG
     g.xlen = (int64_t)c->world * g.q * g.pw;
     if (g.pcol < 1 || g.halo > g.pcol) g.transposed = false;  // blocks narrower than the halo: all-gather form
   }
+  if (g.nblk > 1 && (!g.transposed || s->sub_a)) {
+    // like spMatVec_mpi_normal_main (ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:841-904): every phonon block is exchanged on
+    // its own and the phonon / electron-phonon pass is local, which holds for density couplings only
+    set_error("sharded call: phonon sectors shard through the transposed exchange (whole normal-mode sector, factored "
+              "Hnd, at least `halo` up columns per rank) with density couplings g_ph(a,a) only");
+    return 1;
+  }
   if (!g.transposed) {
     // all-gather form: the handle must BE this rank's shard
     if (s->nloc != g.nloc || s->row_first != g.first * g.unit_len) {
@@ -415,7 +426,7 @@ static int shard_geometry(const edigpu_sector* s, const edigpu_comm_s* c, ShardG
       return 1;
     }
     if (s->nph > 0 || s->kind == 4) {
-      set_error("sharded call: phonon and complex normal-mode sectors are single-shard");
+      set_error("sharded call: superc / nonsu2 phonon sectors and four-product complex sectors are single-shard");
       return 1;
     }
   }
@@ -459,24 +470,35 @@ static int comm_workspace(edigpu_comm_s* c, const ShardGeom& g, int nlanc) {
 static int sharded_hv(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, bool pre_packed, hipStream_t st,
                       const double** back_out = nullptr) {
   if (g.transposed) {
-    if (!pre_packed &&
-        edigpu_transpose_pack(s->dim_up, g.count, g.q, c->world, g.pcol, g.halo, c->vin, c->send, st))
-      return 1;
     // a world of one exchanges nothing: the column half reads the packed buffer and the caller its result in place
     const bool alone = c->world == 1 && !force_collectives(c);
-    if (!alone) {
-      EDIGPU_HIP(hipEventRecord(c->ev_ready, st));
-      EDIGPU_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
-      if (comm_all_to_all(c, c->send, c->recv, (size_t)(g.q * g.pw), c->side)) return 1;
-      EDIGPU_HIP(hipEventRecord(c->ev_done, c->side));
+    for (int b = 0; b < g.nblk; b++) {
+      const double* vb = c->vin + (size_t)b * g.blk;
+      double* tb = c->tmp + (size_t)b * g.blk;
+      if ((!pre_packed || g.nblk > 1) &&
+          edigpu_transpose_pack(s->dim_up, g.count, g.q, c->world, g.pcol, g.halo, vb, c->send, st))
+        return 1;
+      if (!alone) {
+        EDIGPU_HIP(hipEventRecord(c->ev_ready, st));
+        EDIGPU_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
+        if (comm_all_to_all(c, c->send, c->recv, (size_t)(g.q * g.pw), c->side)) return 1;
+        EDIGPU_HIP(hipEventRecord(c->ev_done, c->side));
+      }
+      if (launch_normal_rows(s, g.first, g.count, vb, tb, st)) return 1;
+      if (!alone) EDIGPU_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
+      if (launch_normal_cols(s, g.col_first, g.col_count, g.pw, g.halo, alone ? c->send : c->recv, c->hvc, st)) return 1;
+      const double* back = alone ? c->hvc : c->back;
+      if (g.nblk == 1) {
+        if (back_out) *back_out = back;
+        if (alone) return 0;
+        return comm_all_to_all(c, c->hvc, c->back, (size_t)(g.q * g.pw), st);  // consumed by the caller (unpack)
+      }
+      // phonon sectors: the buffers serve the next block, so the down half is added here
+      if (!alone && comm_all_to_all(c, c->hvc, c->back, (size_t)(g.q * g.pw), st)) return 1;
+      if (edigpu_transpose_unpack_add(s->dim_up, g.count, g.q, c->world, g.pcol, g.halo, back, tb, st)) return 1;
     }
-    if (edigpu_normal_apply_rows_dev(s, g.first, g.count, c->vin, c->tmp, st)) return 1;
-    if (!alone) EDIGPU_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
-    if (edigpu_normal_apply_cols_dev(s, g.col_first, g.col_count, g.pw, g.halo, alone ? c->send : c->recv, c->hvc, st))
-      return 1;
-    if (back_out) *back_out = alone ? c->hvc : c->back;
-    if (alone) return 0;
-    return comm_all_to_all(c, c->hvc, c->back, (size_t)(g.q * g.pw), st);  // consumed by the caller (unpack)
+    if (back_out) *back_out = nullptr;
+    return launch_phonon_rows(s, g.first, g.count, c->vin, c->tmp, st);  // local: stored/H_ph.f90, H_e_ph.f90
   }
   const size_t n = (size_t)g.chunk * g.w;
   if (c->world == 1 && !force_collectives(c)) {  // the chunk is the whole vector
@@ -500,12 +522,12 @@ static int sharded_step(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, 
   const double* tpp = it > 1 ? c->hist + 3 * (size_t)(it - 2) : nullptr;
   if (n > 0)
     hipLaunchKernelGGL(ks_rotate3, sh_grid(n, 256 * 16), dim3(kShNT), 0, st, it == 0 ? 1 : 0, n, s->dim_up, g.q, c->world,
-                       g.pcol, g.halo, c->vin, c->vout, tp, tpp, g.transposed ? c->send : nullptr);
+                       g.pcol, g.halo, c->vin, c->vout, tp, tpp, g.transposed && g.nblk == 1 ? c->send : nullptr);
   const double* back = nullptr;
   if (sharded_hv(s, c, g, true, st, &back)) return 1;
   const dim3 gr = sh_grid(std::max<int64_t>(n, 1), kRedBlocks);
   hipLaunchKernelGGL(ks_add_dot3, gr, dim3(kShNT), 0, st, n, s->dim_up, g.q, g.pcol, g.halo, c->vin, c->vout, c->tmp,
-                     g.transposed ? back : nullptr, tp, c->work);
+                     g.transposed ? back : nullptr, tp, c->work);  // back == NULL: phonon blocks, already added
   hipLaunchKernelGGL(ks_sum3, dim3(1), dim3(1024), 0, st, c->work, (int)gr.x, t);
   EDIGPU_HIP(hipGetLastError());
   return comm_all_reduce(c, t, 3, st);
@@ -519,7 +541,7 @@ static int sharded_step_exact(edigpu_sector* s, edigpu_comm_s* c, const ShardGeo
   if (it > 0 && vec_rotate(n, c->vin, c->vout, c->hist + nlanc + it - 1, st)) return 1;
   const double* back = nullptr;
   if (sharded_hv(s, c, g, false, st, &back)) return 1;
-  if (g.transposed &&
+  if (g.transposed && back &&
       edigpu_transpose_unpack_add(s->dim_up, g.count, g.q, c->world, g.pcol, g.halo, back, c->tmp, st))
     return 1;
   if (vec_add_dot(n, c->vin, c->vout, c->tmp, al, c->work, st)) return 1;
@@ -818,7 +840,8 @@ static int apply_sharded(edigpu_handle s, edigpu_comm c, int64_t nloc, const dou
   if (n > 0) EDIGPU_HIP(hipMemcpyAsync(c->vin, v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
   const double* back = nullptr;
   if (sharded_hv(s, c, g, false, st, &back)) return 1;
-  if (g.transposed && edigpu_transpose_unpack_add(s->dim_up, g.count, g.q, c->world, g.pcol, g.halo, back, c->tmp, st))
+  if (g.transposed && back &&
+      edigpu_transpose_unpack_add(s->dim_up, g.count, g.q, c->world, g.pcol, g.halo, back, c->tmp, st))
     return 1;
   if (n > 0) EDIGPU_HIP(hipMemcpyAsync(hv, c->tmp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
   EDIGPU_HIP(hipStreamSynchronize(st));
@@ -879,7 +902,7 @@ int edigpu_lanczos_bench_sharded(edigpu_handle s, edigpu_comm c, int warmup, int
   const auto t1 = std::chrono::steady_clock::now();
   *ms_per_step = std::chrono::duration<double, std::milli>(t1 - t0).count() / steps;
   if (exchange_bytes)
-    *exchange_bytes = g.transposed ? 2 * 8 * (int64_t)(c->world - 1) * g.q * g.pw
+    *exchange_bytes = g.transposed ? 2 * 8 * (int64_t)(c->world - 1) * g.q * g.pw * g.nblk
                                    : 8 * g.chunk * g.w * (int64_t)(c->world - 1);
   return 0;
 }

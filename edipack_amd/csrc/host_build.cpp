@@ -849,6 +849,38 @@ static void flat_physics(const edigpu_model& m, std::vector<OpTerm>& terms, std:
           terms.push_back({4, {b, b + ns, a + ns, a}, {false, false, true, true}, cplx(ix.jp(a, b))});
       }
 
+  // coulomb_sundry (ED_SUPERC/stored/Hint.f90:127-178 == ED_NONSU2/stored/Hint.f90:127-181): U cd_i cd_j c_k c_l applied
+  // right to left as c_l, cd_j, c_k, cd_i on the 2 Ns-level word (ranges checked by check_flat_fields)
+  for (int il = 0; il < m.nsundry; il++) {
+    const int32_t* op = &m.sundry_op[il * 8];
+    if (m.sundry_u[il] == 0.0) continue;
+    auto lev = [&](int k) { return (op[2 * k] - 1) + ns * (op[2 * k + 1] - 1); };
+    terms.push_back({4, {lev(3), lev(1), lev(2), lev(0)}, {false, true, false, true}, cplx(m.sundry_u[il])});
+  }
+  if (m.ed_mode == 2) {
+    // exc_field = (F_0, F_x, F_y, F_z), F.T (ED_NONSU2/stored/Himp.f90:113-228): entries as inserted, no conjugation
+    const double f0 = m.exc_field[0], fx = m.exc_field[1], fy = m.exc_field[2], fz = m.exc_field[3];
+    auto entry = [&](int q, int p, cplx v) {  // c^+_p c_q, value v at (i, j = O|i>)
+      if (v != cplx(0.0)) terms.push_back({2, {q, p, 0, 0}, {false, true, false, false}, v});
+    };
+    if (f0 != 0.0 || fx != 0.0 || fy != 0.0 || fz != 0.0)
+      for (int a = 0; a < norb; a++)
+        for (int b = 0; b < norb; b++) {
+          if (a != b) {
+            entry(b + ns, a + ns, cplx(f0 - fz));
+            entry(b, a, cplx(f0 + fz));
+          }
+          entry(b, a + ns, cplx(fx, -fy));
+          entry(b + ns, a, cplx(fx, fy));
+        }
+    // spin_field(a, x|y|z), F.S (Himp.f90:235-296); the z part goes to the level energies below
+    for (int a = 0; a < norb; a++) {
+      const double sx = m.spin_field[a * 3 + 0], sy = m.spin_field[a * 3 + 1];
+      entry(a, a + ns, cplx(sx, -sy));
+      entry(a + ns, a, cplx(sx, sy));
+    }
+  }
+
   // ---- diagonal pieces ----
   std::vector<double>& eps = eps_out;
   eps.assign(2 * ns, 0.0);
@@ -864,6 +896,12 @@ static void flat_physics(const edigpu_model& m, std::vector<OpTerm>& terms, std:
     }
     eps[a] = ix.hloc(0, 0, a, a).real() + shift;
     eps[a + ns] = ix.hloc(sd, sd, a, a).real() + shift;
+    if (m.ed_mode == 2) {
+      // F_z (n_up - n_dw).  Himp.f90:237-240 adds this to a variable the blocks before it leave set (`htmp = htmp +`
+      // with no reset), i.e. the reference inserts F_z S^z plus a stale value; built here is what its comment states.
+      eps[a] += m.spin_field[a * 3 + 2];
+      eps[a + ns] -= m.spin_field[a * 3 + 2];
+    }
   }
   if (ix.replica()) {
     for (int a = 0; a < norb; a++)
@@ -890,12 +928,27 @@ static void flat_physics(const edigpu_model& m, std::vector<OpTerm>& terms, std:
 
 }
 
-static std::string refuse_normal_only_fields(const edigpu_model& m, const char* who) {
-  // spin_field, exc_field and coulomb_sundry are built for ed_mode = normal only (include/edigpu.h)
-  bool any = m.nsundry != 0;
-  for (double x : m.spin_field) any = any || x != 0.0;
-  for (double x : m.exc_field) any = any || x != 0.0;
-  if (any) return std::string(who) + ": spin_field / exc_field / coulomb_sundry are not built in this mode";
+// coulomb_sundry lines in range and inside the sector family; the superc files of the reference hold no spin_field /
+// exc_field terms (they would be ignored there): refused, so that nobody relies on them
+static std::string check_flat_fields(const edigpu_model& m, const char* who) {
+  if (m.nsundry < 0 || m.nsundry > EDIGPU_MAXSUNDRY) return std::string(who) + ": nsundry out of range";
+  for (int il = 0; il < m.nsundry; il++) {
+    const int32_t* op = &m.sundry_op[il * 8];
+    int dsz = 0;
+    for (int k = 0; k < 4; k++) {
+      const int orb = op[2 * k], sp = op[2 * k + 1];
+      if (orb < 1 || orb > m.norb || sp < 1 || sp > 2) return std::string(who) + ": coulomb_sundry orbital / spin out of range";
+      dsz += (k < 2 ? 1 : -1) * (sp == 1 ? 1 : -1);  // cd_i, cd_j create; c_k, c_l annihilate
+    }
+    if (m.ed_mode == 1 && dsz != 0 && m.sundry_u[il] != 0.0)
+      return std::string(who) + ": coulomb_sundry line changes Sz (the reference stops with 'impossible operator')";
+  }
+  if (m.ed_mode == 1) {
+    bool any = false;
+    for (double x : m.spin_field) any = any || x != 0.0;
+    for (double x : m.exc_field) any = any || x != 0.0;
+    if (any) return std::string(who) + ": spin_field / exc_field have no terms in the superc Hamiltonian";
+  }
   return "";
 }
 
@@ -905,7 +958,7 @@ std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int
   if (!e.empty()) return e;
   if (m.ed_mode != 1 && m.ed_mode != 2) return "edigpu_flat_build: model.ed_mode must be superc or nonsu2";
   if (m.ed_mode == 2 && m.nspin != 2) return "edigpu_flat_build: nonsu2 needs nspin=2";
-  e = refuse_normal_only_fields(m, "edigpu_flat_build");
+  e = check_flat_fields(m, "edigpu_flat_build");
   if (!e.empty()) return e;
   Idx ix(m);
   const int ns = model_ns(m), norb = m.norb;
@@ -972,7 +1025,7 @@ std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int
       for (int k = 0; k < t.n && ok; k++) ok = apply_op(w, t.pos[k], t.create[k], sg);
       if (!ok) continue;
       const int32_t j = (int32_t)sb.rank(w);
-      if (j < 0) return "edigpu_flat_build_jz: the model does not conserve Jz (a matrix element leaves the sector)";
+      if (j < 0) return "edigpu_flat_build: a matrix element leaves the sector (Jz_basis: the model does not conserve Jz)";
       const cplx v = t.coef * sg;
       bool merged = false;
       for (size_t k = 0; k < rc.size(); k++)
@@ -1098,7 +1151,7 @@ std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, i
   if (!e.empty()) return e;
   if (m.ed_mode != 1 && m.ed_mode != 2) return "edigpu_direct_build: model.ed_mode must be superc or nonsu2";
   if (m.ed_mode == 2 && m.nspin != 2) return "edigpu_direct_build: nonsu2 needs nspin=2";
-  e = refuse_normal_only_fields(m, "edigpu_direct_build");
+  e = check_flat_fields(m, "edigpu_direct_build");
   if (!e.empty()) return e;
   Idx ix(m);
   const int ns = model_ns(m), norb = m.norb;
@@ -1127,17 +1180,28 @@ std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, i
   out.terms.clear();
   for (const OpTerm& t : terms) {
     DirectTerm d{};
-    uint32_t flipped = 0;
+    uint32_t flipped = 0, touched = 0;
     int cs = 0;
-    for (int k = 0; k < t.n; k++) {
+    bool zero = false;
+    for (int k = 0; k < t.n && !zero; k++) {
       const uint32_t b = 1u << t.pos[k];
-      if (flipped & b) return "edigpu_direct_build: operator string touches a level twice";
-      if (t.create[k]) d.need_clear |= b; else d.need_set |= b;
+      if (touched & b) {
+        // a level met again (coulomb_sundry lines such as n_i c^+_j c_k): its occupation is known from the operators
+        // before -- set iff (it had to be set) xor (it has been flipped)
+        const bool occ = ((d.need_set & b) != 0) != ((flipped & b) != 0);
+        if (occ == t.create[k]) zero = true;  // c^+ on a filled / c on an empty level: the line is identically zero
+      } else if (t.create[k]) {
+        d.need_clear |= b;
+      } else {
+        d.need_set |= b;
+      }
+      touched |= b;
       // popc((s ^ flipped) & below) = popc(s & below) + popc(flipped & below)  (mod 2)
       d.sign_mask ^= (b - 1u);
       cs ^= popc(flipped & (b - 1u)) & 1;
-      flipped |= b;
+      flipped ^= b;
     }
+    if (zero) continue;
     d.flip = flipped;
     d.csign = cs;
     d.cre = t.coef.real();
@@ -1153,8 +1217,8 @@ std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, i
     auto delta = [](const DirectTerm& t) {
       int64_t d = 0;
       for (int b = 0; b < 32; b++) {
-        if ((t.need_clear >> b) & 1u) d += (int64_t)1 << b;
-        if ((t.need_set >> b) & 1u) d -= (int64_t)1 << b;
+        if ((t.flip & t.need_clear) >> b & 1u) d += (int64_t)1 << b;
+        if ((t.flip & t.need_set) >> b & 1u) d -= (int64_t)1 << b;
       }
       return d;
     };

@@ -23,6 +23,7 @@ int launch_normal(const edigpu_sector* s, const double* v_local, const double* v
 int normal_pick_rows_per_block(int64_t dim_up, int64_t dw_count);
 // transposed exchange: the row half and the column half of the product on a whole-sector handle
 bool normal_transposable(const edigpu_sector* s);
+bool normal_transposable_el(const edigpu_sector* s);  // ignoring the phonon blocks
 int launch_normal_rows(const edigpu_sector* s, int64_t dw_first, int64_t dw_count, const double* v_rows,
                        double* hv_rows, hipStream_t st);
 int launch_normal_cols(const edigpu_sector* s, int64_t col_first, int64_t ncol, int64_t stride, int halo,
@@ -125,6 +126,10 @@ int launch_apply_op_normal(int64_t dst_dimup, int64_t dst_dimdw, int64_t src_dim
                            int accumulate = 0);
 
 int launch_phonon(const edigpu_sector* s, const double* v, double* hv, hipStream_t st);
+// the same pass on a shard of down rows [dw_first, dw_first + dw_count) of a normal-mode sector: (Nph + 1) blocks of
+// dw_count * DimUp elements (the layout of spMatVec_mpi_normal_main); density couplings only
+int launch_phonon_rows(const edigpu_sector* s, int64_t dw_first, int64_t dw_count, const double* v, double* hv,
+                       hipStream_t st);
 int launch_apply_op_flat(int64_t ndst, int ns, uint32_t bit, int create, const int32_t* dst_states,
                          const int32_t* src_offdw, const int32_t* src_rkup, const double* src, double* dst,
                          hipStream_t st);

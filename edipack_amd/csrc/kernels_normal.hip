@@ -593,12 +593,15 @@ int launch_normal(const edigpu_sector* s, const double* v_local, const double* v
 //         hold those rows (row stride DimUp)
 //   cols: hv_cols = (Hdw (x) 1 + Hnd) v for the up columns [col_first, col_first + ncol) of all rows, buffers
 //         with halo columns on both sides (launch_dw_panel_cols)
-bool normal_transposable(const edigpu_sector* s) {
-  if (s->kind != 0 || s->nloc != s->dim || s->dw_count == 0 || s->nph > 0) return false;
+// the electronic part of the handle can run as a row half + a column half (phonon blocks: one exchange per block)
+bool normal_transposable_el(const edigpu_sector* s) {
+  if (s->kind != 0 || s->nloc != s->dim || s->dw_count == 0) return false;
   if (!s->factored && s->has_nd) return false;  // explicit spH0nd couples arbitrary columns: all-gather form only
   if (s->factored && s->fac_nterms > 0 && s->d_mx_rowptr == nullptr) return false;
   return true;
 }
+
+bool normal_transposable(const edigpu_sector* s) { return s->nph == 0 && normal_transposable_el(s); }
 
 int launch_normal_rows(const edigpu_sector* s, int64_t dw_first, int64_t dw_count, const double* v_rows,
                        double* hv_rows, hipStream_t st) {

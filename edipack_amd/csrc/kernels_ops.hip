@@ -253,6 +253,18 @@ int launch_phonon(const edigpu_sector* s, const double* v, double* hv, hipStream
   return 0;
 }
 
+int launch_phonon_rows(const edigpu_sector* s, int64_t dw_first, int64_t dw_count, const double* v, double* hv,
+                       hipStream_t st) {
+  const int64_t blk = dw_count * s->dim_up, n = blk * (s->nph + 1);
+  if (n <= 0) return 0;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 256 * 16) nb = 256 * 16;
+  hipLaunchKernelGGL(phonon_kernel, dim3((unsigned)nb), dim3(256), 0, st, blk, s->nph + 1, s->dim_up, s->w0_ph, s->a_ph,
+                     s->d_gu, s->d_gd + dw_first, v, hv);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_apply_op_normal(int64_t dst_dimup, int64_t dst_dimdw, int64_t src_dimup, int spin_down,
                            const uint32_t* part, const double* src, double* dst, hipStream_t st, double coef,
                            int accumulate) {

@@ -645,12 +645,14 @@ def library_sharded_sector(model, sector, comm: LibraryComm, direct: bool = Fals
         first, count, _ = comm.plan(d_dw.value)
         if cmplx:       # _CMPLX_NORMAL: whole sector, served through its doubled real sector (transposed exchange)
             return SectorHamiltonian.normal_cmplx_from_model(model, nup, ndw), first, count
+        if model.nph > 0:   # phonon blocks: whole sector, every block through the transposed exchange (density couplings)
+            return SectorHamiltonian.normal_from_model(model, nup, ndw), first, count
         if exchange != "allgather":
             h = SectorHamiltonian.normal_from_model(model, nup, ndw)
             try:
                 h.transpose_halo()
                 return h, first, count
-            except capi.EdigpuError:      # explicit spH0nd, phonons: all-gather form
+            except capi.EdigpuError:      # explicit spH0nd: all-gather form
                 h.destroy()
         return SectorHamiltonian.normal_from_model(model, nup, ndw, dw_first=first, dw_count=count), first, count
     dim = C.c_int64()

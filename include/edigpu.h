@@ -482,6 +482,11 @@ int edigpu_comm_destroy(edigpu_comm c);
  * inside.  Assigned to spHtimesV_p / spHtimesV_cc in a -D_MPI build (fortran/edigpu_shim.f90).
  * A complex normal-mode handle (edigpu_normal_build_z, whole sector on every rank) is served through its doubled real
  * sector with the transposed exchange: nloc = this rank's down rows * DimUp complex elements.
+ * A normal-mode phonon handle (nph > 0, whole sector on every rank, density couplings g_ph(a,a)): the shard is
+ * (Nph + 1) blocks of this rank's down rows, i = iup + idw_local * DimUp + iph * DimUp * count, the layout of
+ * spMatVec_mpi_normal_main (ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:820-904); every block goes through the
+ * exchange on its own, the phonon and electron-phonon terms are local.  A general g_ph(a,b) and the superc / nonsu2
+ * phonon sectors are refused here (one GPU).
  */
 int edigpu_apply_sharded_d(edigpu_handle h, edigpu_comm c, int64_t nloc, const double *v_shard_host,
                            double *hv_shard_host);

@@ -2,6 +2,7 @@
 // from (a) the explicit arrays (hd, Hup, Hdw, Hnd CSR) and (b) the factored tables the kernels consume (eux / ed /
 // impd, partner tables jup / jdw / coef), so that the CPU suite can compare the builders with the oracle without a
 // GPU.  Compiled with g++ by tests/test_host_builders.py; never part of the product.
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -62,6 +63,33 @@ extern "C" int host_flat_dense(const edigpu_model* m, int sector, double* out, i
       out[2 * (i * dim + hf.h.col[k])] += hf.h.val[2 * k];
       out[2 * (i * dim + hf.h.col[k]) + 1] += hf.h.val[2 * k + 1];
     }
+  return 0;
+}
+
+// the on-the-fly image (term list + diagonal tables of build_direct) evaluated the way direct_rows_kernel does
+extern "C" int host_direct_dense(const edigpu_model* m, int sector, double* out, int64_t dim) {
+  HostDirect hd;
+  g_err = build_direct(*m, sector, 0, -1, hd);
+  if (!g_err.empty()) return 1;
+  if (hd.dim != dim) { g_err = "host_direct_dense: dim mismatch"; return 2; }
+  std::memset(out, 0, sizeof(double) * 2 * dim * dim);
+  const uint32_t impmask = (1u << hd.norb) - 1u;
+  for (int64_t i = 0; i < dim; i++) {
+    const uint32_t s = (uint32_t)hd.states[i];
+    double dg = hd.xtab[(((s >> hd.ns) & impmask) << hd.norb) | (s & impmask)];
+    for (int byte = 0; byte < 4; byte++) dg += hd.dtab[byte * 256 + ((s >> (8 * byte)) & 255u)];
+    out[2 * (i * dim + i)] += dg;
+    for (const DirectTerm& t : hd.terms) {
+      if ((s & t.need_set) != t.need_set || (s & t.need_clear) != 0) continue;
+      const uint32_t w = s ^ t.flip;
+      const auto it = std::lower_bound(hd.states.begin(), hd.states.end(), (int32_t)w);
+      if (it == hd.states.end() || (uint32_t)*it != w) { g_err = "host_direct_dense: term leaves the sector"; return 3; }
+      const int64_t j = it - hd.states.begin();
+      const double sg = ((__builtin_popcount(s & t.sign_mask) + t.csign) & 1) ? -1.0 : 1.0;
+      out[2 * (i * dim + j)] += sg * t.cre;
+      out[2 * (i * dim + j) + 1] += sg * t.cim;
+    }
+  }
   return 0;
 }
 

@@ -24,12 +24,17 @@ CASES = [
     ("superc", "hybrid", 2, 3, 0, False, "auto"),            # stored flat CSR, loc / non-loc blocks
     ("nonsu2", "hybrid", 2, 3, 5, True, "auto"),             # on-the-fly kernel: gather first
     ("normal", "hybrid", 3, 2, (3, 2), False, "cmplx"),      # _CMPLX_NORMAL through its doubled real sector
+    ("normal", "normal", 2, 2, (3, 2), False, "phonon"),     # (Nph + 1) blocks, one exchange per block, local phonon pass
 ]
+NPH = 3
 
 
-def _reference(mode, bath, norb, nbath, sector, seed=31, cmplx=False):
+def _reference(mode, bath, norb, nbath, sector, seed=31, cmplx=False, phonon=False):
     from oracle import oracle as O
     om, pm = make_models(mode, bath, norb, nbath, seed=seed)
+    if phonon:
+        for m in (om, pm):
+            m.nph, m.w0_ph, m.a_ph, m.g_ph = NPH, 0.8, 0.15, np.diag([0.4, -0.3][:norb])
     if cmplx:
         from tests.test_gpu_parity import _complexify
         _complexify(om, pm, seed + 1)
@@ -43,6 +48,16 @@ def _reference(mode, bath, norb, nbath, sector, seed=31, cmplx=False):
     return ho, pm, v
 
 
+def _shard_index(ho, mode, first, count, phonon):
+    """Global indices of a rank's shard in the order the reference holds them (phonon sectors: block after block of the
+    rank's down rows, spMatVec_mpi_normal_main's i = iup + (idw-1) DimUp + (iph-1) DimUp MpiQdw)."""
+    ul = ho.dimup if mode == "normal" else 1
+    base = np.arange(first * ul, (first + count) * ul)
+    if not phonon:
+        return base
+    return np.concatenate([b * ho.dim_el + base for b in range(NPH + 1)])
+
+
 def _rank_main(rank, world, name, case, q):
     try:
         import torch  # noqa: F401  (one HIP runtime per process)
@@ -50,17 +65,16 @@ def _rank_main(rank, world, name, case, q):
         from edipack_amd.sharding import LibraryComm, library_sharded_sector
         capi.init(0)
         mode, bath, norb, nbath, sector, direct, exchange = case
-        ho, pm, v = _reference(mode, bath, norb, nbath, sector, cmplx=exchange == "cmplx")
+        ho, pm, v = _reference(mode, bath, norb, nbath, sector, cmplx=exchange == "cmplx", phonon=exchange == "phonon")
         comm = LibraryComm(rank, world, shm_name=name, slot_bytes=1 << 22)
         h, first, count = library_sharded_sector(pm, sector, comm, direct=direct, exchange=exchange,
                                                  cmplx=exchange == "cmplx")
-        ul = ho.dimup if mode == "normal" else 1
-        sl = slice(first * ul, (first + count) * ul)
-        hv = comm.apply(h, v[sl])
-        a, b, nd, n2 = comm.tridiag(h, v[sl], 20)
+        ix = _shard_index(ho, mode, first, count, exchange == "phonon")
+        hv = comm.apply(h, v[ix])
+        a, b, nd, n2 = comm.tridiag(h, v[ix], 20)
         h.destroy()
         comm.destroy()
-        q.put((rank, sl.start, sl.stop, hv, a, b, nd, n2, None))
+        q.put((rank, ix, None, hv, a, b, nd, n2, None))
     except Exception as e:  # pragma: no cover
         import traceback
         q.put((rank, 0, 0, None, None, None, 0, 0.0, traceback.format_exc() + str(e)))
@@ -70,7 +84,7 @@ def _rank_main(rank, world, name, case, q):
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_library_shards_share_one_gpu(gpu, world, case):
     mode, bath, norb, nbath, sector, direct, exchange = case
-    ho, _, v = _reference(mode, bath, norb, nbath, sector, cmplx=exchange == "cmplx")
+    ho, _, v = _reference(mode, bath, norb, nbath, sector, cmplx=exchange == "cmplx", phonon=exchange == "phonon")
     ref = ho.matvec(v)
     a_ref, b_ref, _ = ho.lanc_tridiag(v, 20)
     ctx = mp.get_context("spawn")
@@ -85,8 +99,8 @@ def test_library_shards_share_one_gpu(gpu, world, case):
     for r in res:
         assert r[8] is None, r[8]
     got = np.zeros_like(ref)
-    for rank, lo, hi, hv, a, b, nd, n2, _ in res:
-        got[lo:hi] = hv
+    for rank, ix, _, hv, a, b, nd, n2, _ in res:
+        got[ix] = hv
         assert nd == 20 and abs(n2 - np.real(np.vdot(v, v))) < 1e-10 * abs(n2)
         assert rel_err(a, a_ref) < 1e-10 and rel_err(b, b_ref) < 1e-10      # every rank holds the same coefficients
     assert rel_err(got, ref) < 1e-12
@@ -104,9 +118,9 @@ def test_library_comm_rccl_world_of_one(gpu, monkeypatch, force):
     uid = LibraryComm.unique_id()
     assert len(uid) == 128
     comm = LibraryComm(0, 1, unique_id=uid)
-    for case in CASES[:1] + CASES[3:4]:
+    for case in CASES[:1] + CASES[3:4] + CASES[-1:]:
         mode, bath, norb, nbath, sector, direct, exchange = case
-        ho, pm, v = _reference(mode, bath, norb, nbath, sector)
+        ho, pm, v = _reference(mode, bath, norb, nbath, sector, phonon=exchange == "phonon")
         h, first, count = library_sharded_sector(pm, sector, comm, direct=direct, exchange=exchange)
         assert (first, count) == (0, ho.dimdw if mode == "normal" else ho.dim)
         assert rel_err(comm.apply(h, v), ho.matvec(v)) < 1e-12
@@ -137,4 +151,11 @@ def test_library_shard_error_paths(gpu):
     h.destroy()
     with pytest.raises(capi.EdigpuError):
         LibraryComm(2, 2, shm_name="edigpu_bad")                                # rank outside the world
+    # a general g_ph(a,b) couples electronic states across rows: such phonon sectors stay on one GPU
+    _, pm, _ = _reference("normal", "normal", 2, 2, (3, 2), phonon=True)
+    pm.g_ph = np.array([[0.4, 0.2], [0.2, -0.3]])
+    h = SectorHamiltonian.normal_from_model(pm, 3, 2)
+    with pytest.raises(capi.EdigpuError, match="density couplings"):
+        comm.apply(h, np.zeros(h.dim))
+    h.destroy()
     comm.destroy()

@@ -1775,15 +1775,55 @@ def test_normal_sundry_shards(gpu, world):
     assert got.shape == ref.shape and rel_err(got, ref) < TOL
 
 
-def test_flat_modes_refuse_normal_only_fields(gpu):
+_SUNDRY_FLIP = [(0.2, (0, 0), (1, 0), (1, 1), (0, 0)), (0.2, (0, 0), (1, 1), (1, 0), (0, 0))]   # nonsu2: Sz not conserved
+
+
+@pytest.mark.parametrize("mode,bath,norb,nbath,sec,extra", [
+    ("superc", "hybrid", 3, 2, 0, dict(sundry=_SUNDRY3)),
+    ("superc", "replica", 2, 3, -1, dict(sundry=_SUNDRY2)),
+    ("nonsu2", "hybrid", 3, 2, 5, dict(sundry=_SUNDRY3 + _SUNDRY_FLIP)),
+    ("nonsu2", "normal", 2, 3, 7, dict(exc_field=np.array([0.12, 0.3, -0.2, 0.07]),
+                                       spin_field=np.array([[0.3, 0.1, 0.2], [0.0, -0.25, -0.15]]))),
+    ("nonsu2", "replica", 2, 2, 5, dict(exc_field=np.array([0.1, 0.2, 0.0, -0.2]), sundry=_SUNDRY2 + _SUNDRY_FLIP,
+                                        spin_field=np.array([[0.0, 0.4, 0.1], [0.2, 0.0, 0.2]]))),
+])
+@pytest.mark.parametrize("form", ["stored", "direct", "hostbuild"])
+def test_flat_sundry_and_fields_match_oracle(gpu, monkeypatch, form, mode, bath, norb, nbath, sec, extra):
+    """coulomb_sundry in the superc / nonsu2 Hamiltonians (stored/Hint.f90:127-181: lines that meet a level twice, lines
+    that flip a spin) and exc_field / spin_field in nonsu2 (stored/Himp.f90:113-296): the stored image built on the
+    device and on the host, and the on-the-fly kernel, against the oracle."""
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models(mode, bath, norb, nbath, seed=37, **extra)
+    ho = O.HFlat(om, sec)
+    if form == "hostbuild":
+        monkeypatch.setenv("EDIGPU_FLAT_HOSTBUILD", "1")
+    hg = (SectorHamiltonian.direct_from_model if form == "direct" else SectorHamiltonian.flat_from_model)(pm, sec)
+    assert hg.dim == ho.dim
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(ho.dim) + 1j * rng.standard_normal(ho.dim)
+    ref = ho.matvec(v)
+    om0, _ = make_models(mode, bath, norb, nbath, seed=37)
+    assert rel_err(O.HFlat(om0, sec).matvec(v), ref) > 1e-3           # the switches do something
+    assert rel_err(hg.apply(v), ref) < TOL
+    ao, bo, _ = ho.lanc_tridiag(v, 15)
+    ag, bg, _ = hg.lanczos_tridiag(v, 15)
+    assert rel_err(ag[:10], ao[:10]) < 1e-9 and rel_err(bg[:10], bo[:10]) < 1e-9
+    hg.destroy()
+
+
+def test_flat_modes_field_refusals(gpu):
+    """superc: no spin_field / exc_field terms in the reference's files, and a coulomb_sundry line that changes Sz
+    stops it ("impossible operator")."""
     from edipack_amd import capi
     from edipack_amd.hamiltonian import SectorHamiltonian
-    for mode, sec in (("superc", 0), ("nonsu2", 3)):
-        _, pm = make_models(mode, "normal", 2, 1, seed=1, sundry=_SUNDRY2)
-        with pytest.raises(capi.EdigpuError, match="not built in this mode"):
-            SectorHamiltonian.flat_from_model(pm, sec)
-        with pytest.raises(capi.EdigpuError, match="not built in this mode"):
-            SectorHamiltonian.direct_from_model(pm, sec)
+    for extra, msg in ((dict(sundry=_SUNDRY_FLIP), "changes Sz"),
+                       (dict(spin_field=np.array([[0, 0, 0.1], [0, 0, 0.0]])), "no terms in the superc")):
+        _, pm = make_models("superc", "normal", 2, 1, seed=1, **extra)
+        with pytest.raises(capi.EdigpuError, match=msg):
+            SectorHamiltonian.flat_from_model(pm, 0)
+        with pytest.raises(capi.EdigpuError, match=msg):
+            SectorHamiltonian.direct_from_model(pm, 0)
 
 
 # --------------------------------------------------------------------------------------------

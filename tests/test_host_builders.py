@@ -92,20 +92,59 @@ def test_sundry_lines_that_flip_a_spin_are_refused(shim):
     assert rc == 1 and "out of range" in shim.host_image_error().decode()
 
 
-@pytest.mark.parametrize("mode", ["superc", "nonsu2"])
-def test_flat_builders_refuse_normal_only_fields(shim, mode):
-    """The superc / nonsu2 builders (and the oracle's) do not restate these terms: they must say so, not drop them."""
-    for extra in (dict(sundry=SUNDRY2), dict(spin_field=np.array([[0, 0, 0.1], [0, 0, 0.0]])),
-                  dict(exc_field=np.array([0.1, 0, 0, 0]))):
-        om, pm = make_models(mode, "normal", 2, 1, seed=1, **extra)
+# a spin-flipping line and its conjugate (nonsu2 only: N is conserved, Sz is not)
+SUNDRY_FLIP = [(0.2, (0, 0), (1, 0), (1, 1), (0, 0)), (0.2, (0, 0), (1, 1), (1, 0), (0, 0))]
+FLAT_CASES = [
+    # mode, bath, norb, nbath, sector, extra
+    ("superc", "hybrid", 3, 1, 0, dict(sundry=SUNDRY3)),
+    ("superc", "normal", 2, 2, 1, dict(sundry=SUNDRY2)),
+    ("superc", "replica", 2, 2, -1, dict(sundry=SUNDRY2)),
+    ("nonsu2", "hybrid", 3, 1, 4, dict(sundry=SUNDRY3)),
+    ("nonsu2", "normal", 2, 2, 5, dict(sundry=SUNDRY2 + SUNDRY_FLIP)),
+    ("nonsu2", "normal", 2, 2, 6, dict(exc_field=np.array([0.12, 0.3, -0.2, 0.07]))),
+    ("nonsu2", "hybrid", 3, 1, 4, dict(spin_field=np.array([[0.3, 0.1, 0.2], [0.0, -0.25, -0.15], [0.05, 0.0, 0.0]]))),
+    ("nonsu2", "replica", 2, 2, 5, dict(exc_field=np.array([0.1, 0.2, 0.0, -0.2]), sundry=SUNDRY2 + SUNDRY_FLIP,
+                                        spin_field=np.array([[0.0, 0.4, 0.1], [0.2, 0.0, 0.2]]))),
+]
+
+
+@pytest.mark.parametrize("mode,bath,norb,nbath,sec,extra", FLAT_CASES)
+def test_flat_builder_images_equal_oracle(shim, mode, bath, norb, nbath, sec, extra):
+    """coulomb_sundry in both flat modes (Hint.f90:127-181), exc_field / spin_field in nonsu2 (Himp.f90:113-296): the
+    stored rows and the on-the-fly term list (levels met twice included) against the oracle's matrix."""
+    om, pm = make_models(mode, bath, norb, nbath, seed=5, **extra)
+    h = O.HFlat(om, sec)
+    ref = h.dense()
+    assert np.abs(ref - ref.conj().T).max() < 1e-14
+    om0, _ = make_models(mode, bath, norb, nbath, seed=5)
+    assert np.abs(ref - O.HFlat(om0, sec).dense()).max() > 1e-3           # the switch does something
+    m = pm.to_c()
+    for fn in (shim.host_flat_dense, shim.host_direct_dense):
+        out = np.zeros((h.dim, h.dim), dtype=np.complex128)
+        rc = fn(C.byref(m), sec, out.ctypes.data_as(C.c_void_p), C.c_int64(h.dim))
+        assert rc == 0, shim.host_image_error().decode()
+        assert np.abs(out - ref).max() < 1e-13, np.abs(out - ref).max()
+
+
+def test_flat_builders_refusals(shim):
+    """superc: the reference's files hold no spin_field / exc_field terms, and a coulomb_sundry line that changes Sz
+    STOPs there ("impossible operator"): both are errors here, in the builders and in the oracle."""
+    buf = np.zeros(8)
+    for extra, msg in ((dict(spin_field=np.array([[0, 0, 0.1], [0, 0, 0.0]])), "no terms in the superc"),
+                       (dict(exc_field=np.array([0.1, 0, 0, 0])), "no terms in the superc"),
+                       (dict(sundry=SUNDRY_FLIP), "changes Sz")):
+        om, pm = make_models("superc", "normal", 2, 1, seed=1, **extra)
         m = pm.to_c()
-        sec = 0 if mode == "superc" else 4
-        buf = np.zeros(8)
-        assert shim.host_flat_dense(C.byref(m), sec, buf.ctypes.data_as(C.c_void_p), C.c_int64(1)) == 1
-        assert "not built in this mode" in shim.host_image_error().decode()
-        assert shim.host_direct_refuses(C.byref(m), sec) == 1
-        with pytest.raises(Exception):
-            O.HFlat(om, sec)
+        assert shim.host_flat_dense(C.byref(m), 0, buf.ctypes.data_as(C.c_void_p), C.c_int64(1)) == 1
+        assert msg in shim.host_image_error().decode()
+        assert shim.host_direct_refuses(C.byref(m), 0) == 1
+        if "sundry" not in extra:           # (the oracle aborts like the reference on a line that leaves the sector)
+            with pytest.raises(Exception):
+                O.HFlat(om, 0)
+    _, pm = make_models("nonsu2", "normal", 2, 1, seed=1, sundry=[(0.3, (0, 0), (2, 1), (1, 1), (0, 0))])
+    m = pm.to_c()
+    assert shim.host_flat_dense(C.byref(m), 3, buf.ctypes.data_as(C.c_void_p), C.c_int64(1)) == 1
+    assert "out of range" in shim.host_image_error().decode()
 
 
 def test_model_struct_sizes_agree(shim):
