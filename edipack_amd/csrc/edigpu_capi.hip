@@ -961,8 +961,9 @@ static int apply_any(edigpu_sector* s, const double* v_local, const double* v_fu
   if (s->kind == 0) return launch_normal(s, v_local, v_full, hv, phase, st);
   if ((s->kind == 1 || s->kind == 2) && s->nph > 0) {
     // phonon branches of the superc / nonsu2 products: electronic product per phonon block, then the phonon pass
-    if (phase != 3) {
-      set_error("phonon sectors are single-shard: use the fused product");
+    if (phase != 3 || s->nloc != s->dim) {
+      set_error("phonon sectors: whole sectors take the fused product, row shards edigpu_apply_sharded_* / "
+                "edigpu_lanczos_tridiag_sharded");
       return 1;
     }
     for (int iph = 0; iph <= s->nph; iph++) {
@@ -1000,6 +1001,17 @@ static int apply_any(edigpu_sector* s, const double* v_local, const double* v_fu
     if (launch_csr(s->nonloc, s->is_complex, v_full, hv, 1, st)) return 1;
   }
   return 0;
+}
+
+// One electronic block of a superc / nonsu2 phonon handle (the sharded product: edigpu_shard.hip): phase 1 = the part
+// that needs the rows' own elements only, phase 2 = the part that needs the gathered block
+int apply_flat_block(edigpu_sector* s, const double* v_local, const double* v_full, double* hv, int phase, hipStream_t st) {
+  if (s->kind == 2) {
+    if (phase == 1) return launch_zero(hv, s->dim_el * 2, st);
+    return launch_direct(s, v_full, hv, st);
+  }
+  if (phase == 1) return launch_csr(s->loc, s->is_complex, v_local, hv, 0, st);
+  return launch_csr(s->nonloc, s->is_complex, v_full, hv, 1, st);
 }
 
 // general g_ph(a,b): t = O v[jph] with the electron-phonon operator as its own sector handle (sub_a), then
@@ -1525,18 +1537,20 @@ int edigpu_normal_build_z(edigpu_handle* h, const edigpu_model* model, int nup, 
   return 0;
 }
 
-// phonon branches for a library-built superc / nonsu2 handle holding a whole sector: g_el per row from the map
+// phonon branches for a library-built superc / nonsu2 handle: g_el per row from the map of the rows it holds.  A row
+// shard holds the same rows of every phonon block (dim_el = its electronic rows, the local block stride; the layout
+// of spMatVec_mpi_superc_main / _nonsu2_main, i = i_el + (iph - 1) * MpiQ) and serves the sharded library calls only.
 static int attach_phonons_flat(edigpu_sector* s, const edigpu_model& m, const std::vector<int32_t>& states, int ns) {
   if (m.nph <= 0) return 0;
-  if (s->nloc != s->dim) {
-    set_error("phonons (nph > 0) need the whole sector on one shard");
-    return 1;
-  }
   if (s->dim * (m.nph + 1) >= ((int64_t)1 << 31)) {
     set_error("sector dimension x (Nph+1) >= 2^31");
     return 1;
   }
   const bool offd = eph_offdiagonal(m);
+  if (offd && s->nloc != s->dim) {
+    set_error("phonons with a general g_ph(a,b) need the whole sector on one shard (density couplings shard)");
+    return 1;
+  }
   if (offd) {
     // general g_ab: the electron-phonon operator as a sector handle of the same kind (apply_eph_operator)
     const edigpu_model om = eph_operator_model(m);
@@ -1556,9 +1570,9 @@ static int attach_phonons_flat(edigpu_sector* s, const edigpu_model& m, const st
   s->nph = m.nph;
   s->w0_ph = m.w0_ph;
   s->a_ph = m.a_ph;
-  s->dim_el = s->dim;
+  s->dim_el = s->nloc;
   s->dim *= (m.nph + 1);
-  s->nloc = s->dim;
+  s->nloc *= (m.nph + 1);
   return 0;
 }
 

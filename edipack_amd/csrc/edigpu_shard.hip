@@ -388,12 +388,12 @@ struct ShardGeom {
 static int shard_geometry(const edigpu_sector* s, const edigpu_comm_s* c, ShardGeom& g) {
   g.w = s->is_complex ? 2 : 1;
   g.transposed = s->kind == 0 && s->nloc == s->dim && normal_transposable_el(s);
-  g.nblk = s->kind == 0 && s->nph > 0 ? s->nph + 1 : 1;
+  g.nblk = s->nph > 0 ? s->nph + 1 : 1;
   if (s->kind == 0) {
     g.units = s->dim_dw;
     g.unit_len = s->dim_up;
   } else {
-    g.units = s->dim;
+    g.units = s->dim / g.nblk;  // electronic rows: every phonon block is sharded alike
     g.unit_len = 1;
   }
   g.q = (g.units + c->world - 1) / c->world;
@@ -411,11 +411,13 @@ static int shard_geometry(const edigpu_sector* s, const edigpu_comm_s* c, ShardG
     g.xlen = (int64_t)c->world * g.q * g.pw;
     if (g.pcol < 1 || g.halo > g.pcol) g.transposed = false;  // blocks narrower than the halo: all-gather form
   }
-  if (g.nblk > 1 && (!g.transposed || s->sub_a)) {
-    // like spMatVec_mpi_normal_main (ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:841-904): every phonon block is exchanged on
-    // its own and the phonon / electron-phonon pass is local, which holds for density couplings only
-    set_error("sharded call: phonon sectors shard through the transposed exchange (whole normal-mode sector, factored "
-              "Hnd, at least `halo` up columns per rank) with density couplings g_ph(a,a) only");
+  if (g.nblk > 1 && (s->sub_a || (s->kind == 0 && !g.transposed))) {
+    // like spMatVec_mpi_normal_main (ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:841-904) and spMatVec_mpi_superc_main /
+    // _nonsu2_main: every phonon block is exchanged on its own and the phonon / electron-phonon pass is local, which
+    // holds for density couplings only
+    set_error("sharded call: phonon sectors shard with density couplings g_ph(a,a) only; normal mode through the "
+              "transposed exchange (whole sector, factored Hnd, at least `halo` up columns per rank), superc / nonsu2 "
+              "as row shards");
     return 1;
   }
   if (!g.transposed) {
@@ -425,8 +427,8 @@ static int shard_geometry(const edigpu_sector* s, const edigpu_comm_s* c, ShardG
                 "edigpu_shard_plan, or -- normal mode -- build the whole sector for the transposed exchange)");
       return 1;
     }
-    if (s->nph > 0 || s->kind == 4) {
-      set_error("sharded call: superc / nonsu2 phonon sectors and four-product complex sectors are single-shard");
+    if (s->kind == 4) {
+      set_error("sharded call: four-product complex sectors are single-shard");
       return 1;
     }
   }
@@ -499,6 +501,26 @@ static int sharded_hv(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, bo
     }
     if (back_out) *back_out = nullptr;
     return launch_phonon_rows(s, g.first, g.count, c->vin, c->tmp, st);  // local: stored/H_ph.f90, H_e_ph.f90
+  }
+  if (g.nblk > 1) {
+    // superc / nonsu2 phonon shards: one all-gather per phonon block beside that block's local part, then the phonon
+    // and electron-phonon terms on the rows held here (stored/H_ph.f90, H_e_ph.f90: density couplings)
+    const bool alone = c->world == 1 && !force_collectives(c);
+    const size_t nq = (size_t)g.q * g.unit_len * g.w;  // doubles per rank and block (padded; tails are never addressed)
+    for (int b = 0; b < g.nblk; b++) {
+      const double* vb = c->vin + (size_t)b * g.blk * g.w;
+      double* tb = c->tmp + (size_t)b * g.blk * g.w;
+      if (!alone) {
+        EDIGPU_HIP(hipEventRecord(c->ev_ready, st));
+        EDIGPU_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
+        if (comm_all_gather(c, vb, c->vfull, nq, c->side)) return 1;
+        EDIGPU_HIP(hipEventRecord(c->ev_done, c->side));
+      }
+      if (apply_flat_block(s, vb, nullptr, tb, 1, st)) return 1;
+      if (!alone) EDIGPU_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
+      if (apply_flat_block(s, nullptr, alone ? vb : c->vfull, tb, 2, st)) return 1;
+    }
+    return launch_phonon(s, c->vin, c->tmp, st);
   }
   const size_t n = (size_t)g.chunk * g.w;
   if (c->world == 1 && !force_collectives(c)) {  // the chunk is the whole vector

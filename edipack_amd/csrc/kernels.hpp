@@ -125,6 +125,8 @@ int launch_apply_op_normal(int64_t dst_dimup, int64_t dst_dimdw, int64_t src_dim
                            const uint32_t* part, const double* src, double* dst, hipStream_t st, double coef = 1.0,
                            int accumulate = 0);
 
+// one electronic block of a superc / nonsu2 phonon handle, phase 1 (own rows) / 2 (gathered block)  (edigpu_capi.hip)
+int apply_flat_block(edigpu_sector* s, const double* v_local, const double* v_full, double* hv, int phase, hipStream_t st);
 int launch_phonon(const edigpu_sector* s, const double* v, double* hv, hipStream_t st);
 // the same pass on a shard of down rows [dw_first, dw_first + dw_count) of a normal-mode sector: (Nph + 1) blocks of
 // dw_count * DimUp elements (the layout of spMatVec_mpi_normal_main); density couplings only

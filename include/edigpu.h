@@ -138,21 +138,30 @@ typedef struct edigpu_model {
   /* phonons, all modes (ED_INPUT_VARS.f90:184-198; ED_NORMAL/stored/H_ph.f90, H_e_ph.f90): nph = phonon cut-off
    * Nph (DimPh = Nph + 1; 0 = no phonons), w0_ph, a_ph, g_ph[iorb][jorb] (real symmetric; density couplings g_aa
    * run inside the phonon pass, a general matrix -- GPHFILE in the reference -- as one extra product per phonon block
-   * with the operator sum_ab g_ab sum_s c+_as c_bs held as its own sector).  With nph > 0 edigpu_normal_build / edigpu_flat_build / edigpu_direct_build make a handle whose vectors
-   * have dim_el * (Nph + 1) elements, index i_el + iph * dim_el (whole sectors only). */
+   * with the operator sum_ab g_ab sum_s c+_as c_bs held as its own sector).  With nph > 0 edigpu_normal_build /
+   * edigpu_flat_build / edigpu_direct_build make a handle whose vectors have dim_el * (Nph + 1) elements, index
+   * i_el + iph * dim_el.  Whole sectors serve every entry point; with density couplings edigpu_flat_build /
+   * edigpu_direct_build also make row shards (the same rows of every phonon block, index i_loc + iph * row_count) for
+   * the sharded calls (edigpu_apply_sharded_*, edigpu_lanczos_tridiag_sharded), normal mode shards through the whole-
+   * sector handle there. */
   int32_t nph;
   int32_t pad_;
   double w0_ph, a_ph;
   double g_ph[EDIGPU_MAXORB * EDIGPU_MAXORB];
-  /* Normal mode only (the flat builders refuse a model that sets them):
-   * spin_field[iorb][x,y,z] (ED_INPUT_VARS.f90 SPIN_FIELD_X/Y/Z): the z component enters H_local as
-   *   sum_a spin_field(a,3) (n_a,up - n_a,dw)  (ED_NORMAL/stored/H_local.f90:38-42); x, y are not read in this mode;
-   * exc_field[4] (EXC_FIELD): (1) and (4) add (exc(1) +/- exc(4)) c+_a,s c_b,s, a != b, + for up / - for down
-   *   (ED_NORMAL/stored/H_up.f90:87-104, H_dw.f90); (2), (3) are not read in this mode;
+  /* spin_field[iorb][x,y,z] (ED_INPUT_VARS.f90 SPIN_FIELD_X/Y/Z).  Normal mode: the z component enters H_local as
+   *   sum_a spin_field(a,3) (n_a,up - n_a,dw)  (ED_NORMAL/stored/H_local.f90:38-42); x, y are not read in this mode.
+   *   nonsu2: F.S with all three components (ED_NONSU2/stored/Himp.f90:235-296; the z term as that file's comment
+   *   states it -- the code adds it to a variable the blocks before it leave set, see oracle/edipack_oracle_flat.inc).
+   *   superc: the reference's files have no such term; the builders refuse a model that sets it.
+   * exc_field[4] (EXC_FIELD) = (F_0, F_x, F_y, F_z).  Normal mode: (1) and (4) add (exc(1) +/- exc(4)) c+_a,s c_b,s,
+   *   a != b, + for up / - for down (ED_NORMAL/stored/H_up.f90:87-104, H_dw.f90); (2), (3) are not read.  nonsu2: F.T
+   *   with all four (Himp.f90:113-228).  superc: refused as above.
    * coulomb_sundry (ED_VARS_GLOBAL.f90 coulomb_sundry(:), read from the umatrix file): nsundry lines
    *   sundry_u[l] cd_i cd_j c_k c_l with sundry_op[l][8] = (orb_i, spin_i, orb_j, spin_j, orb_k, spin_k, orb_l,
-   *   spin_l), orbitals 1-based, spin 1 = up / 2 = down, applied right to left as c_l, cd_j, c_k, cd_i on the word of
-   *   their spin (ED_NORMAL/stored/H_sundry.f90:1-111).  Lines that change N_up or N_dw are refused. */
+   *   spin_l), orbitals 1-based, spin 1 = up / 2 = down, applied right to left as c_l, cd_j, c_k, cd_i.  Normal mode: on
+   *   the word of their spin (ED_NORMAL/stored/H_sundry.f90:1-111); lines that change N_up or N_dw are refused.
+   *   superc / nonsu2: on the 2 Ns-level word (stored/Hint.f90:127-181), stored and on the fly; superc refuses lines that
+   *   change Sz (the reference stops with "impossible operator"). */
   double spin_field[EDIGPU_MAXORB * 3];
   double exc_field[4];
   int32_t nsundry;
@@ -485,8 +494,9 @@ int edigpu_comm_destroy(edigpu_comm c);
  * A normal-mode phonon handle (nph > 0, whole sector on every rank, density couplings g_ph(a,a)): the shard is
  * (Nph + 1) blocks of this rank's down rows, i = iup + idw_local * DimUp + iph * DimUp * count, the layout of
  * spMatVec_mpi_normal_main (ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:820-904); every block goes through the
- * exchange on its own, the phonon and electron-phonon terms are local.  A general g_ph(a,b) and the superc / nonsu2
- * phonon sectors are refused here (one GPU).
+ * exchange on its own, the phonon and electron-phonon terms are local.  superc / nonsu2 phonon handles: row shards
+ * (edigpu_flat_build / edigpu_direct_build with the first / count of edigpu_shard_plan over the ELECTRONIC dimension),
+ * nloc = count * (Nph + 1), one all-gather per phonon block.  A general g_ph(a,b) is refused here (one GPU).
  */
 int edigpu_apply_sharded_d(edigpu_handle h, edigpu_comm c, int64_t nloc, const double *v_shard_host,
                            double *hv_shard_host);

@@ -25,6 +25,8 @@ CASES = [
     ("nonsu2", "hybrid", 2, 3, 5, True, "auto"),             # on-the-fly kernel: gather first
     ("normal", "hybrid", 3, 2, (3, 2), False, "cmplx"),      # _CMPLX_NORMAL through its doubled real sector
     ("normal", "normal", 2, 2, (3, 2), False, "phonon"),     # (Nph + 1) blocks, one exchange per block, local phonon pass
+    ("superc", "hybrid", 2, 2, 0, False, "phonon"),          # stored rows: one all-gather per phonon block
+    ("nonsu2", "normal", 2, 2, 4, True, "phonon"),           # on the fly
 ]
 NPH = 3
 
@@ -118,11 +120,11 @@ def test_library_comm_rccl_world_of_one(gpu, monkeypatch, force):
     uid = LibraryComm.unique_id()
     assert len(uid) == 128
     comm = LibraryComm(0, 1, unique_id=uid)
-    for case in CASES[:1] + CASES[3:4] + CASES[-1:]:
+    for case in CASES[:1] + CASES[3:4] + CASES[-3:]:
         mode, bath, norb, nbath, sector, direct, exchange = case
         ho, pm, v = _reference(mode, bath, norb, nbath, sector, phonon=exchange == "phonon")
         h, first, count = library_sharded_sector(pm, sector, comm, direct=direct, exchange=exchange)
-        assert (first, count) == (0, ho.dimdw if mode == "normal" else ho.dim)
+        assert (first, count) == (0, ho.dimdw if mode == "normal" else ho.dim_el)
         assert rel_err(comm.apply(h, v), ho.matvec(v)) < 1e-12
         a, b, nd, n2 = comm.tridiag(h, v, 25)
         a_ref, b_ref, _ = ho.lanc_tridiag(v, 25)

@@ -1181,8 +1181,17 @@ def test_phonon_flat_error_paths(gpu):
     _, pm = make_models("superc", "normal", 2, 2, seed=92)
     pm.nph, pm.w0_ph = 2, 0.8
     pm.g_ph = np.diag([0.3, 0.5])
+    # density couplings: a row shard builds (it serves the sharded library calls), but not the single-GPU products
+    h = SectorHamiltonian.direct_from_model(pm, 0, row_first=0, row_count=8)
+    assert h.nloc == 8 * 3
+    with pytest.raises(RuntimeError):
+        h.apply(np.zeros(h.dim, dtype=complex))
+    h.destroy()
+    pm.g_ph = np.array([[0.3, 0.1], [0.1, 0.5]])      # a general g_ph(a,b): the whole sector on one GPU
     with pytest.raises(RuntimeError, match="one shard"):
         SectorHamiltonian.direct_from_model(pm, 0, row_first=0, row_count=8)
+    with pytest.raises(RuntimeError, match="one shard"):
+        SectorHamiltonian.flat_from_model(pm, 0, row_first=0, row_count=8)
 
 
 # --------------------------------------------------------------------------------------------
