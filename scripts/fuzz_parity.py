@@ -57,9 +57,10 @@ def main():
                 hl = np.asarray(m.hloc, complex).copy()
                 hl[0, 0] = hl[0, 0] + 1j * t
                 m.hloc = hl
-        # the terms only some inputs switch on (normal mode, real algebra): random coulomb_sundry lines with their
-        # Hermitian conjugates, spin_field z, exc_field (1), (4)
-        extra = mode == "normal" and nph == 0 and not cmplx and rng.random() < 0.4
+        # the terms only some inputs switch on: random coulomb_sundry lines with their Hermitian conjugates (normal and
+        # superc: spin-conserving lines; nonsu2: any), spin_field z and exc_field (1), (4) in normal mode (real algebra),
+        # all components in nonsu2, none in superc
+        extra = (mode != "normal" or (nph == 0 and not cmplx)) and rng.random() < 0.4
         if extra:
             lines = []
             for _ in range(int(rng.integers(1, 4))):
@@ -68,7 +69,7 @@ def main():
                     bal = [0, 0]
                     for k_, (_, sp) in enumerate(ops):
                         bal[sp] += 1 if k_ < 2 else -1
-                    if bal == [0, 0]:
+                    if bal == [0, 0] or mode == "nonsu2":
                         break
                 u = float(rng.uniform(-0.5, 0.5))
                 lines.append((u, ops[0], ops[1], ops[2], ops[3]))
@@ -78,6 +79,11 @@ def main():
             sf = np.zeros((norb, 3))
             sf[:, 2] = rng.uniform(-0.3, 0.3, norb)
             ef = np.array([rng.uniform(-0.2, 0.2), 0.0, 0.0, rng.uniform(-0.2, 0.2)])
+            if mode == "nonsu2":
+                sf[:, :2] = rng.uniform(-0.3, 0.3, (norb, 2))
+                ef[1:3] = rng.uniform(-0.2, 0.2, 2)
+            elif mode == "superc":
+                sf[:], ef[:] = 0.0, 0.0
             for m in (om, pm):
                 m.sundry, m.spin_field, m.exc_field = lines, sf, ef
         tag = (trial, mode, bath, norb, nbath, nph, cmplx, extra)
