@@ -3,7 +3,7 @@
 #   gpurun -- 'bash scripts/check_switches.sh'            (all: ~100 s per switch, more than one gpurun call allows)
 #   gpurun -- 'bash scripts/check_switches.sh 12'         (from the 12th switch on)
 SKIP=${1:-0}; N=0
-for sw in EDIGPU_LANCZOS_UNFUSED EDIGPU_NORMAL_EXPLICIT EDIGPU_FLAT_HOSTBUILD EDIGPU_LANCZOS_EXACTBETA EDIGPU_TRL_TWOPASS \
+for sw in EDIGPU_LANCZOS_UNFUSED EDIGPU_NORMAL_EXPLICIT EDIGPU_FLAT_HOSTBUILD EDIGPU_LANCZOS_EXACTBETA EDIGPU_TRL_ONEPASS \
           EDIGPU_ELL_UNTYPED EDIGPU_CSR_NOSELL EDIGPU_CSR_UNPACKED EDIGPU_DIRECT_TERMORDER EDIGPU_PANEL_VEC2_MIN \
           "EDIGPU_ROW_SPLIT=2" "EDIGPU_PANEL_VEC2=0" EDIGPU_ND_IN_ROWS "EDIGPU_PANEL_TILE=0" "EDIGPU_TILE_ROWS=64" \
           EDIGPU_TILE_PERSIST "EDIGPU_HANDOVER_FACTOR=0" EDIGPU_ND_NO_MERGE EDIGPU_CMPLX_FOURPRODUCTS EDIGPU_DIRECT_NOSORT EDIGPU_LANCZOS_GRAPH EDIGPU_LANCZOS_INKERNEL_FINALIZE EDIGPU_EIGH_TWOPASS "EDIGPU_BLOCKED=1 EDIGPU_BLOCKED_MIN=0" \

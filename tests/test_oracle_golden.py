@@ -414,3 +414,63 @@ def test_oracle_jz_sectors_partition_the_ntot_sectors():
         assert np.abs(np.sort(np.concatenate(evs)) - np.linalg.eigvalsh(full.dense())).max() < 1e-10
     # odd twoJz + even Ntot etc.: empty
     assert L.orc_build_sector_nonsu2_jz(3, 1, 6, 1, None) == 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the remaining ground-state fixtures: doubles / energy / imp of all twelve directories, phisc of the *_SUPERC and magX
+# of the NONSU2 ones (tests/observables.py).  They pin the eigenVECTORS (off-diagonal correlators <gs|X|gs> of every
+# interaction family) and, for phisc / magX, apply_Cops between sectors on those vectors.
+# ---------------------------------------------------------------------------------------------------------
+def _golden_model(name):
+    g = GOLD[name]
+    if name in REPLICA_DIRS:
+        om, _ = replica_golden_models(g["input"])
+    else:
+        inp, par = _from_dir(name)
+        pm_par = {k: v for k, v in par.items() if k not in ("ed_hw_bath", "deltasc")}
+        om, _ = golden_models(inp["ED_MODE"], inp["BATH_TYPE"], int(inp["NORB"]), int(inp["NBATH"]), pm_par)
+    O.to_struct(om)   # fills the init_dmft_bath start bath
+    return om, g
+
+
+# *_SUPERC with a normal / hybrid bath: a second state 1.5e-6 .. 1e-5 above the ground state in the same sector, so any
+# eigensolver's vector carries an admixture that shows at first order in observables (see the dens / docc test above)
+_OBS_TOL = {"NORMAL_SUPERC": 5e-8, "HYBRID_SUPERC": 5e-8}
+
+
+@pytest.mark.parametrize("name", DIRS + REPLICA_DIRS)
+def test_oracle_reproduces_doubles_energy_imp(name):
+    from tests import observables as ob
+    om, g = _golden_model(name)
+    e0, states = ob.ground_manifold(om)
+    doubles, energy, imp = ob.doubles_energy_imp(om, states, e0)
+    tol = _OBS_TOL.get(name, 1e-9)
+    assert np.max(np.abs(doubles - np.array(g["doubles"]))) < tol
+    assert np.max(np.abs(energy - np.array(g["energy"]))) < tol
+    assert np.max(np.abs(imp - np.array(g["imp"]))) < tol
+
+
+@pytest.mark.parametrize("name", [d for d in DIRS + REPLICA_DIRS if "phisc" in GOLD[d] or "magX" in GOLD[d]])
+def test_oracle_reproduces_phisc_magx(name):
+    """apply_Cops on the ground state into the neighbouring sector (ED_SECTOR.f90:839-960), as the reference's
+    observables do for the superconducting order parameter and the in-plane magnetisation."""
+    from tests import observables as ob
+    from tests.gf_flat import apply_cops
+    om, g = _golden_model(name)
+    e0, states = ob.ground_manifold(om)
+    cache = {}
+
+    def hsector(sec):
+        if sec not in cache:
+            cache[sec] = O.HFlat(om, sec)
+        return cache[sec]
+
+    def cops(h1, h2, v, ops):
+        return apply_cops(h1, h2, v, ops, om.ns)
+
+    tol = _OBS_TOL.get(name, 1e-9)
+    if "phisc" in g:
+        phi = ob.phisc(om, states, cops, hsector)
+        assert np.max(np.abs(phi.real - np.array(g["phisc"]))) < tol and np.max(np.abs(phi.imag)) < tol
+    if "magX" in g:
+        assert np.max(np.abs(ob.magx(om, states, cops, hsector) - np.array(g["magX"]))) < tol
