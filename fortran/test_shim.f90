@@ -246,7 +246,7 @@ contains
     e = maxval(abs(hv - e0*evec))
     write(*,"(A,F14.9,A,ES10.2)") "gpu_sp_lanc_eigh_d: E0 =", e0, "  residual =", e
     if (e > 1d-9 .or. abs(dot_product(evec, evec) - 1d0) > 1d-12) nfail = nfail + 1
-    call gpu_sp_eigh_d(evals, basis, 20, 300, 1d-12)
+    call gpu_sp_eigh_d(evals, basis, 20, 300, 1d-18)        ! the reference's default lanc_tolerance
     e = abs(evals(1) - e0)
     call spHtimesV_p(n, basis(:,2), hv)
     e = max(e, maxval(abs(hv - evals(2)*basis(:,2))))
