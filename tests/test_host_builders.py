@@ -285,3 +285,36 @@ def test_cmplx_normal_doubled_real_image_equals_oracle(shim, bath, norb, nbath, 
     ref[1::2, 0::2] = hc.imag
     assert np.abs(out - ref).max() < 1e-13 and np.abs(out - out.T).max() < 1e-13
     assert nt.value <= 16
+
+
+@pytest.mark.parametrize("mode", ["superc", "nonsu2"])
+def test_flat_random_sundry_lines(shim, mode):
+    """Random coulomb_sundry lines (any of the 4^4 orbital/spin patterns the sector family allows: levels met twice,
+    identically vanishing lines, diagonal lines) through the stored rows and the on-the-fly term encoding vs the oracle."""
+    rng = np.random.default_rng(2024 if mode == "superc" else 2025)
+    norb, nbath = 2, 2
+    checked = 0
+    for trial in range(40):
+        lines = []
+        for _ in range(int(rng.integers(1, 5))):
+            while True:
+                ops = [(int(rng.integers(0, norb)), int(rng.integers(0, 2))) for _ in range(4)]
+                dsz = sum((1 if k < 2 else -1) * (1 if sp == 0 else -1) for k, (_, sp) in enumerate(ops))
+                if mode == "nonsu2" or dsz == 0:
+                    break
+            lines.append((float(rng.uniform(-0.5, 0.5)), *ops))
+        om, pm = make_models(mode, "hybrid" if trial % 2 else "normal", norb, nbath, seed=100 + trial, sundry=lines)
+        ns = om.ns
+        sec = int(rng.integers(-1, 2)) if mode == "superc" else int(rng.integers(2, 2 * ns - 1))
+        h = O.HFlat(om, sec)
+        if h.dim == 0:
+            continue
+        ref = h.dense()
+        m = pm.to_c()
+        for fn in (shim.host_flat_dense, shim.host_direct_dense):
+            out = np.zeros((h.dim, h.dim), dtype=np.complex128)
+            rc = fn(C.byref(m), sec, out.ctypes.data_as(C.c_void_p), C.c_int64(h.dim))
+            assert rc == 0, shim.host_image_error().decode()
+            assert np.abs(out - ref).max() < 1e-13, (trial, lines, np.abs(out - ref).max())
+        checked += 1
+    assert checked >= 30
