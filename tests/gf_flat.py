@@ -145,8 +145,11 @@ def momenta_superc(om, tridiag, beta=1000.0, lmats=4096, ngfiter=200, gs_thresho
 
 
 def momenta_nonsu2(om, tridiag, beta=300.0, lmats=2000, ngfiter=300, gs_threshold=1e-9, nmom=4):
-    """-> (Sigma11_momenta[norb, nmom], Sigma12_momenta[norb, nmom]) as the *_NONSU2 fixtures store them; bath normal."""
-    assert om.ed_mode == "nonsu2" and om.bath_type == "normal" and om.nspin == 2
+    """-> (Sigma11_momenta[norb, nmom], Sigma12_momenta[norb, nmom]) as the *_NONSU2 fixtures store them; bath normal
+    (G, G0^-1 diagonal in the orbitals) or hybrid (all G_{ab}^{ss'}: build_impG_nonsu2, ED_GF_NONSU2.f90:83-141; the
+    (Nspin Norb)^2 inverse of get_Sigma_nonsu2 :716-748; delta_bath_array_hybrid, ED_BATH/delta_functions/delta_hybrid.f90:74-91)."""
+    assert om.ed_mode == "nonsu2" and om.bath_type in ("normal", "hybrid") and om.nspin == 2
+    hybrid = om.bath_type == "hybrid"
     ns, no = om.ns, om.norb
     nlev = 2 * ns
     e0, states = _ground_states(om, gs_threshold)
@@ -158,39 +161,51 @@ def momenta_nonsu2(om, tridiag, beta=300.0, lmats=2000, ngfiter=300, gs_threshol
     def n_ok(n):
         return n if 0 <= n <= nlev else None
 
-    gf = np.zeros((2, 2, no, lmats), complex)
+    gf = np.zeros((2, 2, no, no, lmats), complex)
     for a in range(no):
         for s in range(2):
-            gf[s, s, a] = _pole_sum(z, tridiag, hcache, om, states, zeta, ngfiter, lambda n: [
+            gf[s, s, a, a] = _pole_sum(z, tridiag, hcache, om, states, zeta, ngfiter, lambda n: [
                 (n_ok(n + 1), [(1.0, True, a, s)], 1, 1.0), (n_ok(n - 1), [(1.0, False, a, s)], -1, 1.0)])
-        for s in range(2):
-            for t in range(2):
-                if s == t:
-                    continue
-                aux = _pole_sum(z, tridiag, hcache, om, states, zeta, ngfiter, lambda n: [
-                    (n_ok(n + 1), [(1.0, True, a, s), (1.0, True, a, t)], 1, 1.0),
-                    (n_ok(n - 1), [(1.0, False, a, s), (1.0, False, a, t)], -1, 1.0),
-                    (n_ok(n + 1), [(1.0, True, a, s), (1j, True, a, t)], 1, -1j),
-                    (n_ok(n - 1), [(1.0, False, a, s), (-1j, False, a, t)], -1, -1j)])
-                gf[s, t, a] = 0.5 * (aux - (1.0 - 1j) * (gf[s, s, a] + gf[t, t, a]))
-    s11 = np.zeros((no, nmom))
-    s12 = np.zeros((no, nmom))
-    # bath normal: G, G0^-1 are diagonal in the orbitals, 2x2 in spin; the (Nspin*Norb) inverse factorises
     for a in range(no):
-        w = np.zeros((2, 2, om.nbath))
-        w[0, 0], w[1, 1] = om.bv[0, a, :], om.bv[1, a, :]
-        w[0, 1], w[1, 0] = om.bu[0, a, :], om.bu[1, a, :]          # get_Whyb_matrix (ED_BATH_AUX.f90:75-102)
-        delta = np.zeros((2, 2, lmats), complex)
-        for s in range(2):
-            for t in range(2):
-                for ih in range(2):
-                    delta[s, t] += np.sum((w[s, ih, :] * w[t, ih, :])[None, :] / (z[:, None] - om.be[ih, a, :][None, :]), axis=1)
-        g0inv = np.zeros((2, 2, lmats), complex)
-        for s in range(2):
-            for t in range(2):
-                g0inv[s, t] = ((z + om.xmu) if s == t else 0.0) - om.hloc[s, t, a, a] - delta[s, t]
-        gm = np.moveaxis(gf[:, :, a, :], 2, 0)                      # [lmats, 2, 2]
-        sg = np.moveaxis(g0inv, 2, 0) - np.linalg.inv(gm)
-        s11[a] = _moments(sg[:, 0, 0], wm, nmom)
-        s12[a] = _moments(sg[:, 0, 1], wm, nmom)
+        for b in range(no):
+            if a != b and not hybrid:
+                continue
+            for s in range(2):
+                for t in range(2):
+                    if s == t and a == b:
+                        continue
+                    # lanc_build_gf_nonsu2_mixOrb_mixSpin(iorb, jorb, ispin, jspin), :236-300
+                    aux = _pole_sum(z, tridiag, hcache, om, states, zeta, ngfiter, lambda n: [
+                        (n_ok(n + 1), [(1.0, True, a, s), (1.0, True, b, t)], 1, 1.0),
+                        (n_ok(n - 1), [(1.0, False, a, s), (1.0, False, b, t)], -1, 1.0),
+                        (n_ok(n + 1), [(1.0, True, a, s), (1j, True, b, t)], 1, -1j),
+                        (n_ok(n - 1), [(1.0, False, a, s), (-1j, False, b, t)], -1, -1j)])
+                    gf[s, t, a, b] = 0.5 * (aux - (1.0 - 1j) * (gf[s, s, a, a] + gf[t, t, b, b]))
+    # hybridisation: W(s, h, a, k) of get_Whyb_matrix (ED_BATH_AUX.f90:75-102), bath levels e(h, a | 1, k)
+    w = np.zeros((2, 2, no, om.nbath))
+    w[0, 0], w[1, 1] = om.bv[0], om.bv[1]
+    w[0, 1], w[1, 0] = om.bu[0], om.bu[1]
+    delta = np.zeros((2, 2, no, no, lmats), complex)
+    for a in range(no):
+        for b in range(no):
+            if a != b and not hybrid:
+                continue
+            for s in range(2):
+                for t in range(2):
+                    for ih in range(2):
+                        eh = om.be[ih, 0, :] if hybrid else om.be[ih, a, :]
+                        delta[s, t, a, b] += np.sum((w[s, ih, a, :] * w[t, ih, b, :])[None, :] / (z[:, None] - eh[None, :]), axis=1)
+    n2 = 2 * no
+    g0inv = np.zeros((lmats, n2, n2), complex)
+    gm = np.zeros((lmats, n2, n2), complex)
+    for s in range(2):
+        for t in range(2):
+            for a in range(no):
+                for b in range(no):
+                    io, jo = a + s * no, b + t * no                       # nn2so_reshape
+                    g0inv[:, io, jo] = ((z + om.xmu) if io == jo else 0.0) - om.hloc[s, t, a, b] - delta[s, t, a, b]
+                    gm[:, io, jo] = gf[s, t, a, b]
+    sg = g0inv - np.linalg.inv(gm)
+    s11 = np.array([_moments(sg[:, a, a], wm, nmom) for a in range(no)])
+    s12 = np.array([_moments(sg[:, a, a + no], wm, nmom) for a in range(no)])
     return s11, s12

@@ -206,7 +206,84 @@ def test_shifted_spectrum_keeps_the_fused_step_accurate(gpu):
     for z in (th[0] - 0.5, th[0] - 0.05 + 0.01j, th[-1] + 0.3):
         g, g_ref = _cf(a, b, z), _cf(a_ref, b_ref, z)
         assert abs(g - g_ref) < 1e-10 * abs(g_ref), (z, g, g_ref)
+    hg.destroy()
 
+
+# --------------------------------------------------------------------------------------------
+# the large-sector forms of the down-term sweep (two columns per lane; LDS-staged row chunks) forced onto small
+# sectors the oracle reaches: whole sectors, odd DimUp, down-row shards in the two-phase form, explicit image
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile,rows", [("0", "72"), ("1", "8"), ("1", "20"), ("1", "72"), ("1", "152")])
+@pytest.mark.parametrize("bath,norb,nbath,sec", [
+    ("normal", 2, 4, (5, 5)),     # DimUp = DimDw = 252, Hnd terms
+    ("hybrid", 3, 5, (4, 4)),     # 3 orbitals: 70 x 70, several Hnd terms per row, one panel narrower than a wave
+    ("hybrid", 3, 4, (3, 4)),     # odd DimUp = 35 (8-byte aligned rows, the EDGE path)
+    ("normal", 1, 6, (3, 4)),     # no Hnd at all
+])
+def test_down_sweep_variants_match_oracle(gpu, monkeypatch, tile, rows, bath, norb, nbath, sec):
+    import torch
+    from oracle import oracle as O
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from tests.common import make_models
+    monkeypatch.setenv("EDIGPU_PANEL_VEC2_MIN", "1")
+    monkeypatch.setenv("EDIGPU_PANEL_TILE", tile)
+    monkeypatch.setenv("EDIGPU_TILE_ROWS", rows)
+    om, pm = make_models("normal", bath, norb, nbath, seed=21)
+    ho = O.HNormal(om, *sec)
+    hg = SectorHamiltonian.normal_from_model(pm, *sec)
+    rng = np.random.default_rng(4)
+    v = rng.standard_normal(ho.dim)
+    ref = ho.matvec(v)
+    assert rel_err(hg.apply(v), ref) < 1e-12
+    a, b, _ = hg.lanczos_tridiag(v, 25)             # the fused step: the three sums in the sweep's epilogue
+    a_ref, b_ref, _ = ho.lanc_tridiag(v, 25)
+    assert rel_err(a, a_ref) < 1e-10 and rel_err(b, b_ref) < 1e-10
+    hg.destroy()
+    # explicit (hand-over) image of the same sector
+    he = SectorHamiltonian.normal_from_arrays(ho.dimup, ho.dimdw, ho.hd, ho.up, ho.dw, ho.nd if ho.has_nd else None)
+    assert rel_err(he.apply(v), ref) < 1e-12
+    he.destroy()
+    # three down-row shards, two-phase form (the sweep runs on local rows with global partner rows)
+    vd = torch.from_numpy(v).cuda()
+    cuts = [0, ho.dimdw // 3, ho.dimdw // 3 + 1, ho.dimdw]
+    out = []
+    for first, last in zip(cuts[:-1], cuts[1:]):
+        hs = SectorHamiltonian.normal_from_model(pm, *sec, dw_first=first, dw_count=last - first)
+        hv = torch.empty(hs.nloc, dtype=torch.float64, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        hs.apply_local_dev(vd[hs.row_first:].data_ptr(), hv.data_ptr(), st)
+        hs.apply_remote_dev(vd.data_ptr(), hv.data_ptr(), st)
+        torch.cuda.synchronize()
+        out.append(hv.cpu().numpy())
+        hs.destroy()
+    assert rel_err(np.concatenate(out), ref) < 1e-12
+
+
+@pytest.mark.parametrize("name,tol", [("NORMAL_SUPERC", 1e-8), ("NORMAL_NONSU2", 1e-10), ("HYBRID_NONSU2", 1e-9)])
+@pytest.mark.parametrize("form", ["stored", "direct"])
+def test_golden_flat_momenta_through_gpu_tridiag(gpu, name, tol, form):
+    """Sigma / Self moments (superc) and Sigma11 / Sigma12 moments (nonsu2: normal bath, and the hybrid bath with every
+    G_{ab}^{ss'} channel) of the reference's fixtures with every tridiagonalisation done by edigpu_lanczos_tridiag on
+    GPU-built sectors: pins the complex device recurrence (stored SELL image and on-the-fly kernel) on the reference's
+    own data."""
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from tests.test_oracle_golden import _flat_golden, flat_momenta
+    _, _, pm = _flat_golden(name)
+    build = SectorHamiltonian.flat_from_model if form == "stored" else SectorHamiltonian.direct_from_model
+    cache = {}
+
+    def tridiag(om):
+        def run(sec, v, nl):
+            if sec not in cache:
+                cache[sec] = build(pm, sec)
+            a, b, _ = cache[sec].lanczos_tridiag(v, nl)
+            return a, b
+        return run
+
+    for got, gold in flat_momenta(name, tridiag):
+        assert np.max(np.abs(got / gold - 1.0)) < tol
+    for h in cache.values():
+        h.destroy()
 
 
 def test_cfg2_handover_image_runs_the_factored_kernels(gpu, monkeypatch):
