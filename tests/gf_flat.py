@@ -110,9 +110,10 @@ def momenta_superc(om, tridiag, beta=1000.0, lmats=4096, ngfiter=200, gs_thresho
     """-> (Sigma_momenta[norb, nmom], Self_momenta[norb, nmom]) as the *_SUPERC fixtures store them; bath normal, or
     hybrid (G^{ab}, F^{ab} for every orbital pair: lanc_build_gf_superc_Gmix / _Fmix, ED_GF_SUPERC.f90:200-361; the
     2 Norb x 2 Norb Nambu inverse of get_Sigma_superc / get_Self_superc :985-1005, 1060-1080; delta / fdelta of the shared
-    bath, ED_BATH/delta_functions/delta_hybrid.f90:50-72, fdelta_hybrid.f90)."""
-    assert om.ed_mode == "superc" and om.bath_type in ("normal", "hybrid")
-    if om.bath_type == "hybrid":
+    bath, ED_BATH/delta_functions/delta_hybrid.f90:50-72, fdelta_hybrid.f90), replica or general (Delta, Fdelta from the
+    Nambu replica matrices; Self_momenta then holds every orbital pair, rows (a, b) with b fastest)."""
+    assert om.ed_mode == "superc"
+    if om.bath_type != "normal":
         return _momenta_superc_hybrid(om, tridiag, beta, lmats, ngfiter, gs_threshold, nmom)
     ns, no = om.ns, om.norb
     e0, states = _ground_states(om, gs_threshold)
@@ -199,16 +200,34 @@ def _momenta_superc_hybrid(om, tridiag, beta, lmats, ngfiter, gs_threshold, nmom
                 (sz_ok(s - 1), [(1.0, False, a, up), (-1j, True, b, dw)], -1, -1j)], also_conj=True)
             F12[a, b] = 0.5 * (aux - (1.0 - 1j) * (G[a, a] + barG[b]))
             F21[a, b] = 0.5 * (auxc - (1.0 - 1j) * (Gc[a] + barG_c[b]))      # get_impF_superc(zconj=.true.)
-    e, d, v = om.be[0, 0, :], om.bd[0, 0, :], om.bv[0, :, :]
-    den = wm[:, None] ** 2 + e[None, :] ** 2 + d[None, :] ** 2
+    replica = om.bath_type in ("replica", "general")
     M = np.zeros((lmats, 2 * no, 2 * no), complex)
     invg0 = np.zeros((lmats, no, no), complex)
     invf0 = np.zeros((lmats, no, no), complex)
+    if replica:
+        # Delta, Fdelta = the (1,1) and (1,2) Nambu blocks of sum_k V_k (z - H_k)^-1 V_k, V_k = sigma_z (x) diag(v_k)
+        # (delta_replica.f90:43-58, fdelta_replica.f90; general: vg in place of the scalar v)
+        n2 = 2 * no
+        dn = np.zeros((lmats, n2, n2), complex)
+        for k in range(om.nbath):
+            hk = np.zeros((n2, n2), complex)
+            for n_ in range(2):
+                for m_ in range(2):
+                    hk[n_ * no:(n_ + 1) * no, m_ * no:(m_ + 1) * no] = om.hb[n_, m_, :, :, k]
+            vd = om.vg[:no, k] if om.bath_type == "general" else np.full(no, om.vr[k])
+            vk = np.kron(np.diag([1.0, -1.0]), np.diag(vd)).astype(complex)
+            dn += vk[None] @ np.linalg.inv(z[:, None, None] * np.eye(n2)[None] - hk[None]) @ vk[None]
+    else:
+        e, d, v = om.be[0, 0, :], om.bd[0, 0, :], om.bv[0, :, :]
+        den = wm[:, None] ** 2 + e[None, :] ** 2 + d[None, :] ** 2
     for a in range(no):
         for b in range(no):
-            vv = (v[a] * v[b])[None, :]
-            delta = -np.sum(vv * (z[:, None] + e[None, :]) / den, axis=1)
-            fdelta = np.sum(d[None, :] * vv / den, axis=1)
+            if replica:
+                delta, fdelta = dn[:, a, b], dn[:, a, no + b]
+            else:
+                vv = (v[a] * v[b])[None, :]
+                delta = -np.sum(vv * (z[:, None] + e[None, :]) / den, axis=1)
+                fdelta = np.sum(d[None, :] * vv / den, axis=1)
             invg0[:, a, b] = ((z + om.xmu) if a == b else 0.0) - om.hloc[0, 0, a, b] - delta
             invf0[:, a, b] = -fdelta
             M[:, a, b] = G[a, b]
@@ -219,18 +238,25 @@ def _momenta_superc_hybrid(om, tridiag, beta, lmats, ngfiter, gs_threshold, nmom
     sig = np.array([_moments(invg0[:, a, a] - Mi[:, a, a], wm, nmom) for a in range(no)])
     # Self_momenta.check of HYBRID_SUPERC is reproduced (3.5e-8, the noise level of the file) by invF0 + invF, not by the
     # invF0 - invF of get_Self_superc in this checkout (6 % away): the moments are those of |Self|, so only the relative
-    # sign of the two pieces shows, and the file is older than the source.  Every Lanczos-derived ingredient -- G_ab, barG,
-    # F_ab for all orbital pairs -- enters either way.
-    slf = np.array([_moments(invf0[:, a, a] + Mi[:, a, no + a], wm, nmom) for a in range(no)])
+    # sign of the two pieces shows, and the file is older than the source (the REPLICA_ / GENERAL_SUPERC files, below, are
+    # matched at 1e-11 with the sign of the source).  Every Lanczos-derived ingredient -- G_ab, barG, F_ab for all orbital
+    # pairs -- enters either way.
+    if replica:      # ASmomAB(iorb, jorb, :) of ed_replica_superc.f90:141: every orbital pair
+        slf = np.array([_moments(invf0[:, a, b] - Mi[:, a, no + b], wm, nmom) for a in range(no) for b in range(no)])
+    else:
+        slf = np.array([_moments(invf0[:, a, a] + Mi[:, a, no + a], wm, nmom) for a in range(no)])
     return sig, slf
 
 
-def momenta_nonsu2(om, tridiag, beta=300.0, lmats=2000, ngfiter=300, gs_threshold=1e-9, nmom=4):
-    """-> (Sigma11_momenta[norb, nmom], Sigma12_momenta[norb, nmom]) as the *_NONSU2 fixtures store them; bath normal
-    (G, G0^-1 diagonal in the orbitals) or hybrid (all G_{ab}^{ss'}: build_impG_nonsu2, ED_GF_NONSU2.f90:83-141; the
-    (Nspin Norb)^2 inverse of get_Sigma_nonsu2 :716-748; delta_bath_array_hybrid, ED_BATH/delta_functions/delta_hybrid.f90:74-91)."""
-    assert om.ed_mode == "nonsu2" and om.bath_type in ("normal", "hybrid") and om.nspin == 2
-    hybrid = om.bath_type == "hybrid"
+def momenta_nonsu2(om, tridiag, beta=300.0, lmats=2000, ngfiter=300, gs_threshold=1e-9, nmom=4, all_components=False):
+    """-> (Sigma11_momenta[norb, nmom], Sigma12_momenta[norb, nmom]) as the NORMAL_ / HYBRID_NONSU2 fixtures store them, or
+    with all_components the moments of every Sigma_{ab}^{ss'}, rows ordered (s, s', a, b) with b fastest as in the REPLICA_ /
+    GENERAL_NONSU2 files (ED_ALL_G = T there).  Bath normal (G, G0^-1 diagonal in the orbitals), hybrid, replica or
+    general (all G_{ab}^{ss'}: build_impG_nonsu2, ED_GF_NONSU2.f90:83-141; the (Nspin Norb)^2 inverse of get_Sigma_nonsu2
+    :716-748; delta_bath_array_hybrid / _replica / _general, ED_BATH/delta_functions/)."""
+    assert om.ed_mode == "nonsu2" and om.nspin == 2
+    hybrid = om.bath_type != "normal"       # "every orbital pair" branch
+    replica = om.bath_type in ("replica", "general")
     ns, no = om.ns, om.norb
     nlev = 2 * ns
     e0, states = _ground_states(om, gs_threshold)
@@ -262,12 +288,27 @@ def momenta_nonsu2(om, tridiag, beta=300.0, lmats=2000, ngfiter=300, gs_threshol
                         (n_ok(n + 1), [(1.0, True, a, s), (1j, True, b, t)], 1, -1j),
                         (n_ok(n - 1), [(1.0, False, a, s), (-1j, False, b, t)], -1, -1j)])
                     gf[s, t, a, b] = 0.5 * (aux - (1.0 - 1j) * (gf[s, s, a, a] + gf[t, t, b, b]))
+    n2 = 2 * no
+    delta = np.zeros((2, 2, no, no, lmats), complex)
+    if replica:
+        # Delta(z) = sum_k V_k (z - H_k)^-1 V_k in spin-orbital space (delta_replica.f90:30-42, delta_general.f90:28-40)
+        for k in range(om.nbath):
+            hk = np.zeros((n2, n2), complex)
+            for s_ in range(2):
+                for t_ in range(2):
+                    hk[s_ * no:(s_ + 1) * no, t_ * no:(t_ + 1) * no] = om.hb[s_, t_, :, :, k]
+            vk = np.diag(om.vg[:, k]).astype(complex) if om.bath_type == "general" else om.vr[k] * np.eye(n2)
+            inv = np.linalg.inv(z[:, None, None] * np.eye(n2)[None] - hk[None])
+            dk = vk[None] @ inv @ vk[None]
+            for s_ in range(2):
+                for t_ in range(2):
+                    delta[s_, t_] += np.moveaxis(dk[:, s_ * no:(s_ + 1) * no, t_ * no:(t_ + 1) * no], 0, 2)
     # hybridisation: W(s, h, a, k) of get_Whyb_matrix (ED_BATH_AUX.f90:75-102), bath levels e(h, a | 1, k)
     w = np.zeros((2, 2, no, om.nbath))
-    w[0, 0], w[1, 1] = om.bv[0], om.bv[1]
-    w[0, 1], w[1, 0] = om.bu[0], om.bu[1]
-    delta = np.zeros((2, 2, no, no, lmats), complex)
-    for a in range(no):
+    if not replica:
+        w[0, 0], w[1, 1] = om.bv[0], om.bv[1]
+        w[0, 1], w[1, 0] = om.bu[0], om.bu[1]
+    for a in range(no if not replica else 0):
         for b in range(no):
             if a != b and not hybrid:
                 continue
@@ -276,7 +317,6 @@ def momenta_nonsu2(om, tridiag, beta=300.0, lmats=2000, ngfiter=300, gs_threshol
                     for ih in range(2):
                         eh = om.be[ih, 0, :] if hybrid else om.be[ih, a, :]
                         delta[s, t, a, b] += np.sum((w[s, ih, a, :] * w[t, ih, b, :])[None, :] / (z[:, None] - eh[None, :]), axis=1)
-    n2 = 2 * no
     g0inv = np.zeros((lmats, n2, n2), complex)
     gm = np.zeros((lmats, n2, n2), complex)
     for s in range(2):
@@ -287,6 +327,9 @@ def momenta_nonsu2(om, tridiag, beta=300.0, lmats=2000, ngfiter=300, gs_threshol
                     g0inv[:, io, jo] = ((z + om.xmu) if io == jo else 0.0) - om.hloc[s, t, a, b] - delta[s, t, a, b]
                     gm[:, io, jo] = gf[s, t, a, b]
     sg = g0inv - np.linalg.inv(gm)
+    if all_components:
+        return np.array([_moments(sg[:, a + s_ * no, b + t_ * no], wm, nmom)
+                         for s_ in range(2) for t_ in range(2) for a in range(no) for b in range(no)])
     s11 = np.array([_moments(sg[:, a, a], wm, nmom) for a in range(no)])
     s12 = np.array([_moments(sg[:, a, a + no], wm, nmom) for a in range(no)])
     return s11, s12

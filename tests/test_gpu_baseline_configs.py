@@ -350,3 +350,35 @@ def test_hbm_resident_ladder_panel_major_vs_natural(gpu, monkeypatch, workload):
     assert rel_err(ab[:25], an[:25]) < 1e-10 and rel_err(bb[:25], bn[:25]) < 1e-10
     for z in (60.0 + 0.1j, -60.0 + 0.1j, 40.0j):
         assert abs(_cf(ab, bb, z) - _cf(an, bn, z)) / abs(_cf(an, bn, z)) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["REPLICA_SUPERC", "GENERAL_SUPERC", "REPLICA_NONSU2", "GENERAL_NONSU2"])
+def test_golden_replica_flat_momenta_through_gpu_tridiag(gpu, name):
+    """The moment files of the replica / general SUPERC and NONSU2 directories (every orbital pair of Self, all sixteen
+    Sigma_{ab}^{ss'}) with every tridiagonalisation done by edigpu_lanczos_tridiag on GPU-built sectors."""
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from oracle import oracle as O
+    from tests.common import replica_golden_models
+    from tests.gf_flat import momenta_nonsu2, momenta_superc
+    from tests.test_oracle_golden import GOLD
+    g = GOLD[name]
+    om, pm = replica_golden_models(g["input"])
+    O.to_struct(om)
+    cache = {}
+
+    def run(sec, v, nl):
+        if sec not in cache:
+            cache[sec] = SectorHamiltonian.flat_from_model(pm, sec)
+        a, b, _ = cache[sec].lanczos_tridiag(v, nl)
+        return a, b
+
+    kw = dict(beta=g["input"]["BETA"], ngfiter=int(g["input"]["LANC_NGFITER"]))
+    if name.endswith("SUPERC"):
+        sig, slf = momenta_superc(om, run, lmats=4096, **kw)
+        assert np.max(np.abs(sig / np.array(g["Sigma_momenta"]).reshape(sig.shape) - 1.0)) < 1e-8
+        assert np.max(np.abs(slf / np.array(g["Self_momenta"]).reshape(slf.shape) - 1.0)) < 1e-8
+    else:
+        m = momenta_nonsu2(om, run, lmats=2000, all_components=True, **kw)
+        assert np.max(np.abs(m / np.array(g["Sigma_momenta"]).reshape(m.shape) - 1.0)) < 1e-8
+    for h in cache.values():
+        h.destroy()

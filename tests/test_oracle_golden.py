@@ -385,6 +385,45 @@ def test_oracle_complex_tridiag_reproduces_flat_momenta(name, tol):
         assert np.max(np.abs(got / gold - 1.0)) < tol
 
 
+@pytest.mark.parametrize("name", ["REPLICA_NONSU2", "GENERAL_NONSU2"])
+def test_oracle_complex_tridiag_reproduces_replica_nonsu2_momenta(name):
+    """Sigma_momenta.check of the replica / general NONSU2 directories: all sixteen Sigma_{ab}^{ss'} (ED_ALL_G = T), four
+    moments each -- every diagonal and mixed channel of build_impG_nonsu2 through the complex recurrence, Delta from the
+    replica matrices.  Measured agreement 1e-10."""
+    from tests.gf_flat import momenta_nonsu2
+    g = GOLD[name]
+    om, _ = replica_golden_models(g["input"])
+    O.to_struct(om)
+
+    def run(sec, v, nl):
+        a, b, _ = O.HFlat(om, sec).lanc_tridiag(v.copy(), nl)
+        return a, b
+
+    m = momenta_nonsu2(om, run, beta=g["input"]["BETA"], lmats=2000, ngfiter=int(g["input"]["LANC_NGFITER"]),
+                       all_components=True)
+    gold = np.array(g["Sigma_momenta"]).reshape(m.shape)
+    assert np.max(np.abs(m / gold - 1.0)) < 1e-8
+
+
+@pytest.mark.parametrize("name", ["REPLICA_SUPERC", "GENERAL_SUPERC"])
+def test_oracle_complex_tridiag_reproduces_replica_superc_momenta(name):
+    """Sigma_momenta.check (diagonal) and Self_momenta.check (every orbital pair) of the replica / general SUPERC
+    directories: G_ab, barG, F_ab through the complex recurrence, the 4 x 4 Nambu-orbital inverse, Delta / Fdelta from the
+    Nambu replica matrices.  Measured agreement 4e-13 / 8e-12."""
+    from tests.gf_flat import momenta_superc
+    g = GOLD[name]
+    om, _ = replica_golden_models(g["input"])
+    O.to_struct(om)
+
+    def run(sec, v, nl):
+        a, b, _ = O.HFlat(om, sec).lanc_tridiag(v.copy(), nl)
+        return a, b
+
+    sig, slf = momenta_superc(om, run, beta=g["input"]["BETA"], lmats=4096, ngfiter=int(g["input"]["LANC_NGFITER"]))
+    assert np.max(np.abs(sig / np.array(g["Sigma_momenta"]).reshape(sig.shape) - 1.0)) < 1e-9
+    assert np.max(np.abs(slf / np.array(g["Self_momenta"]).reshape(slf.shape) - 1.0)) < 1e-9
+
+
 def test_oracle_jz_sectors_partition_the_ntot_sectors():
     """JZ_BASIS=T (ED_SECTOR.f90:289-350): the (Ntot, twoJz) maps are disjoint, ascending, and their union is the Ntot
     map; for a Jz-conserving model the sector Hamiltonians are the diagonal blocks of the Ntot Hamiltonian, so the union
