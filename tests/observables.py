@@ -137,3 +137,60 @@ def magx(om, states, cops, hsector):
             m[a] += float(np.real(np.vdot(vv, vv))) / len(states)
     dup, ddw = _densities(om, states)
     return m - dup - ddw
+
+
+def _apply_c_normal(h_from, h_to, vec, iorb, ispin):
+    """c_{iorb, ispin} on a normal-mode sector vector (apply_op_C, ED_SECTOR.f90:465-536) up to the sector-wide sign
+    (-1)^Nup of a down operator, which drops out of the norms taken below."""
+    out = np.zeros(h_to.dim, dtype=vec.dtype)
+    mp_from, mp_to = (h_from.mapup, h_to.mapup) if ispin == 0 else (h_from.mapdw, h_to.mapdw)
+    rank_to = {int(s): i for i, s in enumerate(mp_to)}
+    bit = 1 << iorb
+    sel = np.nonzero((mp_from & bit) != 0)[0]
+    if sel.size == 0:
+        return out
+    below = mp_from[sel] & (bit - 1)
+    par = np.zeros(sel.size, dtype=np.int64)
+    for k in range(iorb):
+        par += (below >> k) & 1
+    sgn = 1.0 - 2.0 * (par & 1)
+    tgt = np.array([rank_to[int(s) ^ bit] for s in mp_from[sel]], dtype=np.int64)
+    v2, o2 = vec.reshape(h_from.dimdw, h_from.dimup), out.reshape(h_to.dimdw, h_to.dimup)
+    if ispin == 0:
+        o2[:, tgt] = v2[:, sel] * sgn[None, :]
+    else:
+        o2[tgt, :] = v2[sel, :] * sgn[:, None]
+    return out
+
+
+def numpy_cops_normal(h_from, h_to, vec, ops):
+    """sum_s coef_s c_{orb_s, spin_s} |vec> (annihilators of one spin species), ops = [(coef, iorb, ispin)]."""
+    out = np.zeros(h_to.dim, dtype=vec.dtype)
+    for coef, iorb, ispin in ops:
+        out = out + coef * _apply_c_normal(h_from, h_to, vec, iorb, ispin)
+    return out
+
+
+def exciton_normal(om, states, cops=numpy_cops_normal, hsector=None):
+    """[exct_S0(1,2), exct_Tz(1,2)] of ED_OBSERVABLES_NORMAL.f90:228-296 (exciton.check of REPLICA_ / GENERAL_NORMAL):
+    theta_ss = ||(c_{1s} + c_{2s}) gs||^2 through apply_Cops into the sector with one electron of spin s less;
+    S0 = (theta_up + theta_dw - n_1 - n_2) / 2, Tz = (theta_up - theta_dw - m_1 - m_2) / 2."""
+    cache = {}
+
+    def default_hsector(sec):
+        if sec not in cache:
+            cache[sec] = O.HNormal(om, *sec)
+        return cache[sec]
+
+    hsector = hsector or default_hsector
+    th = np.zeros(2)
+    for sec, h, v in states:
+        for ispin in range(2):
+            sec2 = (sec[0] - 1, sec[1]) if ispin == 0 else (sec[0], sec[1] - 1)
+            if min(sec2) < 0:
+                continue
+            vv = cops(h, hsector(sec2), v, [(1.0, 0, ispin), (1.0, 1, ispin)])
+            th[ispin] += float(np.real(np.vdot(vv, vv))) / len(states)
+    dup, ddw = _densities(om, states)
+    dens, magz = dup + ddw, dup - ddw
+    return np.array([0.5 * (th[0] + th[1] - dens[0] - dens[1]), 0.5 * (th[0] - th[1] - magz[0] - magz[1])])

@@ -2085,5 +2085,25 @@ def test_golden_observables_from_gpu_eigenvectors(gpu, name):
             assert np.max(np.abs(phi.real - np.array(g["phisc"]))) < tol and np.max(np.abs(phi.imag)) < tol
         if "magX" in g:
             assert np.max(np.abs(ob.magx(om, states, cops, hsector) - np.array(g["magX"]))) < tol
+    if "exciton" in g and mode == "normal":
+        # exct_S0 / exct_Tz: edigpu_apply_cops_normal (c_1s + c_2s, both spin species) on the GPU eigenvectors
+        ocache = {}
+
+        def hsector_n(sec):
+            if sec not in ocache:
+                ocache[sec] = O.HNormal(om, *sec)
+                secof[id(ocache[sec])] = sec
+            return ocache[sec]
+
+        def cops_n(h1, h2, v, ops):
+            g1, g2 = ghandle(secof[id(h1)]), ghandle(secof[id(h2)])
+            src = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).cuda()
+            dst = torch.zeros(g2.dim, dtype=torch.float64, device="cuda")
+            g1.apply_cops_to(g2, src.data_ptr(), dst.data_ptr(), [c for c, _, _ in ops], [False] * len(ops),
+                             [a for _, a, _ in ops], [sp for _, _, sp in ops], torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            return dst.cpu().numpy()
+
+        assert np.max(np.abs(ob.exciton_normal(om, states, cops=cops_n, hsector=hsector_n) - np.array(g["exciton"]))) < tol
     for h in handles.values():
         h.destroy()

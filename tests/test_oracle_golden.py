@@ -490,6 +490,16 @@ def test_oracle_reproduces_doubles_energy_imp(name):
     assert np.max(np.abs(imp - np.array(g["imp"]))) < tol
 
 
+@pytest.mark.parametrize("name", ["REPLICA_NORMAL", "GENERAL_NORMAL"])
+def test_oracle_reproduces_exciton(name):
+    """exciton.check of the replica / general NORMAL directories: exct_S0 and exct_Tz between the two orbitals through
+    apply_Cops in normal mode (c_1s + c_2s on the ground state, both spin species)."""
+    from tests import observables as ob
+    om, g = _golden_model(name)
+    e0, states = ob.ground_manifold(om)
+    assert np.max(np.abs(ob.exciton_normal(om, states) - np.array(g["exciton"]))) < 1e-9
+
+
 @pytest.mark.parametrize("name", [d for d in DIRS + REPLICA_DIRS if "phisc" in GOLD[d] or "magX" in GOLD[d]])
 def test_oracle_reproduces_phisc_magx(name):
     """apply_Cops on the ground state into the neighbouring sector (ED_SECTOR.f90:839-960), as the reference's
