@@ -194,3 +194,27 @@ def exciton_normal(om, states, cops=numpy_cops_normal, hsector=None):
     dup, ddw = _densities(om, states)
     dens, magz = dup + ddw, dup - ddw
     return np.array([0.5 * (th[0] + th[1] - dens[0] - dens[1]), 0.5 * (th[0] - th[1] - magz[0] - magz[1])])
+
+
+def exciton_nonsu2(om, states, cops, hsector):
+    """[exct_S0, exct_Tx, exct_Ty, exct_Tz](1,2) of ED_OBSERVABLES_NONSU2.f90:325-425 (exciton.check of REPLICA_ /
+    GENERAL_NONSU2; no factor 1/2 in this mode): norms of (c_{1s} + c_{2s'}) gs and (c_{1s} - i c_{2s'}) gs in the sector
+    N - 1.  cops(h_from, h_to, vec, ops) with ops = [(coef, create, iorb, ispin)]."""
+    th = {}
+    keys = {"upup": (0, 0, 1.0), "dwdw": (1, 1, 1.0), "updw": (0, 1, 1.0), "dwup": (1, 0, 1.0),
+            "o_updw": (0, 1, -1.0j), "o_dwup": (1, 0, -1.0j)}
+    for k in keys:
+        th[k] = 0.0
+    for sec, h, v in states:
+        if sec < 1:
+            continue
+        h2 = hsector(sec - 1)
+        for k, (s, t, c2) in keys.items():
+            vv = cops(h, h2, v, [(1.0, False, 0, s), (c2, False, 1, t)])
+            th[k] += float(np.real(np.vdot(vv, vv))) / len(states)
+    dup, ddw = _densities(om, states)
+    dens, magz = dup + ddw, dup - ddw
+    return np.array([th["upup"] + th["dwdw"] - dens[0] - dens[1],
+                     th["updw"] + th["dwup"] - dens[0] - dens[1],
+                     th["o_updw"] - th["o_dwup"] - magz[0] + magz[1],
+                     th["upup"] - th["dwdw"] - magz[0] - magz[1]])

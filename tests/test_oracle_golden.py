@@ -500,6 +500,25 @@ def test_oracle_reproduces_exciton(name):
     assert np.max(np.abs(ob.exciton_normal(om, states) - np.array(g["exciton"]))) < 1e-9
 
 
+@pytest.mark.parametrize("name", ["REPLICA_NONSU2", "GENERAL_NONSU2"])
+def test_oracle_reproduces_exciton_nonsu2(name):
+    """exciton.check of the replica / general NONSU2 directories: S0, Tx, Ty, Tz between the two orbitals, six apply_Cops
+    combinations (same spin, opposite spin, with a factor -i) on the ground state."""
+    from tests import observables as ob
+    from tests.gf_flat import apply_cops
+    om, g = _golden_model(name)
+    e0, states = ob.ground_manifold(om)
+    cache = {}
+
+    def hsector(sec):
+        if sec not in cache:
+            cache[sec] = O.HFlat(om, sec)
+        return cache[sec]
+
+    got = ob.exciton_nonsu2(om, states, lambda h1, h2, v, ops: apply_cops(h1, h2, v, ops, om.ns), hsector)
+    assert np.max(np.abs(got - np.array(g["exciton"]))) < 1e-9
+
+
 @pytest.mark.parametrize("name", [d for d in DIRS + REPLICA_DIRS if "phisc" in GOLD[d] or "magX" in GOLD[d]])
 def test_oracle_reproduces_phisc_magx(name):
     """apply_Cops on the ground state into the neighbouring sector (ED_SECTOR.f90:839-960), as the reference's
