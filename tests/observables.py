@@ -100,6 +100,17 @@ def _densities(om, states):
     return up / len(states), dw / len(states)
 
 
+def dens_docc(om, states):
+    """dens.check, docc.check: <n_a>, <n_a,up n_a,dw> over the ground-state manifold."""
+    dens, docc = np.zeros(om.norb), np.zeros(om.norb)
+    for sec, h, v in states:
+        nu, nd = _occupations(om, sec, h)
+        p = np.abs(v) ** 2
+        dens += (nu + nd) @ p
+        docc += (nu * nd) @ p
+    return dens / len(states), docc / len(states)
+
+
 def phisc(om, states, cops, hsector):
     """Phi_ab (complex) in Fortran element order (a fastest).  cops(h_from, h_to, vec, ops) with ops = [(coef, create,
     iorb, ispin)]; hsector(sector) -> H object of a sector (cached by the caller).  The phisc.check files hold the signed

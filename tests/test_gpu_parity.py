@@ -2059,6 +2059,8 @@ def test_golden_observables_from_gpu_eigenvectors(gpu, name):
     assert np.max(np.abs(doubles - np.array(g["doubles"]))) < tol
     assert np.max(np.abs(energy - np.array(g["energy"]))) < tol
     assert np.max(np.abs(imp - np.array(g["imp"]))) < tol
+    dens, docc = ob.dens_docc(om, states)
+    assert np.max(np.abs(dens - np.array(g["dens"]))) < tol and np.max(np.abs(docc - np.array(g["docc"]))) < tol
     if "phisc" in g or "magX" in g:
         ocache = {}
 
