@@ -130,7 +130,9 @@ struct edigpu_comm_s {
   char* slots = nullptr;
   std::vector<char> stage;
   // sharded-recurrence workspace (grown on demand)
-  int64_t ws_chunk = 0, ws_x = 0;
+  // capacities in doubles: vin / vout / tmp, vfull (all-gather form only), the four exchange buffers.  Grow-only and
+  // tracked one by one: a communicator serves sectors of different geometry (transposed and all-gather) in turn
+  int64_t ws_chunk = 0, ws_full = 0, ws_x = 0;
   double *vin = nullptr, *vout = nullptr, *tmp = nullptr, *vfull = nullptr;
   double *send = nullptr, *recv = nullptr, *hvc = nullptr, *back = nullptr;
   double *hist = nullptr, *work = nullptr, *scr = nullptr;
@@ -448,13 +450,15 @@ static int regrow(T*& p, size_t n) {
 
 static int comm_workspace(edigpu_comm_s* c, const ShardGeom& g, int nlanc) {
   const int64_t chunk = g.chunk * g.w;
-  if (chunk != c->ws_chunk) {
+  if (chunk > c->ws_chunk) {
     if (regrow(c->vin, chunk) || regrow(c->vout, chunk) || regrow(c->tmp, chunk)) return 1;
-    if (!g.transposed && regrow(c->vfull, (size_t)chunk * c->world)) return 1;
     c->ws_chunk = chunk;
   }
-  if (!g.transposed && !c->vfull && regrow(c->vfull, (size_t)chunk * c->world)) return 1;
-  if (g.transposed && g.xlen != c->ws_x) {
+  if (!g.transposed && (chunk * c->world > c->ws_full || !c->vfull)) {
+    if (regrow(c->vfull, (size_t)chunk * c->world)) return 1;
+    c->ws_full = chunk * c->world;
+  }
+  if (g.transposed && g.xlen > c->ws_x) {
     if (regrow(c->send, g.xlen) || regrow(c->recv, g.xlen) || regrow(c->hvc, g.xlen) || regrow(c->back, g.xlen)) return 1;
     c->ws_x = g.xlen;
   }
