@@ -13,6 +13,7 @@
 #include <mutex>
 #include <tuple>
 
+#include "host_ib.hpp"
 #include "kernels.hpp"
 
 namespace edigpu {
@@ -398,6 +399,71 @@ static void plan_tile_chunks(const HostCsr& dw, int64_t dw_first, int64_t dw_cou
   }
 }
 
+
+static void free_ib(IbDev* p) {
+  if (!p) return;
+  dev_free(p->upos); dev_free(p->ublist); dev_free(p->up_vtab); dev_free(p->up_timp); dev_free(p->up_ebath);
+  dev_free(p->xu); dev_free(p->ed); dev_free(p->impd); dev_free(p->pos); dev_free(p->colof); dev_free(p->chunk_row);
+  dev_free(p->chunk_blk); dev_free(p->dcls); dev_free(p->dblist); dev_free(p->dmeta); dev_free(p->dw_vtab);
+  dev_free(p->dw_timp); dev_free(p->ndcoef); dev_free(p->nd_dw); dev_free(p->nd_up);
+}
+
+// device copy of the impurity-block image; leaves s->ib null (and returns 0) when the sector is not of that form
+static int setup_ib(edigpu_sector* s, const HostNormal& hn, int chunk_rows) {
+  HostIb h;
+  build_ib(hn, chunk_rows, h);
+  if (!h.valid) return 0;
+  int nt = 0, nbt = 0;
+  const int plen = h.npanels * kIbPanel;
+  if (!ib_rows_config(h.norb, h.up.nb, (int)h.ublist.size(), plen, &nt, &nbt)) return 0;
+  int mcb = 8;
+  for (size_t c = 0; c + 1 < h.chunk_blk.size(); c++) mcb = std::max(mcb, h.chunk_blk[c + 1] - h.chunk_blk[c]);
+  std::unique_ptr<IbDev> d(new IbDev());
+  d->norb = h.norb;
+  d->nb_up = h.up.nb;
+  d->nb_dw = h.dw.nb;
+  d->npanels = h.npanels;
+  d->plen = plen;
+  d->nlist = (int)h.ublist.size();
+  for (int i = 0; i < 5; i++) d->ucls[i] = h.ucls[std::min(i, h.norb + 1)];
+  d->lowbits = h.lowbits;
+  d->nchunks = (int)h.chunk_row.size() - 1;
+  d->max_chunk_rows = h.max_chunk_rows;
+  d->max_chunk_blocks = mcb;
+  d->nterms = h.nterms;
+  d->dim_up = hn.dim_up;
+  d->dim_dw = hn.dim_dw;
+  d->ps = hn.dim_dw * kIbPanel;
+  d->len = (int64_t)h.npanels * d->ps;
+  d->rows_nt = nt;
+  d->rows_nbt = nbt;
+  d->rows_lds = ib_rows_lds_bytes(h.norb, h.up.nb, plen);
+  d->cols_lds = ib_cols_lds_bytes(h.dw.nb, h.max_chunk_rows, mcb);
+  if (d->cols_lds > 158 * 1024) return 0;
+  std::vector<int32_t> colof((size_t)plen, -1);
+  for (int64_t i = 0; i < hn.dim_up; i++) colof[(size_t)h.pos[(size_t)i]] = (int32_t)i;
+  IbDev* p = d.get();
+  if (dev_upload(&p->upos, h.upos.data(), h.upos.size()) || dev_upload(&p->ublist, h.ublist.data(), h.ublist.size()) ||
+      dev_upload(&p->up_vtab, h.up.vtab.data(), h.up.vtab.size()) || dev_upload(&p->up_timp, h.up.timp.data(), h.up.timp.size()) ||
+      dev_upload(&p->up_ebath, h.up.ebath.data(), h.up.ebath.size()) || dev_upload(&p->xu, h.xu.data(), h.xu.size()) ||
+      dev_upload(&p->ed, h.ed.data(), h.ed.size()) || dev_upload(&p->impd, h.impd.data(), h.impd.size()) ||
+      dev_upload(&p->pos, h.pos.data(), h.pos.size()) || dev_upload(&p->colof, colof.data(), colof.size()) ||
+      dev_upload(&p->chunk_row, h.chunk_row.data(), h.chunk_row.size()) ||
+      dev_upload(&p->chunk_blk, h.chunk_blk.data(), h.chunk_blk.size()) || dev_upload(&p->dcls, h.dcls.data(), h.dcls.size()) ||
+      dev_upload(&p->dblist, h.dblist.data(), h.dblist.size()) || dev_upload(&p->dmeta, h.dmeta.data(), h.dmeta.size()) ||
+      dev_upload(&p->dw_vtab, h.dw.vtab.data(), h.dw.vtab.size()) || dev_upload(&p->dw_timp, h.dw.timp.data(), h.dw.timp.size()) ||
+      dev_upload(&p->nd_dw, h.nd_dw.data(), h.nd_dw.size()) || dev_upload(&p->nd_up, h.nd_up.data(), h.nd_up.size())) {
+    free_ib(p);
+    return 1;
+  }
+  if (h.nterms > 0 && dev_upload(&p->ndcoef, h.ndcoef.data(), h.ndcoef.size())) {
+    free_ib(p);
+    return 1;
+  }
+  s->ib = d.release();
+  return 0;
+}
+
 static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_t dw_first,
                         int64_t dw_count, const double* hd, const HostCsr& up, const HostCsr& dw,
                         const int64_t* nd_rowptr, const int32_t* nd_col, const double* nd_val,
@@ -592,6 +658,18 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
     if (dev_upload(&s->d_tl_val, tv.data(), tv.size())) return 1;
     s->tl_has_nd = with_nd ? 1 : 0;
   }
+  // Impurity-block image (host_ib.hpp, kernels_ib.hip): whole sectors built from a model whose hops connect impurity
+  // levels with single bath levels (normal / hybrid baths), <= 3 orbitals.  The device-resident Lanczos loops then run
+  // on its padded 16-column panel layout and its two kernels.  EDIGPU_IB=0 switches it off, EDIGPU_IB_MIN sets the
+  // smallest sector (rows; tests force it on small ones), EDIGPU_IB_ROWS the rows of a staged chunk (<= 480).
+  if (s->factored && built && built->norb > 0 && dw_first == 0 && dw_count == dim_dw) {
+    const char* e;
+    const bool on = !(e = getenv("EDIGPU_IB")) || atoi(e) != 0;
+    const int64_t min_rows = (e = getenv("EDIGPU_IB_MIN")) ? atoll(e) : ((int64_t)1 << 21);
+    int chunk_rows = (e = getenv("EDIGPU_IB_ROWS")) ? atoi(e) : 480;
+    chunk_rows = std::max(4, std::min(chunk_rows, 480));
+    if (on && s->nloc >= min_rows && !env_flag("EDIGPU_LANCZOS_UNFUSED") && setup_ib(s, *built, chunk_rows)) return 1;
+  }
   // Panel-major vector layout for the device-resident Lanczos loop (normal_args.hpp): large
   // factored whole sectors whose rows fit the LDS row kernel.  Default: 128-column panels (1 KiB line-aligned segments)
   // swept by the LDS-tiled kernel -- measured 6 % (config 2), 14 % (Ns = 15) and 8 % (Ns = 16) faster per product than
@@ -600,7 +678,7 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
   // stay in one L2, fetch traffic 1.1-1.9x of V + result instead of 1.8-5x, but bound by the L2's gather throughput and
   // 10-60 % slower: an experiment that is kept, tested, off); EDIGPU_BLOCKED_MIN the smallest sector (rows),
   // EDIGPU_BLOCKED_LDS_KB the staged block of the narrow sweep.
-  if (s->factored && built && dw_first == 0 && dw_count == dim_dw && s->rows_per_block >= 1 && s->row_split == 1 &&
+  if (!s->ib && s->factored && built && dw_first == 0 && dw_count == dim_dw && s->rows_per_block >= 1 && s->row_split == 1 &&
       dim_dw <= 65535 && dim_up >= 64) {
     const char* e;
     const bool on = !(e = getenv("EDIGPU_BLOCKED")) || atoi(e) != 0;
@@ -916,7 +994,7 @@ static int ensure_workspace(edigpu_sector* s) {
   dev_free(s->d_partial);
   dev_free(s->d_scal);
   // (the panel-major layout of the Lanczos loop pads the last panel: blk_len >= len)
-  const size_t n = (size_t)std::max<int64_t>(std::max(len, s->blk_len), 1);
+  const size_t n = (size_t)std::max<int64_t>(std::max(std::max(len, s->blk_len), s->ib ? s->ib->len : 0), 1);
   EDIGPU_HIP(hipMalloc((void**)&s->d_vin, n * sizeof(double)));
   EDIGPU_HIP(hipMalloc((void**)&s->d_vout, n * sizeof(double)));
   EDIGPU_HIP(hipMalloc((void**)&s->d_tmp, n * sizeof(double)));
@@ -1150,8 +1228,8 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
 static int lanczos_prepare(edigpu_sector* s, int nlanc, double threshold, hipStream_t st) {
   s->lz_exactbeta = getenv("EDIGPU_LANCZOS_EXACTBETA") != nullptr;
   // the recurrence of a large factored normal-mode sector runs on panel-major vectors (set-up decides, blk_shift)
-  s->lz_blocked = s->kind == 0 && s->blk_shift > 0 && s->nph == 0 && normal_lanczos_fusable(s);
-  s->lz_len = s->lz_blocked ? s->blk_len : s->ws_len;
+  s->lz_blocked = s->kind == 0 && (s->blk_shift > 0 || s->ib) && s->nph == 0 && normal_lanczos_fusable(s);
+  s->lz_len = s->lz_blocked ? (s->ib ? s->ib->len : s->blk_len) : s->ws_len;
   const size_t ns = (size_t)SC_AB + 2 * (size_t)nlanc;
   if (!s->d_scal || s->scal_cap < ns) {  // (kept across runs: a captured graph holds its address)
     dev_free(s->d_scal);
@@ -1176,6 +1254,7 @@ static int lanczos_seed(edigpu_sector* s, const double* src, uint64_t seed, hipS
   } else if (lz_fill_random(dst, s->ws_len, seed, st)) {
     return 1;
   }
+  if (s->lz_blocked && s->ib) return vec_to_ib(s->ib, s->d_tmp, s->d_vin, st);
   if (s->lz_blocked) return vec_to_blocked(s->d_tmp, s->d_vin, s->dim_up, s->dim_dw, s->blk_shift, st);
   return 0;
 }
@@ -1242,7 +1321,7 @@ static int lanczos_run(edigpu_sector* s, int from, int to, int nlanc, hipStream_
 // a vector of the current recurrence (device, lz_len doubles) to a host or device buffer in the natural layout
 static int lanczos_fetch(edigpu_sector* s, const double* v, double* dst, hipStream_t st) {
   if (s->lz_blocked) {
-    if (vec_from_blocked(v, s->d_tmp, s->dim_up, s->dim_dw, s->blk_shift, st)) return 1;
+    if (s->ib ? vec_from_ib(s->ib, v, s->d_tmp, st) : vec_from_blocked(v, s->d_tmp, s->dim_up, s->dim_dw, s->blk_shift, st)) return 1;
     v = s->d_tmp;
   }
   EDIGPU_HIP(hipMemcpyAsync(dst, v, (size_t)s->ws_len * sizeof(double), hipMemcpyDefault, st));
@@ -1900,8 +1979,8 @@ int edigpu_image_info(edigpu_handle s, int32_t image[6]) {
   image[1] = s->factored ? s->fac_nterms : 0;
   image[2] = s->factored ? s->fac_nimp : 0;
   image[3] = s->panel_mode;
-  image[4] = s->blk_shift ? (1 << s->blk_shift) : 0;
-  image[5] = 0;
+  image[4] = s->ib ? kIbPanel : (s->blk_shift ? (1 << s->blk_shift) : 0);
+  image[5] = s->ib ? 1 : 0;
   return 0;
 }
 
@@ -2097,6 +2176,17 @@ static int apply_host(edigpu_handle s, int64_t nloc, const double* v_host, doubl
   EDIGPU_HIP(hipSetDevice(s->device));
   if (ensure_workspace(s)) return 1;
   const size_t bytes = (size_t)s->ws_len * sizeof(double);
+  if (s->kind == 0 && s->ib && s->nph == 0) {
+    // host vectors cross PCIe anyway: take the impurity-block kernels of the device-resident loops (two layout
+    // conversions on the device are small next to the transfers)
+    hipStream_t st = s->stream;
+    EDIGPU_HIP(hipMemcpyAsync(s->d_tmp, v_host, bytes, hipMemcpyHostToDevice, st));
+    if (vec_to_ib(s->ib, s->d_tmp, s->d_vin, st) || launch_ib(s, s->d_vin, s->d_vout, st) || vec_from_ib(s->ib, s->d_vout, s->d_tmp, st))
+      return 1;
+    EDIGPU_HIP(hipMemcpyAsync(hv_host, s->d_tmp, bytes, hipMemcpyDeviceToHost, st));
+    EDIGPU_HIP(hipStreamSynchronize(st));
+    return 0;
+  }
   EDIGPU_HIP(hipMemcpyAsync(s->d_vin, v_host, bytes, hipMemcpyHostToDevice, s->stream));
   if (apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, s->stream)) return 1;
   EDIGPU_HIP(hipMemcpyAsync(hv_host, s->d_tmp, bytes, hipMemcpyDeviceToHost, s->stream));
@@ -3047,6 +3137,11 @@ int edigpu_destroy(edigpu_handle s) {
   dev_free(s->d_bl_lend);
   dev_free(s->d_bl_ent);
   dev_free(s->d_bl_wtab);
+  if (s->ib) {
+    free_ib(s->ib);
+    delete s->ib;
+    s->ib = nullptr;
+  }
   dev_free(s->d_tl_meta);
   dev_free(s->d_tl_col);
   dev_free(s->d_tl_val);

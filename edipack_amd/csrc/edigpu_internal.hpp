@@ -79,6 +79,26 @@ struct DevEll {
   double* val = nullptr;
 };
 
+// Impurity-block image of a whole normal-mode sector on the device (host_ib.hpp; kernels_ib.hip).  Vectors of the
+// device-resident Lanczos loops live in the padded panel layout: element (idw, iup) at
+// (pos[iup] / 16) * ps + idw * 16 + pos[iup] % 16, ps = dim_dw * 16, len = npanels * ps doubles, padding = zeros.
+struct IbDev {
+  int norb = 0, nb_up = 0, nb_dw = 0, npanels = 0, plen = 0, nlist = 0;
+  int ucls[5] = {0, 0, 0, 0, 0};
+  int lowbits = 0, nchunks = 0, max_chunk_rows = 0, max_chunk_blocks = 0, nterms = 0;
+  int64_t dim_up = 0, dim_dw = 0, ps = 0, len = 0;
+  int rows_nt = 0, rows_nbt = 0;      // rows kernel: threads per workgroup, blocks per thread
+  size_t rows_lds = 0, cols_lds = 0;  // dynamic LDS of the two kernels
+  uint16_t *upos = nullptr, *ublist = nullptr;
+  double *up_vtab = nullptr, *up_timp = nullptr, *up_ebath = nullptr, *xu = nullptr, *ed = nullptr;
+  uint8_t* impd = nullptr;
+  int32_t *pos = nullptr, *colof = nullptr;  // column -> position, position -> column (-1: padding)
+  int32_t *chunk_row = nullptr, *chunk_blk = nullptr, *dcls = nullptr;
+  uint16_t *dblist = nullptr, *dmeta = nullptr;
+  double *dw_vtab = nullptr, *dw_timp = nullptr, *ndcoef = nullptr;
+  uint8_t *nd_dw = nullptr, *nd_up = nullptr;
+};
+
 }  // namespace edigpu
 
 struct edigpu_sector {
@@ -132,7 +152,10 @@ struct edigpu_sector {
   uint32_t* d_bl_ent = nullptr;
   double* d_bl_wtab = nullptr;
   bool lz_blocked = false;
-  int64_t lz_len = 0;           // doubles per vector of the current recurrence (blk_len or ws_len)
+  int64_t lz_len = 0;           // doubles per vector of the current recurrence (blk_len, ib->len or ws_len)
+  // impurity-block image (large factored whole sectors built from a model; takes precedence over the panel-major image
+  // above: lz_blocked then means "the recurrence runs on ib's padded panel layout")
+  edigpu::IbDev* ib = nullptr;
   int row_split = 1;  // rows longer than the LDS: number of column parts the row kernel stages them in (SPLIT)
   int col_halo = 0;             // max |partner column - column| over the factored Hnd terms (transposed exchange)
   uint32_t* d_jdw = nullptr;    // nterms * dim_dw

@@ -431,6 +431,15 @@ std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_fir
       }
       xt[(iu << norb) | id] = x;
     }
+  out.norb = norb;
+  out.ob_a[0] = oup.a;
+  out.ob_a[1] = odw.a;
+  out.ob_eps[0] = oup.eps;
+  out.ob_eps[1] = odw.eps;
+  out.xt = xt;
+  out.samespin.assign((size_t)norb * norb, 0.0);
+  for (int a = 0; a < norb; a++)
+    for (int bb = a + 1; bb < norb; bb++) out.samespin[(size_t)a * norb + bb] = ix.ust(a, bb) - ix.jh(a, bb);
   // factored diagonal tables
   HostFactored& fac = out.fac;
   fac = HostFactored();

@@ -65,6 +65,12 @@ struct HostNormal {
   HostCsr up, dw, nd;      // nd over local rows, global columns (explicit_arrays only)
   bool has_nd = false;
   int64_t nd_nnz = 0;      // entries of Hnd on the local rows (always set)
+  // what the sector was built from, for the impurity-block image (host_ib.cpp): per species (0 up, 1 down) the
+  // ns x ns hop matrix A(p,q) and the level energies; xt[(imp_up << norb) | imp_dw] = inter-spin impurity interaction
+  // + constant; samespin[a * norb + b] = (Ust - Jh)(a,b), a < b.  Empty for sectors that did not come from a model.
+  int norb = 0;
+  std::vector<double> ob_a[2], ob_eps[2];
+  std::vector<double> xt, samespin;
 };
 
 struct HostFlat {

@@ -1,0 +1,246 @@
+// host_ib.cpp -- see host_ib.hpp.  Product code (host side of kernels_ib.hip); shares nothing with oracle/.
+#include "host_ib.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace edigpu {
+
+namespace {
+
+inline int popc(uint32_t x) { return __builtin_popcount(x); }
+
+// the species tables; "" on success
+std::string build_side(const HostNormal& hn, int sp, const CombBasis& bs, int npart, IbSide& s) {
+  const int ns = hn.ns, norb = hn.norb, nb = ns - norb;
+  s.ns = ns;
+  s.npart = npart;
+  s.norb = norb;
+  s.nb = nb;
+  s.dim = bs.size();
+  const std::vector<double>& a = hn.ob_a[sp];
+  const std::vector<double>& eps = hn.ob_eps[sp];
+  if ((int)a.size() != ns * ns || (int)eps.size() != ns) return "no one-body data";
+  if (s.dim >= 0xFFF0) return "more than 65519 states per species";
+  for (int p = 0; p < ns; p++)
+    for (int q = 0; q < ns; q++) {
+      if (p == q) continue;
+      if (a[p * ns + q] != a[q * ns + p]) return "hop matrix not symmetric";
+      if (p >= norb && q >= norb && a[p * ns + q] != 0.0) return "bath-bath hops";
+    }
+  s.vtab.assign((size_t)nb * 4, 0.0);
+  for (int k = 0; k < nb; k++)
+    for (int ia = 0; ia < norb; ia++) s.vtab[(size_t)k * 4 + ia] = a[(norb + k) * ns + ia];
+  s.timp.assign((size_t)norb * norb, 0.0);
+  for (int p = 0; p < norb; p++)
+    for (int q = 0; q < norb; q++)
+      if (p != q) s.timp[(size_t)p * norb + q] = a[p * ns + q];
+  const size_t nw = (size_t)1 << nb;
+  s.first.assign(nw, kIbNone);
+  for (int64_t i = 0; i < s.dim; i++) {
+    const uint32_t st = (uint32_t)bs.states[i], b = st >> norb;
+    if (s.first[b] == kIbNone) s.first[b] = (uint16_t)i;
+    // the block is the ascending list of the impurity patterns with n bits: position inside = rank of the pattern
+    const uint32_t p = st & ((1u << norb) - 1u);
+    int r = 0;
+    for (uint32_t q = 0; q < p; q++) r += popc(q) == popc(p);
+    if ((int64_t)s.first[b] + r != i) return "basis not in block order";
+  }
+  s.ebath.assign(nw, 0.0);
+  for (size_t b = 0; b < nw; b++) {
+    double e = 0.0;
+    for (int k = 0; k < nb; k++)
+      if ((b >> k) & 1u) e += eps[norb + k];
+    s.ebath[b] = e;
+  }
+  s.eimp.assign((size_t)1 << norb, 0.0);
+  for (uint32_t p = 0; p < (1u << norb); p++) {
+    double e = 0.0;
+    for (int ia = 0; ia < norb; ia++)
+      if ((p >> ia) & 1u) e += eps[ia];
+    for (int ia = 0; ia < norb; ia++)
+      for (int ib = ia + 1; ib < norb; ib++)
+        if (((p >> ia) & 1u) && ((p >> ib) & 1u)) e += hn.samespin[(size_t)ia * norb + ib];
+    s.eimp[p] = e;
+  }
+  return "";
+}
+
+}  // namespace
+
+void build_ib(const HostNormal& hn, int max_chunk_rows, HostIb& out) {
+  out = HostIb();
+  auto fail = [&](const std::string& w) {
+    out.valid = false;
+    out.why = w;
+  };
+  const int norb = hn.norb, ns = hn.ns, nb = ns - norb;
+  if (norb < 1 || norb > kIbMaxNorb) return fail("impurity levels per species not in 1..3");
+  if (nb < 1 || nb > kIbMaxBath) return fail("bath levels per species not in 1..14");
+  if (hn.dw_first != 0 || hn.dw_count != hn.dim_dw) return fail("the handle is a shard");
+  if (!hn.fac.valid || hn.fac.nterms > kIbMaxTerms) return fail("no factored tables / too many Hnd terms");
+  out.norb = norb;
+  std::string e = build_side(hn, 0, hn.bup, hn.nup, out.up);
+  if (e.empty()) e = build_side(hn, 1, hn.bdw, hn.ndw, out.dw);
+  if (!e.empty()) return fail(e);
+  const int64_t du = hn.dim_up, dd = hn.dim_dw;
+  const uint32_t impmask = (1u << norb) - 1u;
+  const size_t nw = (size_t)1 << nb;
+  auto cls_of = [&](const IbSide& s, uint32_t b) { return s.npart - popc(b); };
+  auto rows_of = [&](const IbSide& s, uint32_t b) { return (int)binomial(norb, cls_of(s, b)); };
+
+  // ---- up side: positions, block list ----
+  const bool pad = hn.fac.nterms > 0;
+  out.pos.assign((size_t)du, 0);
+  out.upos.assign(nw, kIbNone);
+  int cur = 0;
+  for (uint32_t b = 0; b < nw; b++) {
+    if (out.up.first[b] == kIbNone) continue;
+    const int m = rows_of(out.up, b);
+    if (pad && (cur % kIbPanel) + m > kIbPanel) cur = (cur / kIbPanel + 1) * kIbPanel;
+    out.upos[b] = (uint16_t)cur;
+    for (int j = 0; j < m; j++) out.pos[(size_t)out.up.first[b] + j] = cur + j;
+    cur += m;
+  }
+  out.npanels = (cur + kIbPanel - 1) / kIbPanel;
+  if (out.npanels * kIbPanel >= 0xFFF0) return fail("padded row longer than 65519 columns");
+  for (int n = 0; n <= norb; n++) {
+    out.ucls[n] = (int)out.ublist.size();
+    uint16_t firstb = kIbNone;
+    for (uint32_t b = 0; b < nw; b++)
+      if (out.up.first[b] != kIbNone && cls_of(out.up, b) == n) {
+        if (firstb == kIbNone) firstb = (uint16_t)b;
+        out.ublist.push_back((uint16_t)b);
+      }
+    while (out.ublist.size() % 64) out.ublist.push_back((uint16_t)(firstb | kIbSkip));
+  }
+  out.ucls[norb + 1] = (int)out.ublist.size();
+
+  // ---- diagonal ----
+  out.xu.assign((size_t)(impmask + 1) * (impmask + 1), 0.0);
+  for (uint32_t pd = 0; pd <= impmask; pd++)
+    for (uint32_t pu = 0; pu <= impmask; pu++)
+      out.xu[(size_t)pd * (impmask + 1) + pu] = out.up.eimp[pu] + hn.xt[((size_t)pu << norb) | pd];
+  out.ed = hn.fac.ed;
+  out.impd = hn.fac.impd;
+  {  // the tables must reproduce the factored diagonal of the generic kernels
+    double scale = 1.0, worst = 0.0;
+    for (uint32_t c = 0; c <= impmask; c++)
+      for (int64_t i = 0; i < du; i++) {
+        const uint32_t st = (uint32_t)hn.bup.states[i];
+        const double ref = hn.fac.eux[(size_t)c * du + i];
+        const double got = out.up.ebath[st >> norb] + out.xu[(size_t)c * (impmask + 1) + (st & impmask)];
+        scale = std::max(scale, std::fabs(ref));
+        worst = std::max(worst, std::fabs(ref - got));
+      }
+    if (!(worst <= 1e-13 * scale)) return fail("diagonal tables disagree");
+  }
+
+  // ---- down side: chunks ----
+  // rows that share the bath levels >= low form a contiguous run ("superblock"); the largest low whose superblocks
+  // fit a chunk
+  int low = -1;
+  std::vector<int> sb_rows;
+  for (int l = nb; l >= 0; l--) {
+    std::vector<int> rows((size_t)1 << (nb - l), 0);
+    for (uint32_t b = 0; b < nw; b++)
+      if (out.dw.first[b] != kIbNone) rows[b >> l] += rows_of(out.dw, b);
+    if (*std::max_element(rows.begin(), rows.end()) <= max_chunk_rows) {
+      low = l;
+      sb_rows = rows;
+      break;
+    }
+  }
+  if (low < 0) return fail("no chunk fits");
+  if (nb - low > 2 * 3) return fail("more than 6 bath levels outside a chunk");
+  out.lowbits = low;
+  {
+    // consecutive superblocks are merged while they fit
+    int rows = 0, row0 = 0;
+    std::vector<uint32_t> hs;
+    auto flush = [&]() {
+      if (hs.empty()) return;
+      const int c = (int)out.chunk_row.size();
+      out.chunk_row.push_back(row0);
+      out.chunk_blk.push_back((int)out.dblist.size());
+      out.dcls.resize((size_t)(c + 1) * (kIbMaxNorb + 2), 0);
+      const int base = (int)out.dblist.size();
+      for (int n = 0; n <= norb; n++) {
+        out.dcls[(size_t)c * (kIbMaxNorb + 2) + n] = (int)out.dblist.size() - base;
+        uint16_t firstb = kIbNone;
+        for (uint32_t h : hs)
+          for (uint32_t lo = 0; lo < (1u << low); lo++) {
+            const uint32_t b = (h << low) | lo;
+            if (out.dw.first[b] == kIbNone || cls_of(out.dw, b) != n) continue;
+            if (firstb == kIbNone) firstb = (uint16_t)b;
+            out.dblist.push_back((uint16_t)b);
+          }
+        while ((out.dblist.size() - base) % 8) out.dblist.push_back((uint16_t)(firstb | kIbSkip));
+      }
+      for (int n = norb + 1; n < kIbMaxNorb + 2; n++)
+        out.dcls[(size_t)c * (kIbMaxNorb + 2) + n] = (int)out.dblist.size() - base;
+      out.max_chunk_rows = std::max(out.max_chunk_rows, rows);
+      row0 += rows;
+      rows = 0;
+      hs.clear();
+    };
+    for (uint32_t h = 0; h < (1u << (nb - low)); h++) {
+      if (sb_rows[h] == 0) continue;
+      if (rows + sb_rows[h] > max_chunk_rows) flush();
+      hs.push_back(h);
+      rows += sb_rows[h];
+    }
+    flush();
+    out.chunk_row.push_back((int32_t)dd);
+    out.chunk_blk.push_back((int32_t)out.dblist.size());
+    if (row0 != dd) return fail("chunk plan does not cover the rows");
+  }
+  out.dmeta.assign(nw * 16, 0);
+  for (uint32_t b = 0; b < nw; b++) {
+    if (out.dw.first[b] == kIbNone) continue;
+    uint16_t sg = 0;
+    for (int k = 0; k < nb; k++) {
+      out.dmeta[(size_t)b * 16 + k] = out.dw.first[b ^ (1u << k)];
+      if (popc(b & ((1u << k) - 1u)) & 1) sg |= (uint16_t)(1u << k);
+    }
+    out.dmeta[(size_t)b * 16 + 14] = out.dw.first[b];
+    out.dmeta[(size_t)b * 16 + 15] = sg;
+  }
+
+  // ---- factored Hnd, block-relative ----
+  out.nterms = hn.fac.nterms;
+  out.ndcoef = hn.fac.coef;
+  out.nd_dw.assign((size_t)std::max(1, out.nterms) * (norb + 1) * 4, 0xFF);
+  out.nd_up.assign((size_t)std::max(1, out.nterms) * out.npanels * kIbPanel, 0xFF);
+  for (int t = 0; t < out.nterms; t++) {
+    std::vector<int> seen((size_t)(norb + 1) * 4, -1);
+    for (uint32_t b = 0; b < nw; b++) {
+      if (out.dw.first[b] == kIbNone) continue;
+      const int n = cls_of(out.dw, b), m = rows_of(out.dw, b);
+      for (int j = 0; j < m; j++) {
+        const uint32_t jd = hn.fac.jdw[(size_t)t * dd + out.dw.first[b] + j];
+        int ent = 0xFF;
+        if (jd != 0xFFFFFFFFu) {
+          const int64_t rel = (int64_t)(jd & 0x7FFFFFFFu) - out.dw.first[b];
+          if (rel < 0 || rel >= m) return fail("an Hnd term leaves its block of rows");
+          ent = (int)rel | ((jd >> 31) ? 0x80 : 0);
+        }
+        int& sv = seen[(size_t)n * 4 + j];
+        if (sv >= 0 && sv != ent) return fail("an Hnd term is not a function of the impurity pattern");
+        sv = ent;
+        out.nd_dw[((size_t)t * (norb + 1) + n) * 4 + j] = (uint8_t)ent;
+      }
+    }
+    for (int64_t i = 0; i < du; i++) {
+      const uint32_t ju = hn.fac.jup[(size_t)t * du + i];
+      if (ju == 0xFFFFFFFFu) continue;
+      const int64_t i2 = (int64_t)(ju & 0x7FFFFFFFu);
+      const int p1 = out.pos[(size_t)i], p2 = out.pos[(size_t)i2];
+      if (p1 / kIbPanel != p2 / kIbPanel || p2 - p1 < -8 || p2 - p1 > 7) return fail("an Hnd term leaves its panel");
+      out.nd_up[(size_t)t * out.npanels * kIbPanel + p1] = (uint8_t)((p2 - p1 + 8) | ((ju >> 31) ? 0x80 : 0));
+    }
+  }
+  out.valid = true;
+}
+
+}  // namespace edigpu

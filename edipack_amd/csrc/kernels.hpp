@@ -85,6 +85,15 @@ int lz_fill_random(double* v, int64_t n, uint64_t seed, hipStream_t st);
 int vec_to_blocked(const double* src, double* dst, int64_t dim_up, int64_t dim_dw, int shift, hipStream_t st);
 int vec_from_blocked(const double* src, double* dst, int64_t dim_up, int64_t dim_dw, int shift, hipStream_t st);
 int launch_normal_blocked(const edigpu_sector* s, const double* v, double* hv, hipStream_t st);
+// impurity-block image (kernels_ib.hip): layout conversion, plain product and fused Lanczos step on its vectors
+int vec_to_ib(const IbDev* ib, const double* src, double* dst, hipStream_t st);
+int vec_from_ib(const IbDev* ib, const double* src, double* dst, hipStream_t st);
+int launch_ib(const edigpu_sector* s, const double* v, double* hv, hipStream_t st);
+int launch_ib_lanczos(const edigpu_sector* s, double* P, double* Q, const double* scal, double* partial, int64_t partial_cap,
+                      bool first, bool lazy_axpy, hipStream_t st, int* npartial);
+size_t ib_rows_lds_bytes(int norb, int nb, int plen);
+size_t ib_cols_lds_bytes(int nb, int max_chunk_rows, int max_chunk_blocks);
+bool ib_rows_config(int norb, int nb, int nlist, int plen, int* nt_out, int* nbt_out);
 int measure_membw(int64_t bytes, double out[3]);
 // stand-alone vector kernels with explicit device scalars (sharded loop)
 int vec_rotate(int64_t n, double* vin, double* vout, const double* beta2, hipStream_t st);

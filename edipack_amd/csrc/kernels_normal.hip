@@ -656,6 +656,8 @@ int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const do
     a.lz_len = s->lz_len;
     *finalized = true;
   }
+  if (s->lz_blocked && s->ib)  // impurity-block image: its own two kernels on its own layout (kernels_ib.hip)
+    return launch_ib_lanczos(s, P, Q, scal, partial, partial_cap, first, lazy_axpy, st, npartial);
   if (s->lz_blocked) {  // P, Q in the panel-major layout (lanczos_prepare)
     a.blk_shift = s->blk_shift;
     a.blk_ps = s->blk_ps;
@@ -674,6 +676,7 @@ int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const do
 
 // plain H*v on panel-major vectors (the product of the blocked Lanczos loop without the fused recurrence)
 int launch_normal_blocked(const edigpu_sector* s, const double* v, double* hv, hipStream_t st) {
+  if (s->ib) return launch_ib(s, v, hv, st);
   if (s->blk_shift == 0 || s->dw_count == 0) {
     set_error("launch_normal_blocked: the sector has no panel-major image");
     return 1;

@@ -1,0 +1,165 @@
+// Test-only shim: the impurity-block image (csrc/host_ib.cpp) and the per-block routines the gfx950 kernels run
+// (csrc/ib_core.hpp) evaluated on the host, against the explicit arrays of the same sector (hd, Hup, Hdw, Hnd CSR from
+// csrc/host_build.cpp).  Compiled with g++ by tests/test_host_ib.py; never part of the product.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_build.hpp"
+#include "host_ib.hpp"
+#include "ib_core.hpp"
+using namespace edigpu;
+
+static std::string g_err;
+extern "C" const char* host_ib_error() { return g_err.c_str(); }
+
+namespace {
+
+int64_t vec_len(const HostIb& ib) { return (int64_t)ib.npanels * kIbPanel * ib.dw.dim; }
+int64_t vec_at(const HostIb& ib, int64_t row, int pos) {
+  return (int64_t)(pos / kIbPanel) * ib.dw.dim * kIbPanel + row * kIbPanel + pos % kIbPanel;
+}
+
+template <int NORB>
+void emulate_rows(const HostIb& ib, const std::vector<double>& v, std::vector<double>& hv) {
+  const int plen = ib.npanels * kIbPanel, nimp = 1 << NORB;
+  std::vector<double> row((size_t)plen + 8, 0.0), out((size_t)plen, 0.0);
+  for (int64_t r = 0; r < ib.dw.dim; r++) {
+    for (int p = 0; p < plen; p++) row[p] = v[vec_at(ib, r, p)];
+    std::fill(out.begin(), out.end(), 0.0);
+    for (int n = 0; n <= NORB; n++)
+      for (int q = ib.ucls[n]; q < ib.ucls[n + 1]; q++) {
+        const uint16_t e = ib.ublist[q];
+        const uint32_t b = e & 0x7FFFu;
+        const uint32_t o = ib.upos[b];
+        ib::for_class<NORB>(n, [&](auto N) {
+          constexpr int nn = decltype(N)::value;
+          double acc[ib::binom(NORB, nn)];
+          ib::rows_block<NORB, nn>(row.data(), b, o, ib.up.nb, ib.upos.data(), ib.up.vtab.data(), ib.up.timp.data(),
+                                   ib.up.ebath[b] + ib.ed[r], &ib.xu[(size_t)ib.impd[r] * nimp], acc);
+          if (!(e & kIbSkip))
+            for (int j = 0; j < ib::binom(NORB, nn); j++) out[o + j] = acc[j];
+        });
+      }
+    for (int p = 0; p < plen; p++) hv[vec_at(ib, r, p)] = out[p];
+  }
+}
+
+template <int NORB>
+void emulate_cols(const HostIb& ib, const std::vector<double>& v, std::vector<double>& hv) {
+  const int64_t dd = ib.dw.dim, ps = dd * kIbPanel;
+  const int nch = (int)ib.chunk_row.size() - 1;
+  for (int pn = 0; pn < ib.npanels; pn++)
+    for (int c = 0; c < nch; c++) {
+      const int row0 = ib.chunk_row[c];
+      const double* chunk = &v[(size_t)pn * ps + (size_t)row0 * kIbPanel];
+      const int32_t* cls = &ib.dcls[(size_t)c * (kIbMaxNorb + 2)];
+      for (int n = 0; n <= NORB; n++)
+        for (int q = cls[n]; q < cls[n + 1]; q++) {
+          const uint16_t e = ib.dblist[(size_t)ib.chunk_blk[c] + q];
+          if (e & kIbSkip) continue;
+          const uint32_t b = e & 0x7FFFu;
+          const int own = ib.dw.first[b];
+          for (int col = 0; col < kIbPanel; col += 2)
+            ib::for_class<NORB>(n, [&](auto N) {
+              constexpr int nn = decltype(N)::value;
+              constexpr int M = ib::binom(NORB, nn);
+              ib::Pair acc[M];
+              for (int j = 0; j < M; j++) {
+                const double* h = &hv[(size_t)pn * ps + (size_t)(own + j) * kIbPanel + col];
+                acc[j].x = h[0];
+                acc[j].y = h[1];
+              }
+              auto gload = [&](int grow) -> ib::Pair {
+                const double* g = &v[(size_t)pn * ps + (size_t)grow * kIbPanel + col];
+                return ib::Pair{g[0], g[1]};
+              };
+              ib::cols_block<NORB, nn>(chunk, row0, b, own, &ib.dmeta[(size_t)b * 16], ib.dw.nb, ib.lowbits,
+                                       ib.dw.vtab.data(), ib.dw.timp.data(), col, gload, acc);
+              if (ib.nterms > 0)
+                ib::cols_block_nd<NORB, nn>(chunk, own - row0, col, ib.nterms, ib.ndcoef.data(), ib.nd_dw.data(),
+                                            &ib.nd_up[(size_t)pn * kIbPanel], ib.npanels * kIbPanel, acc);
+              for (int j = 0; j < M; j++) {
+                double* h = &hv[(size_t)pn * ps + (size_t)(own + j) * kIbPanel + col];
+                h[0] = acc[j].x;
+                h[1] = acc[j].y;
+              }
+            });
+        }
+    }
+}
+
+}  // namespace
+
+// H*v of the sector (nup, ndw) for a seeded vector, through the explicit arrays and through the impurity-block image.
+// info: [0] valid, [1] lowbits, [2] chunks, [3] largest chunk, [4] panels, [5] Hnd terms, [6] padded columns.
+// Returns 0 and *maxdiff = max |difference| / max |reference|; 1 when the image is refused (message in
+// host_ib_error()); 2 on a builder error.
+extern "C" int host_ib_check(const edigpu_model* m, int nup, int ndw, int max_chunk_rows, int32_t* info, double* maxdiff) {
+  HostNormal hn;
+  g_err = build_normal(*m, nup, ndw, 0, -1, hn, true);
+  if (!g_err.empty()) return 2;
+  HostIb ib;
+  build_ib(hn, max_chunk_rows, ib);
+  std::memset(info, 0, 7 * sizeof(int32_t));
+  if (!ib.valid) {
+    g_err = ib.why;
+    return 1;
+  }
+  info[0] = 1;
+  info[1] = ib.lowbits;
+  info[2] = (int)ib.chunk_row.size() - 1;
+  info[3] = ib.max_chunk_rows;
+  info[4] = ib.npanels;
+  info[5] = ib.nterms;
+  info[6] = ib.npanels * kIbPanel - (int)hn.dim_up;
+  const int64_t du = hn.dim_up, dd = hn.dim_dw, dim = du * dd;
+  std::vector<double> v((size_t)dim), ref((size_t)dim, 0.0);
+  uint64_t s = 0x9E3779B97F4A7C15ull;
+  for (auto& x : v) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    x = (double)((int64_t)(s >> 11) - ((int64_t)1 << 52)) / (double)((int64_t)1 << 52);
+  }
+  for (int64_t idw = 0; idw < dd; idw++)
+    for (int64_t iup = 0; iup < du; iup++) {
+      const int64_t i = iup + idw * du;
+      double t = hn.hd[i] * v[i];
+      for (int64_t k = hn.up.rowptr[iup]; k < hn.up.rowptr[iup + 1]; k++) t += hn.up.val[k] * v[hn.up.col[k] + idw * du];
+      for (int64_t k = hn.dw.rowptr[idw]; k < hn.dw.rowptr[idw + 1]; k++) t += hn.dw.val[k] * v[iup + hn.dw.col[k] * du];
+      if (hn.has_nd)
+        for (int64_t k = hn.nd.rowptr[i]; k < hn.nd.rowptr[i + 1]; k++) t += hn.nd.val[k] * v[hn.nd.col[k]];
+      ref[i] = t;
+    }
+  std::vector<double> vi((size_t)vec_len(ib), 0.0), hi((size_t)vec_len(ib), 0.0);
+  for (int64_t idw = 0; idw < dd; idw++)
+    for (int64_t iup = 0; iup < du; iup++) vi[vec_at(ib, idw, ib.pos[iup])] = v[iup + idw * du];
+  switch (ib.norb) {
+    case 1: emulate_rows<1>(ib, vi, hi); emulate_cols<1>(ib, vi, hi); break;
+    case 2: emulate_rows<2>(ib, vi, hi); emulate_cols<2>(ib, vi, hi); break;
+    case 3: emulate_rows<3>(ib, vi, hi); emulate_cols<3>(ib, vi, hi); break;
+    default: g_err = "norb"; return 2;
+  }
+  double worst = 0.0, scale = 0.0;
+  for (int64_t idw = 0; idw < dd; idw++)
+    for (int64_t iup = 0; iup < du; iup++) {
+      const double got = hi[vec_at(ib, idw, ib.pos[iup])], want = ref[iup + idw * du];
+      worst = std::max(worst, std::fabs(got - want));
+      scale = std::max(scale, std::fabs(want));
+    }
+  // the padding columns must stay zero
+  {
+    std::vector<char> real((size_t)ib.npanels * kIbPanel, 0);
+    for (int64_t iup = 0; iup < du; iup++) real[ib.pos[iup]] = 1;
+    for (int p = 0; p < ib.npanels * kIbPanel; p++)
+      if (!real[p])
+        for (int64_t idw = 0; idw < dd; idw++)
+          if (hi[vec_at(ib, idw, p)] != 0.0) {
+            g_err = "a padding column received a value";
+            return 2;
+          }
+  }
+  *maxdiff = scale > 0.0 ? worst / scale : worst;
+  return 0;
+}

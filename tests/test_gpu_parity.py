@@ -1916,6 +1916,69 @@ def test_panel_major_lanczos_matches_oracle(gpu, monkeypatch, w, bath, norb, nba
 
 
 # --------------------------------------------------------------------------------------------
+# impurity-block image (csrc/host_ib.hpp, kernels_ib.hip): large model-built sectors; forced here on small ones
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows", [480, 24, 6])
+@pytest.mark.parametrize("bath,norb,nbath,sec,extra", [
+    ("normal", 2, 3, (4, 4), {}),                      # DimUp = 70, Hnd terms: padded panels
+    ("hybrid", 3, 5, (4, 3), {}),                      # three orbitals, 3 merged Hnd terms, DimUp != DimDw
+    ("normal", 2, 4, (5, 5), dict(jxp=0.0)),           # no Hnd: unpadded columns
+    ("hybrid", 3, 6, (4, 5), {}),                      # 126 x 126
+    ("normal", 1, 8, (4, 5), {}),                      # one orbital: one state per block
+    ("hybrid", 3, 5, (1, 6), {}),                      # classes missing
+    ("hybrid", 2, 7, (5, 4), dict(exc_field=np.array([0.12, 0.5, 0.5, 0.07]))),   # impurity-impurity hops
+])
+def test_impurity_block_image_matches_oracle(gpu, monkeypatch, rows, bath, norb, nbath, sec, extra):
+    """The device-resident loops on the impurity-block image (ib_rows_kernel + ib_cols_kernel on the padded panel
+    layout) against the oracle and against the generic kernels of the same handle type: alpha / beta of the fused
+    recurrence, the continued fraction, the Ritz vector that crosses the layout conversion both ways, and the plain
+    product of the bench probe against H*v through the boundary."""
+    import os
+    if os.environ.get("EDIGPU_NORMAL_EXPLICIT") or os.environ.get("EDIGPU_LANCZOS_UNFUSED") or os.environ.get("EDIGPU_ROW_SPLIT"):
+        pytest.skip("the impurity-block image needs the factored image and the fused step")
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("normal", bath, norb, nbath, seed=71, **extra)
+    ho = O.HNormal(om, *sec)
+    monkeypatch.setenv("EDIGPU_IB", "1")
+    monkeypatch.setenv("EDIGPU_IB_MIN", "0")
+    monkeypatch.setenv("EDIGPU_IB_ROWS", str(rows))
+    hb = SectorHamiltonian.normal_from_model(pm, *sec)
+    assert hb.image_info()[5] == 1 and hb.image_info()[4] == 16
+    monkeypatch.setenv("EDIGPU_IB", "0")
+    hn = SectorHamiltonian.normal_from_model(pm, *sec)
+    assert hn.image_info()[5] == 0
+    v = np.random.default_rng(3).standard_normal(ho.dim)
+    n = min(40, ho.dim)
+    ao, bo, _ = ho.lanc_tridiag(v, n)
+    ab, bb, nb = hb.lanczos_tridiag(v, n)
+    an, bn, nn = hn.lanczos_tridiag(v, n)
+    assert nb == nn == n
+    k = min(15, n)
+    assert rel_err(ab[:k], ao[:k]) < 1e-10 and rel_err(bb[:k], bo[:k]) < 1e-10
+    assert rel_err(ab[:k], an[:k]) < 1e-11 and rel_err(bb[:k], bn[:k]) < 1e-11
+    for z in (40.0 + 0.1j, -40.0 + 0.1j, 25.0j):
+        assert abs(_cf(ab, bb, z) - _cf(ao, bo, z)) / abs(_cf(ao, bo, z)) < 1e-10
+    # the literal two-reduction recurrence takes the same kernels without the lazy axpy
+    monkeypatch.setenv("EDIGPU_LANCZOS_EXACTBETA", "1")
+    ae, be, _ = hb.lanczos_tridiag(v, n)
+    monkeypatch.delenv("EDIGPU_LANCZOS_EXACTBETA")
+    assert rel_err(ae[:k], ao[:k]) < 1e-10 and rel_err(be[:k], bo[:k]) < 1e-10
+    eb, xb, _ = hb.lanczos_eigh(nitermax=min(300, ho.dim), tol=1e-13, v0=v)
+    e0 = np.linalg.eigvalsh(ho.dense())[0] if ho.dim <= 5000 else hn.lanczos_eigh(nitermax=300, tol=1e-13, v0=v)[0]
+    assert abs(eb - e0) < 1e-9 * max(1.0, abs(e0))
+    assert rel_err(hb.apply(xb), eb * xb) < 1e-6
+    assert rel_err(hb.apply(v), ho.matvec(v)) < TOL          # host vectors: the plain product of the two kernels
+    import torch
+    vd, hd = torch.from_numpy(v).cuda(), torch.empty(ho.dim, dtype=torch.float64, device="cuda")
+    hb.apply_dev(vd.data_ptr(), hd.data_ptr())   # device vectors in the reference's layout: the generic kernels
+    torch.cuda.synchronize()
+    assert rel_err(hd.cpu().numpy(), ho.matvec(v)) < TOL
+    assert hb.lanczos_bench(2, 3)[1] > 0.0
+    hb.destroy(), hn.destroy()
+
+
+# --------------------------------------------------------------------------------------------
 # nonsu2 sectors of JZ_BASIS=T (build_sector, ED_SECTOR.f90:289-350)
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("nbath,ntot,twojz", [(1, 6, 0), (1, 5, 1), (2, 9, 1), (2, 8, -4)])
