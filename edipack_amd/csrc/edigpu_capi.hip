@@ -402,7 +402,7 @@ static void plan_tile_chunks(const HostCsr& dw, int64_t dw_first, int64_t dw_cou
 
 static void free_ib(IbDev* p) {
   if (!p) return;
-  dev_free(p->upos); dev_free(p->ublist); dev_free(p->up_vtab); dev_free(p->up_timp); dev_free(p->up_ebath);
+  dev_free(p->urank); dev_free(p->rmap2); dev_free(p->ublist); dev_free(p->up_vtab); dev_free(p->up_timp); dev_free(p->up_ebath);
   dev_free(p->xu); dev_free(p->ed); dev_free(p->impd); dev_free(p->pos); dev_free(p->colof); dev_free(p->chunk_row);
   dev_free(p->chunk_blk); dev_free(p->dcls); dev_free(p->dblist); dev_free(p->dmeta); dev_free(p->dw_vtab);
   dev_free(p->dw_timp); dev_free(p->ndcoef); dev_free(p->nd_dw); dev_free(p->nd_up);
@@ -415,7 +415,7 @@ static int setup_ib(edigpu_sector* s, const HostNormal& hn, int chunk_rows) {
   if (!h.valid) return 0;
   int nt = 0, nbt = 0;
   const int plen = h.npanels * kIbPanel;
-  if (!ib_rows_config(h.norb, h.up.nb, (int)h.ublist.size(), plen, &nt, &nbt)) return 0;
+  if (!ib_rows_config(h.norb, h.up.nb, (int)h.ublist.size(), plen, h.rimg_len, &nt, &nbt)) return 0;
   int mcb = 8;
   for (size_t c = 0; c + 1 < h.chunk_blk.size(); c++) mcb = std::max(mcb, h.chunk_blk[c + 1] - h.chunk_blk[c]);
   std::unique_ptr<IbDev> d(new IbDev());
@@ -437,13 +437,21 @@ static int setup_ib(edigpu_sector* s, const HostNormal& hn, int chunk_rows) {
   d->len = (int64_t)h.npanels * d->ps;
   d->rows_nt = nt;
   d->rows_nbt = nbt;
-  d->rows_lds = ib_rows_lds_bytes(h.norb, h.up.nb, plen);
+  d->rows_lds = ib_rows_lds_bytes(h.up.nb, h.rimg_len);
+  for (int i = 0; i < 5; i++) {
+    d->rcb[i] = h.rcb[i];
+    d->rcs[i] = h.rcs[i];
+  }
+  d->rimg_len = h.rimg_len;
+  std::vector<uint32_t> rmap2((size_t)plen / 2);
+  for (size_t i = 0; i < rmap2.size(); i++) rmap2[i] = (uint32_t)h.rmap[2 * i] | ((uint32_t)h.rmap[2 * i + 1] << 16);
   d->cols_lds = ib_cols_lds_bytes(h.dw.nb, h.max_chunk_rows, mcb);
   if (d->cols_lds > 158 * 1024) return 0;
   std::vector<int32_t> colof((size_t)plen, -1);
   for (int64_t i = 0; i < hn.dim_up; i++) colof[(size_t)h.pos[(size_t)i]] = (int32_t)i;
   IbDev* p = d.get();
-  if (dev_upload(&p->upos, h.upos.data(), h.upos.size()) || dev_upload(&p->ublist, h.ublist.data(), h.ublist.size()) ||
+  if (dev_upload(&p->urank, h.urank.data(), h.urank.size()) || dev_upload(&p->rmap2, rmap2.data(), rmap2.size()) ||
+      dev_upload(&p->ublist, h.ublist.data(), h.ublist.size()) ||
       dev_upload(&p->up_vtab, h.up.vtab.data(), h.up.vtab.size()) || dev_upload(&p->up_timp, h.up.timp.data(), h.up.timp.size()) ||
       dev_upload(&p->up_ebath, h.up.ebath.data(), h.up.ebath.size()) || dev_upload(&p->xu, h.xu.data(), h.xu.size()) ||
       dev_upload(&p->ed, h.ed.data(), h.ed.size()) || dev_upload(&p->impd, h.impd.data(), h.impd.size()) ||
@@ -1184,9 +1192,11 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
     const bool exactbeta = s->lz_exactbeta;  // read once per run in lanczos_prepare
     int np = 0;
     bool finalized = false;
+    bool in_x = false;
     if (launch_normal_lanczos(s, s->d_vin, s->d_vout, s->d_scal, s->d_partial, s->partial_cap, iter == 0, !exactbeta, st, &np,
-                              nlanc, &finalized))
+                              nlanc, &finalized, s->d_tmp, &in_x))
       return 1;
+    if (in_x) std::swap(s->d_vin, s->d_tmp);  // the new Lanczos vector was written to the third buffer
     if (finalized) return 0;  // the sweep's last workgroup wrote alpha, beta and the stop flag
     if (exactbeta) {
       if (lz_finalize_alpha(s->d_partial, np, s->d_scal, iter, nlanc, st)) return 1;

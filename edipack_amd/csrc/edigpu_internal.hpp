@@ -89,7 +89,9 @@ struct IbDev {
   int64_t dim_up = 0, dim_dw = 0, ps = 0, len = 0;
   int rows_nt = 0, rows_nbt = 0;      // rows kernel: threads per workgroup, blocks per thread
   size_t rows_lds = 0, cols_lds = 0;  // dynamic LDS of the two kernels
-  uint16_t *upos = nullptr, *ublist = nullptr;
+  uint16_t *urank = nullptr, *ublist = nullptr;  // rows kernel: rank of a bath word inside its class; block list
+  uint32_t* rmap2 = nullptr;                     // [plen / 2]: image words of a pair of adjacent positions (lo | hi << 16)
+  int rcb[5] = {0, 0, 0, 0, 0}, rcs[5] = {0, 0, 0, 0, 0}, rimg_len = 0;
   double *up_vtab = nullptr, *up_timp = nullptr, *up_ebath = nullptr, *xu = nullptr, *ed = nullptr;
   uint8_t* impd = nullptr;
   int32_t *pos = nullptr, *colof = nullptr;  // column -> position, position -> column (-1: padding)

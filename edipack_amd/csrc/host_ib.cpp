@@ -31,6 +31,7 @@ std::string build_side(const HostNormal& hn, int sp, const CombBasis& bs, int np
   s.vtab.assign((size_t)nb * 4, 0.0);
   for (int k = 0; k < nb; k++)
     for (int ia = 0; ia < norb; ia++) s.vtab[(size_t)k * 4 + ia] = a[(norb + k) * ns + ia];
+  for (int k = 0; k < nb; k++) s.vtab[(size_t)k * 4 + 3] = eps[norb + k];  // (norb <= 3: the fourth entry is free)
   s.timp.assign((size_t)norb * norb, 0.0);
   for (int p = 0; p < norb; p++)
     for (int q = 0; q < norb; q++)
@@ -115,6 +116,29 @@ void build_ib(const HostNormal& hn, int max_chunk_rows, HostIb& out) {
     while (out.ublist.size() % 64) out.ublist.push_back((uint16_t)(firstb | kIbSkip));
   }
   out.ucls[norb + 1] = (int)out.ublist.size();
+  {
+    // LDS image of a row: classes one after the other, each as C(norb, n) arrays of (padded) class size
+    out.urank.assign(nw, kIbNone);
+    int at = 0, maxcs = 0;
+    for (int n = 0; n <= norb; n++) {
+      const int cs = out.ucls[n + 1] - out.ucls[n];
+      out.rcb[n + 1] = at;
+      out.rcs[n + 1] = cs;
+      maxcs = std::max(maxcs, cs);
+      at += (int)binomial(norb, n) * cs;
+      for (int q = out.ucls[n]; q < out.ucls[n + 1]; q++)
+        if (!(out.ublist[q] & kIbSkip)) out.urank[out.ublist[q]] = (uint16_t)(q - out.ucls[n]);
+    }
+    out.rimg_len = at + 2 * maxcs + 8;
+    if (out.rimg_len >= 0xFFF0) return fail("row image longer than 65519 words");
+    out.rmap.assign((size_t)out.npanels * kIbPanel, (uint16_t)(out.rimg_len - 1));
+    for (uint32_t b = 0; b < nw; b++) {
+      if (out.up.first[b] == kIbNone) continue;
+      const int n = cls_of(out.up, b), m = rows_of(out.up, b);
+      for (int j = 0; j < m; j++)
+        out.rmap[(size_t)out.upos[b] + j] = (uint16_t)(out.rcb[n + 1] + j * out.rcs[n + 1] + out.urank[b]);
+    }
+  }
 
   // ---- diagonal ----
   out.xu.assign((size_t)(impmask + 1) * (impmask + 1), 0.0);

@@ -33,7 +33,7 @@ struct IbSide {                  // one spin species
   int64_t dim = 0;
   // first state of block b (index in the species' basis), 0xFFFF = no such block in this sector; [2^nb]
   std::vector<uint16_t> first;
-  std::vector<double> vtab;      // [nb][4]: amplitude between impurity level a (< norb) and bath level k
+  std::vector<double> vtab;      // [nb][4]: [k][a] amplitude between impurity level a (< norb) and bath level k; [k][3] = its energy
   std::vector<double> timp;      // [norb][norb], symmetric, zero diagonal: impurity-impurity hops
   std::vector<double> ebath;     // [2^nb]: one-body energy of the bath part of a block
   std::vector<double> eimp;      // [2^norb]: one-body + same-spin density-density energy of an impurity pattern
@@ -52,6 +52,13 @@ struct HostIb {
   // 64 entries with copies of its first block marked kIbSkip (computed, never written)
   std::vector<uint16_t> ublist;
   int ucls[kIbMaxNorb + 2] = {0};  // ublist range of class n: [ucls[n], ucls[n+1])
+  // rows kernel, LDS image of a staged row (ib_core.hpp RowImage): class by class, word by word.  urank[b] = rank of
+  // bath word b inside its class (= its index in the class's part of ublist); class n starts at rcb[n + 1], its word j
+  // of block i at rcb[n + 1] + j * rcs[n + 1] + i; rimg_len words in all (slack for over-reads, last word = the zero
+  // every padding position maps to).  rmap[position] = word of the image (padding: rimg_len - 1).
+  std::vector<uint16_t> urank, rmap;
+  int rcb[5] = {0, 0, 0, 0, 0}, rcs[5] = {0, 0, 0, 0, 0};
+  int rimg_len = 0;
   // diagonal: Hd(iup, idw) = up.ebath[b_up] + xu[impd(idw)][p_up] + ed[idw]
   std::vector<double> xu;        // [2^norb (impurity pattern of the down word)][2^norb (of the up word)]
   std::vector<double> ed;        // [dim_dw]

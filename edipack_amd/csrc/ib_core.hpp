@@ -17,6 +17,13 @@
 #define IB_HD inline
 #endif
 
+// a value that is the same on every lane of a wave (device: moved to a scalar register, so loops on it are scalar loops)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define IB_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define IB_UNIFORM(x) (x)
+#endif
+
 namespace edigpu {
 namespace ib {
 
@@ -58,12 +65,18 @@ IB_HD void sfor(F&& f) {
   }
 }
 
-// f(std::integral_constant<int, N>) for the class n (0 .. NORB) given at run time (uniform over a wave)
-template <int NORB, class F>
+// f(std::integral_constant<int, N>) for the class n (0 .. NORB) given at run time (uniform over a wave).  An else-chain
+// on purpose: with independent tests the compiler merges what the bodies write with vector selects.
+template <int NORB, int C = 0, class F>
 IB_HD void for_class(int n, F&& f) {
-  sfor<0, NORB + 1>([&](auto N) {
-    if (n == decltype(N)::value) f(N);
-  });
+  if constexpr (C == NORB) {
+    f(std::integral_constant<int, C>{});
+  } else {
+    if (n == C)
+      f(std::integral_constant<int, C>{});
+    else
+      for_class<NORB, C + 1>(n, f);
+  }
 }
 
 struct alignas(16) Pair {
@@ -137,50 +150,82 @@ struct FmaP {
 };
 
 // ---- rows kernel: one block of columns of the staged row -----------------------------------------------------------
-// row   : the staged row in the padded layout (LDS), upos[b] = position of block b's first column
-// vtab  : [nb][4] amplitudes, timp [NORB][NORB]
-// dconst: ebath[b] + ed[idw];  xu: [2^NORB] diagonal part that depends on this block's impurity pattern
+// The staged row is held CLASS BY CLASS, word by word: word j of the i-th block of class n sits at
+// cb[n] + j * cs[n] + i (i = rank of the block's bath word inside its class, ascending).  Lanes of a wave hold
+// consecutive blocks of one class, and the partner block b ^ (1 << k) of consecutive blocks has (almost) consecutive
+// ranks in ITS class: a gather instruction reads (almost) consecutive words -- few bank conflicts, where the position
+// order of the vector scatters the 64 reads over the whole row (measured: 8.9 LDS cycles per instruction, half of
+// them conflicts, the LDS pipe busy 75 % of the kernel).
+struct RowImage {
+  const double* row;     // the staged row (LDS)
+  const uint16_t* rank;  // [2^nb] rank of a bath word inside its class (LDS)
+  int cb[5], cs[5];      // first word / stride between the words of a block, per class (index n + 1: cb[0] = class -1)
+};
+
+// vtab  : [nb][4] (LDS): amplitudes V(a,k), a < NORB, and in [k][3] the level energy eps_k of bath level k
+// timp  : [NORB][NORB] (uniform: scalar loads on the device)
+// dconst: ed[idw];  xu: [2^NORB] diagonal part that depends on this block's impurity pattern (+ that of the down word)
 // acc[M] receives (Hd + 1 (x) Hup) v for the block's columns
 template <int NORB, int N>
-IB_HD void rows_block(const double* row, uint32_t b, uint32_t o, int nb, const uint16_t* upos, const double* vtab,
-                      const double* timp, double dconst, const double* xu, double* acc) {
+IB_HD void rows_block(const RowImage& im, uint32_t b, uint32_t i, int nb, const double* vtab, const double* timp,
+                      double dconst, const double* xu, double* acc) {
   constexpr int M = binom(NORB, N);
+  const double* row = im.row;
+  const double* own = row + im.cb[N + 1] + i;
+  const int so = im.cs[N + 1];
   double x[M];
   sfor<0, M>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    x[j] = row[o + j];
-    acc[j] = (dconst + xu[pat(NORB, N, j)]) * x[j];  // (the reference adds the diagonal first too)
+    x[j] = own[j * so];
+    acc[j] = 0.0;
   });
   if constexpr (NORB > 1) couple_imp<NORB, N, double>(timp, x, acc, FmaD{});
+  // A lane walks the clear bits of its own bath word (hops that fill the level: partner class N - 1), then the set
+  // bits (partner class N + 1): no dead slots, no divergence -- every block of a class has the same number of each --
+  // and only the partner's real words are read.  The price: the level differs from lane to lane, so the amplitudes
+  // V(a,k) come from the LDS copy of vtab (rows of 32 bytes: at most 14 distinct addresses per instruction).
+  // The walk over the set bits also sums the bath part of the diagonal, eps_k of the occupied levels (a per-block
+  // table of it would cost two registers per block for the whole kernel).
+  double ebath = 0.0;
   if constexpr (N >= 1) {
-    // bath levels that are empty in b (the same number for every block of the class)
     constexpr int MP = binom(NORB, N - 1);
+    const double* pbase = row + im.cb[N];
+    const int st2 = im.cs[N];
     uint32_t m0 = ~b & ((1u << nb) - 1u);
     while (m0) {
       const int k = ctz32(m0);
       m0 &= m0 - 1u;
-      const uint32_t o2 = upos[b | (1u << k)];
+      const double* pp = pbase + im.rank[b | (1u << k)];
       const uint32_t neg = (uint32_t)popc32(b & ((1u << k) - 1u)) & 1u;
       double xp[MP], v[NORB];
-      sfor<0, MP>([&](auto J) { xp[decltype(J)::value] = row[o2 + decltype(J)::value]; });
-      sfor<0, NORB>([&](auto A) { v[decltype(A)::value] = flip(vtab[k * 4 + decltype(A)::value], neg); });
+      sfor<0, MP>([&](auto J) { xp[decltype(J)::value] = flip(pp[decltype(J)::value * st2], neg); });
+      sfor<0, NORB>([&](auto A) { v[decltype(A)::value] = vtab[k * 4 + decltype(A)::value]; });
       couple<NORB, N, true, double>(v, xp, acc, FmaD{});
     }
   }
-  if constexpr (N < NORB) {
-    constexpr int MP = binom(NORB, N + 1);
+  {
+    constexpr int MP = binom(NORB, N + 1);  // 0 for the top class: only the energies are summed
+    const double* pbase = row + im.cb[N < NORB ? N + 2 : N + 1];
+    const int st2 = im.cs[N < NORB ? N + 2 : N + 1];
     uint32_t m1 = b;
     while (m1) {
       const int k = ctz32(m1);
       m1 &= m1 - 1u;
-      const uint32_t o2 = upos[b & ~(1u << k)];
-      const uint32_t neg = (uint32_t)popc32(b & ((1u << k) - 1u)) & 1u;
-      double xp[MP], v[NORB];
-      sfor<0, MP>([&](auto J) { xp[decltype(J)::value] = row[o2 + decltype(J)::value]; });
-      sfor<0, NORB>([&](auto A) { v[decltype(A)::value] = flip(vtab[k * 4 + decltype(A)::value], neg); });
-      couple<NORB, N, false, double>(v, xp, acc, FmaD{});
+      ebath += vtab[k * 4 + 3];
+      if constexpr (N < NORB) {
+        const double* pp = pbase + im.rank[b & ~(1u << k)];
+        const uint32_t neg = (uint32_t)popc32(b & ((1u << k) - 1u)) & 1u;
+        double xp[MP > 0 ? MP : 1], v[NORB];
+        sfor<0, MP>([&](auto J) { xp[decltype(J)::value] = flip(pp[decltype(J)::value * st2], neg); });
+        sfor<0, NORB>([&](auto A) { v[decltype(A)::value] = vtab[k * 4 + decltype(A)::value]; });
+        couple<NORB, N, false, double>(v, xp, acc, FmaD{});
+      }
     }
   }
+  sfor<0, M>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    acc[j] = __builtin_fma(ebath + dconst + xu[pat(NORB, N, j)], x[j], acc[j]);
+  });
 }
 
 // ---- columns kernel: one block of rows x two adjacent columns ------------------------------------------------------

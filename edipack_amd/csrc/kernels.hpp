@@ -42,9 +42,11 @@ int launch_transpose_unpack_add(int64_t dim_up, int64_t nrows, int64_t q, int wo
 // fused Lanczos step (normal, single shard): P = Lanczos vector, Q = work vector, see kernels_normal.hip
 bool normal_lanczos_fusable(const edigpu_sector* s);
 // nlanc / finalized: when the sweep finalizes the step in its last workgroup (*finalized = true) no finalize kernel must follow
+// X / in_x: the impurity-block image writes the new Lanczos vector of a later step to X instead of P (*in_x = true: the
+// caller swaps its P and X buffers); other images ignore them
 int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const double* scal,
                           double* partial, int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial,
-                          int nlanc = 0, bool* finalized = nullptr);
+                          int nlanc = 0, bool* finalized = nullptr, double* X = nullptr, bool* in_x = nullptr);
 // alpha = sum(partial[0:np]), beta = sqrt(sum(partial[np:2np]) - alpha^2) with an exact fallback pass
 int lz_finalize_alpha_beta(const double* P, const double* Q, int64_t n, double* partial, int np,
                            double* scal, int iter, int nlanc, hipStream_t st);
@@ -89,11 +91,11 @@ int launch_normal_blocked(const edigpu_sector* s, const double* v, double* hv, h
 int vec_to_ib(const IbDev* ib, const double* src, double* dst, hipStream_t st);
 int vec_from_ib(const IbDev* ib, const double* src, double* dst, hipStream_t st);
 int launch_ib(const edigpu_sector* s, const double* v, double* hv, hipStream_t st);
-int launch_ib_lanczos(const edigpu_sector* s, double* P, double* Q, const double* scal, double* partial, int64_t partial_cap,
-                      bool first, bool lazy_axpy, hipStream_t st, int* npartial);
-size_t ib_rows_lds_bytes(int norb, int nb, int plen);
+int launch_ib_lanczos(const edigpu_sector* s, const double* P, double* Q, double* X, const double* scal, double* partial,
+                      int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial);
+size_t ib_rows_lds_bytes(int nb, int rimg_len);
 size_t ib_cols_lds_bytes(int nb, int max_chunk_rows, int max_chunk_blocks);
-bool ib_rows_config(int norb, int nb, int nlist, int plen, int* nt_out, int* nbt_out);
+bool ib_rows_config(int norb, int nb, int nlist, int plen, int rimg_len, int* nt_out, int* nbt_out);
 int measure_membw(int64_t bytes, double out[3]);
 // stand-alone vector kernels with explicit device scalars (sharded loop)
 int vec_rotate(int64_t n, double* vin, double* vout, const double* beta2, hipStream_t st);

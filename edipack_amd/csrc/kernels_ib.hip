@@ -35,7 +35,9 @@ struct IbArgs {
   int ucls[5];
   int lowbits, nchunks, max_chunk_rows, max_chunk_blocks, nterms;
   int64_t dim_dw, ps;
-  const uint16_t *upos, *ublist;
+  const uint16_t *urank, *ublist;
+  const uint32_t* rmap2;
+  int rcb[5], rcs[5], rimg_len;
   const double *up_vtab, *up_timp, *up_ebath, *xu, *ed;
   const uint8_t* impd;
   const int32_t *chunk_row, *chunk_blk, *dcls;
@@ -51,52 +53,55 @@ struct IbArgs {
 // ---------------------------------------------------------------------------------------------------------
 // rows kernel
 // ---------------------------------------------------------------------------------------------------------
-// FUSE 0: hv = (Hd + 1 (x) Hup) v                       (also the first Lanczos step: v = P, hv = Q)
-// FUSE 1: x = (Q - alpha P) / beta; P <- x; Q <- (Hd + 1 (x) Hup) x - beta P_old   (alpha = 0 unless a.lazy)
+// FUSE 0: Q = (Hd + 1 (x) Hup) P                       (plain product; also the first Lanczos step)
+// FUSE 1: x = (Q - alpha P) / beta; X <- x; Q <- (Hd + 1 (x) Hup) x   (alpha = 0 unless a.lazy).  The new Lanczos
+//         vector goes to a THIRD buffer and the term - beta P_old is left to the columns kernel, which reads P_old's
+//         rows next to Q's: holding P_old in registers until the result leaves cost 28 of the 128 a lane has here and
+//         put spill traffic into the hot loops (measured: 2.7 ms against 1.4 ms for the plain product).
 // pieces of 16 bytes a thread moves per row, given its NBT blocks (a class-n block holds C(NORB, n) columns)
 constexpr int ib_rows_nld(int norb, int nbt) { return norb == 1 ? nbt / 2 + 1 : norb == 2 ? nbt : nbt + 1; }
 
 template <int NORB, int NT, int NBT, int FUSE>
-__global__ void __launch_bounds__(NT, 4) ib_rows_kernel(IbArgs a, double* __restrict__ P, double* __restrict__ Q) {
+__global__ void __launch_bounds__(NT, (NT == 768 ? 3 : (NT == 512 && NBT >= 12) ? 2 : 4)) ib_rows_kernel(IbArgs a, const double* __restrict__ P, double* __restrict__ Q, double* __restrict__ X) {
   extern __shared__ double lds[];
   constexpr int MAXM = ib::binom(NORB, NORB / 2);
   constexpr int NIMP = 1 << NORB;
   constexpr int NLD = ib_rows_nld(NORB, NBT);  // (the set-up checks plen <= 2 NT NLD)
   const int nb = a.nb_up, plen2 = a.plen >> 1;
-  double* row = lds;
-  double* vtab = row + a.plen + 8;
-  double* timp = vtab + nb * 4;
-  double* xu = timp + 16;
-  uint16_t* upos = reinterpret_cast<uint16_t*>(xu + NIMP * NIMP);
+  double* row = lds;                                                      // the row image (ib_core.hpp RowImage)
+  double* vtab = row + a.rimg_len;                                        // [nb][4]
+  uint16_t* rank = reinterpret_cast<uint16_t*>(vtab + nb * 4);            // [2^nb]
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t dd = a.dim_dw, ps = a.ps;
-  double beta = 0.0, ibeta = 1.0, alpha = 0.0;
+  double ibeta = 1.0, alpha = 0.0;
   if (FUSE) {
     if (a.scal[SC_STOP] != 0.0) return;  // recurrence already terminated (uniform)
-    beta = a.scal[SC_BETA];
-    ibeta = 1.0 / beta;
+    ibeta = 1.0 / a.scal[SC_BETA];
     alpha = a.lazy ? a.scal[SC_ALPHA] : 0.0;
   }
-  for (int i = tid; i < (1 << nb); i += NT) upos[i] = a.upos[i];
+  for (int i = tid; i < (1 << nb); i += NT) rank[i] = a.urank[i];
   for (int i = tid; i < nb * 4; i += NT) vtab[i] = a.up_vtab[i];
-  if (tid < 16) timp[tid] = tid < NORB * NORB ? a.up_timp[tid] : 0.0;
-  for (int i = tid; i < NIMP * NIMP; i += NT) xu[i] = a.xu[i];
-  if (tid < 8) row[a.plen + tid] = 0.0;
-  // this thread's blocks: the same list entries for every row
-  uint32_t bw[NBT];  // bath word | skip flag (bit 15) | position of the block's first column << 16
-  double eb[NBT];
-  ib::sfor<0, NBT>([&](auto S) {
-    constexpr int s = decltype(S)::value;
-    const int q = s * NT + tid;
-    bw[s] = q < a.nlist ? (uint32_t)a.ublist[q] : 0u;
-    eb[s] = q < a.nlist ? a.up_ebath[bw[s] & 0x7FFFu] : 0.0;
+  for (int i = tid; i < a.rimg_len; i += NT) row[i] = 0.0;  // slack and the zero word stay zero
+  ib::RowImage im;
+  im.row = row;
+  im.rank = rank;
+#pragma unroll
+  for (int c = 0; c < 5; c++) {
+    im.cb[c] = a.rcb[c];
+    im.cs[c] = a.rcs[c];
+  }
+  // this thread's blocks: the same list entries for every row (two 16-bit entries per register: bath word | skip flag)
+  uint32_t bw[(NBT + 1) / 2];
+  ib::sfor<0, (NBT + 1) / 2>([&](auto S) {
+    constexpr int s2 = decltype(S)::value;
+    const int q0 = 2 * s2 * NT + tid, q1 = q0 + NT;
+    bw[s2] = (q0 < a.nlist ? (uint32_t)a.ublist[q0] : 0u) | ((2 * s2 + 1 < NBT && q1 < a.nlist ? (uint32_t)a.ublist[q1] : 0u) << 16);
   });
-  __syncthreads();
-  ib::sfor<0, NBT>([&](auto S) {
+  auto entry = [&](auto S) -> uint32_t {
     constexpr int s = decltype(S)::value;
-    bw[s] |= (uint32_t)upos[bw[s] & 0x7FFFu] << 16;
-  });
+    return (s & 1) ? bw[s / 2] >> 16 : bw[s / 2] & 0xFFFFu;
+  };
   // class of the 64 list entries a wave holds in slot s (uniform)
   auto cls_of = [&](int q0) -> int {
     int n = 0;
@@ -104,65 +109,84 @@ __global__ void __launch_bounds__(NT, 4) ib_rows_kernel(IbArgs a, double* __rest
     for (int c = 1; c <= NORB; c++) n += q0 >= a.ucls[c] ? 1 : 0;
     return n;
   };
-  // piece i of a row: double2 index, global offset
-  auto piece = [&](int i, int& q2, int64_t& g, int64_t r) -> bool {
-    q2 = tid + i * NT;
-    const int qc = q2 < plen2 ? q2 : plen2 - 1;  // clamped: always a valid address
-    g = (int64_t)(qc >> 3) * ps + r * 16 + ((qc & 7) << 1);
-    return q2 < plen2;
-  };
+  // A thread moves the 16-byte pieces tid, tid + NT, ... of a row: piece q2 is the column pair (q2 & 7) of panel q2 >> 3,
+  // so consecutive pieces of a thread lie (NT / 8) panels apart -- one base offset per row and a uniform stride (kept
+  // that way on purpose: per-piece offsets would be hoisted out of the row loop into registers the blocks need).
+  // a.rmap2[q2] names the two words of the image the piece's columns go to.
+  const int64_t pstride0 = (int64_t)(NT / 8) * ps;
+  int64_t pstride = pstride0;  // (+ an opaque zero inside the row loop, see zr there: the per-piece addresses are not hoisted)
+  auto base_of = [&](int64_t r) -> int64_t { return (int64_t)(tid >> 3) * ps + r * 16 + ((tid & 7) << 1); };
+  // The next row is requested when the blocks are done (its pieces land while the results are written back and leave):
+  // requested before the block updates, the pieces in flight cost 28 registers the updates need.  EARLY where they fit.
+  constexpr bool EARLY = !FUSE && NBT * MAXM <= 12;
   double2 pre[NLD];                    // the next row on its way in (FUSE: Q)
-  double2 pold[FUSE ? NLD : 1];        // FUSE: P of the staged row, needed again when the result leaves
   double2 pin[FUSE ? NLD : 1];
   auto issue = [&](int64_t r) {
+    const int64_t g0 = base_of(r);
 #pragma unroll
     for (int i = 0; i < NLD; i++) {
-      int q2;
-      int64_t g;
-      piece(i, q2, g, r);
-      if (FUSE) {
-        pre[i] = *reinterpret_cast<const double2*>(Q + g);
-        pin[i] = *reinterpret_cast<const double2*>(P + g);
-      } else {
-        pre[i] = *reinterpret_cast<const double2*>(P + g);
+      if (tid + i * NT < plen2) {
+        if (FUSE) {
+          pre[i] = *reinterpret_cast<const double2*>(Q + g0 + i * pstride);
+          pin[i] = *reinterpret_cast<const double2*>(P + g0 + i * pstride);
+        } else {
+          pre[i] = *reinterpret_cast<const double2*>(P + g0 + i * pstride);
+        }
       }
     }
   };
-  // loaded pieces -> LDS (FUSE: x = (Q - alpha P) / beta, P <- x, P_old kept)
-  auto land = [&](int64_t r) {
+  // loaded pieces -> image (FUSE: x = (Q - alpha P) / beta, P <- x, P_old kept)
+  auto land = [&](int64_t r, const uint32_t* mp) {
+    const int64_t g0 = base_of(r);
 #pragma unroll
     for (int i = 0; i < NLD; i++) {
-      int q2;
-      int64_t g;
-      if (!piece(i, q2, g, r)) continue;
-      double2 x = pre[i];
-      if (FUSE) {
-        x.x = (x.x - alpha * pin[i].x) * ibeta;
-        x.y = (x.y - alpha * pin[i].y) * ibeta;
-        pold[i] = pin[i];
-        *reinterpret_cast<double2*>(P + g) = x;
+      if (tid + i * NT < plen2) {
+        double2 x = pre[i];
+        if (FUSE) {
+          x.x = (x.x - alpha * pin[i].x) * ibeta;
+          x.y = (x.y - alpha * pin[i].y) * ibeta;
+          *reinterpret_cast<double2*>(X + g0 + i * pstride) = x;
+        }
+        row[mp[i] & 0xFFFFu] = x.x;
+        row[mp[i] >> 16] = x.y;
       }
-      reinterpret_cast<double2*>(row)[q2] = x;
     }
+  };
+  auto load_map = [&](uint32_t* mp) {
+#pragma unroll
+    for (int i = 0; i < NLD; i++) mp[i] = tid + i * NT < plen2 ? a.rmap2[tid + i * NT] : 0u;
   };
   int64_t r = blockIdx.x;
   if (r >= dd) return;
-  issue(r);
-  land(r);
+  __syncthreads();  // the zeroed image before the first row lands
+  {
+    uint32_t mp[NLD];
+    load_map(mp);
+    issue(r);
+    land(r, mp);
+  }
   __syncthreads();
   for (; r < dd; r += gridDim.x) {
     const int64_t rn = r + gridDim.x;
     const bool more = rn < dd;
-    if (!FUSE && more) issue(rn);  // in flight during the block updates
+    if (EARLY && more) issue(rn);  // in flight during the block updates
+    // an opaque zero, new in every iteration: added to the per-(slot, class) block indices below so that they are
+    // recomputed where they are used (one add) instead of being hoisted out of the row loop into 4 NBT registers
+    int zr, zs;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zr));
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
+    pstride = pstride0 + zs;
     const double edr = a.ed[r];
-    const double* xuc = xu + (int)a.impd[r] * NIMP;
+    const double* xuc = a.xu + (int)a.impd[r] * NIMP;  // uniform: scalar loads (an LDS copy would sit in vector registers)
     double acc[NBT][MAXM];
     ib::sfor<0, NBT>([&](auto S) {
       constexpr int s = decltype(S)::value;
       if (s * NT + wave * 64 < a.nlist) {  // uniform (the list is padded to whole waves)
         const int n = cls_of(s * NT + wave * 64);
         ib::for_class<NORB>(n, [&](auto N) {
-          ib::rows_block<NORB, decltype(N)::value>(row, bw[s] & 0x7FFFu, bw[s] >> 16, nb, upos, vtab, timp, eb[s] + edr, xuc, acc[s]);
+          constexpr int nn = decltype(N)::value;
+          ib::rows_block<NORB, nn>(im, (entry(S) + (uint32_t)zr) & 0x7FFFu, (uint32_t)(s * NT + tid - a.ucls[nn] + zr), nb, vtab, a.up_timp, edr, xuc,
+                                   acc[s]);
         });
       }
     });
@@ -171,28 +195,32 @@ __global__ void __launch_bounds__(NT, 4) ib_rows_kernel(IbArgs a, double* __rest
       constexpr int s = decltype(S)::value;
       if (s * NT + wave * 64 < a.nlist) {
         const int n = cls_of(s * NT + wave * 64);
-        if (!(bw[s] & 0x8000u))
+        if (!(entry(S) & 0x8000u))
           ib::for_class<NORB>(n, [&](auto N) {
-            ib::sfor<0, ib::binom(NORB, decltype(N)::value)>([&](auto J) { row[(bw[s] >> 16) + decltype(J)::value] = acc[s][decltype(J)::value]; });
+            constexpr int nn = decltype(N)::value;
+            double* own = row + im.cb[nn + 1] + (s * NT + tid - a.ucls[nn] + zr);
+            ib::sfor<0, ib::binom(NORB, nn)>([&](auto J) { own[decltype(J)::value * im.cs[nn + 1]] = acc[s][decltype(J)::value]; });
           });
       }
     });
-    if (FUSE && more) issue(rn);
+    uint32_t mp[NLD];
+    load_map(mp);
+    if (!EARLY && more) issue(rn);
     __syncthreads();
     // the result leaves coalesced, the next row takes its place
+    {
+      const int64_t g0 = base_of(r);
 #pragma unroll
-    for (int i = 0; i < NLD; i++) {
-      int q2;
-      int64_t g;
-      if (!piece(i, q2, g, r)) continue;
-      double2 o = reinterpret_cast<const double2*>(row)[q2];
-      if (FUSE) {
-        o.x -= beta * pold[i].x;
-        o.y -= beta * pold[i].y;
+      for (int i = 0; i < NLD; i++) {
+        if (tid + i * NT < plen2) {
+          double2 o;
+          o.x = row[mp[i] & 0xFFFFu];
+          o.y = row[mp[i] >> 16];
+          *reinterpret_cast<double2*>(Q + g0 + i * pstride) = o;
+        }
       }
-      *reinterpret_cast<double2*>(Q + g) = o;
     }
-    if (more) land(rn);
+    if (more) land(rn, mp);
     __syncthreads();
   }
 }
@@ -203,7 +231,7 @@ __global__ void __launch_bounds__(NT, 4) ib_rows_kernel(IbArgs a, double* __rest
 constexpr int kColsNT = 512;
 
 template <int NORB, bool DO_ND, bool ALPHA>
-__global__ void __launch_bounds__(kColsNT, 4) ib_cols_kernel(IbArgs a, const double* __restrict__ v, double* __restrict__ hv) {
+__global__ void __launch_bounds__(kColsNT, 4) ib_cols_kernel(IbArgs a, const double* __restrict__ v, double* __restrict__ hv, const double* __restrict__ pold) {
   __shared__ double red[3 * (kColsNT / 64)];
   extern __shared__ double lds[];
   const int nb = a.nb_dw;
@@ -226,6 +254,8 @@ __global__ void __launch_bounds__(kColsNT, 4) ib_cols_kernel(IbArgs a, const dou
     return;
   }
   const double sg = ALPHA ? a.scal[SC_ALPHA] : 0.0;  // <Q|Q> is accumulated about the previous alpha (k_finalize_ab)
+  // fused Lanczos step after the first: hv starts as (rows kernel's part) - beta * P_old (see ib_rows_kernel FUSE 1)
+  const double nbeta = (ALPHA && pold) ? -a.scal[SC_BETA] : 0.0;
   double asum = 0.0, qsum = 0.0, nsum = 0.0;
   for (int i = tid; i < nb * 4; i += kColsNT) vtab[i] = a.dw_vtab[i];
   if (tid < 16) {
@@ -246,6 +276,7 @@ __global__ void __launch_bounds__(kColsNT, 4) ib_cols_kernel(IbArgs a, const dou
     const int blk0 = a.chunk_blk[c], nblk = a.chunk_blk[c + 1] - blk0;
     const double* __restrict__ vp = v + (int64_t)panel * a.ps;
     double* __restrict__ hp = hv + (int64_t)panel * a.ps;
+    const double* __restrict__ pp = (ALPHA && pold) ? pold + (int64_t)panel * a.ps : nullptr;
     {
       const double2* __restrict__ src = reinterpret_cast<const double2*>(vp + (int64_t)row0 * 16);
       double2* dst = reinterpret_cast<double2*>(chunk);
@@ -294,6 +325,14 @@ __global__ void __launch_bounds__(kColsNT, 4) ib_cols_kernel(IbArgs a, const dou
         ib::sfor<0, M>([&](auto J) {
           acc[decltype(J)::value] = *reinterpret_cast<const ib::Pair*>(hp + (int64_t)(own + decltype(J)::value) * 16 + col);
         });
+        if (ALPHA && pp) {  // uniform
+          ib::sfor<0, M>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const ib::Pair o = *reinterpret_cast<const ib::Pair*>(pp + (int64_t)(own + j) * 16 + col);
+            acc[j].x = __builtin_fma(nbeta, o.x, acc[j].x);
+            acc[j].y = __builtin_fma(nbeta, o.y, acc[j].y);
+          });
+        }
         auto gload = [&](int grow) -> ib::Pair { return *reinterpret_cast<const ib::Pair*>(vp + (int64_t)grow * 16 + col); };
         ib::cols_block<NORB, nn>(chunk, row0, b, own, meta, nb, a.lowbits, vtab, timp, col, gload, acc);
         if (DO_ND) ib::cols_block_nd<NORB, nn>(chunk, own - row0, col, a.nterms, ndc, nddw, ndu, 16, acc);
@@ -396,7 +435,13 @@ static void fill_ib_args(const IbDev* d, IbArgs& a) {
   a.nterms = d->nterms;
   a.dim_dw = d->dim_dw;
   a.ps = d->ps;
-  a.upos = d->upos;
+  a.urank = d->urank;
+  a.rmap2 = d->rmap2;
+  for (int i = 0; i < 5; i++) {
+    a.rcb[i] = d->rcb[i];
+    a.rcs[i] = d->rcs[i];
+  }
+  a.rimg_len = d->rimg_len;
   a.ublist = d->ublist;
   a.up_vtab = d->up_vtab;
   a.up_timp = d->up_timp;
@@ -419,8 +464,8 @@ static void fill_ib_args(const IbDev* d, IbArgs& a) {
   a.lazy = 0;
 }
 
-size_t ib_rows_lds_bytes(int norb, int nb, int plen) {
-  return ((size_t)plen + 8 + (size_t)nb * 4 + 16 + ((size_t)1 << (2 * norb))) * sizeof(double) + ((size_t)1 << nb) * sizeof(uint16_t);
+size_t ib_rows_lds_bytes(int nb, int rimg_len) {
+  return ((size_t)rimg_len + (size_t)nb * 4) * sizeof(double) + ((size_t)1 << nb) * sizeof(uint16_t);
 }
 
 size_t ib_cols_lds_bytes(int nb, int max_chunk_rows, int max_chunk_blocks) {
@@ -430,27 +475,39 @@ size_t ib_cols_lds_bytes(int nb, int max_chunk_rows, int max_chunk_blocks) {
 
 // threads per workgroup / blocks per thread of the rows kernel for a list of nlist blocks and rows of plen columns;
 // false: no instantiation fits (the caller keeps the generic kernels)
-bool ib_rows_config(int norb, int nb, int nlist, int plen, int* nt_out, int* nbt_out) {
-  const size_t lds = ib_rows_lds_bytes(norb, nb, plen);
+bool ib_rows_config(int norb, int nb, int nlist, int plen, int rimg_len, int* nt_out, int* nbt_out) {
+  const size_t lds = ib_rows_lds_bytes(nb, rimg_len);
   if (lds > 158 * 1024) return false;
-  // small rows: several 256-thread workgroups per CU; rows beyond half the LDS: one 1024-thread workgroup
-  static const int opts[3][3] = {{8, 14, 0}, {4, 6, 8}, {4, 6, 0}};  // blocks per thread the kernels are built for
-  for (int nt : {256, 512, 1024}) {
-    if (nt == 256 && lds > 40 * 1024) continue;
-    if (nt == 512 && lds > 80 * 1024) continue;
+  // Candidates: threads per workgroup x blocks per thread the kernels are built for.  A lane has 128 registers when
+  // 1024 threads share a CU; 8 blocks of three words do not fit them (spill traffic in the hot loops: measured), 6 just
+  // do.  Rank: threads resident per CU, then no more than 6 blocks per thread, then workgroups per CU (one workgroup
+  // alone has nothing to overlap its barriers and row moves with), then fewer blocks per thread.
+  static const int opts[3][4] = {{8, 14, 0, 0}, {4, 6, 8, 0}, {4, 6, 8, 12}};
+  int forced = 0;
+  if (const char* e = getenv("EDIGPU_IB_NT")) forced = atoi(e);  // tuning
+  long best = -1;
+  for (int nt : {256, 512, 768, 1024}) {
+    if (forced && nt != forced) continue;
     for (int nbt : opts[norb - 1]) {
-      if (nbt && (int64_t)nbt * nt >= nlist && (int64_t)2 * nt * ib_rows_nld(norb, nbt) >= plen) {
+      if (!nbt) continue;
+      if (nbt == 8 && norb == 3 && nt == 1024) continue;
+      if (nbt == 12 && nt != 512) continue;
+      if ((int64_t)nbt * nt < nlist || (int64_t)2 * nt * ib_rows_nld(norb, nbt) < plen) continue;
+      const int regs_threads = nbt == 12 ? 512 : nt == 768 ? 768 : 1024;  // lanes a CU holds at this register budget
+      const int wgs = std::max(1, std::min<int>((int)((156 * 1024) / lds), regs_threads / nt));
+      const long score = (long)(wgs * nt) * 1000000 + (nbt <= 6 ? 100000 : 0) + (long)std::min(wgs, 4) * 1000 + (100 - nbt);
+      if (score > best) {
+        best = score;
         *nt_out = nt;
         *nbt_out = nbt;
-        return true;
       }
     }
   }
-  return false;
+  return best >= 0;
 }
 
 template <int NORB, int NT, int NBT>
-static int launch_rows_t(const IbDev* d, const IbArgs& a, int fuse, double* P, double* Q, hipStream_t st) {
+static int launch_rows_t(const IbDev* d, const IbArgs& a, int fuse, const double* P, double* Q, double* X, hipStream_t st) {
   const size_t lds = d->rows_lds;
   const void* k0 = (const void*)ib_rows_kernel<NORB, NT, NBT, 0>;
   const void* k1 = (const void*)ib_rows_kernel<NORB, NT, NBT, 1>;
@@ -463,43 +520,46 @@ static int launch_rows_t(const IbDev* d, const IbArgs& a, int fuse, double* P, d
   }
   const int64_t grid = std::min<int64_t>(d->dim_dw, (int64_t)per_cu * device_cu_count());
   if (fuse)
-    hipLaunchKernelGGL((ib_rows_kernel<NORB, NT, NBT, 1>), dim3((unsigned)grid), dim3(NT), lds, st, a, P, Q);
+    hipLaunchKernelGGL((ib_rows_kernel<NORB, NT, NBT, 1>), dim3((unsigned)grid), dim3(NT), lds, st, a, P, Q, X);
   else
-    hipLaunchKernelGGL((ib_rows_kernel<NORB, NT, NBT, 0>), dim3((unsigned)grid), dim3(NT), lds, st, a, P, Q);
+    hipLaunchKernelGGL((ib_rows_kernel<NORB, NT, NBT, 0>), dim3((unsigned)grid), dim3(NT), lds, st, a, P, Q, X);
   EDIGPU_HIP(hipGetLastError());
   return 0;
 }
 
 template <int NORB>
-static int launch_rows_n(const IbDev* d, const IbArgs& a, int fuse, double* P, double* Q, hipStream_t st) {
+static int launch_rows_n(const IbDev* d, const IbArgs& a, int fuse, const double* P, double* Q, double* X, hipStream_t st) {
   constexpr int B0 = NORB == 1 ? 8 : 4, B1 = NORB == 1 ? 14 : 6;
 #define EDIGPU_IB_ROWS(NT)                                                                                   \
   if (d->rows_nt == NT) {                                                                                    \
-    if (d->rows_nbt == B0) return launch_rows_t<NORB, NT, B0>(d, a, fuse, P, Q, st);                         \
-    if (d->rows_nbt == B1) return launch_rows_t<NORB, NT, B1>(d, a, fuse, P, Q, st);                         \
-    if constexpr (NORB == 2)                                                                                 \
-      if (d->rows_nbt == 8) return launch_rows_t<NORB, NT, 8>(d, a, fuse, P, Q, st);                         \
+    if (d->rows_nbt == B0) return launch_rows_t<NORB, NT, B0>(d, a, fuse, P, Q, X, st);                         \
+    if (d->rows_nbt == B1) return launch_rows_t<NORB, NT, B1>(d, a, fuse, P, Q, X, st);                         \
+    if constexpr (NORB >= 2 && (NORB == 2 || NT != 1024))                                                    \
+      if (d->rows_nbt == 8) return launch_rows_t<NORB, NT, 8>(d, a, fuse, P, Q, X, st);                         \
+    if constexpr (NORB == 3 && NT == 512)                                                                    \
+      if (d->rows_nbt == 12) return launch_rows_t<NORB, NT, 12>(d, a, fuse, P, Q, X, st);                       \
   }
   EDIGPU_IB_ROWS(256)
   EDIGPU_IB_ROWS(512)
+  EDIGPU_IB_ROWS(768)
   EDIGPU_IB_ROWS(1024)
 #undef EDIGPU_IB_ROWS
   set_error("ib_rows_kernel: no instantiation for this sector");
   return 1;
 }
 
-static int launch_ib_rows(const IbDev* d, const IbArgs& a, int fuse, double* P, double* Q, hipStream_t st) {
+static int launch_ib_rows(const IbDev* d, const IbArgs& a, int fuse, const double* P, double* Q, double* X, hipStream_t st) {
   switch (d->norb) {
-    case 1: return launch_rows_n<1>(d, a, fuse, P, Q, st);
-    case 2: return launch_rows_n<2>(d, a, fuse, P, Q, st);
-    case 3: return launch_rows_n<3>(d, a, fuse, P, Q, st);
+    case 1: return launch_rows_n<1>(d, a, fuse, P, Q, X, st);
+    case 2: return launch_rows_n<2>(d, a, fuse, P, Q, X, st);
+    case 3: return launch_rows_n<3>(d, a, fuse, P, Q, X, st);
   }
   set_error("ib_rows_kernel: norb");
   return 1;
 }
 
 template <int NORB, bool DO_ND, bool ALPHA>
-static int launch_cols_t(const IbDev* d, const IbArgs& a, const double* v, double* hv, hipStream_t st, int* nblocks) {
+static int launch_cols_t(const IbDev* d, const IbArgs& a, const double* v, double* hv, const double* pold, hipStream_t st, int* nblocks) {
   const size_t lds = d->cols_lds;
   const void* k = (const void*)ib_cols_kernel<NORB, DO_ND, ALPHA>;
   if (ensure_dynamic_lds(k, lds)) return 1;
@@ -516,20 +576,20 @@ static int launch_cols_t(const IbDev* d, const IbArgs& a, const double* v, doubl
     set_error("ib_cols_kernel: partial buffer too small");
     return 1;
   }
-  hipLaunchKernelGGL((ib_cols_kernel<NORB, DO_ND, ALPHA>), dim3((unsigned)grid), dim3(kColsNT), lds, st, a, v, hv);
+  hipLaunchKernelGGL((ib_cols_kernel<NORB, DO_ND, ALPHA>), dim3((unsigned)grid), dim3(kColsNT), lds, st, a, v, hv, pold);
   EDIGPU_HIP(hipGetLastError());
   if (nblocks) *nblocks = (int)grid;
   return 0;
 }
 
-static int launch_ib_cols(const IbDev* d, const IbArgs& a, bool alpha, const double* v, double* hv, hipStream_t st, int* nblocks) {
+static int launch_ib_cols(const IbDev* d, const IbArgs& a, bool alpha, const double* v, double* hv, const double* pold, hipStream_t st, int* nblocks) {
   const bool nd = d->nterms > 0;
 #define EDIGPU_IB_COLS(NORB)                                                                     \
   case NORB:                                                                                     \
-    if (nd) return alpha ? launch_cols_t<NORB, true, true>(d, a, v, hv, st, nblocks)             \
-                         : launch_cols_t<NORB, true, false>(d, a, v, hv, st, nblocks);           \
-    return alpha ? launch_cols_t<NORB, false, true>(d, a, v, hv, st, nblocks)                    \
-                 : launch_cols_t<NORB, false, false>(d, a, v, hv, st, nblocks);
+    if (nd) return alpha ? launch_cols_t<NORB, true, true>(d, a, v, hv, pold, st, nblocks)             \
+                         : launch_cols_t<NORB, true, false>(d, a, v, hv, pold, st, nblocks);           \
+    return alpha ? launch_cols_t<NORB, false, true>(d, a, v, hv, pold, st, nblocks)                    \
+                 : launch_cols_t<NORB, false, false>(d, a, v, hv, pold, st, nblocks);
   switch (d->norb) {
     EDIGPU_IB_COLS(1)
     EDIGPU_IB_COLS(2)
@@ -544,21 +604,27 @@ static int launch_ib_cols(const IbDev* d, const IbArgs& a, bool alpha, const dou
 int launch_ib(const edigpu_sector* s, const double* v, double* hv, hipStream_t st) {
   IbArgs a;
   fill_ib_args(s->ib, a);
-  if (launch_ib_rows(s->ib, a, 0, const_cast<double*>(v), hv, st)) return 1;
-  return launch_ib_cols(s->ib, a, false, v, hv, st, nullptr);
+  if (launch_ib_rows(s->ib, a, 0, v, hv, nullptr, st)) return 1;
+  return launch_ib_cols(s->ib, a, false, v, hv, nullptr, st, nullptr);
 }
 
-// one fused Lanczos step (launch_normal_lanczos, kernels_normal.hip, explains the protocol)
-int launch_ib_lanczos(const edigpu_sector* s, double* P, double* Q, const double* scal, double* partial, int64_t partial_cap,
-                      bool first, bool lazy_axpy, hipStream_t st, int* npartial) {
+// One fused Lanczos step (launch_normal_lanczos, kernels_normal.hip, explains the protocol) on THREE buffers: P = the
+// previous Lanczos vector, Q = the work vector, X = where the new Lanczos vector is written (steps after the first;
+// the caller then takes X as the new P and the old P as the next X).
+int launch_ib_lanczos(const edigpu_sector* s, const double* P, double* Q, double* X, const double* scal, double* partial,
+                      int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial) {
   IbArgs a;
   fill_ib_args(s->ib, a);
   a.scal = scal;
   a.partial = partial;
   a.lazy = lazy_axpy ? 1 : 0;
   (void)partial_cap;  // >= kMaxPartials (ensure_workspace); launch_cols_t checks its grid against that
-  if (launch_ib_rows(s->ib, a, first ? 0 : 1, P, Q, st)) return 1;
-  return launch_ib_cols(s->ib, a, true, P, Q, st, npartial);
+  if (first) {
+    if (launch_ib_rows(s->ib, a, 0, P, Q, nullptr, st)) return 1;
+    return launch_ib_cols(s->ib, a, true, P, Q, nullptr, st, npartial);
+  }
+  if (launch_ib_rows(s->ib, a, 1, P, Q, X, st)) return 1;
+  return launch_ib_cols(s->ib, a, true, X, Q, P, st, npartial);
 }
 
 }  // namespace edigpu

@@ -635,7 +635,7 @@ bool normal_lanczos_fusable(const edigpu_sector* s) {
 
 int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const double* scal,
                           double* partial, int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial,
-                          int nlanc, bool* finalized) {
+                          int nlanc, bool* finalized, double* X, bool* in_x) {
   NormalArgs a;
   fill_args(s, a);
   a.scal = scal;
@@ -656,8 +656,16 @@ int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const do
     a.lz_len = s->lz_len;
     *finalized = true;
   }
-  if (s->lz_blocked && s->ib)  // impurity-block image: its own two kernels on its own layout (kernels_ib.hip)
-    return launch_ib_lanczos(s, P, Q, scal, partial, partial_cap, first, lazy_axpy, st, npartial);
+  if (in_x) *in_x = false;
+  if (s->lz_blocked && s->ib) {  // impurity-block image: its own two kernels on its own layout (kernels_ib.hip)
+    if (finalized) *finalized = false;
+    if (!X || !in_x) {
+      set_error("launch_normal_lanczos: the impurity-block image needs a third buffer");
+      return 1;
+    }
+    *in_x = !first;
+    return launch_ib_lanczos(s, P, Q, X, scal, partial, partial_cap, first, lazy_axpy, st, npartial);
+  }
   if (s->lz_blocked) {  // P, Q in the panel-major layout (lanczos_prepare)
     a.blk_shift = s->blk_shift;
     a.blk_ps = s->blk_ps;

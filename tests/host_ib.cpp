@@ -25,25 +25,32 @@ int64_t vec_at(const HostIb& ib, int64_t row, int pos) {
 template <int NORB>
 void emulate_rows(const HostIb& ib, const std::vector<double>& v, std::vector<double>& hv) {
   const int plen = ib.npanels * kIbPanel, nimp = 1 << NORB;
-  std::vector<double> row((size_t)plen + 8, 0.0), out((size_t)plen, 0.0);
+  std::vector<double> img((size_t)ib.rimg_len, 0.0), res((size_t)ib.rimg_len, 0.0);
+  ib::RowImage im;
+  im.row = img.data();
+  im.rank = ib.urank.data();
+  for (int c = 0; c < 5; c++) {
+    im.cb[c] = ib.rcb[c];
+    im.cs[c] = ib.rcs[c];
+  }
   for (int64_t r = 0; r < ib.dw.dim; r++) {
-    for (int p = 0; p < plen; p++) row[p] = v[vec_at(ib, r, p)];
-    std::fill(out.begin(), out.end(), 0.0);
+    for (int p = 0; p < plen; p++) img[ib.rmap[p]] = v[vec_at(ib, r, p)];   // (padding: zeros into the last word)
+    res = img;   // words no block owns (slack, the zero word) leave as they came
     for (int n = 0; n <= NORB; n++)
       for (int q = ib.ucls[n]; q < ib.ucls[n + 1]; q++) {
         const uint16_t e = ib.ublist[q];
         const uint32_t b = e & 0x7FFFu;
-        const uint32_t o = ib.upos[b];
+        const uint32_t i = (uint32_t)(q - ib.ucls[n]);
         ib::for_class<NORB>(n, [&](auto N) {
           constexpr int nn = decltype(N)::value;
           double acc[ib::binom(NORB, nn)];
-          ib::rows_block<NORB, nn>(row.data(), b, o, ib.up.nb, ib.upos.data(), ib.up.vtab.data(), ib.up.timp.data(),
-                                   ib.up.ebath[b] + ib.ed[r], &ib.xu[(size_t)ib.impd[r] * nimp], acc);
+          ib::rows_block<NORB, nn>(im, b, i, ib.up.nb, ib.up.vtab.data(), ib.up.timp.data(), ib.ed[r],
+                                   &ib.xu[(size_t)ib.impd[r] * nimp], acc);
           if (!(e & kIbSkip))
-            for (int j = 0; j < ib::binom(NORB, nn); j++) out[o + j] = acc[j];
+            for (int j = 0; j < ib::binom(NORB, nn); j++) res[(size_t)ib.rcb[nn + 1] + (size_t)j * ib.rcs[nn + 1] + i] = acc[j];
         });
       }
-    for (int p = 0; p < plen; p++) hv[vec_at(ib, r, p)] = out[p];
+    for (int p = 0; p < plen; p++) hv[vec_at(ib, r, p)] = res[ib.rmap[p]];
   }
 }
 
