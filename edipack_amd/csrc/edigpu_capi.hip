@@ -668,15 +668,21 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
   }
   // Impurity-block image (host_ib.hpp, kernels_ib.hip): whole sectors built from a model whose hops connect impurity
   // levels with single bath levels (normal / hybrid baths), <= 3 orbitals.  The device-resident Lanczos loops then run
-  // on its padded 16-column panel layout and its two kernels.  EDIGPU_IB=0 switches it off, EDIGPU_IB_MIN sets the
-  // smallest sector (rows; tests force it on small ones), EDIGPU_IB_ROWS the rows of a staged chunk (<= 480).
+  // on its padded 16-column panel layout and its two kernels.  Measured (r3): 0.61 against 0.85 ms per product at
+  // Ns = 15, 2.4 against 3.3 ms at Ns = 16, but 0.18 against 0.13 ms on config 2, whose 27 KB rows leave the generic
+  // row kernel four workgroups per CU -- so the default takes it for rows of more than EDIGPU_IB_MINROW bytes (40 KB).
+  // EDIGPU_IB=0 switches it off, EDIGPU_IB_MIN sets the smallest sector (elements; tests force it on small ones with
+  // EDIGPU_IB_MIN=0, which also lifts the row gate), EDIGPU_IB_ROWS the rows of a staged chunk (<= 480).
   if (s->factored && built && built->norb > 0 && dw_first == 0 && dw_count == dim_dw) {
     const char* e;
     const bool on = !(e = getenv("EDIGPU_IB")) || atoi(e) != 0;
     const int64_t min_rows = (e = getenv("EDIGPU_IB_MIN")) ? atoll(e) : ((int64_t)1 << 21);
     int chunk_rows = (e = getenv("EDIGPU_IB_ROWS")) ? atoi(e) : 480;
     chunk_rows = std::max(4, std::min(chunk_rows, 480));
-    if (on && s->nloc >= min_rows && !env_flag("EDIGPU_LANCZOS_UNFUSED") && setup_ib(s, *built, chunk_rows)) return 1;
+    const int64_t min_row_bytes = (e = getenv("EDIGPU_IB_MINROW")) ? atoll(e) : (min_rows == 0 ? 0 : 40 * 1024);
+    if (on && s->nloc >= min_rows && dim_up * 8 >= min_row_bytes && !env_flag("EDIGPU_LANCZOS_UNFUSED") &&
+        setup_ib(s, *built, chunk_rows))
+      return 1;
   }
   // Panel-major vector layout for the device-resident Lanczos loop (normal_args.hpp): large
   // factored whole sectors whose rows fit the LDS row kernel.  Default: 128-column panels (1 KiB line-aligned segments)

@@ -232,7 +232,7 @@ IB_HD void rows_block(const RowImage& im, uint32_t b, uint32_t i, int nb, const 
 // chunk : the chunk's rows of the panel in the LDS, [row - chunk_row0][16] doubles; col = even column in the panel
 // meta  : the 16 entries of the block's bath word (host_ib.hpp dmeta): partner first rows, sign bits in [15]
 // gload(row): the two columns of a global row of the panel (rows outside the chunk: hops to the bath levels >= low)
-// acc[M] (in: what the rows kernel left in hv; out: + (Hdw (x) 1) v)
+// acc[M] is added to: + (Hdw (x) 1) v
 constexpr int kHB = 3;  // high bath levels whose partner rows are in flight together
 
 template <int NORB, int N, class GLoad>
@@ -278,25 +278,32 @@ IB_HD void cols_block(const double* chunk, int chunk_row0, uint32_t b, int own_r
     });
   };
   issue(0);
-  // impurity-impurity hops and the low levels: everything in the LDS
+  // impurity-impurity hops and the low levels: everything in the LDS.  The low levels are walked in as many parts as
+  // there are batches of high levels, one part behind each batch's loads.
   if constexpr (NORB > 1) {
     Pair x[M];
     sfor<0, M>([&](auto J) { x[decltype(J)::value] = lds_pair(own_row - chunk_row0 + decltype(J)::value); });
     couple_imp<NORB, N, Pair>(timp, x, acc, FmaP{});
   }
-  for (int k = 0; k < low; k++) {
-    const int r2 = (int)meta[k] - chunk_row0, n2 = nrows(k);
-    Pair xp[MPX > 0 ? MPX : 1];
-    sfor<0, MPX>([&](auto J) {
-      constexpr int j2 = decltype(J)::value;
-      if (j2 < n2) xp[j2] = lds_pair(r2 + j2);
-    });
-    use(k, xp);
-  }
+  auto low_levels = [&](int k0, int k1) {
+    for (int k = k0; k < k1; k++) {
+      const int r2 = (int)meta[k] - chunk_row0, n2 = nrows(k);
+      Pair xp[MPX > 0 ? MPX : 1];
+      sfor<0, MPX>([&](auto J) {
+        constexpr int j2 = decltype(J)::value;
+        if (j2 < n2) xp[j2] = lds_pair(r2 + j2);
+      });
+      use(k, xp);
+    }
+  };
+  const int nbatch = nhigh > kHB ? 2 : 1;  // (the host keeps nhigh <= 2 kHB)
+  const int kmid = nbatch == 2 ? low / 2 : low;
+  low_levels(0, kmid);
   consume(0);
-  for (int h0 = kHB; h0 < nhigh; h0 += kHB) {
-    issue(h0);
-    consume(h0);
+  if (nbatch == 2) {
+    issue(kHB);
+    low_levels(kmid, low);
+    consume(kHB);
   }
 }
 

@@ -230,6 +230,20 @@ __global__ void __launch_bounds__(NT, (NT == 768 ? 3 : (NT == 512 && NBT >= 12) 
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kColsNT = 512;
 
+// Streamed once: the result rows (read, updated, written) and P_old's rows.  Non-temporal, so that they do not push the
+// panel's V segments -- gathered again and again by the neighbouring chunks -- out of the XCD's L2.
+typedef double ib_d2 __attribute__((ext_vector_type(2)));
+__device__ inline ib::Pair nt_load(const double* p) {
+  const ib_d2 t = __builtin_nontemporal_load(reinterpret_cast<const ib_d2*>(p));
+  return ib::Pair{t.x, t.y};
+}
+__device__ inline void nt_store(double* p, const ib::Pair& v) {
+  ib_d2 t;
+  t.x = v.x;
+  t.y = v.y;
+  __builtin_nontemporal_store(t, reinterpret_cast<ib_d2*>(p));
+}
+
 template <int NORB, bool DO_ND, bool ALPHA>
 __global__ void __launch_bounds__(kColsNT, 4) ib_cols_kernel(IbArgs a, const double* __restrict__ v, double* __restrict__ hv, const double* __restrict__ pold) {
   __shared__ double red[3 * (kColsNT / 64)];
@@ -321,25 +335,37 @@ __global__ void __launch_bounds__(kColsNT, 4) ib_cols_kernel(IbArgs a, const dou
       ib::for_class<NORB>(n, [&](auto N) {
         constexpr int nn = decltype(N)::value;
         constexpr int M = ib::binom(NORB, nn);
-        ib::Pair acc[M];
+        // the rows kernel's part of the result: HBM misses, requested first and added last (plain product).  The fused
+        // step has no registers to park them in (three accumulators + P_old's rows: spills measured slower): there the
+        // accumulators start from them.
+        ib::Pair acc[M], h0[ALPHA ? 1 : M];
         ib::sfor<0, M>([&](auto J) {
-          acc[decltype(J)::value] = *reinterpret_cast<const ib::Pair*>(hp + (int64_t)(own + decltype(J)::value) * 16 + col);
+          constexpr int j = decltype(J)::value;
+          if constexpr (ALPHA) {
+            acc[j] = nt_load(hp + (int64_t)(own + j) * 16 + col);
+            if (pp) {  // uniform
+              const ib::Pair o = nt_load(pp + (int64_t)(own + j) * 16 + col);
+              acc[j].x = __builtin_fma(nbeta, o.x, acc[j].x);
+              acc[j].y = __builtin_fma(nbeta, o.y, acc[j].y);
+            }
+          } else {
+            h0[j] = nt_load(hp + (int64_t)(own + j) * 16 + col);
+            acc[j].x = acc[j].y = 0.0;
+          }
         });
-        if (ALPHA && pp) {  // uniform
-          ib::sfor<0, M>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            const ib::Pair o = *reinterpret_cast<const ib::Pair*>(pp + (int64_t)(own + j) * 16 + col);
-            acc[j].x = __builtin_fma(nbeta, o.x, acc[j].x);
-            acc[j].y = __builtin_fma(nbeta, o.y, acc[j].y);
-          });
-        }
         auto gload = [&](int grow) -> ib::Pair { return *reinterpret_cast<const ib::Pair*>(vp + (int64_t)grow * 16 + col); };
         ib::cols_block<NORB, nn>(chunk, row0, b, own, meta, nb, a.lowbits, vtab, timp, col, gload, acc);
         if (DO_ND) ib::cols_block_nd<NORB, nn>(chunk, own - row0, col, a.nterms, ndc, nddw, ndu, 16, acc);
+        if constexpr (!ALPHA)
+          ib::sfor<0, M>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            acc[j].x += h0[j].x;
+            acc[j].y += h0[j].y;
+          });
         if (!(e & 0x8000u)) {
           ib::sfor<0, M>([&](auto J) {
             constexpr int j = decltype(J)::value;
-            *reinterpret_cast<ib::Pair*>(hp + (int64_t)(own + j) * 16 + col) = acc[j];
+            nt_store(hp + (int64_t)(own + j) * 16 + col, acc[j]);
             if (ALPHA) {
               const ib::Pair o = *reinterpret_cast<const ib::Pair*>(chunk + (own - row0 + j) * 16 + col);
               const double dx = acc[j].x - sg * o.x, dy = acc[j].y - sg * o.y;

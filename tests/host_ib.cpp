@@ -74,11 +74,7 @@ void emulate_cols(const HostIb& ib, const std::vector<double>& v, std::vector<do
               constexpr int nn = decltype(N)::value;
               constexpr int M = ib::binom(NORB, nn);
               ib::Pair acc[M];
-              for (int j = 0; j < M; j++) {
-                const double* h = &hv[(size_t)pn * ps + (size_t)(own + j) * kIbPanel + col];
-                acc[j].x = h[0];
-                acc[j].y = h[1];
-              }
+              for (int j = 0; j < M; j++) acc[j].x = acc[j].y = 0.0;
               auto gload = [&](int grow) -> ib::Pair {
                 const double* g = &v[(size_t)pn * ps + (size_t)grow * kIbPanel + col];
                 return ib::Pair{g[0], g[1]};
@@ -90,8 +86,8 @@ void emulate_cols(const HostIb& ib, const std::vector<double>& v, std::vector<do
                                             &ib.nd_up[(size_t)pn * kIbPanel], ib.npanels * kIbPanel, acc);
               for (int j = 0; j < M; j++) {
                 double* h = &hv[(size_t)pn * ps + (size_t)(own + j) * kIbPanel + col];
-                h[0] = acc[j].x;
-                h[1] = acc[j].y;
+                h[0] += acc[j].x;
+                h[1] += acc[j].y;
               }
             });
         }

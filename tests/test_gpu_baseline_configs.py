@@ -318,18 +318,19 @@ def test_cfg2_handover_image_runs_the_factored_kernels(gpu, monkeypatch):
 
 @pytest.mark.parametrize("workload", ["cfg3_ns15", "cfg3_ns16"])
 def test_hbm_resident_ladder_panel_major_vs_natural(gpu, monkeypatch, workload):
-    """The sectors the roofline fraction is quoted on (41 M and 166 M rows, HBM-resident): the default loop on
-    panel-major vectors against the same recurrence on the reference's layout (EDIGPU_BLOCKED=0) -- two different
-    sweeps (tiled kernel with and without the BLK addressing, conversions on the way in), same coefficients -- and the
-    boundary product's linearity at that size."""
+    """The sectors the roofline fraction is quoted on (41 M and 166 M rows, HBM-resident): the default loop -- the
+    impurity-block image on its padded 16-column panels (csrc/kernels_ib.hip) -- against the same recurrence on the
+    generic kernels, panel-major (EDIGPU_IB=0) and on the reference's layout (EDIGPU_BLOCKED=0): three different pairs
+    of kernels and two layout conversions, same coefficients; and the product's linearity and symmetry at that size
+    (host vectors: the impurity-block product; its first Lanczos coefficient against <v|H|v>)."""
     from edipack_amd.hamiltonian import SectorHamiltonian
     from edipack_amd.synthetic import WORKLOADS, synthetic_model
-    for k in ("EDIGPU_BLOCKED", "EDIGPU_BLOCKED_W", "EDIGPU_BLOCKED_MIN"):
+    for k in ("EDIGPU_BLOCKED", "EDIGPU_BLOCKED_W", "EDIGPU_BLOCKED_MIN", "EDIGPU_IB", "EDIGPU_IB_MIN", "EDIGPU_IB_ROWS"):
         monkeypatch.delenv(k, raising=False)
     w = WORKLOADS[workload]
     pm = synthetic_model(w)
     hb = SectorHamiltonian.normal_from_model(pm, *w.sector)
-    assert hb.image_info()[4] == 128
+    assert hb.image_info()[4] == 16 and hb.image_info()[5] == 1
     rng = np.random.default_rng(11)
     v = rng.standard_normal(hb.dim)
     v /= np.linalg.norm(v)
@@ -340,16 +341,25 @@ def test_hbm_resident_ladder_panel_major_vs_natural(gpu, monkeypatch, workload):
     assert abs(np.dot(x, hv) - np.dot(hx, v)) < 1e-10 * np.linalg.norm(hv) * np.linalg.norm(x)     # symmetric H
     assert abs(np.dot(v, hv) - ab[0]) < 1e-10 * max(1.0, abs(ab[0]))                                # alpha_1 = <v|H|v>
     hb.destroy()
-    del hv, hx, x
+    del hx, x
+    monkeypatch.setenv("EDIGPU_IB", "0")
+    hp = SectorHamiltonian.normal_from_model(pm, *w.sector)
+    assert hp.image_info()[4] == 128 and hp.image_info()[5] == 0
+    ap, bp, npm = hp.lanczos_tridiag(v, 40)
+    assert rel_err(hp.apply(v), hv) < 1e-12          # the generic kernels' product against the impurity-block one
+    hp.destroy()
+    del hv
     monkeypatch.setenv("EDIGPU_BLOCKED", "0")
     hn = SectorHamiltonian.normal_from_model(pm, *w.sector)
     assert hn.image_info()[4] == 0
     an, bn, nn = hn.lanczos_tridiag(v, 40)
     hn.destroy()
-    assert nb == nn == 40
+    assert nb == nn == npm == 40
     assert rel_err(ab[:25], an[:25]) < 1e-10 and rel_err(bb[:25], bn[:25]) < 1e-10
+    assert rel_err(ap[:25], an[:25]) < 1e-10 and rel_err(bp[:25], bn[:25]) < 1e-10
     for z in (60.0 + 0.1j, -60.0 + 0.1j, 40.0j):
         assert abs(_cf(ab, bb, z) - _cf(an, bn, z)) / abs(_cf(an, bn, z)) < 1e-10
+        assert abs(_cf(ap, bp, z) - _cf(an, bn, z)) / abs(_cf(an, bn, z)) < 1e-10
 
 
 @pytest.mark.parametrize("name", ["REPLICA_SUPERC", "GENERAL_SUPERC", "REPLICA_NONSU2", "GENERAL_NONSU2"])
