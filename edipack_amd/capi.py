@@ -140,6 +140,9 @@ SIGNATURES = {
     "edigpu_apply_sharded_d": (C.c_int, [_vp, _vp, _i64, _pd, _pd]),
     "edigpu_apply_sharded_z": (C.c_int, [_vp, _vp, _i64, _pd, _pd]),
     "edigpu_lanczos_tridiag_sharded": (C.c_int, [_vp, _vp, _vp, C.c_int, _pd, _pd, C.c_double, _pint, _pd]),
+    "edigpu_lanczos_eigh_multi_sharded": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int, _vp, _pd, _vp, _pint,
+                                                    _pint]),
+    "edigpu_lanczos_eigh_sharded": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, _pd, _vp, _pint]),
     "edigpu_lanczos_bench_sharded": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _pd, _pi64]),
     "edigpu_destroy": (C.c_int, [_vp]),
 }

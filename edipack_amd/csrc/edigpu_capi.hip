@@ -2724,24 +2724,23 @@ static void jacobi_eigh(int n, std::vector<double>& a, std::vector<double>& w, s
 }
 
 // Thick-restart Lanczos with full re-orthogonalisation: the lowest `neigen` eigenpairs from an
-// ncv-dimensional basis -- the job the reference gives to ARPACK (sp_eigh, ED_NORMAL/ED_DIAG_NORMAL.f90:179-196).
-int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, int maxrestart, const double* v0,
-                              double* evals, double* evecs, int* nconv_out, int* nmatvec_out) {
-  if (!s || !evals || neigen <= 0) {
-    set_error("edigpu_lanczos_eigh_multi: bad argument");
-    return 1;
-  }
-  if (single_shard(s, "edigpu_lanczos_eigh_multi")) return 1;
-  EDIGPU_HIP(hipSetDevice(s->device));
-  if (ensure_workspace(s)) return 1;
-  hipStream_t st = s->stream;
-  const int cplx = s->is_complex;
-  const int64_t n = s->nloc, len = s->ws_len;
-  if ((int64_t)neigen > n) neigen = (int)n;
+// ncv-dimensional basis -- the job the reference gives to ARPACK (sp_eigh, ED_NORMAL/ED_DIAG_NORMAL.f90:179-196; with
+// MpiComm, :221-242, to PARPACK).  One routine for whole sectors and for shards: `n` elements (`len` doubles) of every
+// vector live on this rank, ops.apply is the product on them, ops.allreduce sums small device buffers over the ranks
+// (empty: a single rank).  Every decision is taken from all-reduced numbers, so the ranks stay in step.
+}  // extern "C"
+namespace edigpu {
+int trl_solve(int device, hipStream_t st, int cplx, int64_t n, int64_t len, int64_t nglobal, const TrlOps& ops, int neigen, int ncv,
+              double tol, int maxrestart, const double* v0, uint64_t seed_offset, double* evals, double* evecs,
+              int* nconv_out, int* nmatvec_out) {
+  EDIGPU_HIP(hipSetDevice(device));
+  const bool multi = (bool)ops.allreduce;
+  auto reduce = [&](double* dev, size_t cnt) -> int { return multi ? ops.allreduce(dev, cnt, st) : 0; };
+  if ((int64_t)neigen > nglobal) neigen = (int)nglobal;
   int m = ncv > 0 ? ncv : std::max(2 * neigen + 10, 20);
   if (m < neigen + 2) m = neigen + 2;
   if (m > 128) m = 128;
-  if ((int64_t)m > n) m = (int)n;
+  if ((int64_t)m > nglobal) m = (int)nglobal;
   if (tol <= 0.0) tol = 1e-12;
   if (maxrestart <= 0) maxrestart = 300;
   const size_t vbytes = (size_t)len * sizeof(double);
@@ -2756,7 +2755,7 @@ int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, 
   auto q = [&](int j) { return b.Q + (size_t)j * len; };
   std::vector<double> hh(2 * (size_t)(m + 40));
   auto norm_of = [&](double* w, double& out) -> int {
-    if (trl_norm2(cplx, n, w, b.h, b.part, st)) return 1;
+    if (trl_norm2(cplx, n, w, b.h, b.part, st) || reduce(b.h, 2)) return 1;
     EDIGPU_HIP(hipMemcpyAsync(hh.data(), b.h, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
     EDIGPU_HIP(hipStreamSynchronize(st));
     out = sqrt(std::max(hh[0], 0.0));
@@ -2765,7 +2764,7 @@ int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, 
   // start vector
   if (v0) {
     EDIGPU_HIP(hipMemcpyAsync(q(0), v0, vbytes, hipMemcpyDefault, st));
-  } else if (lz_fill_random(q(0), len, 0x7e57ab1eull, st)) {
+  } else if (lz_fill_random(q(0), len, 0x7e57ab1eull + seed_offset, st)) {
     return 1;
   }
   double nrm = 0.0;
@@ -2811,7 +2810,7 @@ int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, 
     EDIGPU_HIP(hipMemsetAsync(d_coef, 0, sizeof(double) * 2 * hstride * (size_t)m, st));
     for (int j = k; j < m; j++) {
       double* w = q(j + 1);
-      if (apply_any(s, q(j), q(j), w, 3, st)) return 1;
+      if (ops.apply(q(j), w, st)) return 1;
       nmv++;
       // classical Gram-Schmidt against q_0..q_j, twice; the coefficients are column j of Q^H H Q
       double* c1 = d_coef + (size_t)(2 * j) * hstride;
@@ -2820,16 +2819,22 @@ int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, 
       // orthogonality ~10 eps otherwise); decided on the device, c2 stays zero when skipped
       // coefficients below 1e-11 |w_new| (pure rounding: the three-term recurrence makes them zero) are not
       // subtracted, their basis vectors not read (trl_decide_kernel)
-      if (twopass) {
-        if (trl_orthogonalize(cplx, n, j + 1, b.Q, len, w, c1, b.part, st)) return 1;
-        if (trl_orthogonalize(cplx, n, j + 1, b.Q, len, w, c2, b.part, st)) return 1;
+      if (twopass || multi) {
+        // (shards: the coefficients Q^H w are summed over the ranks between the dots and the subtraction -- one
+        // all-reduce of j + 1 numbers per pass, the k-element reduce of SciFortran's MPI Lanczos)
+        if (trl_dots(cplx, n, j + 1, b.Q, len, w, c1, b.part, st) || reduce(c1, 2 * (size_t)(j + 1)) ||
+            trl_subtract(cplx, n, j + 1, b.Q, len, c1, w, st))
+          return 1;
+        if (trl_dots(cplx, n, j + 1, b.Q, len, w, c2, b.part, st) || reduce(c2, 2 * (size_t)(j + 1)) ||
+            trl_subtract(cplx, n, j + 1, b.Q, len, c2, w, st))
+          return 1;
       } else {
         if (trl_dots(cplx, n, j + 2, b.Q, len, w, c1, b.part, st)) return 1;  // column j+1 is w itself: <w|w>
         if (trl_decide(c1, j + 1, 0.5, thr_skip * thr_skip, b.h, d_skip, st)) return 1;
         if (trl_subtract(cplx, n, j + 1, b.Q, len, b.h, w, st)) return 1;
         if (trl_orthogonalize(cplx, n, j + 1, b.Q, len, w, c2, b.part, st, d_skip)) return 1;
       }
-      if (trl_norm2(cplx, n, w, d_nrm + 2 * j, b.part, st)) return 1;
+      if (trl_norm2(cplx, n, w, d_nrm + 2 * j, b.part, st) || reduce(d_nrm + 2 * j, 2)) return 1;
       if (vec_scale(len, w, d_nrm + 2 * j, st)) return 1;  // w / sqrt(<w|w>) with the norm read on the device
     }
     EDIGPU_HIP(hipMemcpyAsync(hcoef.data(), d_coef, sizeof(double) * hcoef.size(), hipMemcpyDeviceToHost, st));
@@ -2928,6 +2933,23 @@ int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, 
   }
   EDIGPU_HIP(hipStreamSynchronize(st));
   return 0;
+}
+}  // namespace edigpu
+extern "C" {
+
+int edigpu_lanczos_eigh_multi(edigpu_handle s, int neigen, int ncv, double tol, int maxrestart, const double* v0,
+                              double* evals, double* evecs, int* nconv_out, int* nmatvec_out) {
+  if (!s || !evals || neigen <= 0) {
+    set_error("edigpu_lanczos_eigh_multi: bad argument");
+    return 1;
+  }
+  if (single_shard(s, "edigpu_lanczos_eigh_multi")) return 1;
+  EDIGPU_HIP(hipSetDevice(s->device));
+  if (ensure_workspace(s)) return 1;
+  TrlOps ops;
+  ops.apply = [s](const double* in, double* out, hipStream_t st) { return apply_any(s, in, in, out, 3, st); };
+  return trl_solve(s->device, s->stream, s->is_complex, s->nloc, s->ws_len, s->nloc, ops, neigen, ncv, tol, maxrestart, v0, 0, evals,
+                   evecs, nconv_out, nmatvec_out);
 }
 
 int edigpu_vec_work_doubles(void) { return kRedBlocks; }

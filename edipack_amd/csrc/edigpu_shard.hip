@@ -896,6 +896,66 @@ int edigpu_lanczos_tridiag_sharded(edigpu_handle h, edigpu_comm c, const double*
   return sharded_tridiag(h, c, vin_shard, nlanc, alanc, blanc, threshold, niter_done, norm2);
 }
 
+// sp_eigh(MpiComm, spHtimesV_p, eval, evec, ...) / sp_lanc_eigh(MpiComm, ...) with every vector a device-resident shard
+// (ED_NORMAL/ED_DIAG_NORMAL.f90:179-214 and the superc / nonsu2 twins): the thick-restart driver of the single-GPU
+// solver (trl_solve, edigpu_capi.hip) on this rank's elements, the product through the sharded exchange, the Gram-
+// Schmidt coefficients and norms through small all-reduces.  Nothing of vector length crosses PCIe.
+int edigpu_lanczos_eigh_multi_sharded(edigpu_handle h, edigpu_comm c, int neigen, int ncv, double tol, int maxrestart,
+                                      const double* v0_shard, double* evals, double* evecs_shard, int* nconv, int* nmatvec) {
+  if (!h || !c || !evals || neigen <= 0) {
+    set_error("edigpu_lanczos_eigh_multi_sharded: bad argument");
+    return 1;
+  }
+  bool realified = false;
+  if (h->kind == 4 && h->sub_d) {  // complex normal sector: the products run on its doubled real sector, whose real
+    h = h->sub_d;                  // vectors ARE the interleaved complex ones -- the solver keeps the complex algebra
+    realified = true;
+  }
+  // a world of one rank holding the whole sector: the single-GPU solver (no exchange buffers)
+  if (c->world == 1 && h->nloc == h->dim && !getenv("EDIGPU_FORCE_COLLECTIVES") && !realified)
+    return edigpu_lanczos_eigh_multi(h, neigen, ncv, tol, maxrestart, v0_shard, evals, evecs_shard, nconv, nmatvec);
+  ShardGeom g;
+  if (shard_geometry(h, c, g)) return 1;
+  EDIGPU_HIP(hipSetDevice(h->device));
+  if (comm_workspace(c, g, 8)) return 1;
+  hipStream_t st = h->stream;
+  const int64_t len = g.nloc * g.w, chunk = g.chunk * g.w;
+  const int cplx = (g.w == 2 || realified) ? 1 : 0;
+  const int64_t n = cplx && g.w == 1 ? g.nloc / 2 : g.nloc;
+  const int64_t nglobal = (cplx && g.w == 1 ? h->dim / 2 : h->dim);
+  // the padded tail of the exchange buffers stays zero for the whole solve
+  EDIGPU_HIP(hipMemsetAsync(c->vin, 0, (size_t)std::max<int64_t>(chunk, 1) * sizeof(double), st));
+  EDIGPU_HIP(hipMemsetAsync(c->tmp, 0, (size_t)std::max<int64_t>(chunk, 1) * sizeof(double), st));
+  TrlOps ops;
+  ops.apply = [&](const double* in, double* out, hipStream_t s2) -> int {
+    if (len > 0) EDIGPU_HIP(hipMemcpyAsync(c->vin, in, (size_t)len * sizeof(double), hipMemcpyDeviceToDevice, s2));
+    const double* back = nullptr;
+    if (sharded_hv(h, c, g, false, s2, &back)) return 1;
+    if (g.transposed && back &&
+        edigpu_transpose_unpack_add(h->dim_up, g.count, g.q, c->world, g.pcol, g.halo, back, c->tmp, s2))
+      return 1;
+    if (len > 0) EDIGPU_HIP(hipMemcpyAsync(out, c->tmp, (size_t)len * sizeof(double), hipMemcpyDeviceToDevice, s2));
+    return 0;
+  };
+  ops.allreduce = [&](double* dev, size_t cnt, hipStream_t s2) -> int { return comm_all_reduce(c, dev, cnt, s2); };
+  return trl_solve(h->device, st, cplx, n, len, nglobal, ops, neigen, ncv, tol, maxrestart, v0_shard, (uint64_t)c->rank * 7919u,
+                   evals, evecs_shard, nconv, nmatvec);
+}
+
+// lanc_method = "lanczos" (sp_lanc_eigh with MpiComm: the lowest pair): the same driver asked for one pair, its basis
+// sized by nitermax (at most 128 vectors before a restart)
+int edigpu_lanczos_eigh_sharded(edigpu_handle h, edigpu_comm c, int nitermax, double tol, const double* v0_shard, double* eval,
+                                double* evec_shard, int* nmatvec) {
+  if (!eval || nitermax <= 0) {
+    set_error("edigpu_lanczos_eigh_sharded: bad argument");
+    return 1;
+  }
+  int nconv = 0;
+  const int ncv = std::max(8, std::min(nitermax, 48));
+  const int maxrestart = std::max(1, nitermax / std::max(1, ncv / 2));
+  return edigpu_lanczos_eigh_multi_sharded(h, c, 1, ncv, tol, maxrestart, v0_shard, eval, evec_shard, &nconv, nmatvec);
+}
+
 int edigpu_lanczos_bench_sharded(edigpu_handle s, edigpu_comm c, int warmup, int steps, double* ms_per_step,
                                  int64_t* exchange_bytes) {
   if (!s || !c || steps < 1 || warmup < 0 || !ms_per_step) {

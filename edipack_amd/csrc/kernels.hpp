@@ -1,5 +1,7 @@
 // kernels.hpp -- launch wrappers of the gfx950 kernels (definitions in kernels_*.hip).
 #pragma once
+#include <functional>
+
 #include "edigpu_internal.hpp"
 
 namespace edigpu {
@@ -113,6 +115,15 @@ int vec_rotate_pack(int first, int64_t dim_up, int64_t nrows, int64_t q, int wor
 int vec_unpack_add_dot2(int64_t dim_up, int64_t nrows, int64_t q, int64_t pcol, int halo, const double* vin,
                         double* vout, const double* tmp, const double* back, double* out2, double* work,
                         hipStream_t st);
+
+// ---- thick-restart Lanczos driver (edigpu_capi.hip), shared by edigpu_lanczos_eigh_multi and its sharded twin ----
+struct TrlOps {
+  std::function<int(const double* in, double* out, hipStream_t st)> apply;  // out = H in on this rank's elements
+  std::function<int(double* dev, size_t n, hipStream_t st)> allreduce;     // sum over the ranks, in place; empty: one rank
+};
+int trl_solve(int device, hipStream_t st, int cplx, int64_t n, int64_t len, int64_t nglobal, const TrlOps& ops, int neigen, int ncv,
+              double tol, int maxrestart, const double* v0, uint64_t seed_offset, double* evals, double* evecs,
+              int* nconv_out, int* nmatvec_out);
 
 // ---- thick-restart Lanczos multi-vector kernels (kernels_trl.hip) ----
 // h_dev (2 doubles per basis vector: re, im) = Q^H w, then w -= Q h; n counts complex or real elements

@@ -610,6 +610,35 @@ class LibraryComm:
             "edigpu_lanczos_tridiag_sharded")
         return a, b, nd.value, n2.value
 
+    def eigh_multi(self, h, neigen: int, nloc: int, v0_shard=None, ncv: int = 0, tol: float = 1e-12, maxrestart: int = 300,
+                   vectors: bool = True):
+        """sp_eigh(MpiComm, ...): lowest `neigen` eigenpairs with every vector a device-resident shard.
+        Returns (evals, evecs[neigen, nloc] or None, nconv, nmatvec); nloc = this rank's elements."""
+        import ctypes as C
+        import numpy as np
+        ev = np.zeros(neigen)
+        x = np.zeros((neigen, nloc), dtype=h.dtype) if vectors else None
+        v0 = None if v0_shard is None else np.ascontiguousarray(v0_shard, dtype=h.dtype)
+        nc, nm = C.c_int(0), C.c_int(0)
+        self._capi.check(self._capi.lib().edigpu_lanczos_eigh_multi_sharded(
+            h._h, self._c, neigen, ncv, tol, maxrestart, None if v0 is None or v0.size == 0 else v0.ctypes.data_as(C.c_void_p),
+            self._capi.pd(ev), None if x is None or x.size == 0 else x.ctypes.data_as(C.c_void_p), C.byref(nc), C.byref(nm)),
+            "edigpu_lanczos_eigh_multi_sharded")
+        return ev, x, nc.value, nm.value
+
+    def eigh(self, h, nloc: int, v0_shard=None, nitermax: int = 300, tol: float = 1e-12):
+        """sp_lanc_eigh(MpiComm, ...): (lowest eigenvalue, this rank's shard of its vector, products used)."""
+        import ctypes as C
+        import numpy as np
+        e = np.zeros(1)
+        x = np.zeros(nloc, dtype=h.dtype)
+        v0 = None if v0_shard is None else np.ascontiguousarray(v0_shard, dtype=h.dtype)
+        nm = C.c_int(0)
+        self._capi.check(self._capi.lib().edigpu_lanczos_eigh_sharded(
+            h._h, self._c, nitermax, tol, None if v0 is None or v0.size == 0 else v0.ctypes.data_as(C.c_void_p),
+            self._capi.pd(e), x.ctypes.data_as(C.c_void_p) if x.size else None, C.byref(nm)), "edigpu_lanczos_eigh_sharded")
+        return e[0], x, nm.value
+
     def bench(self, h, warmup: int, steps: int):
         """(ms per sharded Lanczos step, bytes this rank sends per product)."""
         import ctypes as C

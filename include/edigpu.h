@@ -512,6 +512,21 @@ int edigpu_apply_sharded_z(edigpu_handle h, edigpu_comm c, int64_t nloc, const d
  */
 int edigpu_lanczos_tridiag_sharded(edigpu_handle h, edigpu_comm c, const double *vin_shard, int nlanc, double *alanc,
                                    double *blanc, double threshold, int *niter_done, double *norm2);
+/*
+ * sp_eigh(MpiComm, spHtimesV_p, eval, evec, Nblock, Nitermax, tol) -- the default LANC_METHOD=arpack path under MPI -- and
+ * sp_lanc_eigh(MpiComm, spHtimesV_p, eval, evec, Nitermax) with every vector a device-resident shard (call sites
+ * ED_NORMAL/ED_DIAG_NORMAL.f90:179-214, ED_SUPERC/ED_DIAG_SUPERC.f90:161-196, ED_NONSU2/ED_DIAG_NONSU2.f90:179-214): the
+ * thick-restart solver of edigpu_lanczos_eigh_multi on this rank's shard, the product through the sharded exchange, the
+ * Gram-Schmidt coefficients (j numbers per step, the reduction SciFortran's MPI drivers do with MPI_AllReduce) and the
+ * norms through all-reduces.  v0_shard (host or device, NULL = seeded random) and evecs_shard (host or device, NULL
+ * allowed; neigen consecutive shards) hold this rank's nloc elements as scatter_vector_MPI / es_return_dvector leave
+ * them (ED_EIGENSPACE.f90:723-793).  Every rank receives the same eigenvalues.  Handles as for edigpu_apply_sharded_*.
+ */
+int edigpu_lanczos_eigh_multi_sharded(edigpu_handle h, edigpu_comm c, int neigen, int ncv, double tol, int maxrestart,
+                                      const double *v0_shard, double *evals, double *evecs_shard, int *nconv,
+                                      int *nmatvec);
+int edigpu_lanczos_eigh_sharded(edigpu_handle h, edigpu_comm c, int nitermax, double tol, const double *v0_shard,
+                                double *eval, double *evec_shard, int *nmatvec);
 /* bench.py --gpus N: `warmup` + `steps` sharded Lanczos steps on a seeded random vector; wall time per step between
  * two collectives that act as barriers, and the bytes this rank sends per product */
 int edigpu_lanczos_bench_sharded(edigpu_handle h, edigpu_comm c, int warmup, int steps, double *ms_per_step,

@@ -108,6 +108,73 @@ def test_library_shards_share_one_gpu(gpu, world, case):
     assert rel_err(got, ref) < 1e-12
 
 
+# ---------------------------------------------------------------------------------------------------------
+# eigenpairs with the vector sharded (sp_eigh / sp_lanc_eigh with MpiComm,
+# ED_NORMAL/ED_DIAG_NORMAL.f90:179-214)
+# ---------------------------------------------------------------------------------------------------------
+EIG_CASES = [CASES[0], CASES[1], CASES[2], CASES[3], CASES[4], CASES[5], CASES[6]]
+
+
+def _eig_rank_main(rank, world, name, case, q):
+    try:
+        import torch  # noqa: F401
+        from edipack_amd import capi
+        from edipack_amd.sharding import LibraryComm, library_sharded_sector
+        capi.init(0)
+        mode, bath, norb, nbath, sector, direct, exchange = case
+        ho, pm, v = _reference(mode, bath, norb, nbath, sector, cmplx=exchange == "cmplx", phonon=exchange == "phonon")
+        comm = LibraryComm(rank, world, shm_name=name, slot_bytes=1 << 22)
+        h, first, count = library_sharded_sector(pm, sector, comm, direct=direct, exchange=exchange,
+                                                 cmplx=exchange == "cmplx")
+        ix = _shard_index(ho, mode, first, count, exchange == "phonon")
+        ev, x, nconv, nmv = comm.eigh_multi(h, 3, len(ix), v0_shard=v[ix], tol=1e-11)
+        e1, x1, nm1 = comm.eigh(h, len(ix), v0_shard=v[ix], tol=1e-11)
+        h.destroy()
+        comm.destroy()
+        q.put((rank, ix, ev, x, nconv, nmv, e1, x1, None))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, 0, None, None, 0, 0, 0.0, None, traceback.format_exc() + str(e)))
+
+
+@pytest.mark.parametrize("case", EIG_CASES, ids=[f"{c[0]}-{c[1]}-{c[6]}{'-direct' if c[5] else ''}" for c in EIG_CASES])
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_library_eigenpairs_on_shards(gpu, world, case):
+    """Lowest eigenpairs by the thick-restart solver with every vector a shard: eigenvalues against dense
+    diagonalisation of the oracle's matrix (1e-10 relative), vectors by their residual on the assembled vector and
+    their mutual orthogonality; every rank must report the same numbers."""
+    mode, bath, norb, nbath, sector, direct, exchange = case
+    ho, _, v = _reference(mode, bath, norb, nbath, sector, cmplx=exchange == "cmplx", phonon=exchange == "phonon")
+    dense = ho.dense()
+    w_ref = np.linalg.eigvalsh(dense)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"edigpu_eig_{os.getpid()}_{world}_{abs(hash(case)) % 100000}"
+    procs = [ctx.Process(target=_eig_rank_main, args=(r, world, name, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[8] is None, r[8]
+    X = np.zeros((3, ho.dim), dtype=dense.dtype if np.iscomplexobj(v) else float)
+    x1 = np.zeros(ho.dim, dtype=X.dtype)
+    for rank, ix, ev, x, nconv, nmv, e1, xs, _ in res:
+        assert nconv == 3 and nmv > 0
+        assert np.allclose(ev, res[0][2], rtol=0, atol=0)                      # the same on every rank
+        assert abs(e1 - res[0][6]) == 0.0
+        X[:, ix] = x
+        x1[ix] = xs
+    ev, scale = res[0][2], max(1.0, np.abs(w_ref).max())
+    assert np.max(np.abs(ev - w_ref[:3])) < 1e-10 * scale
+    assert abs(res[0][6] - w_ref[0]) < 1e-10 * scale
+    for i in range(3):
+        assert np.linalg.norm(dense @ X[i] - ev[i] * X[i]) < 1e-8 * scale
+    assert np.linalg.norm(X.conj() @ X.T - np.eye(3)) < 1e-9
+    assert np.linalg.norm(dense @ x1 - res[0][6] * x1) < 1e-7 * scale and abs(np.linalg.norm(x1) - 1.0) < 1e-10
+
+
 @pytest.mark.parametrize("force", [True, False])
 def test_library_comm_rccl_world_of_one(gpu, monkeypatch, force):
     """The RCCL communicator itself (ncclCommInitRank with a unique id, world of one) and the sharded calls on it:
