@@ -2402,16 +2402,18 @@ int edigpu_lanczos_tridiag_dev(edigpu_handle s, const double* vin_dev, int nlanc
 
 // one term of apply_Cops / apply_op_C / apply_op_CDG on device vectors of two normal-mode sectors:
 // v_dst (=|+=) coef * c^(+)_{iorb,ispin} v_src
+// one operator of apply_Cops on normal-mode sectors: the destination's down rows [fd, fd + cd) (v_dst_dev holds those
+// rows), v_src_dev = the whole source vector
 static int apply_op_normal_term(edigpu_handle src, edigpu_handle dst, const double* v_src_dev, double* v_dst_dev,
                                 int iorb, int ispin, int create, double coef, int accumulate, hipStream_t st,
-                                const char* who) {
+                                const char* who, int64_t fd = 0, int64_t cd = -1) {
   const std::string w(who);
   if (src->kind != 0 || dst->kind != 0 || !src->from_model() || !dst->from_model() || src->nph > 0 || dst->nph > 0) {
     set_error(w + ": both handles must be normal-mode sectors built by edigpu_normal_build");
     return 1;
   }
   if (src->nloc != src->dim || dst->nloc != dst->dim) {
-    set_error(w + ": handles must hold whole sectors (single shard)");
+    set_error(w + ": handles must hold whole sectors");
     return 1;
   }
   const int ns = model_ns(src->model);
@@ -2424,6 +2426,11 @@ static int apply_op_normal_term(edigpu_handle src, edigpu_handle dst, const doub
   if (dst->sec_a != nup_s + (ispin == 0 ? d : 0) || dst->sec_b != ndw_s + (ispin == 1 ? d : 0) ||
       model_ns(dst->model) != ns) {
     set_error(w + ": destination sector is not (source sector +- one particle of that spin)");
+    return 1;
+  }
+  if (cd < 0) cd = dst->dim_dw - fd;
+  if (fd < 0 || fd + cd > dst->dim_dw) {
+    set_error(w + ": row window outside the destination sector");
     return 1;
   }
   EDIGPU_HIP(hipSetDevice(src->device));
@@ -2442,12 +2449,96 @@ static int apply_op_normal_term(edigpu_handle src, edigpu_handle dst, const doub
   }
   uint32_t* d_part = nullptr;
   if (dev_upload(&d_part, part.data(), part.size())) return 1;
-  const int rc = launch_apply_op_normal(dst->dim_up, dst->dim_dw, src->dim_up, ispin, d_part, v_src_dev, v_dst_dev, st,
-                                        coef, accumulate);
+  // up operator: the rows keep their down index (the source's rows fd .. are read); down operator: the partner table is
+  // indexed by the destination's down index
+  const int rc = ispin == 0 ? launch_apply_op_normal(dst->dim_up, cd, src->dim_up, 0, d_part, v_src_dev + fd * src->dim_up,
+                                                     v_dst_dev, st, coef, accumulate)
+                            : launch_apply_op_normal(dst->dim_up, cd, src->dim_up, 1, d_part + fd, v_src_dev, v_dst_dev, st,
+                                                     coef, accumulate);
   (void)hipStreamSynchronize(st);
   (void)hipFree(d_part);
   return rc;
 }
+
+// one operator of apply_Cops on superc / nonsu2 sectors (whole sectors or row shards of library-built ones): the
+// destination's rows [fd, fd + cd), v_src_dev = the whole source vector (complex)
+static int apply_op_flat_term(edigpu_handle src, edigpu_handle dst, const double* v_src_dev, double* v_dst_dev, int iorb,
+                              int ispin, int create, double cre, double cim, int accumulate, hipStream_t st, const char* who,
+                              int64_t fd = 0, int64_t cd = -1) {
+  const std::string w(who);
+  if ((src->kind != 1 && src->kind != 2) || (dst->kind != 1 && dst->kind != 2) || !src->built_by_library ||
+      !dst->built_by_library) {
+    set_error(w + ": both handles must be superc / nonsu2 sectors built by edigpu_flat_build or edigpu_direct_build");
+    return 1;
+  }
+  if (src->nph > 0 || dst->nph > 0) {
+    set_error(w + ": phonon sectors are not supported");
+    return 1;
+  }
+  const edigpu_model& m = src->model;
+  const int ns = model_ns(m);
+  if (iorb < 0 || iorb >= m.norb || ispin < 0 || ispin > 1 || dst->model.ed_mode != m.ed_mode ||
+      model_ns(dst->model) != ns) {
+    set_error(w + ": orbital / spin out of range or sectors of different models");
+    return 1;
+  }
+  // superc: sector = Sz = Nup - Ndw; nonsu2: sector = Ntot
+  const int d = create ? 1 : -1;
+  const int want = m.ed_mode == 1 ? src->sec_a + (ispin == 0 ? d : -d) : src->sec_a + d;
+  if (dst->sec_a != want) {
+    set_error(w + ": destination sector is not the one the operator leads to");
+    return 1;
+  }
+  EDIGPU_HIP(hipSetDevice(src->device));
+  HostDirect hs, hd;
+  std::string e = build_direct(src->model, src->sec_a, 0, -1, hs);
+  if (e.empty()) e = build_direct(dst->model, dst->sec_a, 0, -1, hd);
+  if (!e.empty()) {
+    set_error(e);
+    return 1;
+  }
+  if (cd < 0) cd = hd.dim - fd;
+  if (fd < 0 || fd + cd > hd.dim) {
+    set_error(w + ": row window outside the destination sector");
+    return 1;
+  }
+  int32_t *d_states = nullptr, *d_off = nullptr, *d_rk = nullptr;
+  int rc = dev_upload(&d_states, hd.states.data(), hd.states.size());
+  rc |= dev_upload(&d_off, hs.off_dw.data(), hs.off_dw.size());
+  rc |= dev_upload(&d_rk, hs.rk_up.data(), hs.rk_up.size());
+  if (!rc)
+    rc = launch_apply_op_flat(cd, ns, 1u << (iorb + ispin * ns), create, d_states + fd, d_off, d_rk, v_src_dev, v_dst_dev, st,
+                              cre, cim, accumulate);
+  (void)hipStreamSynchronize(st);
+  dev_free(d_states);
+  dev_free(d_off);
+  dev_free(d_rk);
+  return rc;
+}
+
+}  // extern "C"
+namespace edigpu {
+int apply_cops_rows(edigpu_sector* src, edigpu_sector* dst, const double* v_src_full, double* v_dst_rows, int64_t first,
+                    int64_t count, int nops, const double* coef2, const int32_t* create, const int32_t* iorb,
+                    const int32_t* ispin, hipStream_t st, const char* who) {
+  for (int s = 0; s < nops; s++) {
+    if (src->kind == 0) {
+      if (coef2[2 * s + 1] != 0.0) {
+        set_error(std::string(who) + ": complex coefficients belong to the _CMPLX_NORMAL build");
+        return 1;
+      }
+      if (apply_op_normal_term(src, dst, v_src_full, v_dst_rows, iorb[s], ispin[s], create[s] > 0, coef2[2 * s], s > 0, st, who,
+                               first, count))
+        return 1;
+    } else if (apply_op_flat_term(src, dst, v_src_full, v_dst_rows, iorb[s], ispin[s], create[s] > 0, coef2[2 * s],
+                                  coef2[2 * s + 1], s > 0, st, who, first, count)) {
+      return 1;
+    }
+  }
+  return 0;
+}
+}  // namespace edigpu
+extern "C" {
 
 int edigpu_apply_op_normal(edigpu_handle src, edigpu_handle dst, const double* v_src_dev, double* v_dst_dev,
                            int iorb, int ispin, int create, void* stream) {
@@ -2479,54 +2570,30 @@ int edigpu_apply_op_flat(edigpu_handle src, edigpu_handle dst, const double* v_s
     set_error("edigpu_apply_op_flat: NULL argument");
     return 1;
   }
-  if ((src->kind != 1 && src->kind != 2) || (dst->kind != 1 && dst->kind != 2) || !src->built_by_library ||
-      !dst->built_by_library) {
-    set_error("edigpu_apply_op_flat: both handles must be superc / nonsu2 sectors built by edigpu_flat_build or "
-              "edigpu_direct_build");
-    return 1;
-  }
   if (src->nloc != src->dim || dst->nloc != dst->dim) {
     set_error("edigpu_apply_op_flat: handles must hold whole sectors (single shard)");
     return 1;
   }
-  if (src->nph > 0 || dst->nph > 0) {
-    set_error("edigpu_apply_op_flat: phonon sectors are not supported");
+  return apply_op_flat_term(src, dst, v_src_dev, v_dst_dev, iorb, ispin, create, 1.0, 0.0, 0, (hipStream_t)stream,
+                            "edigpu_apply_op_flat");
+}
+
+int edigpu_apply_cops_flat(edigpu_handle src, edigpu_handle dst, const double* v_src_dev, double* v_dst_dev, int nops,
+                           const double* coef_re_im, const int32_t* create, const int32_t* iorb, const int32_t* ispin,
+                           void* stream) {
+  if (!src || !dst || !v_src_dev || !v_dst_dev || nops <= 0 || !coef_re_im || !create || !iorb || !ispin) {
+    set_error("edigpu_apply_cops_flat: bad argument");
     return 1;
   }
-  const edigpu_model& m = src->model;
-  const int ns = model_ns(m);
-  if (iorb < 0 || iorb >= m.norb || ispin < 0 || ispin > 1 || dst->model.ed_mode != m.ed_mode ||
-      model_ns(dst->model) != ns) {
-    set_error("edigpu_apply_op_flat: orbital / spin out of range or sectors of different models");
+  if (src->nloc != src->dim || dst->nloc != dst->dim) {
+    set_error("edigpu_apply_cops_flat: handles must hold whole sectors (single shard)");
     return 1;
   }
-  // superc: sector = Sz = Nup - Ndw; nonsu2: sector = Ntot
-  const int d = create ? 1 : -1;
-  const int want = m.ed_mode == 1 ? src->sec_a + (ispin == 0 ? d : -d) : src->sec_a + d;
-  if (dst->sec_a != want) {
-    set_error("edigpu_apply_op_flat: destination sector is not the one the operator leads to");
-    return 1;
-  }
-  EDIGPU_HIP(hipSetDevice(src->device));
-  HostDirect hs, hd;
-  std::string e = build_direct(src->model, src->sec_a, 0, -1, hs);
-  if (e.empty()) e = build_direct(dst->model, dst->sec_a, 0, -1, hd);
-  if (!e.empty()) {
-    set_error(e);
-    return 1;
-  }
-  int32_t *d_states = nullptr, *d_off = nullptr, *d_rk = nullptr;
-  int rc = dev_upload(&d_states, hd.states.data(), hd.states.size());
-  rc |= dev_upload(&d_off, hs.off_dw.data(), hs.off_dw.size());
-  rc |= dev_upload(&d_rk, hs.rk_up.data(), hs.rk_up.size());
-  if (!rc)
-    rc = launch_apply_op_flat(hd.dim, ns, 1u << (iorb + ispin * ns), create, d_states, d_off, d_rk, v_src_dev,
-                              v_dst_dev, (hipStream_t)stream);
-  (void)hipStreamSynchronize((hipStream_t)stream);
-  dev_free(d_states);
-  dev_free(d_off);
-  dev_free(d_rk);
-  return rc;
+  for (int s = 0; s < nops; s++)
+    if (apply_op_flat_term(src, dst, v_src_dev, v_dst_dev, iorb[s], ispin[s], create[s] > 0, coef_re_im[2 * s],
+                           coef_re_im[2 * s + 1], s > 0, (hipStream_t)stream, "edigpu_apply_cops_flat"))
+      return 1;
+  return 0;
 }
 
 int edigpu_lanczos_eigh(edigpu_handle s, int nitermax, double tol, int check_every,

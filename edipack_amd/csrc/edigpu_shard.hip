@@ -956,6 +956,46 @@ int edigpu_lanczos_eigh_sharded(edigpu_handle h, edigpu_comm c, int nitermax, do
   return edigpu_lanczos_eigh_multi_sharded(h, c, 1, ncv, tol, maxrestart, v0_shard, eval, evec_shard, &nconv, nmatvec);
 }
 
+int edigpu_apply_cops_sharded(edigpu_handle src, edigpu_handle dst, edigpu_comm c, const double* v_src_shard,
+                              double* v_dst_shard, int nops, const double* coef_re_im, const int32_t* create,
+                              const int32_t* iorb, const int32_t* ispin) {
+  if (!src || !dst || !c || nops <= 0 || !coef_re_im || !create || !iorb || !ispin) {
+    set_error("edigpu_apply_cops_sharded: bad argument");
+    return 1;
+  }
+  if (src->kind == 4 || dst->kind == 4 || src->nph > 0 || dst->nph > 0) {
+    set_error("edigpu_apply_cops_sharded: complex normal-mode and phonon sectors are not supported");
+    return 1;
+  }
+  ShardGeom gs, gd;
+  if (shard_geometry(src, c, gs) || shard_geometry(dst, c, gd)) return 1;
+  EDIGPU_HIP(hipSetDevice(src->device));
+  hipStream_t st = src->stream;
+  const size_t chunk = (size_t)std::max<int64_t>(gs.chunk * gs.w, 1), nsrc = (size_t)(gs.nloc * gs.w);
+  const size_t ndst = (size_t)(gd.nloc * gd.w);
+  if ((nsrc && !v_src_shard) || (ndst && !v_dst_shard)) {
+    set_error("edigpu_apply_cops_sharded: NULL vector");
+    return 1;
+  }
+  struct Bufs {
+    double *send = nullptr, *full = nullptr, *out = nullptr;
+    ~Bufs() { (void)hipFree(send); (void)hipFree(full); (void)hipFree(out); }
+  } b;
+  EDIGPU_HIP(hipMalloc((void**)&b.send, chunk * sizeof(double)));
+  EDIGPU_HIP(hipMalloc((void**)&b.full, chunk * (size_t)c->world * sizeof(double)));
+  EDIGPU_HIP(hipMalloc((void**)&b.out, std::max<size_t>(ndst, 1) * sizeof(double)));
+  EDIGPU_HIP(hipMemsetAsync(b.send, 0, chunk * sizeof(double), st));
+  if (nsrc) EDIGPU_HIP(hipMemcpyAsync(b.send, v_src_shard, nsrc * sizeof(double), hipMemcpyDefault, st));
+  // equal padded chunks in rank order = the whole source vector in the reference's layout (+ a tail nobody reads)
+  if (comm_all_gather(c, b.send, b.full, chunk, st)) return 1;
+  if (ndst && apply_cops_rows(src, dst, b.full, b.out, gd.first, gd.count, nops, coef_re_im, create, iorb, ispin, st,
+                              "edigpu_apply_cops_sharded"))
+    return 1;
+  if (ndst) EDIGPU_HIP(hipMemcpyAsync(v_dst_shard, b.out, ndst * sizeof(double), hipMemcpyDefault, st));
+  EDIGPU_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
 int edigpu_lanczos_bench_sharded(edigpu_handle s, edigpu_comm c, int warmup, int steps, double* ms_per_step,
                                  int64_t* exchange_bytes) {
   if (!s || !c || steps < 1 || warmup < 0 || !ms_per_step) {

@@ -156,7 +156,13 @@ int launch_phonon_rows(const edigpu_sector* s, int64_t dw_first, int64_t dw_coun
                        hipStream_t st);
 int launch_apply_op_flat(int64_t ndst, int ns, uint32_t bit, int create, const int32_t* dst_states,
                          const int32_t* src_offdw, const int32_t* src_rkup, const double* src, double* dst,
-                         hipStream_t st);
+                         hipStream_t st, double cre = 1.0, double cim = 0.0, int accumulate = 0);
+// apply_Cops on a window of destination units (edigpu_capi.hip): v_dst_rows = sum_s coef_s O_s v_src for the
+// destination's down rows (normal mode) / rows (superc, nonsu2) [first, first + count); v_src_full holds the WHOLE source
+// vector in the reference's layout; coef2 = (re, im) per operator (normal mode: real).  Returns after the stream finished.
+int apply_cops_rows(edigpu_sector* src, edigpu_sector* dst, const double* v_src_full, double* v_dst_rows, int64_t first,
+                    int64_t count, int nops, const double* coef2, const int32_t* create, const int32_t* iorb,
+                    const int32_t* ispin, hipStream_t st, const char* who);
 
 // ---- ed_total_ud = F sectors (kernels_orbs.hip) ----
 int launch_orbs(const edigpu_sector* s, const double* v, double* hv, hipStream_t st);

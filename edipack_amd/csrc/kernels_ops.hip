@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     apply_op_flat_kernel(int64_t ndst, int ns, uint32_t bit, int create, const int32_t* __restrict__ dst_states,
                          const int32_t* __restrict__ src_offdw, const int32_t* __restrict__ src_rkup,
-                         const double2* __restrict__ src, double2* __restrict__ dst) {
+                         const double2* __restrict__ src, double2* __restrict__ dst, double cre, double cim, int accumulate) {
   const uint32_t lomask = (1u << ns) - 1u;
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < ndst; j += (int64_t)gridDim.x * 256) {
     const uint32_t t = (uint32_t)dst_states[j];
@@ -51,18 +51,25 @@ __global__ void __launch_bounds__(256)
         x.y = -x.y;
       }
     }
-    dst[j] = x;
+    // apply_Cops: a complex coefficient per operator, the operators after the first add to the result
+    double2 y = make_double2(cre * x.x - cim * x.y, cre * x.y + cim * x.x);
+    if (accumulate) {
+      const double2 o = dst[j];
+      y.x += o.x;
+      y.y += o.y;
+    }
+    dst[j] = y;
   }
 }
 
 int launch_apply_op_flat(int64_t ndst, int ns, uint32_t bit, int create, const int32_t* dst_states,
                          const int32_t* src_offdw, const int32_t* src_rkup, const double* src, double* dst,
-                         hipStream_t st) {
+                         hipStream_t st, double cre, double cim, int accumulate) {
   if (ndst == 0) return 0;
   int64_t nb = (ndst + 255) / 256;
   if (nb > 256 * 16) nb = 256 * 16;
   hipLaunchKernelGGL(apply_op_flat_kernel, dim3((unsigned)nb), dim3(256), 0, st, ndst, ns, bit, create, dst_states,
-                     src_offdw, src_rkup, reinterpret_cast<const double2*>(src), reinterpret_cast<double2*>(dst));
+                     src_offdw, src_rkup, reinterpret_cast<const double2*>(src), reinterpret_cast<double2*>(dst), cre, cim, accumulate);
   EDIGPU_HIP(hipGetLastError());
   return 0;
 }

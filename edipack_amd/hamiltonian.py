@@ -376,6 +376,17 @@ class SectorHamiltonian:
         capi.check(capi.lib().edigpu_apply_cops_normal(self._h, dst._h, v_src_ptr, v_dst_ptr, n, a, o, io, sp,
                                                        stream if stream else None), "edigpu_apply_cops_normal")
 
+    def apply_cops_flat_to(self, dst: "SectorHamiltonian", v_src_ptr: int, v_dst_ptr: int, coefs, creates, iorbs, ispins,
+                           stream: int = 0) -> None:
+        """apply_Cops on device vectors of superc / nonsu2 sectors, complex coefficients."""
+        n = len(coefs)
+        a = (C.c_double * (2 * n))(*[x for c in coefs for x in (complex(c).real, complex(c).imag)])
+        o = (C.c_int32 * n)(*[1 if x else -1 for x in creates])
+        io = (C.c_int32 * n)(*[int(x) for x in iorbs])
+        sp = (C.c_int32 * n)(*[int(x) for x in ispins])
+        capi.check(capi.lib().edigpu_apply_cops_flat(self._h, dst._h, v_src_ptr, v_dst_ptr, n, a, o, io, sp,
+                                                     stream if stream else None), "edigpu_apply_cops_flat")
+
     # ---- transposed exchange (normal mode, N > 1; include/edigpu.h) ---------------------------
     def transpose_halo(self) -> int:
         h = C.c_int32(0)

@@ -639,6 +639,22 @@ class LibraryComm:
             self._capi.pd(e), x.ctypes.data_as(C.c_void_p) if x.size else None, C.byref(nm)), "edigpu_lanczos_eigh_sharded")
         return e[0], x, nm.value
 
+    def apply_cops(self, src, dst, v_src_shard, nloc_dst: int, ops):
+        """apply_Cops on shards: ops = [(coef, create, iorb, ispin)]; returns this rank's shard of the destination."""
+        import ctypes as C
+        import numpy as np
+        v = np.ascontiguousarray(v_src_shard, dtype=src.dtype)
+        out = np.zeros(nloc_dst, dtype=dst.dtype)
+        n = len(ops)
+        a = (C.c_double * (2 * n))(*[x for o in ops for x in (complex(o[0]).real, complex(o[0]).imag)])
+        cr = (C.c_int32 * n)(*[1 if o[1] else -1 for o in ops])
+        io = (C.c_int32 * n)(*[int(o[2]) for o in ops])
+        sp = (C.c_int32 * n)(*[int(o[3]) for o in ops])
+        self._capi.check(self._capi.lib().edigpu_apply_cops_sharded(
+            src._h, dst._h, self._c, v.ctypes.data_as(C.c_void_p) if v.size else None,
+            out.ctypes.data_as(C.c_void_p) if out.size else None, n, a, cr, io, sp), "edigpu_apply_cops_sharded")
+        return out
+
     def bench(self, h, warmup: int, steps: int):
         """(ms per sharded Lanczos step, bytes this rank sends per product)."""
         import ctypes as C

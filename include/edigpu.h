@@ -407,6 +407,12 @@ int edigpu_apply_cops_normal(edigpu_handle src, edigpu_handle dst, const double 
  * The sign counts every occupied level below the operator's level in the 2*Ns-bit state (up levels first). */
 int edigpu_apply_op_flat(edigpu_handle src, edigpu_handle dst, const double *v_src_dev, double *v_dst_dev,
                          int iorb, int ispin, int create, void *stream);
+/* apply_Cops for superc / nonsu2 sectors (ED_SECTOR.f90:654-839: the six two-operator combinations behind the NONSU2
+ * exciton order parameters, ED_NONSU2/ED_OBSERVABLES_NONSU2.f90:325-425, and the off-diagonal Green's-function seeds):
+ * v_dst = sum_s coef[s] * O_s v_src with COMPLEX coefficients coef_re_im[2 s], [2 s + 1] (e.g. c_a,up - i c_b,dw). */
+int edigpu_apply_cops_flat(edigpu_handle src, edigpu_handle dst, const double *v_src_dev, double *v_dst_dev, int nops,
+                           const double *coef_re_im, const int32_t *create, const int32_t *iorb, const int32_t *ispin,
+                           void *stream);
 /* edigpu_lanczos_tridiag with the seed in device memory (e.g. the output of edigpu_apply_op_normal; it must be
  * complete when the call is made) and norm2 = <vin|vin> returned as tridiag_Hv_sector_* does.
  * edigpu_lanczos_eigh likewise accepts device pointers for v0 and for the eigenvector. */
@@ -527,6 +533,18 @@ int edigpu_lanczos_eigh_multi_sharded(edigpu_handle h, edigpu_comm c, int neigen
                                       int *nmatvec);
 int edigpu_lanczos_eigh_sharded(edigpu_handle h, edigpu_comm c, int nitermax, double tol, const double *v0_shard,
                                 double *eval, double *evec_shard, int *nmatvec);
+/*
+ * apply_op_C / apply_op_CDG / apply_Cops on shards: the Green's-function seeds the reference builds on the master rank
+ * from the gathered eigenvector and scatters again (ED_NORMAL/ED_GF_NORMAL.f90:141-175, ED_AUX_FUNX.f90:598-692).  Here
+ * v_src_shard (host or device: this rank's shard of a vector of sector `src`) is all-gathered on the device and every
+ * rank computes ITS shard of the destination vector; v_dst_shard (host or device) receives the nloc elements of this
+ * rank's shard of sector `dst`.  Handles as for the other sharded calls (normal mode: whole sectors from
+ * edigpu_normal_build; superc / nonsu2: this rank's row shards); coefficients as in edigpu_apply_cops_flat (normal mode:
+ * imaginary parts must be zero).
+ */
+int edigpu_apply_cops_sharded(edigpu_handle src, edigpu_handle dst, edigpu_comm c, const double *v_src_shard,
+                              double *v_dst_shard, int nops, const double *coef_re_im, const int32_t *create,
+                              const int32_t *iorb, const int32_t *ispin);
 /* bench.py --gpus N: `warmup` + `steps` sharded Lanczos steps on a seeded random vector; wall time per step between
  * two collectives that act as barriers, and the bytes this rank sends per product */
 int edigpu_lanczos_bench_sharded(edigpu_handle h, edigpu_comm c, int warmup, int steps, double *ms_per_step,

@@ -175,6 +175,84 @@ def test_library_eigenpairs_on_shards(gpu, world, case):
     assert np.linalg.norm(dense @ x1 - res[0][6] * x1) < 1e-7 * scale and abs(np.linalg.norm(x1) - 1.0) < 1e-10
 
 
+# ---------------------------------------------------------------------------------------------------------
+# apply_Cops on shards: the Green's-function seeds (ED_NORMAL/ED_GF_NORMAL.f90:141-175) without gathering on a master
+# ---------------------------------------------------------------------------------------------------------
+COPS_CASES = [
+    # mode, bath, norb, nbath, source sector, destination sector, ops [(coef, create, iorb, ispin)]
+    ("normal", "normal", 2, 3, (4, 4), (3, 4), [(1.0, False, 0, 0), (0.7, False, 1, 0)]),     # c_up combination
+    ("normal", "normal", 2, 3, (4, 4), (4, 3), [(1.0, False, 1, 1)]),                         # c_dw: rows move
+    ("normal", "hybrid", 3, 3, (3, 2), (3, 3), [(1.0, True, 2, 1), (-0.4, True, 0, 1)]),      # c+_dw, ragged shards
+    ("normal", "hybrid", 3, 3, (3, 2), (4, 2), [(1.0, True, 1, 0)]),                          # c+_up
+    ("nonsu2", "hybrid", 2, 3, 5, 4, [(1.0, False, 0, 0), (-1.0j, False, 1, 1)]),             # c_1up - i c_2dw
+    ("nonsu2", "hybrid", 2, 3, 5, 6, [(0.5, True, 1, 1)]),
+    ("superc", "hybrid", 2, 3, 0, -1, [(1.0, False, 0, 0), (1.0, True, 1, 1)]),               # both lead to Sz - 1
+]
+
+
+def _cops_rank_main(rank, world, name, case, q):
+    try:
+        import torch  # noqa: F401
+        from edipack_amd import capi
+        from edipack_amd.sharding import LibraryComm, library_sharded_sector
+        capi.init(0)
+        mode, bath, norb, nbath, s1, s2, ops = case
+        ho, pm, v = _reference(mode, bath, norb, nbath, s1)
+        comm = LibraryComm(rank, world, shm_name=name, slot_bytes=1 << 22)
+        h1, f1, c1 = library_sharded_sector(pm, s1, comm)
+        h2, f2, c2 = library_sharded_sector(pm, s2, comm)
+        ul1 = ho.dimup if mode == "normal" else 1
+        ul2 = h2.dim_up if mode == "normal" else 1
+        out = comm.apply_cops(h1, h2, v[f1 * ul1:(f1 + c1) * ul1], c2 * ul2, ops)
+        h1.destroy(), h2.destroy()
+        comm.destroy()
+        q.put((rank, f2 * ul2, out, None))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, 0, None, traceback.format_exc() + str(e)))
+
+
+@pytest.mark.parametrize("case", COPS_CASES, ids=[f"{c[0]}-{c[4]}-{c[5]}" for c in COPS_CASES])
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_library_apply_cops_on_shards(gpu, world, case):
+    """Every rank's shard of sum_s coef_s O_s v against the same combination applied to the whole vector on one GPU
+    (edigpu_apply_cops_normal / edigpu_apply_cops_flat, which the golden observables pin on the reference's files)."""
+    import torch
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    mode, bath, norb, nbath, s1, s2, ops = case
+    ho, pm, v = _reference(mode, bath, norb, nbath, s1)
+    if mode == "normal":
+        g1, g2 = SectorHamiltonian.normal_from_model(pm, *s1), SectorHamiltonian.normal_from_model(pm, *s2)
+        src = torch.from_numpy(np.ascontiguousarray(v)).cuda()
+        dst = torch.zeros(g2.dim, dtype=torch.float64, device="cuda")
+        g1.apply_cops_to(g2, src.data_ptr(), dst.data_ptr(), [o[0] for o in ops], [o[1] for o in ops], [o[2] for o in ops],
+                         [o[3] for o in ops], torch.cuda.current_stream().cuda_stream)
+    else:
+        g1, g2 = SectorHamiltonian.flat_from_model(pm, s1), SectorHamiltonian.flat_from_model(pm, s2)
+        src = torch.from_numpy(np.ascontiguousarray(v, dtype=np.complex128)).cuda()
+        dst = torch.zeros(g2.dim, dtype=torch.complex128, device="cuda")
+        g1.apply_cops_flat_to(g2, src.data_ptr(), dst.data_ptr(), [o[0] for o in ops], [o[1] for o in ops],
+                              [o[2] for o in ops], [o[3] for o in ops], torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = dst.cpu().numpy()
+    assert np.linalg.norm(ref) > 0.0
+    g1.destroy(), g2.destroy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"edigpu_cops_{os.getpid()}_{world}_{abs(hash(str(case))) % 100000}"
+    procs = [ctx.Process(target=_cops_rank_main, args=(r, world, name, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    got = np.zeros_like(ref)
+    for rank, off, out, err in res:
+        assert err is None, err
+        got[off:off + len(out)] = out
+    assert rel_err(got, ref) < 1e-14
+
+
 @pytest.mark.parametrize("force", [True, False])
 def test_library_comm_rccl_world_of_one(gpu, monkeypatch, force):
     """The RCCL communicator itself (ncclCommInitRank with a unique id, world of one) and the sharded calls on it:

@@ -2150,6 +2150,27 @@ def test_golden_observables_from_gpu_eigenvectors(gpu, name):
             assert np.max(np.abs(phi.real - np.array(g["phisc"]))) < tol and np.max(np.abs(phi.imag)) < tol
         if "magX" in g:
             assert np.max(np.abs(ob.magx(om, states, cops, hsector) - np.array(g["magX"]))) < tol
+    if "exciton" in g and mode == "nonsu2":
+        # exct_S0 / Tx / Ty / Tz of the NONSU2 directories: the six two-operator combinations of apply_Cops
+        # (ED_OBSERVABLES_NONSU2.f90:325-425) through edigpu_apply_cops_flat on the GPU eigenvectors
+        ocache = {}
+
+        def hsector_f(sec):
+            if sec not in ocache:
+                ocache[sec] = O.HFlat(om, sec)
+                secof[id(ocache[sec])] = sec
+            return ocache[sec]
+
+        def cops_f(h1, h2, v, ops):
+            g1, g2 = ghandle(secof[id(h1)]), ghandle(secof[id(h2)])
+            src = torch.from_numpy(np.ascontiguousarray(v, dtype=np.complex128)).cuda()
+            dst = torch.zeros(g2.dim, dtype=torch.complex128, device="cuda")
+            g1.apply_cops_flat_to(g2, src.data_ptr(), dst.data_ptr(), [o[0] for o in ops], [o[1] for o in ops],
+                                  [o[2] for o in ops], [o[3] for o in ops], torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            return dst.cpu().numpy()
+
+        assert np.max(np.abs(ob.exciton_nonsu2(om, states, cops_f, hsector_f) - np.array(g["exciton"]))) < tol
     if "exciton" in g and mode == "normal":
         # exct_S0 / exct_Tz: edigpu_apply_cops_normal (c_1s + c_2s, both spin species) on the GPU eigenvectors
         ocache = {}
