@@ -351,6 +351,25 @@ module EDIGPU_SHIM
        real(c_double), intent(out) :: norm2
        integer(c_int) :: ierr
      end function edigpu_lanczos_tridiag_sharded
+     function edigpu_lanczos_eigh_multi_sharded(h, c, neigen, ncv, tol, maxrestart, v0, evals, evecs, nconv, nmatvec) &
+          bind(C, name="edigpu_lanczos_eigh_multi_sharded") result(ierr)
+       import :: c_ptr, c_int, c_double
+       type(c_ptr), value :: h, c, v0, evecs
+       integer(c_int), value :: neigen, ncv, maxrestart
+       real(c_double), value :: tol
+       real(c_double), intent(inout) :: evals(*)
+       integer(c_int), intent(out) :: nconv, nmatvec
+       integer(c_int) :: ierr
+     end function edigpu_lanczos_eigh_multi_sharded
+     function edigpu_apply_cops_sharded(src, dst, c, v_src, v_dst, nops, coef2, create, iorb, ispin) &
+          bind(C, name="edigpu_apply_cops_sharded") result(ierr)
+       import :: c_ptr, c_int, c_int32_t, c_double
+       type(c_ptr), value :: src, dst, c, v_src, v_dst
+       integer(c_int), value :: nops
+       real(c_double), intent(in) :: coef2(*)
+       integer(c_int32_t), intent(in) :: create(*), iorb(*), ispin(*)
+       integer(c_int) :: ierr
+     end function edigpu_apply_cops_sharded
      function edigpu_destroy(h) bind(C, name="edigpu_destroy") result(ierr)
        import :: c_ptr, c_int
        type(c_ptr), value :: h
@@ -379,6 +398,7 @@ module EDIGPU_SHIM
   ! N > 1: communicator + the MPI twins of the product and of the tridiagonalisation
   public :: gpu_comm_unique_id, gpu_comm_create, gpu_comm_create_shm, gpu_comm_destroy, gpu_shard_plan
   public :: spMatVec_mpi_gpu_d, spMatVec_mpi_gpu_c, gpu_lanc_tridiag_mpi_d, gpu_lanc_tridiag_mpi_c
+  public :: gpu_sp_eigh_mpi_d, gpu_sp_eigh_mpi_c, gpu_apply_op_mpi_d
 
 contains
 
@@ -721,11 +741,11 @@ contains
     tol_ = 1d-12; if (present(tol)) tol_ = max(tol, 1d-12)
     call gpu_check(edigpu_lanczos_eigh_multi(gpu_sector, int(size(eig_values), c_int), int(Nblock, c_int), tol_, &
          int(Nitermax, c_int), c_null_ptr, eig_values, c_loc(eig_basis), nconv, nmv), "gpu_sp_eigh_d")
-    if (nconv < size(eig_values)) then
+    if (nconv < size(eig_values) .and. tol_ < 1d-9) then   ! (a caller's looser tolerance is not tightened)
        call gpu_check(edigpu_lanczos_eigh_multi(gpu_sector, int(size(eig_values), c_int), int(Nblock, c_int), 1d-9, &
             int(Nitermax, c_int), c_null_ptr, eig_values, c_loc(eig_basis), nconv, nmv), "gpu_sp_eigh_d")
-       if (nconv < size(eig_values)) stop "gpu_sp_eigh_d: not all eigenpairs converged"
     end if
+    if (nconv < size(eig_values)) stop "gpu_sp_eigh_d: not all eigenpairs converged"
   end subroutine gpu_sp_eigh_d
 
   subroutine gpu_sp_eigh_c(eig_values, eig_basis, Nblock, Nitermax, tol)
@@ -742,11 +762,11 @@ contains
     tol_ = 1d-12; if (present(tol)) tol_ = max(tol, 1d-12)
     call gpu_check(edigpu_lanczos_eigh_multi(gpu_sector, int(size(eig_values), c_int), int(Nblock, c_int), tol_, &
          int(Nitermax, c_int), c_null_ptr, eig_values, c_loc(eig_basis), nconv, nmv), "gpu_sp_eigh_c")
-    if (nconv < size(eig_values)) then
+    if (nconv < size(eig_values) .and. tol_ < 1d-9) then   ! (a caller's looser tolerance is not tightened)
        call gpu_check(edigpu_lanczos_eigh_multi(gpu_sector, int(size(eig_values), c_int), int(Nblock, c_int), 1d-9, &
             int(Nitermax, c_int), c_null_ptr, eig_values, c_loc(eig_basis), nconv, nmv), "gpu_sp_eigh_c")
-       if (nconv < size(eig_values)) stop "gpu_sp_eigh_c: not all eigenpairs converged"
     end if
+    if (nconv < size(eig_values)) stop "gpu_sp_eigh_c: not all eigenpairs converged"
   end subroutine gpu_sp_eigh_c
 
   !> device vectors of n real(8) (ncomplex = 2 n for complex(8)) elements
@@ -926,6 +946,73 @@ contains
          alanc, blanc, lanc_threshold, niter, n2), "gpu_lanc_tridiag_mpi_c")
     if (present(norm2)) norm2 = n2
   end subroutine gpu_lanc_tridiag_mpi_c
+
+  !> call sp_eigh(MpiComm, spHtimesV_p, eig_values, eig_basis, Nblock, Nitermax, tol=lanc_tolerance) -- the spectrum
+  !! solve of a -D_MPI build (ED_NORMAL/ED_DIAG_NORMAL.f90:221-242): eig_basis(:, k) = this rank's shard of eigenvector
+  !! k, as PARPACK leaves it (and as es_return_dvector_mpi hands it on, ED_EIGENSPACE.f90:723-793).  Every vector of
+  !! the solve is a device-resident shard; only the Gram-Schmidt coefficients and norms cross ranks.
+  subroutine gpu_sp_eigh_mpi_d(eig_values, eig_basis, Nblock, Nitermax, tol)
+    real(8), intent(inout) :: eig_values(:)
+    real(8), intent(inout), target :: eig_basis(:,:)
+    integer, intent(in) :: Nblock, Nitermax
+    real(8), intent(in), optional :: tol
+    real(c_double) :: tol_
+    integer(c_int) :: nconv, nmv
+    type(c_ptr) :: pv
+    if (.not. c_associated(gpu_sector)) stop "gpu_sp_eigh_mpi_d: Hsector NOT allocated"
+    if (.not. c_associated(gpu_comm)) stop "gpu_sp_eigh_mpi_d: no communicator"
+    tol_ = 1d-12; if (present(tol)) tol_ = max(tol, 1d-12)
+    pv = c_null_ptr; if (size(eig_basis) > 0) pv = c_loc(eig_basis)
+    call gpu_check(edigpu_lanczos_eigh_multi_sharded(gpu_sector, gpu_comm, int(size(eig_values), c_int), int(Nblock, c_int), &
+         tol_, int(Nitermax, c_int), c_null_ptr, eig_values, pv, nconv, nmv), "gpu_sp_eigh_mpi_d")
+    if (nconv < size(eig_values) .and. tol_ < 1d-9) then
+       call gpu_check(edigpu_lanczos_eigh_multi_sharded(gpu_sector, gpu_comm, int(size(eig_values), c_int), &
+            int(Nblock, c_int), 1d-9, int(Nitermax, c_int), c_null_ptr, eig_values, pv, nconv, nmv), "gpu_sp_eigh_mpi_d")
+    end if
+    if (nconv < size(eig_values)) stop "gpu_sp_eigh_mpi_d: not all eigenpairs converged"
+  end subroutine gpu_sp_eigh_mpi_d
+
+  subroutine gpu_sp_eigh_mpi_c(eig_values, eig_basis, Nblock, Nitermax, tol)
+    real(8), intent(inout) :: eig_values(:)
+    complex(8), intent(inout), target :: eig_basis(:,:)
+    integer, intent(in) :: Nblock, Nitermax
+    real(8), intent(in), optional :: tol
+    real(c_double) :: tol_
+    integer(c_int) :: nconv, nmv
+    type(c_ptr) :: pv
+    if (.not. c_associated(gpu_sector)) stop "gpu_sp_eigh_mpi_c: Hsector NOT allocated"
+    if (.not. c_associated(gpu_comm)) stop "gpu_sp_eigh_mpi_c: no communicator"
+    tol_ = 1d-12; if (present(tol)) tol_ = max(tol, 1d-12)
+    pv = c_null_ptr; if (size(eig_basis) > 0) pv = c_loc(eig_basis)
+    call gpu_check(edigpu_lanczos_eigh_multi_sharded(gpu_sector, gpu_comm, int(size(eig_values), c_int), int(Nblock, c_int), &
+         tol_, int(Nitermax, c_int), c_null_ptr, eig_values, pv, nconv, nmv), "gpu_sp_eigh_mpi_c")
+    if (nconv < size(eig_values) .and. tol_ < 1d-9) then
+       call gpu_check(edigpu_lanczos_eigh_multi_sharded(gpu_sector, gpu_comm, int(size(eig_values), c_int), &
+            int(Nblock, c_int), 1d-9, int(Nitermax, c_int), c_null_ptr, eig_values, pv, nconv, nmv), "gpu_sp_eigh_mpi_c")
+    end if
+    if (nconv < size(eig_values)) stop "gpu_sp_eigh_mpi_c: not all eigenpairs converged"
+  end subroutine gpu_sp_eigh_mpi_c
+
+  !> vvloc = apply_op_C / apply_op_CDG(v_state, ...) followed by scatter_vector_MPI (ED_NORMAL/ED_GF_NORMAL.f90:141-175),
+  !! without the master rank: v_shard = this rank's shard of the eigenvector (sector hsrc), vv_shard = this rank's shard
+  !! of the seed (sector hdst).  iorb 1-based, ispin 1 = up / 2 = down as in the reference.
+  subroutine gpu_apply_op_mpi_d(hsrc, hdst, v_shard, vv_shard, iorb, ispin, create)
+    type(c_ptr), intent(in) :: hsrc, hdst
+    real(8), intent(in), target :: v_shard(:)
+    real(8), intent(inout), target :: vv_shard(:)
+    integer, intent(in) :: iorb, ispin
+    logical, intent(in) :: create
+    real(c_double) :: coef2(2)
+    integer(c_int32_t) :: cr(1), io(1), sp(1)
+    type(c_ptr) :: p1, p2
+    if (.not. c_associated(gpu_comm)) stop "gpu_apply_op_mpi_d: no communicator"
+    coef2 = [1d0, 0d0]
+    cr(1) = -1; if (create) cr(1) = 1
+    io(1) = int(iorb - 1, c_int32_t); sp(1) = int(ispin - 1, c_int32_t)
+    p1 = c_null_ptr; if (size(v_shard) > 0) p1 = c_loc(v_shard)
+    p2 = c_null_ptr; if (size(vv_shard) > 0) p2 = c_loc(vv_shard)
+    call gpu_check(edigpu_apply_cops_sharded(hsrc, hdst, gpu_comm, p1, p2, 1_c_int, coef2, cr, io, sp), "gpu_apply_op_mpi_d")
+  end subroutine gpu_apply_op_mpi_d
 
   !> delete_Hv_sector_* counterpart (ED_NORMAL/ED_HAMILTONIAN_NORMAL.f90:212-279)
   subroutine gpu_delete_sector()
