@@ -272,6 +272,7 @@ def run_multi(args):
     torch.cuda.synchronize()
     dist.barrier()
     wall = time.perf_counter() - t0
+    rccl_ranks, ms_exchange = comm.exchange_bench(h, max(5, min(args.steps, 50)))   # after the timed region
     t = torch.tensor([ms_step, wall], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     tb = torch.tensor([bytes_hv], dtype=torch.float64)
@@ -293,7 +294,10 @@ def run_multi(args):
                                        f"shard-local part of H*v"),
                        "transport": {"nccl": "rccl", "shm-fallback": "shared memory, host-staged (RCCL NOT AVAILABLE: "
                                      "not an xGMI measurement)"}.get(backend, "shared memory (one-GPU rehearsal)"),
-                       "exchange_bytes_per_rank_per_hv": int(sent)},
+                       "exchange_bytes_per_rank_per_hv": int(sent),
+                       # what RCCL itself reports (ncclCommCount; 0 = not an RCCL communicator) and what one step's
+                       # collectives cost with nothing else running (rank 0's figure)
+                       "rccl_ranks": int(rccl_ranks), "exchange_ms_per_step": ms_exchange},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK_GBS * world), "traffic": None,
                          "note": "whole-job: algorithmic bytes of one H*v / slowest rank's time per Lanczos step "

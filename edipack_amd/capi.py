@@ -143,6 +143,7 @@ SIGNATURES = {
     "edigpu_lanczos_eigh_multi_sharded": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_double, C.c_int, _vp, _pd, _vp, _pint,
                                                     _pint]),
     "edigpu_lanczos_eigh_sharded": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, _pd, _vp, _pint]),
+    "edigpu_exchange_bench": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(C.c_int32), _pd]),
     "edigpu_apply_cops_sharded": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _pd, _vp, _vp, _vp]),
     "edigpu_apply_cops_flat": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _pd, _vp, _vp, _vp, _vp]),
     "edigpu_lanczos_bench_sharded": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _pd, _pi64]),

@@ -58,6 +58,7 @@ struct RcclApi {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;  // optional
 };
 
 static RcclApi* rccl() {
@@ -90,6 +91,7 @@ static RcclApi* rccl() {
   EDIGPU_SYM(GroupEnd, "ncclGroupEnd")
   EDIGPU_SYM(GetErrorString, "ncclGetErrorString")
 #undef EDIGPU_SYM
+  *(void**)(&api.CommCount) = dlsym(api.lib, "ncclCommCount");
   return &api;
 }
 
@@ -113,6 +115,7 @@ struct ShmHeader {
   std::atomic<int> generation;  // barrier: bumped by the last arriver
   int world;
   int64_t slot_bytes;
+  int64_t created_s;            // CLOCK_REALTIME seconds when rank 0 made the segment (stale leftovers are refused)
 };
 
 struct edigpu_comm_s {
@@ -121,7 +124,8 @@ struct edigpu_comm_s {
   int device = 0;
   ncclComm_t nccl = nullptr;
   hipStream_t side = nullptr;  // exchange stream: the all-to-all / all-gather of a product runs beside its local part
-  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;   // overlapped exchange: compute stream -> side, side -> compute stream
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;       // bracket of every other collective (side_begin / side_end)
   // shm transport
   std::string shm_name;
   void* shm = nullptr;
@@ -176,13 +180,38 @@ static int shm_fits(edigpu_comm_s* c, size_t bytes) {
   return 0;
 }
 
+// Every collective of a communicator is enqueued on the communicator's OWN stream (c->side), whatever stream the caller
+// computes on: one communicator driven from two streams is legal only as long as every rank issues the same order, and
+// that is exactly what a single in-order stream guarantees (the first multi-GPU run should not be the one to find out).
+// side_begin: the collective waits for what `st` has enqueued so far; side_end: `st` waits for the collective.  A caller
+// that overlaps the exchange with its own kernels passes c->side itself and places the two events where it needs them.
+static int side_begin(edigpu_comm_s* c, hipStream_t st) {
+  if (st == c->side) return 0;
+  EDIGPU_HIP(hipEventRecord(c->ev_in, st));
+  EDIGPU_HIP(hipStreamWaitEvent(c->side, c->ev_in, 0));
+  return 0;
+}
+static int side_end(edigpu_comm_s* c, hipStream_t st) {
+  if (st == c->side) return 0;
+  EDIGPU_HIP(hipEventRecord(c->ev_out, c->side));
+  EDIGPU_HIP(hipStreamWaitEvent(st, c->ev_out, 0));
+  return 0;
+}
+
 // recv[s * n .. (s+1) * n) <- block `rank` of rank s's send buffer; n doubles per block (equal split)
-static int comm_all_to_all(edigpu_comm_s* c, const double* send, double* recv, size_t n, hipStream_t st) {
+static int comm_all_to_all(edigpu_comm_s* c, const double* send, double* recv, size_t n, hipStream_t caller) {
   const size_t bytes = n * sizeof(double);
   if (c->world == 1 && !force_collectives(c)) {
-    EDIGPU_HIP(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, st));
+    EDIGPU_HIP(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, caller));
     return 0;
   }
+  hipStream_t st = c->side;
+  if (side_begin(c, caller)) return 1;
+  struct End {
+    edigpu_comm_s* c;
+    hipStream_t s;
+    ~End() { (void)side_end(c, s); }
+  } end_{c, caller};
   if (c->kind == 0) {
     RcclApi* r = rccl();
     EDIGPU_RCCL(r->GroupStart());
@@ -206,12 +235,19 @@ static int comm_all_to_all(edigpu_comm_s* c, const double* send, double* recv, s
 }
 
 // recv[s * n .. (s+1) * n) <- send of rank s
-static int comm_all_gather(edigpu_comm_s* c, const double* send, double* recv, size_t n, hipStream_t st) {
+static int comm_all_gather(edigpu_comm_s* c, const double* send, double* recv, size_t n, hipStream_t caller) {
   const size_t bytes = n * sizeof(double);
   if (c->world == 1 && !force_collectives(c)) {
-    EDIGPU_HIP(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, st));
+    EDIGPU_HIP(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, caller));
     return 0;
   }
+  hipStream_t st = c->side;
+  if (side_begin(c, caller)) return 1;
+  struct End {
+    edigpu_comm_s* c;
+    hipStream_t s;
+    ~End() { (void)side_end(c, s); }
+  } end_{c, caller};
   if (c->kind == 0) {
     EDIGPU_RCCL(rccl()->AllGather(send, recv, n, RCCL_FLOAT64, c->nccl, st));
     return 0;
@@ -229,8 +265,15 @@ static int comm_all_gather(edigpu_comm_s* c, const double* send, double* recv, s
 }
 
 // buf[0..n) <- sum over the ranks (the same order on every rank: bit-identical results everywhere)
-static int comm_all_reduce(edigpu_comm_s* c, double* buf, size_t n, hipStream_t st) {
+static int comm_all_reduce(edigpu_comm_s* c, double* buf, size_t n, hipStream_t caller) {
   if (c->world == 1 && !force_collectives(c)) return 0;
+  hipStream_t st = c->side;
+  if (side_begin(c, caller)) return 1;
+  struct End {
+    edigpu_comm_s* c;
+    hipStream_t s;
+    ~End() { (void)side_end(c, s); }
+  } end_{c, caller};
   if (c->kind == 0) {
     EDIGPU_RCCL(rccl()->AllReduce(buf, buf, n, RCCL_FLOAT64, RCCL_SUM, c->nccl, st));
     return 0;
@@ -689,6 +732,8 @@ static int comm_common(edigpu_comm_s* c) {
   EDIGPU_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   EDIGPU_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
   EDIGPU_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  EDIGPU_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+  EDIGPU_HIP(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
   return 0;
 }
 
@@ -757,50 +802,73 @@ int edigpu_comm_create_shm(edigpu_comm* out, int32_t rank, int32_t world, const 
       close(fd);
       fd = -1;
     }
-  } else {
-    const auto t0 = std::chrono::steady_clock::now();
-    while (fd < 0 && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(60)) {
-      fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
-      struct stat sb;
-      if (fd >= 0 && (fstat(fd, &sb) != 0 || (size_t)sb.st_size < c->shm_bytes)) {
-        close(fd);
-        fd = -1;
+  }
+  const int64_t started_s = (int64_t)time(nullptr);
+  const auto t_open = std::chrono::steady_clock::now();
+  // Ranks > 0 may find a segment a crashed run left under the same name (right size, ready = 1) before rank 0 has
+  // replaced it.  A segment is taken only if rank 0 made it no more than two minutes before this call and the name
+  // still refers to it once it reads ready; otherwise it is dropped and the name is opened again.
+  for (;;) {
+    if (rank != 0) {
+      fd = -1;
+      while (fd < 0 && std::chrono::steady_clock::now() - t_open < std::chrono::seconds(60)) {
+        fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
+        struct stat sb;
+        if (fd >= 0 && (fstat(fd, &sb) != 0 || (size_t)sb.st_size < c->shm_bytes)) {
+          close(fd);
+          fd = -1;
+        }
+        if (fd < 0) std::this_thread::sleep_for(std::chrono::milliseconds(5));
       }
-      if (fd < 0) std::this_thread::sleep_for(std::chrono::milliseconds(5));
     }
-  }
-  if (fd < 0) {
-    set_error("edigpu_comm_create_shm: cannot open the shared-memory segment " + c->shm_name);
-    delete c;
-    return 1;
-  }
-  c->shm = mmap(nullptr, c->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (c->shm == MAP_FAILED) {
-    set_error("edigpu_comm_create_shm: mmap failed");
+    if (fd < 0) {
+      set_error("edigpu_comm_create_shm: cannot open the shared-memory segment " + c->shm_name);
+      delete c;
+      return 1;
+    }
+    struct stat mine;
+    const bool have_ino = fstat(fd, &mine) == 0;
+    c->shm = mmap(nullptr, c->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (c->shm == MAP_FAILED) {
+      set_error("edigpu_comm_create_shm: mmap failed");
+      c->shm = nullptr;
+      delete c;
+      return 1;
+    }
+    c->hdr = reinterpret_cast<ShmHeader*>(c->shm);
+    c->slots = reinterpret_cast<char*>(c->shm) + 4096;
+    if (rank == 0) {
+      c->hdr->arrived.store(0);
+      c->hdr->generation.store(0);
+      c->hdr->world = world;
+      c->hdr->slot_bytes = slot_bytes;
+      c->hdr->created_s = started_s;
+      c->hdr->ready.store(1, std::memory_order_release);
+      break;
+    }
+    bool ok = false, timeout = false;
+    while (!ok && !timeout) {
+      if (c->hdr->ready.load(std::memory_order_acquire) == 1) {
+        struct stat now;
+        const std::string path = "/dev/shm" + c->shm_name;
+        const bool same = !have_ino || (stat(path.c_str(), &now) == 0 && now.st_ino == mine.st_ino);
+        ok = same && c->hdr->created_s >= started_s - 120 && c->hdr->world == world && c->hdr->slot_bytes == slot_bytes;
+        if (!ok) break;  // a leftover: map the name again
+      } else {
+        std::this_thread::yield();
+      }
+      timeout = std::chrono::steady_clock::now() - t_open > std::chrono::seconds(60);
+    }
+    if (ok) break;
+    munmap(c->shm, c->shm_bytes);
     c->shm = nullptr;
-    delete c;
-    return 1;
-  }
-  c->hdr = reinterpret_cast<ShmHeader*>(c->shm);
-  c->slots = reinterpret_cast<char*>(c->shm) + 4096;
-  if (rank == 0) {
-    c->hdr->arrived.store(0);
-    c->hdr->generation.store(0);
-    c->hdr->world = world;
-    c->hdr->slot_bytes = slot_bytes;
-    c->hdr->ready.store(1, std::memory_order_release);
-  } else {
-    const auto t0 = std::chrono::steady_clock::now();
-    while (c->hdr->ready.load(std::memory_order_acquire) != 1) {
-      std::this_thread::yield();
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
-        set_error("edigpu_comm_create_shm: rank 0 never initialised the segment");
-        munmap(c->shm, c->shm_bytes);
-        delete c;
-        return 1;
-      }
+    if (timeout || std::chrono::steady_clock::now() - t_open > std::chrono::seconds(60)) {
+      set_error("edigpu_comm_create_shm: rank 0 never initialised the segment");
+      delete c;
+      return 1;
     }
+    std::this_thread::sleep_for(std::chrono::milliseconds(5));
   }
   if (comm_common(c) || shm_barrier(c)) {
     munmap(c->shm, c->shm_bytes);
@@ -831,6 +899,8 @@ int edigpu_comm_destroy(edigpu_comm c) {
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  if (c->ev_out) (void)hipEventDestroy(c->ev_out);
   if (c->shm) {
     munmap(c->shm, c->shm_bytes);
     if (c->rank == 0) shm_unlink(c->shm_name.c_str());
@@ -993,6 +1063,62 @@ int edigpu_apply_cops_sharded(edigpu_handle src, edigpu_handle dst, edigpu_comm 
     return 1;
   if (ndst) EDIGPU_HIP(hipMemcpyAsync(v_dst_shard, b.out, ndst * sizeof(double), hipMemcpyDefault, st));
   EDIGPU_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+// bench.py --gpus N: what the transport itself reports and costs.  *rccl_ranks = ncclCommCount of the communicator (0:
+// shared-memory transport, -1: RCCL without that symbol) -- the driver's scaling record can then show that RCCL saw N
+// ranks; *ms_exchange = average time of the collectives of ONE product + step (the two all-to-alls or the all-gather, and
+// the 3-double all-reduce) with nothing else running, HIP events on the communicator's stream.
+int edigpu_exchange_bench(edigpu_handle s, edigpu_comm c, int steps, int32_t* rccl_ranks, double* ms_exchange) {
+  if (!s || !c || steps < 1) {
+    set_error("edigpu_exchange_bench: bad argument");
+    return 1;
+  }
+  if (s->kind == 4 && s->sub_d) s = s->sub_d;
+  if (rccl_ranks) {
+    *rccl_ranks = 0;
+    if (c->kind == 0) {
+      int n = -1;
+      if (c->nccl && rccl() && rccl()->CommCount && rccl()->CommCount(c->nccl, &n) != ncclSuccess) n = -1;
+      *rccl_ranks = c->nccl ? n : 1;  // (a world of one makes no RCCL communicator)
+    }
+  }
+  if (!ms_exchange) return 0;
+  ShardGeom g;
+  if (shard_geometry(s, c, g)) return 1;
+  EDIGPU_HIP(hipSetDevice(s->device));
+  if (comm_workspace(c, g, 8)) return 1;
+  hipEvent_t e0, e1;
+  EDIGPU_HIP(hipEventCreate(&e0));
+  EDIGPU_HIP(hipEventCreate(&e1));
+  int rc = 0;
+  auto once = [&]() -> int {
+    for (int b = 0; b < g.nblk; b++) {
+      if (g.transposed) {
+        if (comm_all_to_all(c, c->send, c->recv, (size_t)(g.q * g.pw), c->side)) return 1;
+        if (comm_all_to_all(c, c->hvc, c->back, (size_t)(g.q * g.pw), c->side)) return 1;
+      } else {
+        const size_t n = g.nblk > 1 ? (size_t)g.q * g.unit_len * g.w : (size_t)g.chunk * g.w;
+        if (comm_all_gather(c, c->vin, c->vfull, n, c->side)) return 1;
+      }
+    }
+    return comm_all_reduce(c, c->scr, 3, c->side);
+  };
+  for (int k = 0; k < 2 && !rc; k++) rc |= once();
+  rc |= (hipEventRecord(e0, c->side) != hipSuccess);
+  for (int k = 0; k < steps && !rc; k++) rc |= once();
+  rc |= (hipEventRecord(e1, c->side) != hipSuccess);
+  rc |= (hipEventSynchronize(e1) != hipSuccess);
+  float ms = 0.f;
+  if (!rc) rc |= (hipEventElapsedTime(&ms, e0, e1) != hipSuccess);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc) {
+    set_error("edigpu_exchange_bench: failed");
+    return 1;
+  }
+  *ms_exchange = (double)ms / steps;
   return 0;
 }
 

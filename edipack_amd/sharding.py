@@ -663,6 +663,14 @@ class LibraryComm:
                                                                        C.byref(xb)), "edigpu_lanczos_bench_sharded")
         return ms.value, xb.value
 
+    def exchange_bench(self, h, steps: int = 20):
+        """(ranks RCCL reports for this communicator: 0 = shared-memory transport, ms of one product's collectives)."""
+        import ctypes as C
+        n, ms = C.c_int32(0), C.c_double(0.0)
+        self._capi.check(self._capi.lib().edigpu_exchange_bench(h._h, self._c, steps, C.byref(n), C.byref(ms)),
+                         "edigpu_exchange_bench")
+        return n.value, ms.value
+
     def destroy(self):
         if self._c:
             self._capi.lib().edigpu_comm_destroy(self._c)

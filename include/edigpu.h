@@ -550,6 +550,11 @@ int edigpu_apply_cops_sharded(edigpu_handle src, edigpu_handle dst, edigpu_comm 
 int edigpu_lanczos_bench_sharded(edigpu_handle h, edigpu_comm c, int warmup, int steps, double *ms_per_step,
                                  int64_t *exchange_bytes);
 
+/* bench.py --gpus N: *rccl_ranks = ncclCommCount of the communicator (0: shared-memory transport, -1: not available),
+ * *ms_exchange = average duration of the collectives of one product + step alone (the two all-to-alls or the all-gather,
+ * and the 3-double all-reduce), HIP events on the communicator's stream; either pointer may be NULL. */
+int edigpu_exchange_bench(edigpu_handle h, edigpu_comm c, int steps, int32_t *rccl_ranks, double *ms_exchange);
+
 /* ----------------------------------------------------------------------- */
 /* Per-solve cache of sector handles                     */
 /* ----------------------------------------------------------------------- */

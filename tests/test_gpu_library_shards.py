@@ -281,6 +281,33 @@ def test_library_comm_rccl_world_of_one(gpu, monkeypatch, force):
     comm.destroy()
 
 
+def test_one_communicator_serves_sectors_of_changing_geometry(gpu, monkeypatch):
+    """A communicator is shared across sectors: all-gather shards (superc / nonsu2, explicit arrays) and transposed
+    whole sectors of different sizes in turn.  Its workspace buffers grow one by one (the gathered-vector buffer used to
+    keep the size of the first all-gather call when a larger transposed call came in between: a device heap overflow
+    on the third call).  RCCL world of one with the collectives forced, so that every buffer is really written."""
+    import torch  # noqa: F401
+    monkeypatch.setenv("EDIGPU_FORCE_COLLECTIVES", "1")
+    from edipack_amd.sharding import LibraryComm, library_sharded_sector
+    comm = LibraryComm(0, 1, unique_id=LibraryComm.unique_id())
+    seq = [("superc", "hybrid", 2, 2, 0, False, "auto"),        # all-gather, small
+           ("normal", "normal", 2, 3, (4, 4), False, "auto"),   # transposed, larger chunk
+           ("nonsu2", "hybrid", 2, 3, 5, False, "auto"),        # all-gather again, larger than the first
+           ("normal", "hybrid", 3, 3, (3, 2), False, "allgather"),
+           ("superc", "hybrid", 2, 3, 0, False, "auto"),
+           ("normal", "normal", 2, 3, (4, 4), False, "allgather")]
+    for mode, bath, norb, nbath, sector, direct, exchange in seq:
+        ho, pm, v = _reference(mode, bath, norb, nbath, sector)
+        h, first, count = library_sharded_sector(pm, sector, comm, direct=direct, exchange=exchange)
+        assert rel_err(comm.apply(h, v), ho.matvec(v)) < 1e-12
+        a, b, nd, _ = comm.tridiag(h, v, 12)
+        a_ref, b_ref, _ = ho.lanc_tridiag(v, 12)
+        assert nd == 12 and rel_err(a, a_ref) < 1e-10 and rel_err(b, b_ref) < 1e-10
+        assert comm.exchange_bench(h, 3)[0] in (-1, 1)          # RCCL (world of one: no communicator object, reported as 1)
+        h.destroy()
+    comm.destroy()
+
+
 def test_library_shard_error_paths(gpu):
     import torch  # noqa: F401
     from edipack_amd import capi
