@@ -2863,6 +2863,9 @@ int trl_solve(int device, hipStream_t st, int cplx, int64_t n, int64_t len, int6
   // earlier 1 % criterion, x1000 per restart: Ritz values below the spectrum after five restarts on a 36-dimensional
   // sector), so it is not the default.
   static const bool twopass = getenv("EDIGPU_TRL_ONEPASS") == nullptr;
+  // EDIGPU_TRL_FULL=1: full CGS2 on every step (the round-2 solver)
+  static const bool selective = getenv("EDIGPU_TRL_FULL") == nullptr && getenv("EDIGPU_TRL_ONEPASS") == nullptr;
+  constexpr double kSelThr = 1e-14;
   // coefficients below thr_skip * |w_new| are left in w: three orders below the requested residual
   const double thr_skip = getenv("EDIGPU_TRL_THR") ? atof(getenv("EDIGPU_TRL_THR")) : 1e-3 * tol;
   int* d_skip = nullptr;
@@ -2886,7 +2889,22 @@ int trl_solve(int device, hipStream_t st, int cplx, int64_t n, int64_t len, int6
       // orthogonality ~10 eps otherwise); decided on the device, c2 stays zero when skipped
       // coefficients below 1e-11 |w_new| (pure rounding: the three-term recurrence makes them zero) are not
       // subtracted, their basis vectors not read (trl_decide_kernel)
-      if (twopass || multi) {
+      if (selective && j > k) {
+        // Selective re-orthogonalisation (every step but the first after a restart).  Pass A: classical Gram-Schmidt
+        // against the two vectors the three-term recurrence couples to, q_(j-1) and q_j -- the only directions in
+        // which a large component is removed and cancellation can leave an error.  Pass B: the dots against the WHOLE
+        // basis (for those two the second of "twice is enough", for all others a first pass on components that are
+        // small next to |w|: one pass is accurate), and only the coefficients above kSelThr |w| are subtracted: what
+        // is skipped leaves an orthogonality error of that size (1e-14), the basis vectors of zero coefficients are
+        // not read.  ~j + 13 vector passes per step instead of the 4 (j + 1) of the full CGS2 it replaces.
+        const int nl = std::min(2, j + 1), l0 = j + 1 - nl;
+        if (trl_dots(cplx, n, nl, q(l0), len, w, c1 + 2 * l0, b.part, st) || reduce(c1 + 2 * l0, 2 * (size_t)nl) ||
+            trl_subtract(cplx, n, nl, q(l0), len, c1 + 2 * l0, w, st))
+          return 1;
+        if (trl_dots(cplx, n, j + 2, b.Q, len, w, c2, b.part, st) || reduce(c2, 2 * (size_t)(j + 2)) ||
+            trl_filter(c2, j + 1, kSelThr * kSelThr, st) || trl_subtract(cplx, n, j + 1, b.Q, len, c2, w, st))
+          return 1;
+      } else if (twopass || multi) {
         // (shards: the coefficients Q^H w are summed over the ranks between the dots and the subtraction -- one
         // all-reduce of j + 1 numbers per pass, the k-element reduce of SciFortran's MPI Lanczos)
         if (trl_dots(cplx, n, j + 1, b.Q, len, w, c1, b.part, st) || reduce(c1, 2 * (size_t)(j + 1)) ||

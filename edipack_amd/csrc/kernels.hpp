@@ -137,6 +137,8 @@ int trl_subtract(int cplx, int64_t n, int nvec, const double* Q, int64_t ldq, co
 // pass); hf_dev <- the coefficients with those below thr * |w_new| set to exactly zero (all kept when skip = 0)
 int trl_decide(const double* h_dev, int nvec, double eta2, double thr2, double* hf_dev, int* skip, hipStream_t st);
 int trl_norm2(int cplx, int64_t n, const double* w, double* h_dev, double* partial, hipStream_t st);
+// coefficients (nvec pairs + <w|w>) below sqrt(thr2) * |w| -> exact zeros, in place
+int trl_filter(double* h_dev, int nvec, double thr2, hipStream_t st);
 int trl_partial_doubles(void);
 int trl_rotate_basis(int64_t len, int m, int k, const double* Q, int64_t ldq, const double* Y_dev, int ldy,
                      double* out, int64_t ldo, hipStream_t st);

@@ -232,6 +232,25 @@ __global__ void trl_decide_kernel(const double* __restrict__ h, int nvec, double
   }
 }
 
+// Selective second pass: h = nvec coefficient pairs followed by <w|w> (w counted as one more column of the sweep).
+// Coefficients below thr * |w| are set to exactly zero IN PLACE (the subtraction kernel then does not read those
+// basis vectors; when all of a group are zero it does not touch w either); the <w|w> slot is cleared.
+__global__ void trl_filter_kernel(double* __restrict__ h, int nvec, double thr2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double cut = thr2 * h[2 * nvec];
+  for (int c = 0; c < nvec; c++) {
+    const double a = h[2 * c], b = h[2 * c + 1];
+    if (!(a * a + b * b > cut)) h[2 * c] = h[2 * c + 1] = 0.0;
+  }
+  h[2 * nvec] = h[2 * nvec + 1] = 0.0;
+}
+
+int trl_filter(double* h_dev, int nvec, double thr2, hipStream_t st) {
+  hipLaunchKernelGGL(trl_filter_kernel, dim3(1), dim3(64), 0, st, h_dev, nvec, thr2);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 // h_dev[2c..2c+1] = <Q_c|w> for c < ndot (Q_c = Q + c*ldq; the caller may count w itself as the last column)
 int trl_dots(int cplx, int64_t n, int ndot, const double* Q, int64_t ldq, const double* w, double* h_dev,
              double* partial, hipStream_t st, const int* skip) {
