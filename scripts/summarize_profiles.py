@@ -14,7 +14,7 @@ def main():
     lines = []
     for f in glob.glob(os.path.join(out, "stats", "*", "*_kernel_stats.csv")):
         rows = list(csv.DictReader(open(f)))
-        lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --steps 50 --warmup 5 --no-cpu")
+        lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --steps 50 --warmup 5 --no-cpu --no-resident")
         lines.append(f"{'kernel':100s} {'calls':>6s} {'avg_us':>10s} {'total_ms':>10s} {'pct':>6s}")
         for r in rows[:14]:
             lines.append(f"{r['Name'][:100]:100s} {r['Calls']:>6s} {float(r['AverageNs']) / 1e3:10.2f} "
@@ -23,7 +23,7 @@ def main():
     for f in glob.glob(os.path.join(out, "pmc_*", "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
-            key = ("tile" if "dw_tile" in kn else "panel2" if "panel2" in kn else "panel" if "panel" in kn else "rows" if "normal_rows" in kn else
+            key = ("ib_rows" if "ib_rows" in kn else "ib_cols" if "ib_cols" in kn else "tile" if "dw_tile" in kn else "panel2" if "panel2" in kn else "panel" if "panel" in kn else "rows" if "normal_rows" in kn else
                    "csr" if ("csr_rows" in kn or "sell_rows" in kn) else "direct" if "direct_rows" in kn else None)
             if key:
                 agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -32,7 +32,7 @@ def main():
     lines.append(f"# rocprofv3 --pmc <one group per pass> -- python3 scripts/probe_hv.py --workload {wl} (mean per launch)")
     for k, d in pmc.items():
         for c, v in sorted(d.items()):
-            lines.append(f"{k:6s} {c:24s} {v:.6g}")
+            lines.append(f"{k:8s} {c:24s} {v:.6g}")
     # HBM-side traffic per H*v = sum over the H*v kernels of (2 * FETCH_SIZE + WRITE_SIZE) KiB.
     # gfx950: FETCH_SIZE counts 64 bytes per 128-byte fabric read request (= TCC_EA0_RDREQ * 64), i.e. exactly HALF of
     # the bytes read, for every access shape of these kernels -- contiguous or 512 / 1024-byte row segments, 8 or 16
