@@ -10,7 +10,7 @@ for wl in $WLS; do
 import json, sys
 d = json.load(open(sys.argv[2]))
 r = d["roofline"]
-print(sys.argv[1], round(d["value"], 1), "it/s  hv_ms", round(r["ms_per_launch"], 4), "frac", round(r["frac"], 3), "traffic_frac", r.get("traffic_frac"),
+print(sys.argv[1], round(d["value"], 1), "it/s  hv_ms", round(r["ms_per_launch"], 4), "frac", r["frac"], "traffic_frac", r.get("traffic_frac"),
       "cpu", d.get("cpu_baseline", {}).get("value"), "resident", (d["config"].get("hbm_resident") or {}).get("frac"))
 PY
 done
