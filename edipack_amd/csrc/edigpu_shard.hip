@@ -185,6 +185,11 @@ static int shm_fits(edigpu_comm_s* c, size_t bytes) {
 // that is exactly what a single in-order stream guarantees (the first multi-GPU run should not be the one to find out).
 // side_begin: the collective waits for what `st` has enqueued so far; side_end: `st` waits for the collective.  A caller
 // that overlaps the exchange with its own kernels passes c->side itself and places the two events where it needs them.
+// EDIGPU_COMM_TWO_STREAMS=1 (measurement only): collectives on the caller's stream, as before round 3
+static bool comm_two_streams() {
+  static const bool f = getenv("EDIGPU_COMM_TWO_STREAMS") != nullptr;
+  return f;
+}
 static int side_begin(edigpu_comm_s* c, hipStream_t st) {
   if (st == c->side) return 0;
   EDIGPU_HIP(hipEventRecord(c->ev_in, st));
@@ -205,13 +210,13 @@ static int comm_all_to_all(edigpu_comm_s* c, const double* send, double* recv, s
     EDIGPU_HIP(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, caller));
     return 0;
   }
-  hipStream_t st = c->side;
-  if (side_begin(c, caller)) return 1;
+  hipStream_t st = comm_two_streams() ? caller : c->side;
+  if (side_begin(c, st == c->side ? caller : st)) return 1;
   struct End {
     edigpu_comm_s* c;
     hipStream_t s;
     ~End() { (void)side_end(c, s); }
-  } end_{c, caller};
+  } end_{c, st == c->side ? caller : st};
   if (c->kind == 0) {
     RcclApi* r = rccl();
     EDIGPU_RCCL(r->GroupStart());
@@ -241,13 +246,13 @@ static int comm_all_gather(edigpu_comm_s* c, const double* send, double* recv, s
     EDIGPU_HIP(hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, caller));
     return 0;
   }
-  hipStream_t st = c->side;
-  if (side_begin(c, caller)) return 1;
+  hipStream_t st = comm_two_streams() ? caller : c->side;
+  if (side_begin(c, st == c->side ? caller : st)) return 1;
   struct End {
     edigpu_comm_s* c;
     hipStream_t s;
     ~End() { (void)side_end(c, s); }
-  } end_{c, caller};
+  } end_{c, st == c->side ? caller : st};
   if (c->kind == 0) {
     EDIGPU_RCCL(rccl()->AllGather(send, recv, n, RCCL_FLOAT64, c->nccl, st));
     return 0;
@@ -267,13 +272,13 @@ static int comm_all_gather(edigpu_comm_s* c, const double* send, double* recv, s
 // buf[0..n) <- sum over the ranks (the same order on every rank: bit-identical results everywhere)
 static int comm_all_reduce(edigpu_comm_s* c, double* buf, size_t n, hipStream_t caller) {
   if (c->world == 1 && !force_collectives(c)) return 0;
-  hipStream_t st = c->side;
-  if (side_begin(c, caller)) return 1;
+  hipStream_t st = comm_two_streams() ? caller : c->side;
+  if (side_begin(c, st == c->side ? caller : st)) return 1;
   struct End {
     edigpu_comm_s* c;
     hipStream_t s;
     ~End() { (void)side_end(c, s); }
-  } end_{c, caller};
+  } end_{c, st == c->side ? caller : st};
   if (c->kind == 0) {
     EDIGPU_RCCL(rccl()->AllReduce(buf, buf, n, RCCL_FLOAT64, RCCL_SUM, c->nccl, st));
     return 0;
