@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(NT, (NT == 768 ? 3 : (NT == 512 && NBT >= 12) 
   auto base_of = [&](int64_t r) -> int64_t { return (int64_t)(tid >> 3) * ps + r * 16 + ((tid & 7) << 1); };
   // The next row is requested when the blocks are done (its pieces land while the results are written back and leave):
   // requested before the block updates, the pieces in flight cost 28 registers the updates need.  EARLY where they fit.
-  constexpr bool EARLY = !FUSE && NBT * MAXM <= 12;
+  constexpr bool EARLY = !FUSE && NBT * MAXM <= 18;
   double2 pre[NLD];                    // the next row on its way in (FUSE: Q)
   double2 pin[FUSE ? NLD : 1];
   auto issue = [&](int64_t r) {
