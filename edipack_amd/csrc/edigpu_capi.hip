@@ -430,6 +430,14 @@ static int setup_ib(edigpu_sector* s, const HostNormal& hn, int chunk_rows) {
   d->nchunks = (int)h.chunk_row.size() - 1;
   d->max_chunk_rows = h.max_chunk_rows;
   d->max_chunk_blocks = mcb;
+  {
+    // workgroups per chunk of the columns kernel (EDIGPU_IB_NSUB, default 1).  Two per chunk make one panel's tasks cover
+    // the 64 workgroup slots of an XCD, so that a single panel is in flight per L2 -- measured SLOWER (Ns = 16: 2.79
+    // against 2.42 ms per product, Ns = 15: 0.69 against 0.64): staging the chunk twice costs more than the gathers that
+    // then hit the L2 save.
+    const char* e = getenv("EDIGPU_IB_NSUB");
+    d->nsub = e ? std::max(1, std::min(8, atoi(e))) : 1;
+  }
   d->nterms = h.nterms;
   d->dim_up = hn.dim_up;
   d->dim_dw = hn.dim_dw;

@@ -85,7 +85,7 @@ struct DevEll {
 struct IbDev {
   int norb = 0, nb_up = 0, nb_dw = 0, npanels = 0, plen = 0, nlist = 0;
   int ucls[5] = {0, 0, 0, 0, 0};
-  int lowbits = 0, nchunks = 0, max_chunk_rows = 0, max_chunk_blocks = 0, nterms = 0;
+  int lowbits = 0, nchunks = 0, max_chunk_rows = 0, max_chunk_blocks = 0, nterms = 0, nsub = 1;
   int64_t dim_up = 0, dim_dw = 0, ps = 0, len = 0;
   int rows_nt = 0, rows_nbt = 0;      // rows kernel: threads per workgroup, blocks per thread
   size_t rows_lds = 0, cols_lds = 0;  // dynamic LDS of the two kernels

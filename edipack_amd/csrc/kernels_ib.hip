@@ -34,6 +34,7 @@ struct IbArgs {
   int nb_up, nb_dw, npanels, plen, nlist;
   int ucls[5];
   int lowbits, nchunks, max_chunk_rows, max_chunk_blocks, nterms;
+  int nsub;  // workgroups that share a chunk of the columns kernel (each takes a part of its blocks)
   int64_t dim_dw, ps;
   const uint16_t *urank, *ublist;
   const uint32_t* rmap2;
@@ -279,13 +280,18 @@ __global__ void __launch_bounds__(kColsNT, 4) ib_cols_kernel(IbArgs a, const dou
   if (DO_ND)
     for (int i = tid; i < a.nterms * (NORB + 1) * 4; i += kColsNT) nddw[i] = a.nd_dw[i];
   const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  const int nch = a.nchunks;
+  const int nch = a.nchunks, nsub = a.nsub, tpp = nch * nsub;  // tasks per panel
   const int panels_x = (a.npanels - x + 7) >> 3;
   const int col = (lane & 7) << 1;
   int cur_panel = -1;
-  for (int tt = slot; tt < panels_x * nch; tt += nslots) {
-    const int pi = tt / nch, panel = pi * 8 + x;
-    const int c = (tt - pi * nch + pi) % nch;  // rotated: a slot meets chunks of every size
+  // A panel's tasks are consecutive: the slots of an XCD sweep one or two panels at a time, whose V segments (1.6 MB per
+  // panel at Ns = 16) the chunks gather their partners from.  With two panels in flight the L2 is over-subscribed
+  // (measured: 4.4 GB fetched per product for 2.7 GB of V + result); nsub > 1 workgroups per chunk (each stages the
+  // chunk and takes a part of its blocks) keep a single panel in flight, and measured slower (edigpu_capi.hip).
+  for (int tt = slot; tt < panels_x * tpp; tt += nslots) {
+    const int pi = tt / tpp, panel = pi * 8 + x;
+    const int tc = tt - pi * tpp, sub = tc % nsub;
+    const int c = (tc / nsub + pi) % nch;  // rotated: a slot meets chunks of every size
     const int row0 = a.chunk_row[c], nrows = a.chunk_row[c + 1] - row0;
     const int blk0 = a.chunk_blk[c], nblk = a.chunk_blk[c + 1] - blk0;
     const double* __restrict__ vp = v + (int64_t)panel * a.ps;
@@ -323,7 +329,8 @@ __global__ void __launch_bounds__(kColsNT, 4) ib_cols_kernel(IbArgs a, const dou
 #pragma unroll
     for (int n = 1; n <= NORB; n++) cb[n] = cl[n];
     __syncthreads();
-    for (int q0 = wave * 8; q0 < nblk; q0 += kColsNT / 8) {  // uniform per wave (classes are padded to 8 blocks)
+    const int ng = nblk >> 3, gb = (int)((int64_t)sub * ng / nsub), ge = (int)((int64_t)(sub + 1) * ng / nsub);
+    for (int q0 = (gb + wave) * 8; q0 < ge * 8; q0 += kColsNT / 8) {  // uniform per wave (classes are padded to 8 blocks)
       int n = 0;
 #pragma unroll
       for (int k = 1; k <= NORB; k++) n += q0 >= cb[k] ? 1 : 0;
@@ -459,6 +466,7 @@ static void fill_ib_args(const IbDev* d, IbArgs& a) {
   a.max_chunk_rows = d->max_chunk_rows;
   a.max_chunk_blocks = d->max_chunk_blocks;
   a.nterms = d->nterms;
+  a.nsub = d->nsub;
   a.dim_dw = d->dim_dw;
   a.ps = d->ps;
   a.urank = d->urank;
@@ -595,7 +603,7 @@ static int launch_cols_t(const IbDev* d, const IbArgs& a, const double* v, doubl
     return 1;
   }
   int64_t grid = (int64_t)per_cu * device_cu_count();
-  const int64_t tasks = (int64_t)d->npanels * d->nchunks;
+  const int64_t tasks = (int64_t)d->npanels * d->nchunks * d->nsub;
   grid = std::min<int64_t>(grid, (tasks + 7) / 8 * 8);
   grid = std::max<int64_t>(8, grid / 8 * 8);
   if (ALPHA && 3 * grid > kMaxPartials) {
