@@ -285,26 +285,35 @@ IB_HD void cols_block(const double* chunk, int chunk_row0, uint32_t b, int own_r
     sfor<0, M>([&](auto J) { x[decltype(J)::value] = lds_pair(own_row - chunk_row0 + decltype(J)::value); });
     couple_imp<NORB, N, Pair>(timp, x, acc, FmaP{});
   }
-  auto low_levels = [&](int k0, int k1) {
-    for (int k = k0; k < k1; k++) {
-      const int r2 = (int)meta[k] - chunk_row0, n2 = nrows(k);
-      Pair xp[MPX > 0 ? MPX : 1];
-      sfor<0, MPX>([&](auto J) {
-        constexpr int j2 = decltype(J)::value;
-        if (j2 < n2) xp[j2] = lds_pair(r2 + j2);
-      });
-      use(k, xp);
+  // Low levels: a lane walks the CLEAR low bits of its own bath word (partner class N - 1), then the SET ones (class
+  // N + 1), as the rows kernel does.  A loop over k with a branch on the bit would run BOTH couplings for every level
+  // (the eight blocks of a wave differ in their low bits), and read partner rows that are then thrown away.
+  const uint32_t lowmask = (1u << low) - 1u;
+  auto low_walk = [&](auto DOWNC, uint32_t m) {
+    constexpr bool DOWN = decltype(DOWNC)::value;
+    constexpr int MP = DOWN ? MPD : MPU;
+    if constexpr (MP > 0) {
+      while (m) {
+        const int k = ctz32(m);
+        m &= m - 1u;
+        const int r2 = (int)meta[k] - chunk_row0;
+        Pair xp[MP];
+        sfor<0, MP>([&](auto J) { xp[decltype(J)::value] = lds_pair(r2 + decltype(J)::value); });
+        const uint32_t neg = (sbits >> k) & 1u;
+        double v[NORB];
+        sfor<0, NORB>([&](auto A) { v[decltype(A)::value] = flip(vtab[k * 4 + decltype(A)::value], neg); });
+        couple<NORB, N, DOWN, Pair>(v, xp, acc, FmaP{});
+      }
     }
   };
   const int nbatch = nhigh > kHB ? 2 : 1;  // (the host keeps nhigh <= 2 kHB)
-  const int kmid = nbatch == 2 ? low / 2 : low;
-  low_levels(0, kmid);
-  consume(0);
+  low_walk(std::true_type{}, ~b & lowmask);
   if (nbatch == 2) {
+    consume(0);
     issue(kHB);
-    low_levels(kmid, low);
-    consume(kHB);
   }
+  low_walk(std::false_type{}, b & lowmask);
+  consume(nbatch == 2 ? kHB : 0);
 }
 
 // ---- columns kernel: the factored Hnd terms of one block of rows x two columns -------------------------------------

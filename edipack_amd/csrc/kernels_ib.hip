@@ -234,6 +234,11 @@ constexpr int kColsNT = 512;
 // Streamed once: the result rows (read, updated, written) and P_old's rows.  Non-temporal, so that they do not push the
 // panel's V segments -- gathered again and again by the neighbouring chunks -- out of the XCD's L2.
 typedef double ib_d2 __attribute__((ext_vector_type(2)));
+// compile-time ablations for scripts/r3_abl.sh (never set in the shipped build): 1 = no read of the rows kernel's
+// result, 2 = partner rows outside the chunk read from the LDS instead, 4 = no stores
+#ifndef IB_ABL
+#define IB_ABL 0
+#endif
 __device__ inline ib::Pair nt_load(const double* p) {
   const ib_d2 t = __builtin_nontemporal_load(reinterpret_cast<const ib_d2*>(p));
   return ib::Pair{t.x, t.y};
@@ -356,11 +361,14 @@ __global__ void __launch_bounds__(kColsNT, 4) ib_cols_kernel(IbArgs a, const dou
               acc[j].y = __builtin_fma(nbeta, o.y, acc[j].y);
             }
           } else {
-            h0[j] = nt_load(hp + (int64_t)(own + j) * 16 + col);
+            h0[j] = (IB_ABL & 1) ? ib::Pair{0.0, 0.0} : nt_load(hp + (int64_t)(own + j) * 16 + col);
             acc[j].x = acc[j].y = 0.0;
           }
         });
-        auto gload = [&](int grow) -> ib::Pair { return *reinterpret_cast<const ib::Pair*>(vp + (int64_t)grow * 16 + col); };
+        auto gload = [&](int grow) -> ib::Pair {
+            if (IB_ABL & 2) return *reinterpret_cast<const ib::Pair*>(chunk + (grow & 63) * 16 + col);
+            return *reinterpret_cast<const ib::Pair*>(vp + (int64_t)grow * 16 + col);
+          };
         ib::cols_block<NORB, nn>(chunk, row0, b, own, meta, nb, a.lowbits, vtab, timp, col, gload, acc);
         if (DO_ND) ib::cols_block_nd<NORB, nn>(chunk, own - row0, col, a.nterms, ndc, nddw, ndu, 16, acc);
         if constexpr (!ALPHA)
@@ -372,7 +380,7 @@ __global__ void __launch_bounds__(kColsNT, 4) ib_cols_kernel(IbArgs a, const dou
         if (!(e & 0x8000u)) {
           ib::sfor<0, M>([&](auto J) {
             constexpr int j = decltype(J)::value;
-            nt_store(hp + (int64_t)(own + j) * 16 + col, acc[j]);
+            if (!(IB_ABL & 4) || acc[j].x == 1.2345) nt_store(hp + (int64_t)(own + j) * 16 + col, acc[j]);
             if (ALPHA) {
               const ib::Pair o = *reinterpret_cast<const ib::Pair*>(chunk + (own - row0 + j) * 16 + col);
               const double dx = acc[j].x - sg * o.x, dy = acc[j].y - sg * o.y;
@@ -412,6 +420,234 @@ __global__ void __launch_bounds__(kColsNT, 4) ib_cols_kernel(IbArgs a, const dou
       a.partial[2 * gridDim.x + blockIdx.x] = n;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// columns kernel, pipelined form: ONE 1024-thread workgroup per CU, two LDS buffers, two LOADER waves
+// ---------------------------------------------------------------------------------------------------------
+// The form above alternates staging and block updates in every workgroup and relies on a second workgroup per CU to
+// overlap them; its 64 workgroup slots per XCD keep two panels in flight, which over-subscribes the 4 MiB L2 (4.4 GB
+// fetched per product at Ns = 16 for 2.7 GB of V + result).  Here a CU runs one workgroup whose last two waves do
+// nothing but bring the NEXT task's chunk into the other LDS buffer -- by LDS-DMA (global_load_lds_dwordx4: no
+// registers, no ds_write pass), plus the task's block records -- while the other fourteen update the blocks of the
+// current task.  The loaders' counter (vmcnt) is their own, so the prefetch does not sit in front of the partner-row
+// loads of the computing waves (within one wave it would: loads retire in order).  32 slots per XCD = one panel at a
+// time at Ns = 16.
+constexpr int kCols2NT = 1024, kCols2Loaders = 2, kCols2NCW = kCols2NT / 64 - kCols2Loaders;
+
+struct Cols2Lds {  // byte offsets inside the dynamic LDS; buffer b of a pair sits at base + b * stride
+  uint32_t chunk, chunk_stride, meta, meta_stride, lbl, lbl_stride, ndu, ndu_stride, vtab, timp, ndc, nddw, total;
+};
+__host__ __device__ inline Cols2Lds cols2_layout(int nb, int mcr, int mcb) {
+  Cols2Lds l;
+  uint32_t at = 0;
+  l.chunk = at;
+  l.chunk_stride = ((uint32_t)mcr * 128 + 1023) / 1024 * 1024;  // whole 1 KiB DMA pieces
+  at += 2 * l.chunk_stride;
+  l.meta = at;
+  l.meta_stride = (uint32_t)mcb * 32;
+  at += 2 * l.meta_stride;
+  l.lbl = at;
+  l.lbl_stride = (uint32_t)((mcb + 7) & ~7) * 2;
+  at += 2 * l.lbl_stride;
+  l.ndu = at;
+  l.ndu_stride = 16 * 16;
+  at += 2 * l.ndu_stride;
+  at = (at + 15) & ~15u;
+  l.vtab = at;
+  at += (uint32_t)nb * 32;
+  l.timp = at;
+  at += 16 * 8;
+  l.ndc = at;
+  at += 16 * 8;
+  l.nddw = at;
+  at += 16 * 4 * 4;
+  l.total = at;
+  return l;
+}
+
+template <int NORB, bool DO_ND, bool ALPHA>
+__global__ void __launch_bounds__(kCols2NT) ib_cols2_kernel(IbArgs a, const double* __restrict__ v, double* __restrict__ hv,
+                                                            const double* __restrict__ pold) {
+  __shared__ double red[3 * (kCols2NT / 64)];
+  extern __shared__ double lds[];
+  char* base = reinterpret_cast<char*>(lds);
+  const int nb = a.nb_dw;
+  const Cols2Lds L = cols2_layout(nb, a.max_chunk_rows, a.max_chunk_blocks);
+  double* vtab = reinterpret_cast<double*>(base + L.vtab);
+  double* timp = reinterpret_cast<double*>(base + L.timp);
+  double* ndc = reinterpret_cast<double*>(base + L.ndc);
+  uint8_t* nddw = reinterpret_cast<uint8_t*>(base + L.nddw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= kCols2NCW;
+  if (ALPHA && a.scal[SC_STOP] != 0.0) {
+    if (tid == 0) {
+      a.partial[blockIdx.x] = 0.0;
+      a.partial[gridDim.x + blockIdx.x] = 0.0;
+      a.partial[2 * gridDim.x + blockIdx.x] = 0.0;
+    }
+    return;
+  }
+  const double sg = ALPHA ? a.scal[SC_ALPHA] : 0.0;
+  const double nbeta = (ALPHA && pold) ? -a.scal[SC_BETA] : 0.0;
+  double asum = 0.0, qsum = 0.0, nsum = 0.0;
+  for (int i = tid; i < nb * 4; i += kCols2NT) vtab[i] = a.dw_vtab[i];
+  if (tid < 16) {
+    timp[tid] = tid < NORB * NORB ? a.dw_timp[tid] : 0.0;
+    ndc[tid] = DO_ND && tid < a.nterms ? a.ndcoef[tid] : 0.0;
+  }
+  if (DO_ND)
+    for (int i = tid; i < a.nterms * (NORB + 1) * 4; i += kCols2NT) nddw[i] = a.nd_dw[i];
+  const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int nch = a.nchunks;
+  const int panels_x = (a.npanels - x + 7) >> 3, ntask = panels_x * nch;
+  const int col = (lane & 7) << 1;
+  auto task_of = [&](int tt, int& panel, int& c) {
+    const int pi = tt / nch;
+    panel = pi * 8 + x;
+    c = (tt - pi * nch + pi) % nch;  // rotated: a slot meets chunks of every size
+  };
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void glb_void;
+  // loader waves: task tt into buffer bs
+  auto stage = [&](int tt, int bs) {
+    int panel, c;
+    task_of(tt, panel, c);
+    const int row0 = a.chunk_row[c], nrows = a.chunk_row[c + 1] - row0;
+    const int blk0 = a.chunk_blk[c], nblk = a.chunk_blk[c + 1] - blk0;
+    const int lw = wave - kCols2NCW, ll = lw * 64 + lane;  // 0 .. 64 * loaders - 1
+    const double* src = v + (int64_t)panel * a.ps + (int64_t)row0 * 16;
+    char* dstc = base + (L.chunk + bs * L.chunk_stride);
+    const int n16 = nrows * 8;  // 16-byte units; a DMA instruction moves 64 of them (1 KiB) to consecutive LDS bytes
+    for (int u0 = lw * 64; u0 < n16; u0 += kCols2Loaders * 64) {
+      const int u = u0 + lane < n16 ? u0 + lane : n16 - 1;  // the tail lanes re-read the last unit (their bytes are never used)
+      __builtin_amdgcn_global_load_lds((glb_void*)(src + (int64_t)u * 2), (lds_void*)(dstc + (size_t)u0 * 16), 16, 0, 0);
+    }
+    uint16_t* lbl = reinterpret_cast<uint16_t*>(base + (L.lbl + bs * L.lbl_stride));
+    uint4* lmeta = reinterpret_cast<uint4*>(base + (L.meta + bs * L.meta_stride));
+    for (int i = ll; i < nblk; i += kCols2Loaders * 64) lbl[i] = a.dblist[blk0 + i];
+    for (int i = ll; i < nblk * 2; i += kCols2Loaders * 64) {
+      const uint32_t b = a.dblist[blk0 + (i >> 1)] & 0x7FFFu;
+      lmeta[i] = reinterpret_cast<const uint4*>(a.dmeta + (size_t)b * 16)[i & 1];
+    }
+    if (DO_ND) {
+      uint8_t* ndu = reinterpret_cast<uint8_t*>(base + (L.ndu + bs * L.ndu_stride));
+      for (int i = ll; i < a.nterms * 16; i += kCols2Loaders * 64) ndu[i] = a.nd_up[(size_t)(i >> 4) * a.plen + panel * 16 + (i & 15)];
+    }
+    // the DMA counts on vmcnt; a workgroup barrier alone does not wait for it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  if (loader && slot < ntask) stage(slot, 0);
+  __syncthreads();
+  int it = 0;
+  for (int tt = slot; tt < ntask; tt += nslots, it++) {
+    const int bs = it & 1;
+    if (loader) {
+      if (tt + nslots < ntask) stage(tt + nslots, bs ^ 1);
+    } else {
+      int panel, c;
+      task_of(tt, panel, c);
+      const int row0 = a.chunk_row[c];
+      const int nblk = a.chunk_blk[c + 1] - a.chunk_blk[c];
+      const double* chunk = reinterpret_cast<const double*>(base + (L.chunk + bs * L.chunk_stride));
+      const uint16_t* lmeta = reinterpret_cast<const uint16_t*>(base + (L.meta + bs * L.meta_stride));
+      const uint16_t* lbl = reinterpret_cast<const uint16_t*>(base + (L.lbl + bs * L.lbl_stride));
+      const uint8_t* ndu = reinterpret_cast<const uint8_t*>(base + (L.ndu + bs * L.ndu_stride));
+      const double* __restrict__ vp = v + (int64_t)panel * a.ps;
+      double* __restrict__ hp = hv + (int64_t)panel * a.ps;
+      const double* __restrict__ pp = (ALPHA && pold) ? pold + (int64_t)panel * a.ps : nullptr;
+      const int32_t* cl = a.dcls + (size_t)c * (kIbMaxNorb + 2);
+      int cb[NORB + 1];
+#pragma unroll
+      for (int n = 1; n <= NORB; n++) cb[n] = cl[n];
+      for (int q0 = wave * 8; q0 < nblk; q0 += kCols2NCW * 8) {  // uniform per wave (classes are padded to 8 blocks)
+        int n = 0;
+#pragma unroll
+        for (int k = 1; k <= NORB; k++) n += q0 >= cb[k] ? 1 : 0;
+        const int bi = q0 + (lane >> 3);
+        const uint32_t e = lbl[bi];
+        const uint32_t b = e & 0x7FFFu;
+        const uint16_t* meta = lmeta + (size_t)bi * 16;
+        const int own = meta[14];
+        ib::for_class<NORB>(n, [&](auto N) {
+          constexpr int nn = decltype(N)::value;
+          constexpr int M = ib::binom(NORB, nn);
+          ib::Pair acc[M], h0[ALPHA ? 1 : M];
+          ib::sfor<0, M>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (ALPHA) {
+              acc[j] = nt_load(hp + (int64_t)(own + j) * 16 + col);
+              if (pp) {  // uniform
+                const ib::Pair o = nt_load(pp + (int64_t)(own + j) * 16 + col);
+                acc[j].x = __builtin_fma(nbeta, o.x, acc[j].x);
+                acc[j].y = __builtin_fma(nbeta, o.y, acc[j].y);
+              }
+            } else {
+              h0[j] = (IB_ABL & 1) ? ib::Pair{0.0, 0.0} : nt_load(hp + (int64_t)(own + j) * 16 + col);
+              acc[j].x = acc[j].y = 0.0;
+            }
+          });
+          auto gload = [&](int grow) -> ib::Pair {
+            if (IB_ABL & 2) return *reinterpret_cast<const ib::Pair*>(chunk + (grow & 63) * 16 + col);
+            return *reinterpret_cast<const ib::Pair*>(vp + (int64_t)grow * 16 + col);
+          };
+          ib::cols_block<NORB, nn>(chunk, row0, b, own, meta, nb, a.lowbits, vtab, timp, col, gload, acc);
+          if (DO_ND) ib::cols_block_nd<NORB, nn>(chunk, own - row0, col, a.nterms, ndc, nddw, ndu, 16, acc);
+          if constexpr (!ALPHA)
+            ib::sfor<0, M>([&](auto J) {
+              constexpr int j = decltype(J)::value;
+              acc[j].x += h0[j].x;
+              acc[j].y += h0[j].y;
+            });
+          if (!(e & 0x8000u)) {
+            ib::sfor<0, M>([&](auto J) {
+              constexpr int j = decltype(J)::value;
+              if (!(IB_ABL & 4) || acc[j].x == 1.2345) nt_store(hp + (int64_t)(own + j) * 16 + col, acc[j]);
+              if (ALPHA) {
+                const ib::Pair o = *reinterpret_cast<const ib::Pair*>(chunk + (own - row0 + j) * 16 + col);
+                const double dx = acc[j].x - sg * o.x, dy = acc[j].y - sg * o.y;
+                asum += o.x * acc[j].x + o.y * acc[j].y;
+                qsum += dx * dx + dy * dy;
+                nsum += o.x * o.x + o.y * o.y;
+              }
+            });
+          }
+        });
+      }
+    }
+    __syncthreads();  // the other buffer is complete (the loaders' DMA has retired), this one may be overwritten
+  }
+  if (ALPHA) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      asum += __shfl_down(asum, off, 64);
+      qsum += __shfl_down(qsum, off, 64);
+      nsum += __shfl_down(nsum, off, 64);
+    }
+    if (lane == 0) {
+      red[wave] = asum;
+      red[kCols2NT / 64 + wave] = qsum;
+      red[2 * (kCols2NT / 64) + wave] = nsum;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0, q = 0.0, n = 0.0;
+#pragma unroll
+      for (int i = 0; i < kCols2NT / 64; i++) {
+        t += red[i];
+        q += red[kCols2NT / 64 + i];
+        n += red[2 * (kCols2NT / 64) + i];
+      }
+      a.partial[blockIdx.x] = t;
+      a.partial[gridDim.x + blockIdx.x] = q;
+      a.partial[2 * gridDim.x + blockIdx.x] = n;
+    }
+  }
+}
+
+size_t ib_cols2_lds_bytes(int nb, int max_chunk_rows, int max_chunk_blocks) {
+  return cols2_layout(nb, max_chunk_rows, max_chunk_blocks).total;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -593,7 +829,37 @@ static int launch_ib_rows(const IbDev* d, const IbArgs& a, int fuse, const doubl
 }
 
 template <int NORB, bool DO_ND, bool ALPHA>
+static int launch_cols2_t(const IbDev* d, const IbArgs& a, const double* v, double* hv, const double* pold, hipStream_t st, int* nblocks) {
+  const size_t lds = ib_cols2_lds_bytes(d->nb_dw, d->max_chunk_rows, d->max_chunk_blocks);
+  const void* k = (const void*)ib_cols2_kernel<NORB, DO_ND, ALPHA>;
+  if (ensure_dynamic_lds(k, lds)) return 1;
+  if (resident_blocks(k, kCols2NT, lds) < 1) {
+    set_error("ib_cols2_kernel: does not fit a CU");
+    return 1;
+  }
+  int64_t grid = device_cu_count();  // one workgroup per CU
+  const int64_t tasks = (int64_t)d->npanels * d->nchunks;
+  grid = std::min<int64_t>(grid, (tasks + 7) / 8 * 8);
+  grid = std::max<int64_t>(8, grid / 8 * 8);
+  hipLaunchKernelGGL((ib_cols2_kernel<NORB, DO_ND, ALPHA>), dim3((unsigned)grid), dim3(kCols2NT), lds, st, a, v, hv, pold);
+  EDIGPU_HIP(hipGetLastError());
+  if (nblocks) *nblocks = (int)grid;
+  return 0;
+}
+
+// which form of the columns kernel.  Measured at Ns = 16 (round 3): the pipelined form 1.15 ms against 1.20-1.24 ms
+// under the profiler, H*v 2.33 against 2.36 ms -- inside the run-to-run spread, because the kernel is bound by the
+// block updates themselves (with every per-element global access compiled out, -DIB_ABL=7, it still takes 0.94 ms).
+// It stays an option (EDIGPU_IB_COLS2=1) until the block update is cheaper.
+static bool use_cols2(const IbDev* d) {
+  static const char* e = getenv("EDIGPU_IB_COLS2");
+  if (!e || atoi(e) == 0) return false;
+  return ib_cols2_lds_bytes(d->nb_dw, d->max_chunk_rows, d->max_chunk_blocks) <= 156 * 1024;
+}
+
+template <int NORB, bool DO_ND, bool ALPHA>
 static int launch_cols_t(const IbDev* d, const IbArgs& a, const double* v, double* hv, const double* pold, hipStream_t st, int* nblocks) {
+  if (use_cols2(d)) return launch_cols2_t<NORB, DO_ND, ALPHA>(d, a, v, hv, pold, st, nblocks);
   const size_t lds = d->cols_lds;
   const void* k = (const void*)ib_cols_kernel<NORB, DO_ND, ALPHA>;
   if (ensure_dynamic_lds(k, lds)) return 1;
