@@ -79,6 +79,7 @@ SIGNATURES = {
     "edigpu_normal_build_z": (C.c_int, [C.POINTER(_vp), C.POINTER(EdigpuModel), C.c_int, C.c_int]),
     "edigpu_flat_build": (C.c_int, [C.POINTER(_vp), C.POINTER(EdigpuModel), C.c_int, _i64, _i64]),
     "edigpu_flat_build_jz": (C.c_int, [C.POINTER(_vp), C.POINTER(EdigpuModel), C.c_int, C.c_int, _i64, _i64]),
+    "edigpu_direct_build_jz": (C.c_int, [C.POINTER(_vp), C.POINTER(EdigpuModel), C.c_int, C.c_int, _i64, _i64]),
     "edigpu_sector_map_jz": (C.c_int, [_vp, C.c_int, C.c_int, _pi32, _pi64]),
     "edigpu_direct_build": (C.c_int, [C.POINTER(_vp), C.POINTER(EdigpuModel), C.c_int, _i64, _i64]),
     "edigpu_sector_dim": (C.c_int, [C.POINTER(EdigpuModel), C.c_int, C.c_int, _pi64]),

@@ -406,16 +406,42 @@ static void free_ib(IbDev* p) {
   dev_free(p->xu); dev_free(p->ed); dev_free(p->impd); dev_free(p->pos); dev_free(p->colof); dev_free(p->chunk_row);
   dev_free(p->chunk_blk); dev_free(p->dcls); dev_free(p->dblist); dev_free(p->dmeta); dev_free(p->dw_vtab);
   dev_free(p->dw_timp); dev_free(p->ndcoef); dev_free(p->nd_dw); dev_free(p->nd_up);
+  dev_free(p->urank_low);
+  for (IbDevHalf& h : p->half) {
+    dev_free(h.ublist); dev_free(h.utop); dev_free(h.rmap2);
+  }
 }
 
 // device copy of the impurity-block image; leaves s->ib null (and returns 0) when the sector is not of that form
 static int setup_ib(edigpu_sector* s, const HostNormal& hn, int chunk_rows) {
   HostIb h;
-  build_ib(hn, chunk_rows, h);
+  // Rows whose image does not fit the LDS beside the tables are staged one half at a time (host_ib.hpp IbUpHalf);
+  // EDIGPU_IB_SPLIT=1 forces that form on any sector (tests), =0 leaves such sectors to the generic kernels.
+  int max_img_words = 0;
+  {
+    const char* e = getenv("EDIGPU_IB_SPLIT");
+    const int nb = hn.ns - hn.norb;
+    if (e && atoi(e) != 0)
+      max_img_words = -1;
+    else if (!e && nb >= 1 && nb <= kIbMaxBath)
+      max_img_words = (int)((156 * 1024 - (((size_t)1 << nb) * sizeof(uint16_t)) - (size_t)(nb + 1) * 32) / sizeof(double));
+  }
+  build_ib(hn, chunk_rows, h, max_img_words);
   if (!h.valid) return 0;
   int nt = 0, nbt = 0;
   const int plen = h.npanels * kIbPanel;
-  if (!ib_rows_config(h.norb, h.up.nb, (int)h.ublist.size(), plen, h.rimg_len, &nt, &nbt)) return 0;
+  size_t rows_lds = 0;
+  if (h.nhalf == 2) {
+    const IbUpHalf &a = h.half[0], &b = h.half[1];
+    const int rimg = std::max(a.rimg_len, b.rimg_len);
+    if (!ib_rows_config(h.norb, h.up.nb - 1, (int)std::max(a.ublist.size(), b.ublist.size()),
+                        std::max(a.npanels, b.npanels) * kIbPanel, rimg, &nt, &nbt, true))
+      return 0;
+    rows_lds = ib_rows_lds_bytes(h.up.nb - 1, rimg);
+  } else {
+    if (!ib_rows_config(h.norb, h.up.nb, (int)h.ublist.size(), plen, h.rimg_len, &nt, &nbt)) return 0;
+    rows_lds = ib_rows_lds_bytes(h.up.nb, h.rimg_len);
+  }
   int mcb = 8;
   for (size_t c = 0; c + 1 < h.chunk_blk.size(); c++) mcb = std::max(mcb, h.chunk_blk[c + 1] - h.chunk_blk[c]);
   std::unique_ptr<IbDev> d(new IbDev());
@@ -445,7 +471,7 @@ static int setup_ib(edigpu_sector* s, const HostNormal& hn, int chunk_rows) {
   d->len = (int64_t)h.npanels * d->ps;
   d->rows_nt = nt;
   d->rows_nbt = nbt;
-  d->rows_lds = ib_rows_lds_bytes(h.up.nb, h.rimg_len);
+  d->rows_lds = rows_lds;
   for (int i = 0; i < 5; i++) {
     d->rcb[i] = h.rcb[i];
     d->rcs[i] = h.rcs[i];
@@ -475,6 +501,32 @@ static int setup_ib(edigpu_sector* s, const HostNormal& hn, int chunk_rows) {
   if (h.nterms > 0 && dev_upload(&p->ndcoef, h.ndcoef.data(), h.ndcoef.size())) {
     free_ib(p);
     return 1;
+  }
+  p->nhalf = h.nhalf;
+  if (h.nhalf == 2) {
+    p->top_eps = h.up.vtab[(size_t)(h.up.nb - 1) * 4 + 3];
+    int rc = dev_upload(&p->urank_low, h.urank_low.data(), h.urank_low.size());
+    for (int k = 0; k < 2 && !rc; k++) {
+      const IbUpHalf& src = h.half[k];
+      IbDevHalf& dst = p->half[k];
+      dst.panel0 = src.panel0;
+      dst.npanels = src.npanels;
+      dst.nlist = (int)src.ublist.size();
+      dst.rimg_len = src.rimg_len;
+      for (int i = 0; i < 5; i++) {
+        dst.ucls[i] = src.ucls[std::min(i, h.norb + 1)];
+        dst.rcb[i] = src.rcb[i];
+        dst.rcs[i] = src.rcs[i];
+      }
+      std::vector<uint32_t> m2((size_t)src.npanels * kIbPanel / 2);
+      for (size_t i = 0; i < m2.size(); i++) m2[i] = (uint32_t)src.rmap[2 * i] | ((uint32_t)src.rmap[2 * i + 1] << 16);
+      rc = dev_upload(&dst.ublist, src.ublist.data(), src.ublist.size()) || dev_upload(&dst.utop, src.utop.data(), src.utop.size()) ||
+           dev_upload(&dst.rmap2, m2.data(), m2.size());
+    }
+    if (rc) {
+      free_ib(p);
+      return 1;
+    }
   }
   s->ib = d.release();
   return 0;
@@ -1200,7 +1252,9 @@ static bool flat_lanczos_fusable(const edigpu_sector* s) {
 static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
   const int64_t len = s->lz_len;
   const bool later = iter != 0;
-  if (normal_lanczos_fusable(s)) {
+  // (split rows of the impurity-block image: plain product only -- the unfused forms below, on its padded layout)
+  const bool ib_split = s->kind == 0 && s->ib && s->ib->nhalf == 2;
+  if (normal_lanczos_fusable(s) && !ib_split) {
     // rotate (and the pending axpy) fused into the row kernel, alpha and <Q|Q> into the panel sweep
     // (kernels_normal.hip); EDIGPU_LANCZOS_EXACTBETA=1 keeps the separate axpy+norm kernel
     const bool exactbeta = s->lz_exactbeta;  // read once per run in lanczos_prepare
@@ -1236,15 +1290,18 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
   // beta (k_finalize_ab) is what makes this safe: with beta^2 = <w|w> - alpha^2 the same loop made the lowest Ritz value
   // jitter at 6e-14 |H| (round 1, removed then).  EDIGPU_LANCZOS_EXACTBETA=1 / EDIGPU_LANCZOS_UNFUSED=1: the literal form.
   static const bool literal = getenv("EDIGPU_LANCZOS_UNFUSED") != nullptr;
+  auto product = [&]() -> int {  // tmp <- H vin, in the layout lanczos_prepare chose
+    return s->lz_blocked ? launch_normal_blocked(s, s->d_vin, s->d_tmp, st) : apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st);
+  };
   if (literal || s->lz_exactbeta) {
     if (iter > 0 && lz_rotate(s->d_vin, s->d_vout, len, s->d_scal, st)) return 1;
-    if (apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st)) return 1;
+    if (product()) return 1;
     if (lz_alpha(s->d_vin, s->d_vout, s->d_tmp, len, s->d_partial, s->d_scal, iter, nlanc, st)) return 1;
     return lz_beta(s->d_vin, s->d_vout, len, s->d_partial, s->d_scal, iter, nlanc, st);
   }
   int np = 0;
   if (later && lz_rotate_lazy(s->d_vin, s->d_vout, len, s->d_scal, st)) return 1;
-  if (apply_any(s, s->d_vin, s->d_vin, s->d_tmp, 3, st)) return 1;
+  if (product()) return 1;
   if (lz_add_dot3(s->d_vin, s->d_vout, s->d_tmp, len, s->d_scal, s->d_partial, &np, st)) return 1;
   return lz_finalize_alpha_beta(s->d_vin, s->d_vout, len, s->d_partial, np, s->d_scal, iter, nlanc, st);
 }
@@ -1252,7 +1309,10 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
 static int lanczos_prepare(edigpu_sector* s, int nlanc, double threshold, hipStream_t st) {
   s->lz_exactbeta = getenv("EDIGPU_LANCZOS_EXACTBETA") != nullptr;
   // the recurrence of a large factored normal-mode sector runs on panel-major vectors (set-up decides, blk_shift)
-  s->lz_blocked = s->kind == 0 && (s->blk_shift > 0 || s->ib) && s->nph == 0 && normal_lanczos_fusable(s);
+  // (the impurity-block image with split rows brings its layout but no fused step: rows_per_block == 0 there)
+  const bool ib_whole = s->kind == 0 && s->ib && s->nph == 0 && s->nloc == s->dim && !getenv("EDIGPU_LANCZOS_UNFUSED");
+  s->lz_blocked = s->kind == 0 && (s->blk_shift > 0 || s->ib) && s->nph == 0 &&
+                  (normal_lanczos_fusable(s) || (ib_whole && s->ib->nhalf == 2));
   s->lz_len = s->lz_blocked ? (s->ib ? s->ib->len : s->blk_len) : s->ws_len;
   const size_t ns = (size_t)SC_AB + 2 * (size_t)nlanc;
   if (!s->d_scal || s->scal_cap < ns) {  // (kept across runs: a captured graph holds its address)
@@ -1679,19 +1739,26 @@ static int attach_phonons_flat(edigpu_sector* s, const edigpu_model& m, const st
   return 0;
 }
 
-int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, int64_t row_first,
-                      int64_t row_count) {
+}  // extern "C"
+namespace edigpu {
+// edigpu_flat_build / edigpu_flat_build_jz: the stored image, generated on the device unless EDIGPU_FLAT_HOSTBUILD=1
+static int flat_build_common(edigpu_handle* h, const edigpu_model* model, int sector, int64_t row_first, int64_t row_count,
+                             bool jz, int twojz) {
   if (!h || !model) {
     set_error("edigpu_flat_build: NULL argument");
     return 1;
   }
   *h = nullptr;
   if (ensure_device()) return 1;
+  if (jz && model->nph > 0) {
+    set_error("edigpu_flat_build_jz: phonon sectors are not built in the Jz basis");
+    return 1;
+  }
   if (!env_flag("EDIGPU_FLAT_HOSTBUILD")) {
     // generate the stored image on the device from the on-the-fly description (kernels_build.hip);
     // the host CSR builder below is the fallback and what edigpu_csr_export materialises
     HostDirect hd;
-    std::string e = build_direct(*model, sector, row_first, row_count, hd);
+    std::string e = build_direct(*model, sector, row_first, row_count, hd, jz, twojz);
     if (!e.empty()) {
       set_error(e);
       return 1;
@@ -1709,6 +1776,8 @@ int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, i
     s->row_first = hd.row_first;
     s->model = *model;
     s->sec_a = sector;
+    s->sec_b = jz ? twojz : 0;
+    s->jz = jz;
     s->built_by_library = true;
     s->lazy_export = true;
     const int rc = build_flat_on_device(s.get(), hd);
@@ -1728,7 +1797,7 @@ int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, i
     if (rc == 1) return 1;
   }
   HostFlat hf;
-  std::string e = build_flat(*model, sector, row_first, row_count, hf);
+  std::string e = build_flat(*model, sector, row_first, row_count, hf, jz, twojz);
   if (!e.empty()) {
     set_error(e);
     return 1;
@@ -1740,6 +1809,8 @@ int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, i
   std::unique_ptr<edigpu_sector> s(new edigpu_sector());
   s->model = *model;
   s->sec_a = sector;
+  s->sec_b = jz ? twojz : 0;
+  s->jz = jz;
   s->built_by_library = true;
   if (setup_flat(s.get(), hf.row_count, hf.dim, hf.row_first, hf.h.rowptr.data(), hf.h.col.data(),
                  hf.h.val.data(), 1)) {
@@ -1748,7 +1819,7 @@ int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, i
   }
   if (model->nph > 0) {
     HostDirect hd;  // for the sector map
-    e = build_direct(*model, sector, row_first, row_count, hd);
+    e = build_direct(*model, sector, row_first, row_count, hd, jz, twojz);
     if (!e.empty()) set_error(e);
     if (!e.empty() || attach_phonons_flat(s.get(), *model, hd.states, hd.ns)) {
       edigpu_destroy(s.release());
@@ -1758,9 +1829,40 @@ int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, i
   *h = s.release();
   return 0;
 }
+}  // namespace edigpu
+extern "C" {
+
+int edigpu_flat_build(edigpu_handle* h, const edigpu_model* model, int sector, int64_t row_first,
+                      int64_t row_count) {
+  return flat_build_common(h, model, sector, row_first, row_count, false, 0);
+}
+
+int edigpu_flat_build_jz(edigpu_handle* h, const edigpu_model* model, int ntot, int twojz, int64_t row_first,
+                         int64_t row_count) {
+  return flat_build_common(h, model, ntot, row_first, row_count, true, twojz);
+}
+
+}  // extern "C"
+namespace edigpu {
+static int direct_build_common(edigpu_handle* h, const edigpu_model* model, int sector, int64_t row_first, int64_t row_count,
+                               bool jz, int twojz);
+}
+extern "C" {
 
 int edigpu_direct_build(edigpu_handle* h, const edigpu_model* model, int sector, int64_t row_first,
                         int64_t row_count) {
+  return direct_build_common(h, model, sector, row_first, row_count, false, 0);
+}
+
+int edigpu_direct_build_jz(edigpu_handle* h, const edigpu_model* model, int ntot, int twojz, int64_t row_first,
+                           int64_t row_count) {
+  return direct_build_common(h, model, ntot, row_first, row_count, true, twojz);
+}
+
+}  // extern "C"
+namespace edigpu {
+static int direct_build_common(edigpu_handle* h, const edigpu_model* model, int sector, int64_t row_first, int64_t row_count,
+                               bool jz, int twojz) {
   if (!h || !model) {
     set_error("edigpu_direct_build: NULL argument");
     return 1;
@@ -1768,7 +1870,7 @@ int edigpu_direct_build(edigpu_handle* h, const edigpu_model* model, int sector,
   *h = nullptr;
   if (ensure_device()) return 1;
   HostDirect hd;
-  std::string e = build_direct(*model, sector, row_first, row_count, hd);
+  std::string e = build_direct(*model, sector, row_first, row_count, hd, jz, twojz);
   if (!e.empty()) {
     set_error(e);
     return 1;
@@ -1777,6 +1879,8 @@ int edigpu_direct_build(edigpu_handle* h, const edigpu_model* model, int sector,
   s->kind = 2;
   s->model = *model;
   s->sec_a = sector;
+  s->sec_b = jz ? twojz : 0;
+  s->jz = jz;
   s->built_by_library = true;
   s->is_complex = 1;
   s->device = g_device;
@@ -1806,6 +1910,8 @@ int edigpu_direct_build(edigpu_handle* h, const edigpu_model* model, int sector,
   *h = s.release();
   return 0;
 }
+}  // namespace edigpu
+extern "C" {
 
 int edigpu_orbs_build(edigpu_handle* h, const edigpu_model* model, const int32_t* nups, const int32_t* ndws) {
   return edigpu_orbs_build_rows(h, model, nups, ndws, 0, -1);
@@ -1962,38 +2068,6 @@ int edigpu_sector_map_jz(const edigpu_model* model, int ntot, int twojz, int32_t
   return 0;
 }
 
-int edigpu_flat_build_jz(edigpu_handle* h, const edigpu_model* model, int ntot, int twojz, int64_t row_first,
-                         int64_t row_count) {
-  if (!h || !model) {
-    set_error("edigpu_flat_build_jz: NULL argument");
-    return 1;
-  }
-  *h = nullptr;
-  if (ensure_device()) return 1;
-  if (model->nph > 0) {
-    set_error("edigpu_flat_build_jz: phonon sectors are not built in the Jz basis");
-    return 1;
-  }
-  HostFlat hf;
-  std::string e = build_flat(*model, ntot, row_first, row_count, hf, true, twojz);
-  if (!e.empty()) {
-    set_error(e);
-    return 1;
-  }
-  if (hf.dim == 0) {
-    set_error("edigpu_flat_build_jz: empty sector");
-    return 1;
-  }
-  // a hand-over-like handle: the stored image only (apply_op / lazy export need the plain sector labels)
-  std::unique_ptr<edigpu_sector> s(new edigpu_sector());
-  if (setup_flat(s.get(), hf.row_count, hf.dim, hf.row_first, hf.h.rowptr.data(), hf.h.col.data(), hf.h.val.data(), 1)) {
-    edigpu_destroy(s.release());
-    return 1;
-  }
-  *h = s.release();
-  return 0;
-}
-
 int edigpu_image_info(edigpu_handle s, int32_t image[6]) {
   if (!s || !image || s->kind != 0) {
     set_error("edigpu_image_info: not a normal-mode handle");
@@ -2004,7 +2078,7 @@ int edigpu_image_info(edigpu_handle s, int32_t image[6]) {
   image[2] = s->factored ? s->fac_nimp : 0;
   image[3] = s->panel_mode;
   image[4] = s->ib ? kIbPanel : (s->blk_shift ? (1 << s->blk_shift) : 0);
-  image[5] = s->ib ? 1 : 0;
+  image[5] = s->ib ? s->ib->nhalf : 0;  // 1: impurity-block image, 2: with rows staged in halves
   return 0;
 }
 
@@ -2148,7 +2222,7 @@ int edigpu_csr_export(edigpu_handle s, int64_t* rowptr, int32_t* col, double* va
     // device-built sector: the CSR image only exists if somebody asks for it
     HostFlat hf;
     // (phonon sectors: the electronic block, as edigpu_normal_export hands back the electronic factors)
-    std::string e = build_flat(s->model, s->sec_a, s->row_first, s->nph > 0 ? s->dim_el : s->nloc, hf);
+    std::string e = build_flat(s->model, s->sec_a, s->row_first, s->nph > 0 ? s->dim_el : s->nloc, hf, s->jz, s->sec_b);
     if (!e.empty()) {
       set_error(e);
       return 1;
@@ -2493,14 +2567,16 @@ static int apply_op_flat_term(edigpu_handle src, edigpu_handle dst, const double
   // superc: sector = Sz = Nup - Ndw; nonsu2: sector = Ntot
   const int d = create ? 1 : -1;
   const int want = m.ed_mode == 1 ? src->sec_a + (ispin == 0 ? d : -d) : src->sec_a + d;
-  if (dst->sec_a != want) {
+  // Jz_basis=T: the operator also moves twoJz by the spin and the Lz of its level (ED_SECTOR.f90:289-350)
+  const int want_jz = src->jz ? src->sec_b + d * twojz_of_level(iorb + ispin * ns, ns, m.norb) : 0;
+  if (dst->sec_a != want || dst->jz != src->jz || (src->jz && dst->sec_b != want_jz)) {
     set_error(w + ": destination sector is not the one the operator leads to");
     return 1;
   }
   EDIGPU_HIP(hipSetDevice(src->device));
   HostDirect hs, hd;
-  std::string e = build_direct(src->model, src->sec_a, 0, -1, hs);
-  if (e.empty()) e = build_direct(dst->model, dst->sec_a, 0, -1, hd);
+  std::string e = build_direct(src->model, src->sec_a, 0, -1, hs, src->jz, src->sec_b);
+  if (e.empty()) e = build_direct(dst->model, dst->sec_a, 0, -1, hd, dst->jz, dst->sec_b);
   if (!e.empty()) {
     set_error(e);
     return 1;

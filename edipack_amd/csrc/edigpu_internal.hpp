@@ -82,7 +82,18 @@ struct DevEll {
 // Impurity-block image of a whole normal-mode sector on the device (host_ib.hpp; kernels_ib.hip).  Vectors of the
 // device-resident Lanczos loops live in the padded panel layout: element (idw, iup) at
 // (pos[iup] / 16) * ps + idw * 16 + pos[iup] % 16, ps = dim_dw * 16, len = npanels * ps doubles, padding = zeros.
+struct IbDevHalf {  // rows kernel's tables of one half of a split row (host_ib.hpp IbUpHalf)
+  int panel0 = 0, npanels = 0, nlist = 0, rimg_len = 0;
+  int ucls[5] = {0, 0, 0, 0, 0}, rcb[5] = {0, 0, 0, 0, 0}, rcs[5] = {0, 0, 0, 0, 0};
+  uint16_t *ublist = nullptr, *utop = nullptr;
+  uint32_t* rmap2 = nullptr;
+};
+
 struct IbDev {
+  int nhalf = 1;                 // 2: rows longer than the LDS, staged one half (value of the top bath bit) at a time
+  IbDevHalf half[2];
+  uint16_t* urank_low = nullptr; // [2^(nb_up - 1)]
+  double top_eps = 0.0;          // energy of the top bath level of the up species
   int norb = 0, nb_up = 0, nb_dw = 0, npanels = 0, plen = 0, nlist = 0;
   int ucls[5] = {0, 0, 0, 0, 0};
   int lowbits = 0, nchunks = 0, max_chunk_rows = 0, max_chunk_blocks = 0, nterms = 0, nsub = 1;
@@ -176,6 +187,7 @@ struct edigpu_sector {
   bool lazy_export = false;
   edigpu_model model;           // library-built sectors: what edigpu_*_build was given
   int sec_a = 0, sec_b = 0;
+  bool jz = false;                 // nonsu2 sector of Jz_basis=T: (Ntot, twoJz) = (sec_a, sec_b)
   bool built_by_library = false;   // made by edigpu_*_build: model, sec_a, sec_b are valid
   bool from_model() const { return built_by_library; }
   // ---- flat ----

@@ -673,8 +673,11 @@ struct SpinBasis {
   }
   // Jz_basis=T sectors of nonsu2 (ED_SECTOR.f90:289-350): Ntot = q and twoJz = (Nup - Ndw) + twoLz with twoLz = sum over
   // the levels iorb + Norb * ibath of 2 Lzdiag(iorb) (n_up + n_dw), Lzdiag = [-1, +1, 0] (ED_VARS_GLOBAL.f90:283).  The
-  // states stay in ascending order; ranking is a binary search (the two-table form does not apply: which up words
-  // go with a down word depends on its Lz as well as on its occupation).
+  // states stay in ascending order.  The up words that go with a down word d are those of ONE (occupation, Lz) class,
+  // (Ntot - n(d), the Lz that completes twoJz), so the two-table rank still holds with rk_up = rank of a word inside
+  // its (occupation, Lz) class -- for states OF the sector.  rank() is asked about states that may lie outside (a model
+  // that does not conserve Jz), so the host builder searches; the device kernels use the tables after
+  // build_direct has checked every term against the conservation law.
   bool jz = false;
   void init_jz(int ns_, int norb, int ntot, int twojz) {
     static const int lzdiag[3] = {-1, +1, 0};
@@ -691,12 +694,22 @@ struct SpinBasis {
       lz[w] = (int8_t)x;
     }
     states.clear();
-    for (uint32_t d = 0; d < nw; d++)
+    // rank of a word inside its (occupation, Lz) class; Lz of ns levels lies in [-ns, ns]
+    rk_up.assign(nw, 0);
+    {
+      std::vector<int32_t> cnt((size_t)(ns + 1) * (2 * ns + 1), 0);
+      for (uint32_t w = 0; w < nw; w++) rk_up[w] = cnt[(size_t)popc(w) * (2 * ns + 1) + (lz[w] + ns)]++;
+    }
+    off_dw.assign(nw, 0);
+    for (uint32_t d = 0; d < nw; d++) {
+      off_dw[d] = (int32_t)states.size();
       for (uint32_t u = 0; u < nw; u++) {
         const int nu = popc(u), nd = popc(d);
         if (nu + nd == ntot && (nu - nd) + 2 * (lz[u] + lz[d]) == twojz) states.push_back((int32_t)(u | (d << ns)));
       }
+    }
   }
+
   inline int64_t rank(uint32_t s) const {
     if (jz) {
       auto it = std::lower_bound(states.begin(), states.end(), (int32_t)s);
@@ -1154,8 +1167,13 @@ std::string build_orbs(const edigpu_model& m, const int* nups, const int* ndws, 
   return "";
 }
 
+int twojz_of_level(int p, int ns, int norb) {
+  static const int lzdiag[3] = {-1, +1, 0};
+  return (p < ns ? 1 : -1) + 2 * lzdiag[(p % ns) % norb];
+}
+
 std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
-                         HostDirect& out) {
+                         HostDirect& out, bool jz_basis, int twojz) {
   std::string e = check_model(m);
   if (!e.empty()) return e;
   if (m.ed_mode != 1 && m.ed_mode != 2) return "edigpu_direct_build: model.ed_mode must be superc or nonsu2";
@@ -1166,7 +1184,16 @@ std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, i
   const int ns = model_ns(m), norb = m.norb;
   if (2 * ns > 30) return "edigpu_direct_build: 2*Ns > 30 bits (the reference's integer range)";
   SpinBasis sb;
-  sb.init(ns, m.ed_mode, sector);
+  if (jz_basis) {
+    if (m.ed_mode != 2 || norb != 3) return "Jz_basis needs ed_mode = nonsu2 and Norb = 3 (Lzdiag = [-1, +1, 0])";
+    if (m.nbath > 1 && m.bath_type != 2 && m.bath_type != 3)
+      return "Jz_basis labels the levels as iorb + Norb * ibath: replica / general bath (or Nbath = 1)";
+    if (m.nph > 0) return "phonon sectors are not built in the Jz basis";
+    if (sector < 0 || sector > 2 * ns) return "Jz_basis: bad sector";
+    sb.init_jz(ns, norb, sector, twojz);
+  } else {
+    sb.init(ns, m.ed_mode, sector);
+  }
   out.ns = ns;
   out.norb = norb;
   out.dim = (int64_t)sb.states.size();
@@ -1215,6 +1242,17 @@ std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, i
     d.csign = cs;
     d.cre = t.coef.real();
     d.cim = t.coef.imag();
+    if (jz_basis) {
+      // the two-table rank is only defined inside the sector: a term that changes twoJz would be ranked to a wrong
+      // row silently (the reference's binary_search fails on it)
+      int dj = 0;
+      for (int b = 0; b < 2 * ns; b++) {
+        if (((flipped & d.need_clear) >> b) & 1u) dj += twojz_of_level(b, ns, norb);
+        if (((flipped & d.need_set) >> b) & 1u) dj -= twojz_of_level(b, ns, norb);
+      }
+      if (dj != 0 && (d.cre != 0.0 || d.cim != 0.0))
+        return "a matrix element leaves the sector (Jz_basis: the model does not conserve Jz)";
+    }
     out.terms.push_back(d);
   }
   // Order the terms by where they lead: a term takes state s to s + delta with delta = sum(+2^b over the levels it

@@ -135,8 +135,12 @@ std::string build_normal(const edigpu_model& m, int nup, int ndw, int64_t dw_fir
 std::string build_flat(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
                        HostFlat& out, bool jz_basis = false, int twojz = 0);
 std::string sector_map_jz(const edigpu_model& m, int ntot, int twojz, std::vector<int32_t>& out);
+// jz_basis: the nonsu2 sector (Ntot = sector, twoJz) of Jz_basis=T; refuses models whose terms change twoJz
 std::string build_direct(const edigpu_model& m, int sector, int64_t row_first, int64_t row_count,
-                         HostDirect& out);
+                         HostDirect& out, bool jz_basis = false, int twojz = 0);
+// change of twoJz when level p (0 .. 2 Ns - 1, up levels first) is filled: +-1 from the spin, 2 Lzdiag(iorb) from the
+// orbital (levels labelled iorb + Norb * ibath; Lzdiag = [-1, +1, 0], ED_VARS_GLOBAL.f90:283)
+int twojz_of_level(int p, int ns, int norb);
 // Hand-over images: the factored tables recovered from spH0d / spH0nd as the reference built them (local rows of a
 // dw-shard, global columns).  true: fac reproduces the diagonal within 8 ulp of max|Hd| and Hnd entry by entry with at
 // most max_terms terms; false: not of that form (the caller keeps the explicit image).

@@ -69,7 +69,7 @@ std::string build_side(const HostNormal& hn, int sp, const CombBasis& bs, int np
 
 }  // namespace
 
-void build_ib(const HostNormal& hn, int max_chunk_rows, HostIb& out) {
+void build_ib(const HostNormal& hn, int max_chunk_rows, HostIb& out, int max_img_words) {
   out = HostIb();
   auto fail = [&](const std::string& w) {
     out.valid = false;
@@ -92,52 +92,122 @@ void build_ib(const HostNormal& hn, int max_chunk_rows, HostIb& out) {
 
   // ---- up side: positions, block list ----
   const bool pad = hn.fac.nterms > 0;
-  out.pos.assign((size_t)du, 0);
-  out.upos.assign(nw, kIbNone);
-  int cur = 0;
-  for (uint32_t b = 0; b < nw; b++) {
-    if (out.up.first[b] == kIbNone) continue;
-    const int m = rows_of(out.up, b);
-    if (pad && (cur % kIbPanel) + m > kIbPanel) cur = (cur / kIbPanel + 1) * kIbPanel;
-    out.upos[b] = (uint16_t)cur;
-    for (int j = 0; j < m; j++) out.pos[(size_t)out.up.first[b] + j] = cur + j;
-    cur += m;
-  }
-  out.npanels = (cur + kIbPanel - 1) / kIbPanel;
-  if (out.npanels * kIbPanel >= 0xFFF0) return fail("padded row longer than 65519 columns");
-  for (int n = 0; n <= norb; n++) {
-    out.ucls[n] = (int)out.ublist.size();
-    uint16_t firstb = kIbNone;
-    for (uint32_t b = 0; b < nw; b++)
-      if (out.up.first[b] != kIbNone && cls_of(out.up, b) == n) {
-        if (firstb == kIbNone) firstb = (uint16_t)b;
-        out.ublist.push_back((uint16_t)b);
-      }
-    while (out.ublist.size() % 64) out.ublist.push_back((uint16_t)(firstb | kIbSkip));
-  }
-  out.ucls[norb + 1] = (int)out.ublist.size();
-  {
-    // LDS image of a row: classes one after the other, each as C(norb, n) arrays of (padded) class size
-    out.urank.assign(nw, kIbNone);
-    int at = 0, maxcs = 0;
-    for (int n = 0; n <= norb; n++) {
-      const int cs = out.ucls[n + 1] - out.ucls[n];
-      out.rcb[n + 1] = at;
-      out.rcs[n + 1] = cs;
-      maxcs = std::max(maxcs, cs);
-      at += (int)binomial(norb, n) * cs;
-      for (int q = out.ucls[n]; q < out.ucls[n + 1]; q++)
-        if (!(out.ublist[q] & kIbSkip)) out.urank[out.ublist[q]] = (uint16_t)(q - out.ucls[n]);
-    }
-    out.rimg_len = at + 2 * maxcs + 8;
-    if (out.rimg_len >= 0xFFF0) return fail("row image longer than 65519 words");
-    out.rmap.assign((size_t)out.npanels * kIbPanel, (uint16_t)(out.rimg_len - 1));
+  const int top = nb - 1;
+  // lays the columns out (split: the first block with the top bath bit set starts a panel) and builds the row image
+  auto build_up = [&](bool split) -> std::string {
+    out.pos.assign((size_t)du, 0);
+    out.upos.assign(nw, kIbNone);
+    out.ublist.clear();
+    int cur = 0, panel_b = -1;
     for (uint32_t b = 0; b < nw; b++) {
       if (out.up.first[b] == kIbNone) continue;
-      const int n = cls_of(out.up, b), m = rows_of(out.up, b);
-      for (int j = 0; j < m; j++)
-        out.rmap[(size_t)out.upos[b] + j] = (uint16_t)(out.rcb[n + 1] + j * out.rcs[n + 1] + out.urank[b]);
+      const int m = rows_of(out.up, b);
+      if (split && panel_b < 0 && (b >> top)) {
+        cur = (cur + kIbPanel - 1) / kIbPanel * kIbPanel;
+        panel_b = cur / kIbPanel;
+      }
+      if (pad && (cur % kIbPanel) + m > kIbPanel) cur = (cur / kIbPanel + 1) * kIbPanel;
+      out.upos[b] = (uint16_t)cur;
+      for (int j = 0; j < m; j++) out.pos[(size_t)out.up.first[b] + j] = cur + j;
+      cur += m;
     }
+    out.npanels = (cur + kIbPanel - 1) / kIbPanel;
+    if (out.npanels * kIbPanel >= 0xFFF0) return "padded row longer than 65519 columns";
+    for (int n = 0; n <= norb; n++) {
+      out.ucls[n] = (int)out.ublist.size();
+      uint16_t firstb = kIbNone;
+      for (uint32_t b = 0; b < nw; b++)
+        if (out.up.first[b] != kIbNone && cls_of(out.up, b) == n) {
+          if (firstb == kIbNone) firstb = (uint16_t)b;
+          out.ublist.push_back((uint16_t)b);
+        }
+      while (out.ublist.size() % 64) out.ublist.push_back((uint16_t)(firstb | kIbSkip));
+    }
+    out.ucls[norb + 1] = (int)out.ublist.size();
+    {
+      // LDS image of a row: classes one after the other, each as C(norb, n) arrays of (padded) class size
+      out.urank.assign(nw, kIbNone);
+      int at = 0, maxcs = 0;
+      for (int n = 0; n <= norb; n++) {
+        const int cs = out.ucls[n + 1] - out.ucls[n];
+        out.rcb[n + 1] = at;
+        out.rcs[n + 1] = cs;
+        maxcs = std::max(maxcs, cs);
+        at += (int)binomial(norb, n) * cs;
+        for (int q = out.ucls[n]; q < out.ucls[n + 1]; q++)
+          if (!(out.ublist[q] & kIbSkip)) out.urank[out.ublist[q]] = (uint16_t)(q - out.ucls[n]);
+      }
+      out.rimg_len = at + 2 * maxcs + 8;
+      if (out.rimg_len >= 0xFFF0) return "row image longer than 65519 words";
+      out.rmap.assign((size_t)out.npanels * kIbPanel, (uint16_t)(out.rimg_len - 1));
+      for (uint32_t b = 0; b < nw; b++) {
+        if (out.up.first[b] == kIbNone) continue;
+        const int n = cls_of(out.up, b), m = rows_of(out.up, b);
+        for (int j = 0; j < m; j++)
+          out.rmap[(size_t)out.upos[b] + j] = (uint16_t)(out.rcb[n + 1] + j * out.rcs[n + 1] + out.urank[b]);
+      }
+    }
+    out.nhalf = 1;
+    if (!split) return "";
+    if (panel_b <= 0 || panel_b >= out.npanels) return "a half of the split row is empty";
+    const uint32_t lowmask = (1u << top) - 1u;
+    out.urank_low.assign((size_t)1 << top, 0);
+    {
+      std::vector<int> cnt(nb + 1, 0);
+      for (uint32_t w = 0; w <= lowmask; w++) out.urank_low[w] = (uint16_t)cnt[popc(w)]++;
+    }
+    for (int h = 0; h < 2; h++) {
+      IbUpHalf& hf = out.half[h];
+      hf = IbUpHalf();
+      hf.panel0 = h ? panel_b : 0;
+      hf.npanels = h ? out.npanels - panel_b : panel_b;
+      int at = 0, maxcs = 0;
+      for (int n = 0; n <= norb; n++) {
+        hf.ucls[n] = (int)hf.ublist.size();
+        uint16_t firstw = kIbNone;
+        int count = 0;
+        for (uint32_t b = 0; b < nw; b++)
+          if ((int)(b >> top) == h && out.up.first[b] != kIbNone && cls_of(out.up, b) == n) {
+            if (firstw == kIbNone) firstw = (uint16_t)(b & lowmask);
+            // the class's part of the list must be in rank order: the position of a partner block is looked up in
+            // urank_low
+            if (out.urank_low[b & lowmask] != count) return "a half does not hold every low word of an occupation";
+            hf.ublist.push_back((uint16_t)(b & lowmask));
+            count++;
+          }
+        while (hf.ublist.size() % 64) hf.ublist.push_back((uint16_t)((firstw == kIbNone ? 0 : firstw) | kIbSkip));
+        const int cs = (int)hf.ublist.size() - hf.ucls[n];
+        hf.rcb[n + 1] = at;
+        hf.rcs[n + 1] = cs;
+        maxcs = std::max(maxcs, cs);
+        at += (int)binomial(norb, n) * cs;
+      }
+      for (int n = norb + 1; n < kIbMaxNorb + 2; n++) hf.ucls[n] = (int)hf.ublist.size();
+      hf.rimg_len = at + 2 * maxcs + 8;
+      hf.rmap.assign((size_t)hf.npanels * kIbPanel, (uint16_t)(hf.rimg_len - 1));
+      hf.utop.assign(hf.ublist.size(), kIbNone);
+      for (int n = 0; n <= norb; n++)
+        for (int q = hf.ucls[n]; q < hf.ucls[n + 1]; q++) {
+          const uint32_t b = (uint32_t)(hf.ublist[q] & 0x7FFFu) | ((uint32_t)h << top);
+          if (out.up.first[b] == kIbNone) continue;  // (an empty class's padding)
+          hf.utop[q] = out.upos[b ^ (1u << top)];     // kIbNone when that block does not exist
+          if (hf.ublist[q] & kIbSkip) continue;
+          const int m = rows_of(out.up, b);
+          for (int j = 0; j < m; j++)
+            hf.rmap[(size_t)out.upos[b] - (size_t)hf.panel0 * kIbPanel + j] = (uint16_t)(hf.rcb[n + 1] + j * hf.rcs[n + 1] + (q - hf.ucls[n]));
+        }
+    }
+    out.nhalf = 2;
+    return "";
+  };
+  e = build_up(false);
+  if (!e.empty()) return fail(e);
+  if (max_img_words < 0 || (max_img_words > 0 && out.rimg_len > max_img_words)) {  // (< 0: always, tests)
+    if (nb < 2) return fail("row image longer than the LDS");
+    e = build_up(true);
+    if (!e.empty()) return fail(e);
+    if (max_img_words > 0 && std::max(out.half[0].rimg_len, out.half[1].rimg_len) > max_img_words)
+      return fail("half a row image is longer than the LDS");
   }
 
   // ---- diagonal ----

@@ -39,6 +39,20 @@ struct IbSide {                  // one spin species
   std::vector<double> eimp;      // [2^norb]: one-body + same-spin density-density energy of an impurity pattern
 };
 
+// Rows longer than the LDS: the row image is built for ONE value of the top bath bit at a time ("half").  The hops over
+// the other nb - 1 levels stay inside a half; the hop over the top level reads the partner block's words from the
+// vector itself (kernels_ib.hip, TOP).  A half starts on a panel edge, so its pieces of a row are whole.
+struct IbUpHalf {
+  int panel0 = 0, npanels = 0;       // this half's panels of the padded row
+  std::vector<uint16_t> ublist;      // LOW bath word (without the top bit) | kIbSkip, classes padded to 64 as in HostIb
+  int ucls[kIbMaxNorb + 2] = {0};
+  std::vector<uint16_t> rmap;        // [npanels * 16]: image word of a position counted from panel0 * 16
+  int rcb[5] = {0, 0, 0, 0, 0}, rcs[5] = {0, 0, 0, 0, 0};
+  int rimg_len = 0;
+  std::vector<uint16_t> utop;        // [ublist.size()]: position (whole padded row) of the first column of the block
+                                     // with the top bit toggled, kIbNone when the sector has no such block
+};
+
 struct HostIb {
   bool valid = false;
   std::string why;               // when not valid: what the image cannot express
@@ -59,6 +73,12 @@ struct HostIb {
   std::vector<uint16_t> urank, rmap;
   int rcb[5] = {0, 0, 0, 0, 0}, rcs[5] = {0, 0, 0, 0, 0};
   int rimg_len = 0;
+  // split rows (see IbUpHalf): nhalf = 2, half[h] = the blocks with top bit h; urank_low[w] = rank of the (nb - 1)-bit
+  // word w among the words of equal occupation -- the position of a block inside its class in EITHER half (a half holds
+  // every low word of an occupation or none)
+  int nhalf = 1;
+  IbUpHalf half[2];
+  std::vector<uint16_t> urank_low;
   // diagonal: Hd(iup, idw) = up.ebath[b_up] + xu[impd(idw)][p_up] + ed[idw]
   std::vector<double> xu;        // [2^norb (impurity pattern of the down word)][2^norb (of the up word)]
   std::vector<double> ed;        // [dim_dw]
@@ -88,8 +108,9 @@ constexpr uint16_t kIbSkip = 0x8000u;
 constexpr uint16_t kIbNone = 0xFFFFu;
 
 // Builds the image of the whole sector held by hn (made by build_normal, which leaves the one-body data in hn).
-// max_chunk_rows: rows a chunk of the columns kernel may hold (LDS budget / 128 bytes).  out.valid = false with out.why
-// set when the sector is not of this form (the caller keeps the generic kernels).
-void build_ib(const HostNormal& hn, int max_chunk_rows, HostIb& out);
+// max_chunk_rows: rows a chunk of the columns kernel may hold (LDS budget / 128 bytes).  max_img_words > 0: a row image
+// longer than that is split in halves (nhalf = 2); < 0: always split (tests).  out.valid = false with out.why set when the sector is not of this
+// form (the caller keeps the generic kernels).
+void build_ib(const HostNormal& hn, int max_chunk_rows, HostIb& out, int max_img_words = 0);
 
 }  // namespace edigpu

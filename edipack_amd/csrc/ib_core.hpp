@@ -228,6 +228,24 @@ IB_HD void rows_block(const RowImage& im, uint32_t b, uint32_t i, int nb, const 
   });
 }
 
+// ---- rows kernel, split rows: the hop over the TOP bath level ----------------------------------------------------------
+// The image holds the blocks with one value of the top bath bit (host_ib.hpp IbUpHalf); rows_block walks the other
+// levels with nb - 1 and the LOW bath word.  xp: the words of the partner block (top bit toggled), read from the vector.
+// TOPSET = the top level is occupied in our block: partner class N + 1, else N - 1.  Every level below the top one is
+// in blow, so the bath sign is its parity.
+template <int NORB, int N, bool TOPSET>
+IB_HD void rows_top(uint32_t blow, const double* vtop /* [NORB]: V(a, top) */, const double* xp, double* acc) {
+  const uint32_t neg = (uint32_t)popc32(blow) & 1u;
+  double v[NORB];
+  sfor<0, NORB>([&](auto A) { v[decltype(A)::value] = flip(vtop[decltype(A)::value], neg); });
+  couple<NORB, N, !TOPSET, double>(v, xp, acc, FmaD{});
+}
+// words of the partner block of a class-N block over the top level (0: no such class)
+template <int NORB, int N, bool TOPSET>
+constexpr int rows_top_words() {
+  return TOPSET ? (N < NORB ? binom(NORB, N + 1) : 0) : (N >= 1 ? binom(NORB, N - 1) : 0);
+}
+
 // ---- columns kernel: one block of rows x two adjacent columns ------------------------------------------------------
 // chunk : the chunk's rows of the panel in the LDS, [row - chunk_row0][16] doubles; col = even column in the panel
 // meta  : the 16 entries of the block's bath word (host_ib.hpp dmeta): partner first rows, sign bits in [15]

@@ -97,7 +97,7 @@ int launch_ib_lanczos(const edigpu_sector* s, const double* P, double* Q, double
                       int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial);
 size_t ib_rows_lds_bytes(int nb, int rimg_len);
 size_t ib_cols_lds_bytes(int nb, int max_chunk_rows, int max_chunk_blocks);
-bool ib_rows_config(int norb, int nb, int nlist, int plen, int rimg_len, int* nt_out, int* nbt_out);
+bool ib_rows_config(int norb, int nb, int nlist, int plen, int rimg_len, int* nt_out, int* nbt_out, bool split = false);
 int measure_membw(int64_t bytes, double out[3]);
 // stand-alone vector kernels with explicit device scalars (sharded loop)
 int vec_rotate(int64_t n, double* vin, double* vout, const double* beta2, hipStream_t st);

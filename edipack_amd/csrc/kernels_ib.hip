@@ -45,6 +45,13 @@ struct IbArgs {
   const uint16_t *dblist, *dmeta;
   const double *dw_vtab, *dw_timp, *ndcoef;
   const uint8_t *nd_dw, *nd_up;
+  // split rows (host_ib.hpp IbUpHalf): the rows kernel sees ONE half -- nb_up, nlist, plen, ucls, rcb, rcs, rimg_len,
+  // ublist, rmap2 and urank are that half's; panel0 = its first panel; utop = per list entry the position of the partner
+  // block over the top bath level; top_eps = that level's energy when it is occupied in this half (else 0).  up_vtab
+  // keeps all nb_up + 1 rows.
+  int panel0;
+  const uint16_t* utop;
+  double top_eps;
   // fused Lanczos step
   const double* scal;
   double* partial;
@@ -62,16 +69,18 @@ struct IbArgs {
 // pieces of 16 bytes a thread moves per row, given its NBT blocks (a class-n block holds C(NORB, n) columns)
 constexpr int ib_rows_nld(int norb, int nbt) { return norb == 1 ? nbt / 2 + 1 : norb == 2 ? nbt : nbt + 1; }
 
-template <int NORB, int NT, int NBT, int FUSE>
+// TOP (split rows, FUSE 0 only): 0 = the whole row is staged; 1 / 2 = the half with the top bath level empty / occupied.
+template <int NORB, int NT, int NBT, int FUSE, int TOP = 0>
 __global__ void __launch_bounds__(NT, (NT == 768 ? 3 : (NT == 512 && NBT >= 12) ? 2 : 4)) ib_rows_kernel(IbArgs a, const double* __restrict__ P, double* __restrict__ Q, double* __restrict__ X) {
+  static_assert(TOP == 0 || FUSE == 0, "split rows: plain product only");
   extern __shared__ double lds[];
   constexpr int MAXM = ib::binom(NORB, NORB / 2);
   constexpr int NIMP = 1 << NORB;
   constexpr int NLD = ib_rows_nld(NORB, NBT);  // (the set-up checks plen <= 2 NT NLD)
   const int nb = a.nb_up, plen2 = a.plen >> 1;
   double* row = lds;                                                      // the row image (ib_core.hpp RowImage)
-  double* vtab = row + a.rimg_len;                                        // [nb][4]
-  uint16_t* rank = reinterpret_cast<uint16_t*>(vtab + nb * 4);            // [2^nb]
+  double* vtab = row + a.rimg_len;                                        // [nb + 1][4] (the last row: split rows)
+  uint16_t* rank = reinterpret_cast<uint16_t*>(vtab + (nb + 1) * 4);      // [2^nb]
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t dd = a.dim_dw, ps = a.ps;
@@ -82,7 +91,7 @@ __global__ void __launch_bounds__(NT, (NT == 768 ? 3 : (NT == 512 && NBT >= 12) 
     alpha = a.lazy ? a.scal[SC_ALPHA] : 0.0;
   }
   for (int i = tid; i < (1 << nb); i += NT) rank[i] = a.urank[i];
-  for (int i = tid; i < nb * 4; i += NT) vtab[i] = a.up_vtab[i];
+  for (int i = tid; i < (nb + (TOP ? 1 : 0)) * 4; i += NT) vtab[i] = a.up_vtab[i];
   for (int i = tid; i < a.rimg_len; i += NT) row[i] = 0.0;  // slack and the zero word stay zero
   ib::RowImage im;
   im.row = row;
@@ -103,6 +112,18 @@ __global__ void __launch_bounds__(NT, (NT == 768 ? 3 : (NT == 512 && NBT >= 12) 
     constexpr int s = decltype(S)::value;
     return (s & 1) ? bw[s / 2] >> 16 : bw[s / 2] & 0xFFFFu;
   };
+  // split rows: where the partner block over the top level starts in the padded row (0xFFFF: no such block)
+  uint32_t tw[TOP ? (NBT + 1) / 2 : 1];
+  if constexpr (TOP != 0)
+    ib::sfor<0, (NBT + 1) / 2>([&](auto S) {
+      constexpr int s2 = decltype(S)::value;
+      const int q0 = 2 * s2 * NT + tid, q1 = q0 + NT;
+      tw[s2] = (q0 < a.nlist ? (uint32_t)a.utop[q0] : 0xFFFFu) | ((2 * s2 + 1 < NBT && q1 < a.nlist ? (uint32_t)a.utop[q1] : 0xFFFFu) << 16);
+    });
+  auto tentry = [&](auto S) -> uint32_t {
+    constexpr int s = TOP ? decltype(S)::value : 0;
+    return (s & 1) ? tw[s / 2] >> 16 : tw[s / 2] & 0xFFFFu;
+  };
   // class of the 64 list entries a wave holds in slot s (uniform)
   auto cls_of = [&](int q0) -> int {
     int n = 0;
@@ -116,7 +137,7 @@ __global__ void __launch_bounds__(NT, (NT == 768 ? 3 : (NT == 512 && NBT >= 12) 
   // a.rmap2[q2] names the two words of the image the piece's columns go to.
   const int64_t pstride0 = (int64_t)(NT / 8) * ps;
   int64_t pstride = pstride0;  // (+ an opaque zero inside the row loop, see zr there: the per-piece addresses are not hoisted)
-  auto base_of = [&](int64_t r) -> int64_t { return (int64_t)(tid >> 3) * ps + r * 16 + ((tid & 7) << 1); };
+  auto base_of = [&](int64_t r) -> int64_t { return (int64_t)((tid >> 3) + (TOP ? a.panel0 : 0)) * ps + r * 16 + ((tid & 7) << 1); };
   // The next row is requested when the blocks are done (its pieces land while the results are written back and leave):
   // requested before the block updates, the pieces in flight cost 28 registers the updates need.  EARLY where they fit.
   constexpr bool EARLY = !FUSE && NBT * MAXM <= 18;
@@ -177,7 +198,7 @@ __global__ void __launch_bounds__(NT, (NT == 768 ? 3 : (NT == 512 && NBT >= 12) 
     asm volatile("v_mov_b32 %0, 0" : "=v"(zr));
     asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
     pstride = pstride0 + zs;
-    const double edr = a.ed[r];
+    const double edr = a.ed[r] + (TOP ? a.top_eps : 0.0);
     const double* xuc = a.xu + (int)a.impd[r] * NIMP;  // uniform: scalar loads (an LDS copy would sit in vector registers)
     double acc[NBT][MAXM];
     ib::sfor<0, NBT>([&](auto S) {
@@ -186,8 +207,20 @@ __global__ void __launch_bounds__(NT, (NT == 768 ? 3 : (NT == 512 && NBT >= 12) 
         const int n = cls_of(s * NT + wave * 64);
         ib::for_class<NORB>(n, [&](auto N) {
           constexpr int nn = decltype(N)::value;
+          constexpr int MPT = TOP ? ib::rows_top_words<NORB, nn, TOP == 2>() : 0;
+          double xg[MPT > 0 ? MPT : 1];
+          if constexpr (MPT > 0) {
+            // the partner block over the top level: requested before the walk over the other levels, used after it
+            // (word by word: without Hnd terms the columns are not padded and a block may cross a panel edge)
+            const uint32_t tp = tentry(S) + (uint32_t)zr;
+            ib::sfor<0, MPT>([&](auto J) {
+              const uint32_t pj = tp + (uint32_t)decltype(J)::value;
+              xg[decltype(J)::value] = tp != 0xFFFFu ? P[(int64_t)(pj >> 4) * ps + r * 16 + (pj & 15u)] : 0.0;
+            });
+          }
           ib::rows_block<NORB, nn>(im, (entry(S) + (uint32_t)zr) & 0x7FFFu, (uint32_t)(s * NT + tid - a.ucls[nn] + zr), nb, vtab, a.up_timp, edr, xuc,
                                    acc[s]);
+          if constexpr (MPT > 0) ib::rows_top<NORB, nn, TOP == 2>((entry(S) + (uint32_t)zr) & 0x7FFFu, vtab + nb * 4, xg, acc[s]);
         });
       }
     });
@@ -690,7 +723,8 @@ int vec_from_ib(const IbDev* ib, const double* src, double* dst, hipStream_t st)
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
-static void fill_ib_args(const IbDev* d, IbArgs& a) {
+// half < 0: the whole row; 0 / 1: the rows kernel's view of one half of a split row
+static void fill_ib_args(const IbDev* d, IbArgs& a, int half = -1) {
   a.nb_up = d->nb_up;
   a.nb_dw = d->nb_dw;
   a.npanels = d->npanels;
@@ -732,10 +766,31 @@ static void fill_ib_args(const IbDev* d, IbArgs& a) {
   a.scal = nullptr;
   a.partial = nullptr;
   a.lazy = 0;
+  a.panel0 = 0;
+  a.utop = nullptr;
+  a.top_eps = 0.0;
+  if (half >= 0) {
+    const IbDevHalf& h = d->half[half];
+    a.nb_up = d->nb_up - 1;
+    a.nlist = h.nlist;
+    a.plen = h.npanels * kIbPanel;
+    a.panel0 = h.panel0;
+    for (int i = 0; i < 5; i++) {
+      a.ucls[i] = h.ucls[i];
+      a.rcb[i] = h.rcb[i];
+      a.rcs[i] = h.rcs[i];
+    }
+    a.rimg_len = h.rimg_len;
+    a.ublist = h.ublist;
+    a.rmap2 = h.rmap2;
+    a.utop = h.utop;
+    a.urank = d->urank_low;
+    a.top_eps = half ? d->top_eps : 0.0;
+  }
 }
 
 size_t ib_rows_lds_bytes(int nb, int rimg_len) {
-  return ((size_t)rimg_len + (size_t)nb * 4) * sizeof(double) + ((size_t)1 << nb) * sizeof(uint16_t);
+  return ((size_t)rimg_len + (size_t)(nb + 1) * 4) * sizeof(double) + ((size_t)1 << nb) * sizeof(uint16_t);
 }
 
 size_t ib_cols_lds_bytes(int nb, int max_chunk_rows, int max_chunk_blocks) {
@@ -745,7 +800,7 @@ size_t ib_cols_lds_bytes(int nb, int max_chunk_rows, int max_chunk_blocks) {
 
 // threads per workgroup / blocks per thread of the rows kernel for a list of nlist blocks and rows of plen columns;
 // false: no instantiation fits (the caller keeps the generic kernels)
-bool ib_rows_config(int norb, int nb, int nlist, int plen, int rimg_len, int* nt_out, int* nbt_out) {
+bool ib_rows_config(int norb, int nb, int nlist, int plen, int rimg_len, int* nt_out, int* nbt_out, bool split) {
   const size_t lds = ib_rows_lds_bytes(nb, rimg_len);
   if (lds > 158 * 1024) return false;
   // Candidates: threads per workgroup x blocks per thread the kernels are built for.  A lane has 128 registers when
@@ -757,9 +812,10 @@ bool ib_rows_config(int norb, int nb, int nlist, int plen, int rimg_len, int* nt
   if (const char* e = getenv("EDIGPU_IB_NT")) forced = atoi(e);  // tuning
   long best = -1;
   for (int nt : {256, 512, 768, 1024}) {
-    if (forced && nt != forced) continue;
+    if (split ? nt != 1024 : (forced && nt != forced)) continue;  // (split rows: built for 1024 threads only)
     for (int nbt : opts[norb - 1]) {
       if (!nbt) continue;
+      if (split && nbt > (norb == 1 ? 14 : 6)) continue;
       if (nbt == 8 && norb == 3 && nt == 1024) continue;
       if (nbt == 12 && nt != 512) continue;
       if ((int64_t)nbt * nt < nlist || (int64_t)2 * nt * ib_rows_nld(norb, nbt) < plen) continue;
@@ -774,6 +830,40 @@ bool ib_rows_config(int norb, int nb, int nlist, int plen, int rimg_len, int* nt
     }
   }
   return best >= 0;
+}
+
+// split rows: the half named by top (1 / 2), plain product; built for the 1024-thread configurations only
+template <int NORB, int NBT>
+static int launch_rows_top(const IbDev* d, const IbArgs& a, int top, const double* P, double* Q, hipStream_t st) {
+  constexpr int NT = 1024;
+  const size_t lds = d->rows_lds;
+  const void* k = top == 1 ? (const void*)ib_rows_kernel<NORB, NT, NBT, 0, 1> : (const void*)ib_rows_kernel<NORB, NT, NBT, 0, 2>;
+  if (ensure_dynamic_lds(k, lds)) return 1;
+  const int per_cu = resident_blocks(k, NT, lds);
+  if (per_cu < 1) {
+    set_error("ib_rows_kernel (split rows): does not fit a CU");
+    return 1;
+  }
+  const int64_t grid = std::min<int64_t>(d->dim_dw, (int64_t)per_cu * device_cu_count());
+  if (top == 1)
+    hipLaunchKernelGGL((ib_rows_kernel<NORB, NT, NBT, 0, 1>), dim3((unsigned)grid), dim3(NT), lds, st, a, P, Q, nullptr);
+  else
+    hipLaunchKernelGGL((ib_rows_kernel<NORB, NT, NBT, 0, 2>), dim3((unsigned)grid), dim3(NT), lds, st, a, P, Q, nullptr);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+static int launch_ib_rows_top(const IbDev* d, const IbArgs& a, int top, const double* P, double* Q, hipStream_t st) {
+  if (d->rows_nt == 1024) {
+    if (d->norb == 1 && d->rows_nbt == 8) return launch_rows_top<1, 8>(d, a, top, P, Q, st);
+    if (d->norb == 1 && d->rows_nbt == 14) return launch_rows_top<1, 14>(d, a, top, P, Q, st);
+    if (d->norb == 2 && d->rows_nbt == 4) return launch_rows_top<2, 4>(d, a, top, P, Q, st);
+    if (d->norb == 2 && d->rows_nbt == 6) return launch_rows_top<2, 6>(d, a, top, P, Q, st);
+    if (d->norb == 3 && d->rows_nbt == 4) return launch_rows_top<3, 4>(d, a, top, P, Q, st);
+    if (d->norb == 3 && d->rows_nbt == 6) return launch_rows_top<3, 6>(d, a, top, P, Q, st);
+  }
+  set_error("ib_rows_kernel (split rows): no instantiation for this sector");
+  return 1;
 }
 
 template <int NORB, int NT, int NBT>
@@ -903,6 +993,15 @@ static int launch_ib_cols(const IbDev* d, const IbArgs& a, bool alpha, const dou
 // plain product on vectors in the padded panel layout
 int launch_ib(const edigpu_sector* s, const double* v, double* hv, hipStream_t st) {
   IbArgs a;
+  if (s->ib->nhalf == 2) {
+    // rows longer than the LDS: one launch per half of the row (each reads the other half's words for the top level)
+    for (int h = 0; h < 2; h++) {
+      fill_ib_args(s->ib, a, h);
+      if (launch_ib_rows_top(s->ib, a, h + 1, v, hv, st)) return 1;
+    }
+    fill_ib_args(s->ib, a);
+    return launch_ib_cols(s->ib, a, false, v, hv, nullptr, st, nullptr);
+  }
   fill_ib_args(s->ib, a);
   if (launch_ib_rows(s->ib, a, 0, v, hv, nullptr, st)) return 1;
   return launch_ib_cols(s->ib, a, false, v, hv, nullptr, st, nullptr);

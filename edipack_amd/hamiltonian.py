@@ -220,6 +220,16 @@ class SectorHamiltonian:
         return cls(h)
 
     @classmethod
+    def direct_jz_from_model(cls, model: ImpurityModel, ntot: int, twojz: int, row_first: int = 0,
+                             row_count: int = -1) -> "SectorHamiltonian":
+        """on-the-fly form of the nonsu2 sector (Ntot, twoJz) of JZ_BASIS=T."""
+        h = C.c_void_p()
+        cm = model.to_c()
+        capi.check(capi.lib().edigpu_direct_build_jz(C.byref(h), C.byref(cm), ntot, twojz, row_first, row_count),
+                   "edigpu_direct_build_jz")
+        return cls(h)
+
+    @classmethod
     def direct_from_model(cls, model: ImpurityModel, sector: int, row_first: int = 0,
                           row_count: int = -1) -> "SectorHamiltonian":
         """ed_sparse_H=F: on-the-fly H*v, nothing stored (directMatVec_*_main)."""

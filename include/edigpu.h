@@ -198,12 +198,18 @@ int edigpu_flat_build(edigpu_handle *h, const edigpu_model *model, int sector, i
  * and twoJz = (Nup - Ndw) + twoLz, twoLz = sum over the levels iorb + Norb*ibath of 2 Lzdiag(iorb) (n_up + n_dw),
  * Lzdiag = [-1, +1, 0] (ED_VARS_GLOBAL.f90:283) -- three orbitals, replica / general bath (or Nbath = 1), the level
  * order that labelling assumes.  The Hamiltonian is the nonsu2 one (ed_buildH_nonsu2_main) on that map; a model whose
- * terms leave the sector (Jz not conserved: the reference's binary_search would fail) is refused.  The stored image
- * is built on the host (no on-the-fly / device-built form); apply / Lanczos / eigensolver entry points as for
- * edigpu_flat_build, shards by rows.  edigpu_sector_map_jz returns the map (as edigpu_sector_map).
+ * terms leave the sector (Jz not conserved: the reference's binary_search would fail) is refused.  The up words that go
+ * with a down word all have one (occupation, Lz), so a state's row is still the sum of two table entries and the
+ * sector has the same three forms as an Ntot sector: the stored image generated on the device (edigpu_flat_build_jz;
+ * EDIGPU_FLAT_HOSTBUILD=1: host CSR), the on-the-fly product (edigpu_direct_build_jz), and edigpu_apply_op_flat /
+ * edigpu_apply_cops_flat between two Jz sectors (the destination must be (Ntot +- 1, twoJz +- (spin + 2 Lz of the level))).
+ * apply / Lanczos / eigensolver entry points as for edigpu_flat_build, shards by rows.  edigpu_sector_map_jz returns the
+ * map (as edigpu_sector_map).
  */
 int edigpu_flat_build_jz(edigpu_handle *h, const edigpu_model *model, int ntot, int twojz, int64_t row_first,
                          int64_t row_count);
+int edigpu_direct_build_jz(edigpu_handle *h, const edigpu_model *model, int ntot, int twojz, int64_t row_first,
+                           int64_t row_count);
 int edigpu_sector_map_jz(const edigpu_model *model, int ntot, int twojz, int32_t *map, int64_t *n);
 
 /*
@@ -260,7 +266,8 @@ int edigpu_info(edigpu_handle h, int64_t info[10]);
  * whose arrays edigpu_normal_create could factor), 0 for the explicit image (spH0d + spH0nd as given);
  * [1] = Hnd terms, [2] = diagonal classes, [3] = panel sweep variant (0 one column per lane, 1 two, 2 LDS-tiled),
  * [4] = columns per panel of the panel-major vector layout the device-resident Lanczos loops of this sector run on
- * (0: natural layout; DESIGN.md "panel-major vectors"), [5] = reserved (0). */
+ * (0: natural layout; DESIGN.md "panel-major vectors"), [5] = 1 when those loops run the impurity-block kernels
+ * (16-column padded panels), 2 when their rows are staged in two halves (rows longer than the LDS), else 0. */
 int edigpu_image_info(edigpu_handle h, int32_t image[6]);
 /* algorithmic bytes of one H*v in the reference's storage format */
 int edigpu_algorithmic_bytes(edigpu_handle h, double *bytes_hv, double *bytes_lanczos_step);

@@ -54,6 +54,54 @@ void emulate_rows(const HostIb& ib, const std::vector<double>& v, std::vector<do
   }
 }
 
+// split rows: one half image at a time, the hop over the top bath level from the vector itself
+template <int NORB>
+void emulate_rows_split(const HostIb& ib, const std::vector<double>& v, std::vector<double>& hv) {
+  const int nimp = 1 << NORB, top = ib.up.nb - 1;
+  for (int h = 0; h < 2; h++) {
+    const IbUpHalf& hf = ib.half[h];
+    const int plen = hf.npanels * kIbPanel, p0 = hf.panel0 * kIbPanel;
+    std::vector<double> img((size_t)hf.rimg_len, 0.0), res;
+    ib::RowImage im;
+    im.row = img.data();
+    im.rank = ib.urank_low.data();
+    for (int c = 0; c < 5; c++) {
+      im.cb[c] = hf.rcb[c];
+      im.cs[c] = hf.rcs[c];
+    }
+    const double eps_top = h ? ib.up.vtab[(size_t)top * 4 + 3] : 0.0;
+    for (int64_t r = 0; r < ib.dw.dim; r++) {
+      for (int p = 0; p < plen; p++) img[hf.rmap[p]] = v[vec_at(ib, r, p0 + p)];
+      res = img;
+      for (int n = 0; n <= NORB; n++)
+        for (int q = hf.ucls[n]; q < hf.ucls[n + 1]; q++) {
+          const uint16_t e = hf.ublist[q];
+          const uint32_t bl = e & 0x7FFFu;
+          const uint32_t i = (uint32_t)(q - hf.ucls[n]);
+          ib::for_class<NORB>(n, [&](auto N) {
+            constexpr int nn = decltype(N)::value;
+            double acc[ib::binom(NORB, nn)];
+            ib::rows_block<NORB, nn>(im, bl, i, top, ib.up.vtab.data(), ib.up.timp.data(), ib.ed[r] + eps_top,
+                                     &ib.xu[(size_t)ib.impd[r] * nimp], acc);
+            auto top_hop = [&](auto TS) {
+              constexpr bool ts = decltype(TS)::value;
+              constexpr int MP = ib::rows_top_words<NORB, nn, ts>();
+              if constexpr (MP > 0) {
+                double xp[MP];
+                for (int j = 0; j < MP; j++) xp[j] = hf.utop[q] == kIbNone ? 0.0 : v[vec_at(ib, r, hf.utop[q] + j)];
+                ib::rows_top<NORB, nn, ts>(bl, &ib.up.vtab[(size_t)top * 4], xp, acc);
+              }
+            };
+            if (h) top_hop(std::true_type{}); else top_hop(std::false_type{});
+            if (!(e & kIbSkip))
+              for (int j = 0; j < ib::binom(NORB, nn); j++) res[(size_t)hf.rcb[nn + 1] + (size_t)j * hf.rcs[nn + 1] + i] = acc[j];
+          });
+        }
+      for (int p = 0; p < plen; p++) hv[vec_at(ib, r, p0 + p)] = res[hf.rmap[p]];
+    }
+  }
+}
+
 template <int NORB>
 void emulate_cols(const HostIb& ib, const std::vector<double>& v, std::vector<double>& hv) {
   const int64_t dd = ib.dw.dim, ps = dd * kIbPanel;
@@ -100,13 +148,15 @@ void emulate_cols(const HostIb& ib, const std::vector<double>& v, std::vector<do
 // info: [0] valid, [1] lowbits, [2] chunks, [3] largest chunk, [4] panels, [5] Hnd terms, [6] padded columns.
 // Returns 0 and *maxdiff = max |difference| / max |reference|; 1 when the image is refused (message in
 // host_ib_error()); 2 on a builder error.
-extern "C" int host_ib_check(const edigpu_model* m, int nup, int ndw, int max_chunk_rows, int32_t* info, double* maxdiff) {
+// max_img_words > 0: rows whose image is longer are split (info[7] = halves).
+extern "C" int host_ib_check2(const edigpu_model* m, int nup, int ndw, int max_chunk_rows, int max_img_words, int32_t* info,
+                              double* maxdiff) {
   HostNormal hn;
   g_err = build_normal(*m, nup, ndw, 0, -1, hn, true);
   if (!g_err.empty()) return 2;
   HostIb ib;
-  build_ib(hn, max_chunk_rows, ib);
-  std::memset(info, 0, 7 * sizeof(int32_t));
+  build_ib(hn, max_chunk_rows, ib, max_img_words);
+  std::memset(info, 0, 8 * sizeof(int32_t));
   if (!ib.valid) {
     g_err = ib.why;
     return 1;
@@ -118,6 +168,7 @@ extern "C" int host_ib_check(const edigpu_model* m, int nup, int ndw, int max_ch
   info[4] = ib.npanels;
   info[5] = ib.nterms;
   info[6] = ib.npanels * kIbPanel - (int)hn.dim_up;
+  info[7] = ib.nhalf;
   const int64_t du = hn.dim_up, dd = hn.dim_dw, dim = du * dd;
   std::vector<double> v((size_t)dim), ref((size_t)dim, 0.0);
   uint64_t s = 0x9E3779B97F4A7C15ull;
@@ -139,9 +190,9 @@ extern "C" int host_ib_check(const edigpu_model* m, int nup, int ndw, int max_ch
   for (int64_t idw = 0; idw < dd; idw++)
     for (int64_t iup = 0; iup < du; iup++) vi[vec_at(ib, idw, ib.pos[iup])] = v[iup + idw * du];
   switch (ib.norb) {
-    case 1: emulate_rows<1>(ib, vi, hi); emulate_cols<1>(ib, vi, hi); break;
-    case 2: emulate_rows<2>(ib, vi, hi); emulate_cols<2>(ib, vi, hi); break;
-    case 3: emulate_rows<3>(ib, vi, hi); emulate_cols<3>(ib, vi, hi); break;
+    case 1: ib.nhalf == 2 ? emulate_rows_split<1>(ib, vi, hi) : emulate_rows<1>(ib, vi, hi); emulate_cols<1>(ib, vi, hi); break;
+    case 2: ib.nhalf == 2 ? emulate_rows_split<2>(ib, vi, hi) : emulate_rows<2>(ib, vi, hi); emulate_cols<2>(ib, vi, hi); break;
+    case 3: ib.nhalf == 2 ? emulate_rows_split<3>(ib, vi, hi) : emulate_rows<3>(ib, vi, hi); emulate_cols<3>(ib, vi, hi); break;
     default: g_err = "norb"; return 2;
   }
   double worst = 0.0, scale = 0.0;
@@ -165,4 +216,11 @@ extern "C" int host_ib_check(const edigpu_model* m, int nup, int ndw, int max_ch
   }
   *maxdiff = scale > 0.0 ? worst / scale : worst;
   return 0;
+}
+
+extern "C" int host_ib_check(const edigpu_model* m, int nup, int ndw, int max_chunk_rows, int32_t* info, double* maxdiff) {
+  int32_t tmp[8];
+  const int rc = host_ib_check2(m, nup, ndw, max_chunk_rows, 0, tmp, maxdiff);
+  std::memcpy(info, tmp, 7 * sizeof(int32_t));
+  return rc;
 }

@@ -138,6 +138,35 @@ extern "C" int host_flat_jz_dense(const edigpu_model* m, int ntot, int twojz, do
   return 0;
 }
 
+// the same sector from its ON-THE-FLY description (build_direct with jz_basis: what the device-built image and the
+// direct kernel evaluate): dense (re, im interleaved).  Returns 3 if the two-table rank of a state of the sector is not
+// its position in the map.
+extern "C" int host_direct_jz_dense(const edigpu_model* m, int ntot, int twojz, double* out, int64_t dim) {
+  HostDirect hd;
+  g_err = build_direct(*m, ntot, 0, -1, hd, true, twojz);
+  if (!g_err.empty()) return 1;
+  if (hd.dim != dim) { g_err = "host_direct_jz_dense: dim mismatch"; return 2; }
+  const int ns = hd.ns;
+  const uint32_t lomask = (1u << ns) - 1u, impmask = (1u << hd.norb) - 1u;
+  auto rank = [&](uint32_t w) { return (int64_t)hd.off_dw[w >> ns] + hd.rk_up[w & lomask]; };
+  std::memset(out, 0, sizeof(double) * 2 * dim * dim);
+  for (int64_t i = 0; i < dim; i++) {
+    const uint32_t s = (uint32_t)hd.states[i];
+    if (rank(s) != i) { g_err = "host_direct_jz_dense: two-table rank != position"; return 3; }
+    out[2 * (i * dim + i)] += hd.dtab[s & 255u] + hd.dtab[256 + ((s >> 8) & 255u)] + hd.dtab[512 + ((s >> 16) & 255u)] +
+                              hd.dtab[768 + (s >> 24)] + hd.xtab[(((s >> ns) & impmask) << hd.norb) | (s & impmask)];
+    for (const DirectTerm& t : hd.terms) {
+      if ((s & t.need_set) != t.need_set || (s & t.need_clear) != 0u) continue;
+      const int64_t j = rank(s ^ t.flip);
+      if (j < 0 || j >= dim) { g_err = "host_direct_jz_dense: partner outside the sector"; return 4; }
+      const double sg = ((__builtin_popcount(s & t.sign_mask) + (t.csign & 1)) & 1) ? -1.0 : 1.0;
+      out[2 * (i * dim + j)] += sg * t.cre;
+      out[2 * (i * dim + j) + 1] += sg * t.cim;
+    }
+  }
+  return 0;
+}
+
 // the _CMPLX_NORMAL sector as one real sector on the doubled up index (build_normal_doubled): its dense REAL image of
 // size (2 dim) x (2 dim) from the factored tables, rows / columns ordered (idw, iup, re|im) -- i.e. the interleaved
 // complex layout read as real

@@ -1978,6 +1978,60 @@ def test_impurity_block_image_matches_oracle(gpu, monkeypatch, rows, bath, norb,
     hb.destroy(), hn.destroy()
 
 
+@pytest.mark.parametrize("rows", [480, 12])
+@pytest.mark.parametrize("bath,norb,nbath,sec,extra", [
+    ("normal", 2, 3, (4, 4), {}),
+    ("hybrid", 3, 5, (4, 3), {}),
+    ("normal", 2, 4, (5, 5), dict(jxp=0.0)),
+    ("hybrid", 3, 6, (4, 5), {}),
+    ("normal", 1, 8, (4, 5), {}),
+    ("hybrid", 2, 7, (5, 4), dict(exc_field=np.array([0.12, 0.5, 0.5, 0.07]))),
+])
+def test_impurity_block_split_rows_match_oracle(gpu, monkeypatch, rows, bath, norb, nbath, sec, extra):
+    """Rows longer than the LDS (Ns = 17: 194 KB) are staged one half at a time -- the blocks with the top bath level
+    empty, then those with it occupied -- and the hop over that level reads the partner block from the vector
+    (ib_rows_kernel TOP).  Forced here on small sectors: the plain product, the (unfused) recurrence on the padded
+    layout and the ground state against the oracle and the generic kernels."""
+    import os
+    if os.environ.get("EDIGPU_NORMAL_EXPLICIT") or os.environ.get("EDIGPU_LANCZOS_UNFUSED") or os.environ.get("EDIGPU_ROW_SPLIT"):
+        pytest.skip("the impurity-block image needs the factored image")
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("normal", bath, norb, nbath, seed=73, **extra)
+    ho = O.HNormal(om, *sec)
+    monkeypatch.setenv("EDIGPU_IB", "1")
+    monkeypatch.setenv("EDIGPU_IB_MIN", "0")
+    monkeypatch.setenv("EDIGPU_IB_ROWS", str(rows))
+    monkeypatch.setenv("EDIGPU_IB_SPLIT", "1")
+    hb = SectorHamiltonian.normal_from_model(pm, *sec)
+    assert hb.image_info()[5] == 2 and hb.image_info()[4] == 16
+    v = np.random.default_rng(5).standard_normal(ho.dim)
+    assert rel_err(hb.apply(v), ho.matvec(v)) < TOL
+    assert rel_err(hb.apply(np.ones(ho.dim)), ho.matvec(np.ones(ho.dim))) < TOL
+    n = min(40, ho.dim)
+    ao, bo, _ = ho.lanc_tridiag(v, n)
+    ab, bb, nb = hb.lanczos_tridiag(v, n)
+    assert nb == n
+    k = min(15, n)
+    assert rel_err(ab[:k], ao[:k]) < 1e-10 and rel_err(bb[:k], bo[:k]) < 1e-10
+    monkeypatch.setenv("EDIGPU_LANCZOS_EXACTBETA", "1")
+    ae, be, _ = hb.lanczos_tridiag(v, n)
+    monkeypatch.delenv("EDIGPU_LANCZOS_EXACTBETA")
+    assert rel_err(ae[:k], ao[:k]) < 1e-10 and rel_err(be[:k], bo[:k]) < 1e-10
+    eb, xb, _ = hb.lanczos_eigh(nitermax=min(300, ho.dim), tol=1e-13, v0=v)
+    e0 = np.linalg.eigvalsh(ho.dense())[0] if ho.dim <= 5000 else None
+    if e0 is not None:
+        assert abs(eb - e0) < 1e-9 * max(1.0, abs(e0))
+    assert rel_err(hb.apply(xb), eb * xb) < 1e-6
+    ev, vec, _, _ = hb.lanczos_eigh_multi(2, 12, 1e-12, 300)
+    if e0 is not None:
+        assert abs(ev[0] - e0) < 1e-9 * max(1.0, abs(e0))
+    assert hb.lanczos_bench(2, 3)[1] > 0.0
+    ms = hb.time_apply(1, 2, lanczos=2)
+    assert ms > 0.0
+    hb.destroy()
+
+
 # --------------------------------------------------------------------------------------------
 # nonsu2 sectors of JZ_BASIS=T (build_sector, ED_SECTOR.f90:289-350)
 # --------------------------------------------------------------------------------------------
@@ -2022,6 +2076,119 @@ def test_jz_sectors_match_oracle(gpu, nbath, ntot, twojz):
         out.append(hv.cpu().numpy())
         hs.destroy()
     assert rel_err(np.concatenate(out), ho.matvec(v)) < TOL
+
+
+@pytest.mark.parametrize("nbath,ntot,twojz", [(1, 6, 0), (1, 5, 1), (2, 9, 1), (2, 8, -4), (2, 10, 2)])
+def test_jz_sector_three_forms(gpu, nbath, ntot, twojz):
+    """The Jz sector as the device-built stored image (default), the host-built CSR and the on-the-fly product: the same
+    H*v as the oracle's ed_buildH_nonsu2_main on build_sector's Jz map, whole and as row shards of the on-the-fly form."""
+    import torch
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from tests.common import make_jz_models
+    O = _oracle()
+    om, pm = make_jz_models(nbath, seed=13)
+    ho = O.HFlat(om, ntot, twojz=twojz)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(ho.dim) + 1j * rng.standard_normal(ho.dim)
+    want = ho.matvec(v)
+    hdev = SectorHamiltonian.flat_jz_from_model(pm, ntot, twojz)
+    hdir = SectorHamiltonian.direct_jz_from_model(pm, ntot, twojz)
+    assert hdev.dim == ho.dim == hdir.dim and hdir.kind == 2
+    assert rel_err(hdev.apply(v), want) < TOL
+    assert rel_err(hdir.apply(v), want) < TOL
+    # the CSR the device-built handle exports on request is the oracle's matrix
+    rp, col, val = hdev.export_csr()
+    assert np.max(np.abs(csr_to_dense(rp, col, val, ho.dim) - ho.dense())) < 1e-13
+    a, b, _ = hdir.lanczos_tridiag(v, min(20, ho.dim))
+    ao, bo, _ = ho.lanc_tridiag(v, min(20, ho.dim))
+    k = min(8, ho.dim)
+    assert rel_err(a[:k], ao[:k]) < 1e-9 and rel_err(b[:k], bo[:k]) < 1e-9
+    hdev.destroy(), hdir.destroy()
+    import os
+    os.environ["EDIGPU_FLAT_HOSTBUILD"] = "1"
+    try:
+        hh = SectorHamiltonian.flat_jz_from_model(pm, ntot, twojz)
+        assert rel_err(hh.apply(v), want) < TOL
+        hh.destroy()
+    finally:
+        del os.environ["EDIGPU_FLAT_HOSTBUILD"]
+    cut = (2 * ho.dim) // 5
+    vd = torch.from_numpy(v).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    out = []
+    for first, cnt in ((0, cut), (cut, ho.dim - cut)):
+        hs = SectorHamiltonian.direct_jz_from_model(pm, ntot, twojz, row_first=first, row_count=cnt)
+        hv = torch.empty(hs.nloc, dtype=torch.complex128, device="cuda")
+        hs.apply_local_dev(vd[first:].data_ptr(), hv.data_ptr(), st)
+        hs.apply_remote_dev(vd.data_ptr(), hv.data_ptr(), st)
+        torch.cuda.synchronize()
+        out.append(hv.cpu().numpy())
+        hs.destroy()
+    assert rel_err(np.concatenate(out), want) < TOL
+
+
+def test_jz_sector_refuses_model_without_jz(gpu):
+    """A model whose terms change twoJz has no Jz sectors: the two-table rank of the device forms would point at wrong
+    rows silently, so every form refuses it (the reference's binary_search fails on the first such element)."""
+    from edipack_amd import capi
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    _, pm = make_models("nonsu2", "replica", 3, 1, seed=3)   # generic complex replica matrices: Jz is not conserved
+    for build in (SectorHamiltonian.flat_jz_from_model, SectorHamiltonian.direct_jz_from_model):
+        with pytest.raises(capi.EdigpuError, match="Jz"):
+            build(pm, 6, 0)
+
+
+def test_apply_op_between_jz_sectors(gpu):
+    """apply_op_C / apply_op_CDG with Jz_basis=T (ED_SECTOR.f90:654-839 on the maps of :289-350): the operator on level
+    (iorb, ispin) leads from (Ntot, twoJz) to (Ntot +- 1, twoJz +- (spin + 2 Lz)); any other destination is refused."""
+    import torch
+    from edipack_amd import capi
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from tests.common import make_jz_models
+    O = _oracle()
+    om, pm = make_jz_models(2, seed=21)
+    ns = om.ns
+    ntot, twojz = 9, 1
+    lzdiag = (-1, 1, 0)
+    hs_o = O.HFlat(om, ntot, twojz=twojz)
+    hs = SectorHamiltonian.flat_jz_from_model(pm, ntot, twojz)
+    rng = np.random.default_rng(8)
+    v = rng.standard_normal(hs.dim) + 1j * rng.standard_normal(hs.dim)
+    vd = torch.from_numpy(v).cuda()
+    done = 0
+    for iorb in range(3):
+        for ispin in range(2):
+            for create in (True, False):
+                d = 1 if create else -1
+                tj = twojz + d * ((1 if ispin == 0 else -1) + 2 * lzdiag[iorb])
+                ht_o = O.HFlat(om, ntot + d, twojz=tj)
+                if ht_o.dim == 0:
+                    continue
+                build = SectorHamiltonian.direct_jz_from_model if create else SectorHamiltonian.flat_jz_from_model
+                ht = build(pm, ntot + d, tj)
+                out = torch.full((ht.dim,), 3.0 + 0j, dtype=torch.complex128, device="cuda")
+                hs.apply_op_to(ht, vd.data_ptr(), out.data_ptr(), iorb, ispin, create)
+                ref = np.zeros(ht_o.dim, complex)
+                rank = {int(s): i for i, s in enumerate(ht_o.map)}
+                bit = 1 << (iorb + ispin * ns)
+                for i, st in enumerate(hs_o.map):
+                    st = int(st)
+                    if bool(st & bit) == create:
+                        continue
+                    sg = -1.0 if bin(st & (bit - 1)).count("1") & 1 else 1.0
+                    ref[rank[st ^ bit]] = sg * v[i]
+                assert np.max(np.abs(out.cpu().numpy() - ref)) < 1e-15
+                done += 1
+                if done == 1:
+                    wrong = build(pm, ntot + d, tj + 2)
+                    if wrong.dim > 0:
+                        o2 = torch.zeros(wrong.dim, dtype=torch.complex128, device="cuda")
+                        with pytest.raises(capi.EdigpuError, match="destination sector"):
+                            hs.apply_op_to(wrong, vd.data_ptr(), o2.data_ptr(), iorb, ispin, create)
+                    wrong.destroy()
+                ht.destroy()
+    assert done >= 8
+    hs.destroy()
 
 
 # --------------------------------------------------------------------------------------------

@@ -232,6 +232,11 @@ def test_jz_sector_builder_equals_oracle(shim, nbath, ntot, twojz):
     assert rc == 0, shim.host_image_error().decode()
     got = out[..., 0] + 1j * out[..., 1]
     assert np.abs(got - ho.dense()).max() < 1e-13
+    # the on-the-fly description the device forms evaluate (two-table rank inside an (occupation, Lz) class)
+    out2 = np.zeros((ho.dim, ho.dim, 2))
+    rc = shim.host_direct_jz_dense(C.byref(m), ntot, twojz, out2.ctypes.data_as(C.c_void_p), C.c_int64(ho.dim))
+    assert rc == 0, shim.host_image_error().decode()
+    assert np.abs(out2[..., 0] + 1j * out2[..., 1] - ho.dense()).max() < 1e-13
 
 
 def test_jz_sector_builder_refusals(shim):
@@ -243,6 +248,8 @@ def test_jz_sector_builder_refusals(shim):
     n = len(O.HFlat(make_jz_models(1, seed=4)[0], 6, twojz=0).map)
     big = np.zeros(2 * n * n)
     assert shim.host_flat_jz_dense(C.byref(m), 6, 0, big.ctypes.data_as(C.c_void_p), C.c_int64(n)) == 1
+    assert "does not conserve Jz" in shim.host_image_error().decode()
+    assert shim.host_direct_jz_dense(C.byref(m), 6, 0, big.ctypes.data_as(C.c_void_p), C.c_int64(n)) == 1
     assert "does not conserve Jz" in shim.host_image_error().decode()
     _, p2 = make_models("nonsu2", "normal", 2, 2, seed=1)                   # two orbitals
     m = p2.to_c()

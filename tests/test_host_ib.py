@@ -69,6 +69,26 @@ def test_image_product_matches_explicit_arrays(shim, bath, norb, nbath, sec, row
         assert info[5] > 0
 
 
+@pytest.mark.parametrize("bath,norb,nbath,sec,rows,extra", CASES)
+def test_split_row_image_matches_explicit_arrays(shim, bath, norb, nbath, sec, rows, extra):
+    """Rows longer than the LDS: the image of half a row at a time (one value of the top bath bit), the hop over the top
+    level from the vector.  Forced here on small sectors (budget < 0)."""
+    _, pm = make_models("normal", bath, norb, nbath, seed=37, **extra)
+    info = (C.c_int32 * 8)()
+    diff = C.c_double(-1.0)
+    m = pm.to_c()
+    rc = shim.host_ib_check2(C.byref(m), sec[0], sec[1], rows, 10 ** 6, info, C.byref(diff))
+    assert rc == 0 and info[7] == 1                           # the budget is not exceeded: one image
+    rc = shim.host_ib_check2(C.byref(m), sec[0], sec[1], rows, -1, info, C.byref(diff))
+    msg = shim.host_ib_error().decode()
+    if rc == 1:
+        assert "half of the split row is empty" in msg, msg    # every block has the same top bit: refused, generic kernels
+        assert sec in ((1, 7),)
+        return
+    assert rc == 0, msg
+    assert info[0] == 1 and info[7] == 2 and diff.value < 1e-13, (list(info), diff.value)
+
+
 def test_chunks_follow_the_row_budget(shim):
     _, pm = make_models("normal", "hybrid", 3, 6, seed=5)
     few = _check(shim, pm, 4, 4, 480)[1]
