@@ -190,6 +190,8 @@ def run_single(args):
                                               "note": "streaming kernels on 1 GiB buffers, this device, this run"},
                      "kernel": {0: ("ib_rows_kernel + ib_cols_kernel (impurity-block image, padded 16-column panels)"
                                     if h.kind == 0 and h.image_info()[5] == 1 else
+                                    "ib_rows_kernel x 2 (rows staged in halves) + ib_cols_kernel (impurity-block image)"
+                                    if h.kind == 0 and h.image_info()[5] == 2 else
                                     "normal_rows_kernel + normal_dw_tile_kernel (sectors of >= 2M rows; normal_dw_panel_kernel below)"),
                                 1: "sell_rows_packed_kernel (SELL-64 + value dictionary; csr_rows_kernel fallback)",
                                 2: "direct_rows_kernel"}[h.kind],

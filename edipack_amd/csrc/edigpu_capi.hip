@@ -417,17 +417,13 @@ static int setup_ib(edigpu_sector* s, const HostNormal& hn, int chunk_rows) {
   HostIb h;
   // Rows whose image does not fit the LDS beside the tables are staged one half at a time (host_ib.hpp IbUpHalf);
   // EDIGPU_IB_SPLIT=1 forces that form on any sector (tests), =0 leaves such sectors to the generic kernels.
-  int max_img_words = 0;
-  {
-    const char* e = getenv("EDIGPU_IB_SPLIT");
-    const int nb = hn.ns - hn.norb;
-    if (e && atoi(e) != 0)
-      max_img_words = -1;
-    else if (!e && nb >= 1 && nb <= kIbMaxBath)
-      max_img_words = (int)((156 * 1024 - (((size_t)1 << nb) * sizeof(uint16_t)) - (size_t)(nb + 1) * 32) / sizeof(double));
+  int lds_budget = 156 * 1024;
+  if (const char* e = getenv("EDIGPU_IB_SPLIT")) lds_budget = atoi(e) != 0 ? -1 : 0;
+  build_ib(hn, chunk_rows, h, lds_budget);
+  if (!h.valid) {
+    if (getenv("EDIGPU_IB_VERBOSE")) fprintf(stderr, "edigpu: no impurity-block image: %s\n", h.why.c_str());
+    return 0;
   }
-  build_ib(hn, chunk_rows, h, max_img_words);
-  if (!h.valid) return 0;
   int nt = 0, nbt = 0;
   const int plen = h.npanels * kIbPanel;
   size_t rows_lds = 0;

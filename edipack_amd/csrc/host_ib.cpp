@@ -69,7 +69,7 @@ std::string build_side(const HostNormal& hn, int sp, const CombBasis& bs, int np
 
 }  // namespace
 
-void build_ib(const HostNormal& hn, int max_chunk_rows, HostIb& out, int max_img_words) {
+void build_ib(const HostNormal& hn, int max_chunk_rows, HostIb& out, int lds_budget) {
   out = HostIb();
   auto fail = [&](const std::string& w) {
     out.valid = false;
@@ -202,11 +202,13 @@ void build_ib(const HostNormal& hn, int max_chunk_rows, HostIb& out, int max_img
   };
   e = build_up(false);
   if (!e.empty()) return fail(e);
-  if (max_img_words < 0 || (max_img_words > 0 && out.rimg_len > max_img_words)) {  // (< 0: always, tests)
+  // LDS of the rows kernel: the image, the amplitudes, the rank table of the bath words it looks partners up in
+  auto rows_lds = [](int img_words, int nbits) { return (int64_t)img_words * 8 + (int64_t)(nbits + 2) * 32 + ((int64_t)2 << nbits); };
+  if (lds_budget < 0 || (lds_budget > 0 && rows_lds(out.rimg_len, nb) > lds_budget)) {  // (< 0: always, tests)
     if (nb < 2) return fail("row image longer than the LDS");
     e = build_up(true);
     if (!e.empty()) return fail(e);
-    if (max_img_words > 0 && std::max(out.half[0].rimg_len, out.half[1].rimg_len) > max_img_words)
+    if (lds_budget > 0 && rows_lds(std::max(out.half[0].rimg_len, out.half[1].rimg_len), nb - 1) > lds_budget)
       return fail("half a row image is longer than the LDS");
   }
 

@@ -108,9 +108,9 @@ constexpr uint16_t kIbSkip = 0x8000u;
 constexpr uint16_t kIbNone = 0xFFFFu;
 
 // Builds the image of the whole sector held by hn (made by build_normal, which leaves the one-body data in hn).
-// max_chunk_rows: rows a chunk of the columns kernel may hold (LDS budget / 128 bytes).  max_img_words > 0: a row image
-// longer than that is split in halves (nhalf = 2); < 0: always split (tests).  out.valid = false with out.why set when the sector is not of this
+// max_chunk_rows: rows a chunk of the columns kernel may hold (LDS budget / 128 bytes).  lds_budget > 0 (bytes): a row whose
+// image and tables need more is staged in two halves (nhalf = 2); < 0: always (tests); 0: never.  out.valid = false with out.why set when the sector is not of this
 // form (the caller keeps the generic kernels).
-void build_ib(const HostNormal& hn, int max_chunk_rows, HostIb& out, int max_img_words = 0);
+void build_ib(const HostNormal& hn, int max_chunk_rows, HostIb& out, int lds_budget = 0);
 
 }  // namespace edigpu

@@ -148,14 +148,14 @@ void emulate_cols(const HostIb& ib, const std::vector<double>& v, std::vector<do
 // info: [0] valid, [1] lowbits, [2] chunks, [3] largest chunk, [4] panels, [5] Hnd terms, [6] padded columns.
 // Returns 0 and *maxdiff = max |difference| / max |reference|; 1 when the image is refused (message in
 // host_ib_error()); 2 on a builder error.
-// max_img_words > 0: rows whose image is longer are split (info[7] = halves).
-extern "C" int host_ib_check2(const edigpu_model* m, int nup, int ndw, int max_chunk_rows, int max_img_words, int32_t* info,
+// lds_budget as build_ib takes it (bytes; < 0: always split; info[7] = halves).
+extern "C" int host_ib_check2(const edigpu_model* m, int nup, int ndw, int max_chunk_rows, int lds_budget, int32_t* info,
                               double* maxdiff) {
   HostNormal hn;
   g_err = build_normal(*m, nup, ndw, 0, -1, hn, true);
   if (!g_err.empty()) return 2;
   HostIb ib;
-  build_ib(hn, max_chunk_rows, ib, max_img_words);
+  build_ib(hn, max_chunk_rows, ib, lds_budget);
   std::memset(info, 0, 8 * sizeof(int32_t));
   if (!ib.valid) {
     g_err = ib.why;

@@ -77,7 +77,7 @@ def test_split_row_image_matches_explicit_arrays(shim, bath, norb, nbath, sec, r
     info = (C.c_int32 * 8)()
     diff = C.c_double(-1.0)
     m = pm.to_c()
-    rc = shim.host_ib_check2(C.byref(m), sec[0], sec[1], rows, 10 ** 6, info, C.byref(diff))
+    rc = shim.host_ib_check2(C.byref(m), sec[0], sec[1], rows, 10 ** 8, info, C.byref(diff))
     assert rc == 0 and info[7] == 1                           # the budget is not exceeded: one image
     rc = shim.host_ib_check2(C.byref(m), sec[0], sec[1], rows, -1, info, C.byref(diff))
     msg = shim.host_ib_error().decode()
