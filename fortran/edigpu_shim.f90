@@ -120,6 +120,15 @@ module EDIGPU_SHIM
        integer(c_int64_t), value :: row_first, row_count
        integer(c_int) :: ierr
      end function edigpu_flat_build_jz
+     function edigpu_direct_build_jz(h, model, ntot, twojz, row_first, row_count) &
+          bind(C, name="edigpu_direct_build_jz") result(ierr)
+       import :: c_ptr, c_int, c_int64_t, edigpu_model_t
+       type(c_ptr) :: h
+       type(edigpu_model_t), intent(in) :: model
+       integer(c_int), value :: ntot, twojz
+       integer(c_int64_t), value :: row_first, row_count
+       integer(c_int) :: ierr
+     end function edigpu_direct_build_jz
      function edigpu_direct_build(h, model, sector, row_first, row_count) &
           bind(C, name="edigpu_direct_build") result(ierr)
        import :: c_ptr, c_int, c_int64_t, edigpu_model_t
@@ -563,13 +572,23 @@ contains
     end if
   end subroutine gpu_build_flat
 
-  !> build_Hv_sector_nonsu2 with Jz_basis=T: sector (getN(isector), gettwoJz(isector)) (ED_SECTOR.f90:289-350)
-  subroutine gpu_build_flat_jz(m, ntot, twojz, row_first, row_count)
+  !> build_Hv_sector_nonsu2 with Jz_basis=T: sector (getN(isector), gettwoJz(isector)) (ED_SECTOR.f90:289-350);
+  !> direct=.true. selects ed_sparse_H=F (nothing stored)
+  subroutine gpu_build_flat_jz(m, ntot, twojz, row_first, row_count, direct)
     type(edigpu_model_t), intent(in) :: m
     integer, intent(in) :: ntot, twojz, row_first, row_count
+    logical, intent(in), optional :: direct
+    logical :: direct_
     if (c_associated(gpu_sector)) stop "gpu_build_flat_jz: a sector is already allocated"
-    call gpu_check(edigpu_flat_build_jz(gpu_sector, m, int(ntot, c_int), int(twojz, c_int), int(row_first, c_int64_t), &
-         int(row_count, c_int64_t)), "gpu_build_flat_jz")
+    direct_ = .false.
+    if (present(direct)) direct_ = direct
+    if (direct_) then
+       call gpu_check(edigpu_direct_build_jz(gpu_sector, m, int(ntot, c_int), int(twojz, c_int), int(row_first, c_int64_t), &
+            int(row_count, c_int64_t)), "gpu_build_flat_jz(direct)")
+    else
+       call gpu_check(edigpu_flat_build_jz(gpu_sector, m, int(ntot, c_int), int(twojz, c_int), int(row_first, c_int64_t), &
+            int(row_count, c_int64_t)), "gpu_build_flat_jz")
+    end if
   end subroutine gpu_build_flat_jz
 
   !> build_Hv_sector_normal with ed_total_ud=F: per-orbital (Nups, Ndws)
