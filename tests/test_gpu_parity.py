@@ -1886,6 +1886,7 @@ def test_panel_major_lanczos_matches_oracle(gpu, monkeypatch, w, bath, norb, nba
     from edipack_amd.hamiltonian import SectorHamiltonian
     om, pm = make_models("normal", bath, norb, nbath, seed=71, jxp=jxp)
     ho = O.HNormal(om, *sec)
+    monkeypatch.setenv("EDIGPU_IB", "0")          # (the generic panel-major loop is what this test is about)
     monkeypatch.setenv("EDIGPU_BLOCKED", "1")
     monkeypatch.setenv("EDIGPU_BLOCKED_MIN", "0")
     monkeypatch.setenv("EDIGPU_BLOCKED_W", str(w))
@@ -1944,7 +1945,8 @@ def test_impurity_block_image_matches_oracle(gpu, monkeypatch, rows, bath, norb,
     monkeypatch.setenv("EDIGPU_IB_MIN", "0")
     monkeypatch.setenv("EDIGPU_IB_ROWS", str(rows))
     hb = SectorHamiltonian.normal_from_model(pm, *sec)
-    assert hb.image_info()[5] == 1 and hb.image_info()[4] == 16
+    # (scripts/check_switches.sh runs the suite with EDIGPU_IB_SPLIT=1: rows staged in halves, unfused recurrence)
+    assert hb.image_info()[5] == (2 if os.environ.get("EDIGPU_IB_SPLIT") == "1" else 1) and hb.image_info()[4] == 16
     monkeypatch.setenv("EDIGPU_IB", "0")
     hn = SectorHamiltonian.normal_from_model(pm, *sec)
     assert hn.image_info()[5] == 0
