@@ -938,14 +938,17 @@ static int launch_cols2_t(const IbDev* d, const IbArgs& a, const double* v, doub
   return 0;
 }
 
-// which form of the columns kernel.  Measured at Ns = 16 (round 3): the pipelined form 1.15 ms against 1.20-1.24 ms
-// under the profiler, H*v 2.33 against 2.36 ms -- inside the run-to-run spread, because the kernel is bound by the
-// block updates themselves (with every per-element global access compiled out, -DIB_ABL=7, it still takes 0.94 ms).
-// It stays an option (EDIGPU_IB_COLS2=1) until the block update is cheaper.
+// which form of the columns kernel.  Measured (round 3): at Ns = 16 (panels of 1.6 MB) the pipelined form takes 2.33 ms
+// per product against 2.36 -- inside the run-to-run spread, because the kernel is bound by the block updates themselves
+// (with every per-element global access compiled out, -DIB_ABL=7, it still takes 0.94 ms).  At Ns = 17 a panel is 3.1 MB
+// and the two panels per XCD that the plain form keeps in flight no longer fit its 4 MB L2 (23.8 GB fetched per product
+// for 9.4 GB of V + result read-in): there the pipelined form, with one panel per XCD, measures 9.6 against 10.1 ms.
+// Default: panels above 2 MiB.  EDIGPU_IB_COLS2=0 / 1 overrides.
 static bool use_cols2(const IbDev* d) {
   static const char* e = getenv("EDIGPU_IB_COLS2");
-  if (!e || atoi(e) == 0) return false;
-  return ib_cols2_lds_bytes(d->nb_dw, d->max_chunk_rows, d->max_chunk_blocks) <= 156 * 1024;
+  if (ib_cols2_lds_bytes(d->nb_dw, d->max_chunk_rows, d->max_chunk_blocks) > 156 * 1024) return false;
+  if (e) return atoi(e) != 0;
+  return d->dim_dw * (int64_t)(kIbPanel * sizeof(double)) > ((int64_t)2 << 20);
 }
 
 template <int NORB, bool DO_ND, bool ALPHA>
