@@ -1248,9 +1248,9 @@ static bool flat_lanczos_fusable(const edigpu_sector* s) {
 static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
   const int64_t len = s->lz_len;
   const bool later = iter != 0;
-  // (split rows of the impurity-block image: plain product only -- the unfused forms below, on its padded layout)
-  const bool ib_split = s->kind == 0 && s->ib && s->ib->nhalf == 2;
-  if (normal_lanczos_fusable(s) && !ib_split) {
+  // (impurity-block image with rows staged in halves: rows_per_block == 0, but launch_ib_lanczos has a step for it)
+  const bool ib_split = s->kind == 0 && s->ib && s->ib->nhalf == 2 && s->lz_blocked;
+  if (normal_lanczos_fusable(s) || ib_split) {
     // rotate (and the pending axpy) fused into the row kernel, alpha and <Q|Q> into the panel sweep
     // (kernels_normal.hip); EDIGPU_LANCZOS_EXACTBETA=1 keeps the separate axpy+norm kernel
     const bool exactbeta = s->lz_exactbeta;  // read once per run in lanczos_prepare
@@ -1305,7 +1305,7 @@ static int lanczos_step(edigpu_sector* s, int iter, int nlanc, hipStream_t st) {
 static int lanczos_prepare(edigpu_sector* s, int nlanc, double threshold, hipStream_t st) {
   s->lz_exactbeta = getenv("EDIGPU_LANCZOS_EXACTBETA") != nullptr;
   // the recurrence of a large factored normal-mode sector runs on panel-major vectors (set-up decides, blk_shift)
-  // (the impurity-block image with split rows brings its layout but no fused step: rows_per_block == 0 there)
+  // (the impurity-block image with rows staged in halves: rows_per_block == 0 there, its step is in launch_ib_lanczos)
   const bool ib_whole = s->kind == 0 && s->ib && s->nph == 0 && s->nloc == s->dim && !getenv("EDIGPU_LANCZOS_UNFUSED");
   s->lz_blocked = s->kind == 0 && (s->blk_shift > 0 || s->ib) && s->nph == 0 &&
                   (normal_lanczos_fusable(s) || (ib_whole && s->ib->nhalf == 2));

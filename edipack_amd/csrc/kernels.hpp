@@ -70,6 +70,7 @@ int launch_csr_lanczos(const DevCsr& a, int cplx, const double* x, double* y, do
                        const double* sig, hipStream_t st);
 // (P, Q) <- ((Q - alpha*P)/beta, -beta*P): rotate with the pending axpy of the fused step folded in
 int lz_rotate_lazy(double* P, double* Q, int64_t n, const double* scal, hipStream_t st);
+int lz_next_vector(const double* P, const double* Q, double* X, int64_t n, const double* scal, bool lazy, hipStream_t st);
 int launch_direct(const edigpu_sector* s, const double* v_full, double* hv, hipStream_t st);
 
 // ---- Lanczos vector kernels (kernels_lanczos.hip); n counts doubles ----

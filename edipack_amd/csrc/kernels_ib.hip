@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(NT, (NT == 768 ? 3 : (NT == 512 && NBT >= 12) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t dd = a.dim_dw, ps = a.ps;
   double ibeta = 1.0, alpha = 0.0;
+  if (TOP != 0 && a.scal && a.scal[SC_STOP] != 0.0) return;  // (inside a recurrence that has terminated: uniform)
   if (FUSE) {
     if (a.scal[SC_STOP] != 0.0) return;  // recurrence already terminated (uniform)
     ibeta = 1.0 / a.scal[SC_BETA];
@@ -1022,6 +1023,25 @@ int launch_ib_lanczos(const edigpu_sector* s, const double* P, double* Q, double
   a.partial = partial;
   a.lazy = lazy_axpy ? 1 : 0;
   (void)partial_cap;  // >= kMaxPartials (ensure_workspace); launch_cols_t checks its grid against that
+  if (s->ib->nhalf == 2) {
+    // rows staged in halves: the rotation the rows kernel does while it stages a WHOLE row is its own pass here; the
+    // columns kernel with the - beta P_old term and the three sums is the one of the fused step
+    auto rows2 = [&](const double* in, double* out) -> int {
+      for (int h = 0; h < 2; h++) {
+        IbArgs ah;
+        fill_ib_args(s->ib, ah, h);
+        ah.scal = scal;
+        if (launch_ib_rows_top(s->ib, ah, h + 1, in, out, st)) return 1;
+      }
+      return 0;
+    };
+    if (first) {
+      if (rows2(P, Q)) return 1;
+      return launch_ib_cols(s->ib, a, true, P, Q, nullptr, st, npartial);
+    }
+    if (lz_next_vector(P, Q, X, s->ib->len, scal, lazy_axpy, st) || rows2(X, Q)) return 1;
+    return launch_ib_cols(s->ib, a, true, X, Q, P, st, npartial);
+  }
   if (first) {
     if (launch_ib_rows(s->ib, a, 0, P, Q, nullptr, st)) return 1;
     return launch_ib_cols(s->ib, a, true, P, Q, nullptr, st, npartial);

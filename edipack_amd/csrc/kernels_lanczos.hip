@@ -207,6 +207,25 @@ int lz_rotate_lazy(double* P, double* Q, int64_t n, const double* scal, hipStrea
   return 0;
 }
 
+// X <- (Q - alpha P) / beta: the next Lanczos vector into a third buffer (alpha = 0 unless the axpy is still pending).
+// The step of the impurity-block image with rows staged in halves (kernels_ib.hip): what its rows kernel does while
+// it stages a whole row has to be its own pass there.
+__global__ void __launch_bounds__(kLzNT)
+    k_next_vector(const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ X, int64_t n,
+                  const double* __restrict__ scal, int lazy) {
+  if (scal[SC_STOP] != 0.0) return;
+  const double a = lazy ? scal[SC_ALPHA] : 0.0, ib = 1.0 / scal[SC_BETA];
+  for (int64_t i = (int64_t)blockIdx.x * kLzNT + threadIdx.x; i < n; i += (int64_t)gridDim.x * kLzNT)
+    X[i] = (Q[i] - a * P[i]) * ib;
+}
+
+int lz_next_vector(const double* P, const double* Q, double* X, int64_t n, const double* scal, bool lazy, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_next_vector, ew_grid(n), dim3(kLzNT), 0, st, P, Q, X, n, scal, lazy ? 1 : 0);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
 // Q += tmp (the product H P that was written to its own buffer) with the three sums of the one-reduction recurrence:
 // <P|Q>, sum (Q - sg P)^2 about sg = the previous alpha, <P|P> (k_finalize_ab).  For the sectors whose product has no
 // fused epilogue (ed_total_ud = F, phonon branches, complex normal mode, rows staged in column parts).
