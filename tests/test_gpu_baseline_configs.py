@@ -362,6 +362,51 @@ def test_hbm_resident_ladder_panel_major_vs_natural(gpu, monkeypatch, workload):
         assert abs(_cf(ap, bp, z) - _cf(an, bn, z)) / abs(_cf(an, bn, z)) < 1e-10
 
 
+def test_ns17_rows_staged_in_halves_vs_generic_kernels(gpu, monkeypatch):
+    """Ns = 17 (591 M rows, rows of 194 KB: longer than the LDS): the impurity-block kernels with the row staged in two
+    halves (image_info[5] == 2) against the generic split-row kernels on the reference's layout -- the product on the same
+    vector, its linearity and symmetry at that size, alpha_1 = <v|H|v>, and the first coefficients of the recurrence
+    (fused step of the halves form against the unfused natural-layout loop)."""
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    from edipack_amd.synthetic import WORKLOADS, synthetic_model
+    for k in ("EDIGPU_BLOCKED", "EDIGPU_BLOCKED_W", "EDIGPU_BLOCKED_MIN", "EDIGPU_IB", "EDIGPU_IB_MIN", "EDIGPU_IB_ROWS",
+              "EDIGPU_IB_SPLIT", "EDIGPU_IB_COLS2"):
+        monkeypatch.delenv(k, raising=False)
+    w = WORKLOADS["cfg3_ns17"]
+    pm = synthetic_model(w)
+    hb = SectorHamiltonian.normal_from_model(pm, *w.sector)
+    assert hb.image_info()[4] == 16 and hb.image_info()[5] == 2
+    rng = np.random.default_rng(17)
+    v = rng.standard_normal(hb.dim)
+    v /= np.linalg.norm(v)
+    x = rng.standard_normal(hb.dim)
+    ab, bb, nb = hb.lanczos_tridiag(v, 12)
+    hv, hx = hb.apply(v), hb.apply(x)
+    y = 2.0 * v
+    y -= 3.0 * x
+    hy = hb.apply(y)
+    del y
+    hy -= 2.0 * hv
+    hy += 3.0 * hx
+    assert np.linalg.norm(hy) < 1e-12 * np.linalg.norm(hx)                                          # linear
+    del hy
+    assert abs(np.dot(x, hv) - np.dot(hx, v)) < 1e-10 * np.linalg.norm(hv) * np.linalg.norm(x)     # symmetric H
+    assert abs(np.dot(v, hv) - ab[0]) < 1e-10 * max(1.0, abs(ab[0]))                                # alpha_1 = <v|H|v>
+    hb.destroy()
+    del hx, x
+    monkeypatch.setenv("EDIGPU_IB", "0")
+    hn = SectorHamiltonian.normal_from_model(pm, *w.sector)
+    assert hn.image_info()[5] == 0
+    g = hn.apply(v)
+    g -= hv
+    assert np.linalg.norm(g) < 1e-12 * np.linalg.norm(hv)
+    del g, hv
+    an, bn, nn = hn.lanczos_tridiag(v, 12)
+    hn.destroy()
+    assert nb == nn == 12
+    assert rel_err(ab, an) < 1e-10 and rel_err(bb, bn) < 1e-10
+
+
 @pytest.mark.parametrize("name", ["REPLICA_SUPERC", "GENERAL_SUPERC", "REPLICA_NONSU2", "GENERAL_NONSU2"])
 def test_golden_replica_flat_momenta_through_gpu_tridiag(gpu, name):
     """The moment files of the replica / general SUPERC and NONSU2 directories (every orbital pair of Self, all sixteen
