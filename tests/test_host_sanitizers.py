@@ -15,7 +15,8 @@ def test_host_builders_under_asan_ubsan(tmp_path):
     cmd = ["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17",
            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "edipack_amd", "csrc"), "-o", exe,
            os.path.join(ROOT, "tests", "host_sanitize_main.cpp"),
-           os.path.join(ROOT, "edipack_amd", "csrc", "host_build.cpp")]
+           os.path.join(ROOT, "edipack_amd", "csrc", "host_build.cpp"),
+           os.path.join(ROOT, "edipack_amd", "csrc", "host_ib.cpp")]
     subprocess.check_call(cmd)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1")
     out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
