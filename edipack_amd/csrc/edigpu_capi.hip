@@ -14,6 +14,7 @@
 #include <tuple>
 
 #include "host_ib.hpp"
+#include "host_sb.hpp"
 #include "kernels.hpp"
 
 namespace edigpu {
@@ -400,8 +401,18 @@ static void plan_tile_chunks(const HostCsr& dw, int64_t dw_first, int64_t dw_cou
 }
 
 
+static void free_sb(DevSb* q) {
+  if (!q) return;
+  dev_free(q->urank); dev_free(q->ublist); dev_free(q->uslot); dev_free(q->rmap2); dev_free(q->up_vtab); dev_free(q->up_tloc);
+  dev_free(q->e0); dev_free(q->ebw); dev_free(q->up_korb); dev_free(q->chunk_row); dev_free(q->chunk_slot); dev_free(q->cdesc_off);
+  dev_free(q->cdesc); dev_free(q->dw_vtab); dev_free(q->dw_tloc); dev_free(q->dw_korb); dev_free(q->nd_dw);
+  delete q;
+}
+
 static void free_ib(IbDev* p) {
   if (!p) return;
+  free_sb(p->sb);
+  p->sb = nullptr;
   dev_free(p->urank); dev_free(p->rmap2); dev_free(p->ublist); dev_free(p->up_vtab); dev_free(p->up_timp); dev_free(p->up_ebath);
   dev_free(p->xu); dev_free(p->ed); dev_free(p->impd); dev_free(p->pos); dev_free(p->colof); dev_free(p->chunk_row);
   dev_free(p->chunk_blk); dev_free(p->dcls); dev_free(p->dblist); dev_free(p->dmeta); dev_free(p->dw_vtab);
@@ -410,6 +421,66 @@ static void free_ib(IbDev* p) {
   for (IbDevHalf& h : p->half) {
     dev_free(h.ublist); dev_free(h.utop); dev_free(h.rmap2);
   }
+}
+
+// Local-block tables (host_sb.hpp, kernels_sb.hip) on the layout of the impurity-block image d: when the sector is of that
+// form and a geometry of the kernels fits, the product and the fused step of the device-resident loops run on them
+// (EDIGPU_SB=0: keep the round-3 impurity-block kernels; EDIGPU_SB_VERBOSE=1 says why a sector gets none).
+static int setup_sb(IbDev* d, const HostNormal& hn, const HostIb& h, int chunk_rows) {
+  if (const char* e = getenv("EDIGPU_SB"))
+    if (atoi(e) == 0) return 0;
+  const bool verbose = getenv("EDIGPU_SB_VERBOSE") != nullptr;
+  auto skip = [&](const std::string& why) {
+    if (verbose) fprintf(stderr, "edigpu: no local-block tables: %s\n", why.c_str());
+    return 0;
+  };
+  if (h.nhalf != 1) return skip("rows staged in halves");
+  const int nb0 = sb_nb0(h.norb);
+  if (nb0 < 1 || hn.ns - h.norb - nb0 < 2) return skip("too few bath levels");
+  const int slots = sb_rows_slots(hn, nb0);
+  if (slots < 1) return skip("not of the local-block form");
+  HostSb t;
+  build_sb(hn, h, nb0, chunk_rows, 64 * slots, 1, sb_cols_waves(), t, sb_cols_gs());  // (the class stride of the row image: needed to choose the geometry)
+  if (!t.valid) return skip(t.why);
+  int nt = 0, nbt = 0;
+  if (!sb_rows_config(h.norb, slots, h.npanels * kIbPanel, t.rcs, &nt, &nbt)) return skip("no geometry of the rows kernel fits");
+  build_sb(hn, h, nb0, chunk_rows, nt, nbt, sb_cols_waves(), t, sb_cols_gs());
+  if (!t.valid) return skip(t.why);
+  std::unique_ptr<DevSb, void (*)(DevSb*)> q(new DevSb(), free_sb);
+  q->nb0 = t.nb0;
+  q->nloc = t.nloc;
+  q->amode = t.amode;
+  q->nbw_up = t.up.nbw;
+  q->nbw_dw = t.dw.nbw;
+  q->rows_nt = nt;
+  q->rows_nbt = nbt;
+  q->rimg_len = t.rimg_len;
+  q->rcs = t.rcs;
+  q->rows_lds = sb_rows_lds(t.up.nbw, t.rimg_len);
+  q->lowbits = t.lowbits;
+  q->nchunks = (int)t.chunk_row.size() - 1;
+  q->max_chunk_rows = t.max_chunk_rows;
+  q->max_chunk_slots = t.max_chunk_slots;
+  q->cols_gs = t.cols_gs;
+  q->cols_lds = sb_cols_lds(t.dw.nbw, t.nloc, t.max_chunk_rows, t.max_chunk_slots, t.cols_gs);
+  if (q->rows_lds > 158 * 1024 || q->cols_lds > 158 * 1024) return skip("tables larger than the LDS");
+  std::vector<uint32_t> rmap2(t.rmap.size() / 2);
+  for (size_t i = 0; i < rmap2.size(); i++) rmap2[i] = (uint32_t)t.rmap[2 * i] | ((uint32_t)t.rmap[2 * i + 1] << 16);
+  if (dev_upload(&q->urank, t.urank.data(), t.urank.size()) || dev_upload(&q->ublist, t.ublist.data(), t.ublist.size()) ||
+      dev_upload(&q->uslot, t.uslot.data(), t.uslot.size()) || dev_upload(&q->rmap2, rmap2.data(), rmap2.size()) ||
+      dev_upload(&q->up_vtab, t.up.vtab.data(), t.up.vtab.size()) || dev_upload(&q->up_tloc, t.up.tloc.data(), t.up.tloc.size()) ||
+      dev_upload(&q->e0, t.e0.data(), t.e0.size()) || dev_upload(&q->ebw, t.ebw.data(), t.ebw.size()) || dev_upload(&q->up_korb, t.up.korb.data(), t.up.korb.size()) ||
+      dev_upload(&q->chunk_row, t.chunk_row.data(), t.chunk_row.size()) ||
+      dev_upload(&q->chunk_slot, t.chunk_slot.data(), t.chunk_slot.size()) ||
+      dev_upload(&q->cdesc_off, t.cdesc_off.data(), t.cdesc_off.size()) || dev_upload(&q->cdesc, t.cdesc.data(), t.cdesc.size()) ||
+      dev_upload(&q->dw_vtab, t.dw.vtab.data(), t.dw.vtab.size()) || dev_upload(&q->dw_tloc, t.dw.tloc.data(), t.dw.tloc.size()) ||
+      dev_upload(&q->dw_korb, t.dw.korb.data(), t.dw.korb.size()) || dev_upload(&q->nd_dw, t.nd_dw.data(), t.nd_dw.size()))
+    return 1;
+  if (verbose)
+    fprintf(stderr, "edigpu: local-block tables: nb0 %d amode %d rows %d x %d cs %d (%d slots, %zu B LDS) cols low %d chunks %d (%zu B LDS)\n", t.nb0, t.amode,
+            nt, nbt, t.rcs, slots, q->rows_lds, t.lowbits, q->nchunks, q->cols_lds);
+  d->sb = q.release();
+  return 0;
 }
 
 // device copy of the impurity-block image; leaves s->ib null (and returns 0) when the sector is not of that form
@@ -525,7 +596,7 @@ static int setup_ib(edigpu_sector* s, const HostNormal& hn, int chunk_rows) {
     }
   }
   s->ib = d.release();
-  return 0;
+  return setup_sb(s->ib, hn, h, chunk_rows);
 }
 
 static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_t dw_first,
@@ -2074,7 +2145,7 @@ int edigpu_image_info(edigpu_handle s, int32_t image[6]) {
   image[2] = s->factored ? s->fac_nimp : 0;
   image[3] = s->panel_mode;
   image[4] = s->ib ? kIbPanel : (s->blk_shift ? (1 << s->blk_shift) : 0);
-  image[5] = s->ib ? s->ib->nhalf : 0;  // 1: impurity-block image, 2: with rows staged in halves
+  image[5] = s->ib ? (s->ib->sb ? 3 : s->ib->nhalf) : 0;  // 1: impurity-block image, 2: with rows staged in halves, 3: local-block tables
   return 0;
 }
 

@@ -89,7 +89,28 @@ struct IbDevHalf {  // rows kernel's tables of one half of a split row (host_ib.
   uint32_t* rmap2 = nullptr;
 };
 
+// local-block tables on the same vector layout (host_sb.hpp, kernels_sb.hip; round 4): when present, the product and
+// the fused Lanczos step of the impurity-block image run on these
+struct DevSb {
+  int nb0 = 0, nloc = 0, amode = 0, nbw_up = 0, nbw_dw = 0;
+  int rows_nt = 0, rows_nbt = 0, rimg_len = 0, rcs = 0;
+  size_t rows_lds = 0, cols_lds = 0;
+  uint16_t *urank = nullptr, *ublist = nullptr;
+  double* ebw = nullptr;
+  int32_t* uslot = nullptr;
+  uint32_t* rmap2 = nullptr;
+  double *up_vtab = nullptr, *up_tloc = nullptr, *e0 = nullptr;
+  uint32_t* up_korb = nullptr;
+  int lowbits = 0, nchunks = 0, max_chunk_rows = 0, max_chunk_slots = 0, cols_gs = 8;
+  int32_t *chunk_row = nullptr, *chunk_slot = nullptr, *cdesc_off = nullptr;
+  uint8_t* cdesc = nullptr;
+  double *dw_vtab = nullptr, *dw_tloc = nullptr;
+  uint32_t* dw_korb = nullptr;
+  uint32_t* nd_dw = nullptr;
+};
+
 struct IbDev {
+  DevSb* sb = nullptr;
   int nhalf = 1;                 // 2: rows longer than the LDS, staged one half (value of the top bath bit) at a time
   IbDevHalf half[2];
   uint16_t* urank_low = nullptr; // [2^(nb_up - 1)]

@@ -96,6 +96,16 @@ int vec_from_ib(const IbDev* ib, const double* src, double* dst, hipStream_t st)
 int launch_ib(const edigpu_sector* s, const double* v, double* hv, hipStream_t st);
 int launch_ib_lanczos(const edigpu_sector* s, const double* P, double* Q, double* X, const double* scal, double* partial,
                       int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial);
+// local-block kernels on the same layout (kernels_sb.hip, round 4); launch_ib / launch_ib_lanczos take them when IbDev::sb is set
+int launch_sb(const edigpu_sector* s, const double* v, double* hv, hipStream_t st);
+int launch_sb_lanczos(const edigpu_sector* s, const double* P, double* Q, double* X, const double* scal, double* partial,
+                      int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial);
+int sb_nb0(int norb);
+int sb_cols_waves();
+int sb_cols_gs();
+size_t sb_rows_lds(int nbw, int rimg_len);
+size_t sb_cols_lds(int nbw, int nloc, int max_chunk_rows, int max_chunk_slots, int gs);
+bool sb_rows_config(int norb, int slots, int plen, int cs, int* nt_out, int* nbt_out);
 size_t ib_rows_lds_bytes(int nb, int rimg_len);
 size_t ib_cols_lds_bytes(int nb, int max_chunk_rows, int max_chunk_blocks);
 bool ib_rows_config(int norb, int nb, int nlist, int plen, int rimg_len, int* nt_out, int* nbt_out, bool split = false);

@@ -997,6 +997,7 @@ static int launch_ib_cols(const IbDev* d, const IbArgs& a, bool alpha, const dou
 
 // plain product on vectors in the padded panel layout
 int launch_ib(const edigpu_sector* s, const double* v, double* hv, hipStream_t st) {
+  if (s->ib->sb) return launch_sb(s, v, hv, st);
   IbArgs a;
   if (s->ib->nhalf == 2) {
     // rows longer than the LDS: one launch per half of the row (each reads the other half's words for the top level)
@@ -1017,6 +1018,7 @@ int launch_ib(const edigpu_sector* s, const double* v, double* hv, hipStream_t s
 // the caller then takes X as the new P and the old P as the next X).
 int launch_ib_lanczos(const edigpu_sector* s, const double* P, double* Q, double* X, const double* scal, double* partial,
                       int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial) {
+  if (s->ib->sb) return launch_sb_lanczos(s, P, Q, X, scal, partial, partial_cap, first, lazy_axpy, st, npartial);
   IbArgs a;
   fill_ib_args(s->ib, a);
   a.scal = scal;

@@ -1,0 +1,15 @@
+// kernels_sb1.hip -- the local-block kernels (kernels_sb_impl.hpp) for 1 impurity level(s) per species, 4 low bath
+// levels folded into the blocks (5 local levels).  One translation unit per orbital count: they compile in parallel.
+#include "kernels_sb_impl.hpp"
+
+namespace edigpu {
+
+int sb_rows_1(const IbDev* d, const SbArgs& a, int fuse, const double* P, double* Q, double* X, hipStream_t st) {
+  return sb_launch_rows<1, 4, 0>(d, a, fuse, P, Q, X, st);
+}
+
+int sb_cols_1(const IbDev* d, const SbArgs& a, bool alpha, const double* v, double* hv, hipStream_t st, int* nblocks) {
+  return sb_launch_cols<1, 4, 0>(d, a, alpha, v, hv, st, nblocks);
+}
+
+}  // namespace edigpu

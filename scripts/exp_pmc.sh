@@ -18,7 +18,7 @@ import csv,sys,collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     k=r['Kernel_Name']
-    if 'panel' in k or 'tile' in k or 'rows_kernel' in k or 'ib_' in k:
+    if 'panel' in k or 'tile' in k or 'rows_kernel' in k or 'ib_' in k or 'sb_' in k:
         acc[k[:48]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k,d in acc.items():
     print("  ",k, "  ".join("%s=%.4g" % (c, sum(v)/len(v)) for c,v in d.items()))
