@@ -129,58 +129,42 @@ __global__ void __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) sb_rows_kernel
   double2 pre[NLD];  // the next row on its way in (FUSE: Q)
   double2 pin[FUSE ? NLD : 1];
   int64_t gkeep = 0;  // (see the row loop: the prefetch's address register must stay untouched while the loads fly)
-  // f(piece index) for the pieces this thread moves: the first nfull of every thread (a uniform test), then one more of the
-  // threads below the tail -- one lane mask instead of one per piece
-  const int nfull = plen2 / NT;
-  const bool tail = tid < plen2 - nfull * NT;
-  auto pieces = [&](auto&& f) {
-    sb::sfor<0, NLD>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      if (tid + i * NT < plen2) f(I);
-    });
-  };
-  (void)nfull;
-  (void)tail;
-  // the pieces of row r: what (FUSE: Q) into pre, and with FUSE P into pin
-  // (the pieces [0, NE) are requested before the block updates, the others after them: see NE in the row loop)
-  auto issue = [&](int64_t r, auto LO, auto HI) {
+  // the pieces of row r: what (FUSE: Q) into pre; with FUSE P into pin
+  auto issue = [&](int64_t r) {
     const int64_t g0 = base_of(r);
     gkeep = g0;
-    pieces([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      if constexpr (i >= decltype(LO)::value && i < decltype(HI)::value)
-        pre[i] = *reinterpret_cast<const double2*>((FUSE ? Q : P) + g0 + i * pstride);
-    });
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using IN = std::integral_constant<int, NLD>;
-  auto issue_pin = [&](int64_t r) {
-    const int64_t g0 = base_of(r);
-    pieces([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      if constexpr (FUSE) pin[i] = *reinterpret_cast<const double2*>(P + g0 + i * pstride);
-    });
+#pragma unroll
+    for (int i = 0; i < NLD; i++) {
+      if (tid + i * NT < plen2) {
+        if (FUSE) {
+          pre[i] = *reinterpret_cast<const double2*>(Q + g0 + i * pstride);
+          pin[i] = *reinterpret_cast<const double2*>(P + g0 + i * pstride);
+        } else {
+          pre[i] = *reinterpret_cast<const double2*>(P + g0 + i * pstride);
+        }
+      }
+    }
   };
   // loaded pieces -> image (FUSE: x = (Q - alpha P) / beta, X <- x)
   auto land = [&](int64_t r, const uint32_t* mp) {
     const int64_t g0 = base_of(r);
-    pieces([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      double2 x = pre[i];
-      if constexpr (FUSE) {
-        x.x = (x.x - alpha * pin[i].x) * ibeta;
-        x.y = (x.y - alpha * pin[i].y) * ibeta;
-        *reinterpret_cast<double2*>(X + g0 + i * pstride) = x;
+#pragma unroll
+    for (int i = 0; i < NLD; i++) {
+      if (tid + i * NT < plen2) {
+        double2 x = pre[i];
+        if (FUSE) {
+          x.x = (x.x - alpha * pin[i].x) * ibeta;
+          x.y = (x.y - alpha * pin[i].y) * ibeta;
+          *reinterpret_cast<double2*>(X + g0 + i * pstride) = x;
+        }
+        row[mp[i] & 0xFFFFu] = x.x;
+        row[mp[i] >> 16] = x.y;
       }
-      row[mp[i] & 0xFFFFu] = x.x;
-      row[mp[i] >> 16] = x.y;
-    });
+    }
   };
   auto load_map = [&](uint32_t* mp) {
-    pieces([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      mp[i] = a.rmap2[tid + i * NT];
-    });
+#pragma unroll
+    for (int i = 0; i < NLD; i++) mp[i] = tid + i * NT < plen2 ? a.rmap2[tid + i * NT] : 0u;
   };
   int64_t r = blockIdx.x;
   if (r >= dd) return;
@@ -188,8 +172,7 @@ __global__ void __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) sb_rows_kernel
   {
     uint32_t mp[NLD];
     load_map(mp);
-    issue(r, I0{}, IN{});
-    issue_pin(r);
+    issue(r);
     land(r, mp);
   }
   __syncthreads();
@@ -201,12 +184,8 @@ __global__ void __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) sb_rows_kernel
     const bool more = rn < dd;
     const long long t0 = now();
     asm volatile("v_mov_b32 %0, 0" : "=v"(zt));
-    // pieces of the next row (FUSE: of its Q) in flight during the block updates: as many as the registers hold beside the
-    // accumulators without spilling (a spill in the updates costs more than it saves: scratch and global loads share one
-    // in-order counter, so a reload waits for the whole prefetch)
-    constexpr int NE = (NT > 768 || FUSE) ? 0 : NT == 768 ? NLD - SB_V_LATE : NLD;
-    using INE = std::integral_constant<int, NE>;
-    if (NE > 0 && more) issue(rn, I0{}, INE{});
+    constexpr bool EARLY = !FUSE && NT <= 768;  // registers for the next row beside the accumulators
+    if (EARLY && more) issue(rn);  // in flight during the block updates
     // an opaque zero, new in every iteration: added to the block indices below so that the per-(slot, class) addresses are
     // recomputed where they are used (one add) instead of being hoisted out of the row loop into registers
     int zr, zs;
@@ -246,13 +225,12 @@ __global__ void __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) sb_rows_kernel
     uint32_t mp[NLD];
     load_map(mp);
     double2 pold[FUSE ? NLD : 1];
-    if (NE < NLD && more) issue(rn, INE{}, IN{});
-    if constexpr (FUSE) {
+    if (!EARLY && more) issue(rn);
+    if (FUSE) {
       const int64_t g0 = base_of(r);
-      pieces([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        pold[i] = *reinterpret_cast<const double2*>(P + g0 + i * pstride);
-      });
+#pragma unroll
+      for (int i = 0; i < NLD; i++)
+        if (tid + i * NT < plen2) pold[i] = *reinterpret_cast<const double2*>(P + g0 + i * pstride);
     }
     const long long t3 = now();
     __syncthreads();
@@ -260,19 +238,20 @@ __global__ void __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) sb_rows_kernel
     // the result leaves coalesced, the next row takes its place
     {
       const int64_t g0 = base_of(r);
-      pieces([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        double2 o;
-        o.x = row[mp[i] & 0xFFFFu];
-        o.y = row[mp[i] >> 16];
-        if constexpr (FUSE) {
-          o.x -= beta * pold[i].x;
-          o.y -= beta * pold[i].y;
+#pragma unroll
+      for (int i = 0; i < NLD; i++) {
+        if (tid + i * NT < plen2) {
+          double2 o;
+          o.x = row[mp[i] & 0xFFFFu];
+          o.y = row[mp[i] >> 16];
+          if (FUSE) {
+            o.x -= beta * pold[i].x;
+            o.y -= beta * pold[i].y;
+          }
+          *reinterpret_cast<double2*>(Q + g0 + i * pstride) = o;
         }
-        *reinterpret_cast<double2*>(Q + g0 + i * pstride) = o;
-      });
+      }
     }
-    if (FUSE && more) issue_pin(rn);  // (after the result has left: beside P_old's pieces they do not fit the registers)
     if (more) land(rn, mp);
     const long long t5 = now();
     __syncthreads();
