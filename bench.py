@@ -188,7 +188,10 @@ def run_single(args):
                      "traffic_frac": (traffic / (ms_hv * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "measured_ceiling_GBs": {"read": rd, "copy": cp, "triad": tr,
                                               "note": "streaming kernels on 1 GiB buffers, this device, this run"},
-                     "kernel": {0: ("ib_rows_kernel + ib_cols_kernel (impurity-block image, padded 16-column panels)"
+                     "kernel": {0: ("sb_rows_kernel + sb_cols_kernel (local blocks of 5 levels on padded 16-column panels; the fused "
+                                    "step of `value` runs ib_rows_kernel + ib_cols_kernel on the same vectors)"
+                                    if h.kind == 0 and h.image_info()[5] == 3 else
+                                    "ib_rows_kernel + ib_cols_kernel (impurity-block image, padded 16-column panels)"
                                     if h.kind == 0 and h.image_info()[5] == 1 else
                                     "ib_rows_kernel x 2 (rows staged in halves) + ib_cols_kernel (impurity-block image)"
                                     if h.kind == 0 and h.image_info()[5] == 2 else
@@ -197,11 +200,13 @@ def run_single(args):
                                 2: "direct_rows_kernel"}[h.kind],
                      "algorithmic_bytes_per_launch": bytes_hv, "ms_per_launch": ms_hv},
     }
-    if h.kind != 0:
-        # superc / nonsu2: the device image (SELL-64 + value dictionary, or nothing at all on the fly) moves a fraction
-        # of the bytes the reference's CSR format holds, so the algorithmic figure overstates the use of the memory
-        # system (it can exceed the peak).  roofline.frac is therefore the COUNTER-based fraction where a counter pass
-        # of this build exists (null otherwise); the algorithmic one stays as frac_reference_format.
+    if h.kind == 1:
+        # superc / nonsu2 STORED: the device image (SELL-64 + value dictionary) moves a fraction of the bytes the
+        # reference's CSR format holds, so the algorithmic figure overstates the use of the memory system (it can exceed
+        # the peak).  roofline.frac is therefore the COUNTER-based fraction where a counter pass of this build exists
+        # (null otherwise); the algorithmic one stays as frac_reference_format.  On the fly (kind 2) the kernel fetches
+        # MORE than the algorithmic bytes (scattered gathers): there frac stays the algorithmic fraction -- a fraction
+        # that rises when a kernel wastes traffic is not a roofline fraction -- and traffic_frac stands beside it.
         r = out["roofline"]
         r["frac_reference_format"] = r["frac"]
         r["frac"] = r["traffic_frac"]
@@ -347,6 +352,41 @@ def run_multi(args):
     dist.destroy_process_group()
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh processes, one rank per GPU, with the environment
+    torch.distributed.run would give them, forward rank 0's JSON line and return the worst exit code.  This process has
+    not touched the GPU (nothing above imports torch or loads libedigpu.so), and the children are new interpreters: no
+    exec of a process that holds a HIP context."""
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket() as sk:            # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr.fileno()))
+    out0, _ = procs[0].communicate()
+    worst = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=600 if worst == 0 else 20)
+        except subprocess.TimeoutExpired:
+            p.kill()          # (the exact process started above)
+            p.wait()
+        worst = worst or p.returncode
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif worst == 0:
+        worst = 1
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -362,12 +402,13 @@ def main():
     args = ap.parse_args()
     # EDIGPU_FORCE_MULTI=1: take the N > 1 code path with a single rank (RCCL world of one; with
     # EDIGPU_FORCE_COLLECTIVES=1 the collectives are issued too) -- a one-GPU rehearsal of the nccl calls
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        # a scaling script that forgets the launcher must not record one-GPU numbers as N-GPU ones
-        sys.exit(f"bench.py: --gpus {args.gpus} needs one rank per GPU (WORLD_SIZE={world}): launch it as\n"
-                 f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
-                 f"--master-port 29533 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
+        # a launcher that started a different number of ranks must not record its numbers as N-GPU ones
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (or none: bench.py then "
+                 f"starts its own)")
     if args.gpus > 1 or world > 1 or os.environ.get("EDIGPU_FORCE_MULTI"):
         run_multi(args)
     else:

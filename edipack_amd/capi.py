@@ -133,6 +133,8 @@ SIGNATURES = {
     "edigpu_dev_upload": (C.c_int, [_vp, _vp, _i64]),
     "edigpu_dev_download": (C.c_int, [_vp, _vp, _i64]),
     "edigpu_shard_plan": (C.c_int, [_i64, C.c_int32, C.c_int32, _pi64, _pi64, _pi64]),
+    "edigpu_exchange_send_map": (C.c_int, [_i64, _i64, _i64, C.c_int32, _i64, C.c_int32, _pi64]),
+    "edigpu_exchange_back_map": (C.c_int, [_i64, _i64, _i64, C.c_int32, _i64, C.c_int32, _pi64]),
     "edigpu_comm_unique_id": (C.c_int, [_vp]),
     "edigpu_comm_create": (C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int32, _vp]),
     "edigpu_comm_create_shm": (C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int32, C.c_char_p, _i64]),

@@ -33,6 +33,7 @@
 
 #include <rccl/rccl.h>
 
+#include "exchange_index.hpp"
 #include "kernels.hpp"
 
 namespace edigpu {
@@ -350,14 +351,12 @@ __global__ void __launch_bounds__(kShNT)
                 double* __restrict__ vout, const double* __restrict__ tmp, const double* __restrict__ back,
                 const double* __restrict__ tprev, double* __restrict__ partial) {
   const double sg = tprev ? tprev[0] : 0.0;
-  const int64_t pw = pcol + 2 * halo;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   for (int64_t e = (int64_t)blockIdx.x * kShNT + threadIdx.x; e < n; e += (int64_t)gridDim.x * kShNT) {
     double w = vout[e] + tmp[e];
     if (back) {
       const int64_t i = e / dim_up, col = e - i * dim_up;
-      const int64_t c = col / pcol, j = col - c * pcol;
-      w += back[(c * q + i) * pw + halo + j];
+      w += back[xch_back_slot(i, col, q, pcol, halo)];
     }
     vout[e] = w;
     const double v = vin[e], d = w - sg * v;
@@ -395,7 +394,6 @@ __global__ void __launch_bounds__(kShNT)
   double a = 0.0, b = 1.0;
   if (!first) ab_from_sums(t, tprev, a, b);
   const double ib = 1.0 / b;
-  const int64_t pw = pcol + 2 * halo;
   for (int64_t e = (int64_t)blockIdx.x * kShNT + threadIdx.x; e < n; e += (int64_t)gridDim.x * kShNT) {
     double x = vin[e];
     if (!first) {
@@ -406,9 +404,9 @@ __global__ void __launch_bounds__(kShNT)
     }
     if (send) {
       const int64_t i = e / dim_up, col = e - i * dim_up;
-      int64_t clo = col >= halo ? (col - halo) / pcol : 0, chi = (col + halo) / pcol;
-      if (chi > world - 1) chi = world - 1;
-      for (int64_t c = clo; c <= chi; c++) send[(c * q + i) * pw + (col - c * pcol + halo)] = x;
+      int64_t clo, chi;
+      xch_blocks_of(col, pcol, halo, world, clo, chi);
+      for (int64_t c = clo; c <= chi; c++) send[xch_send_slot(c, i, col, q, pcol, halo)] = x;
     }
   }
 }
@@ -713,6 +711,28 @@ int edigpu_shard_plan(int64_t units, int32_t world, int32_t rank, int64_t* first
   if (first) *first = f;
   if (count) *count = std::max<int64_t>(0, std::min<int64_t>(qq, units - f));
   if (q) *q = qq;
+  return 0;
+}
+
+// Host-only (no GPU is touched): the index arithmetic of the transposed exchange as the kernels use it
+// (exchange_index.hpp), for hosts that stage the exchange themselves and for the CPU suite.
+int edigpu_exchange_send_map(int64_t dim_up, int64_t nrows, int64_t q, int32_t world, int64_t pcol, int32_t halo, int64_t* src) {
+  if (!src || dim_up < 1 || nrows < 0 || q < nrows || world < 1 || pcol < 1 || halo < 0) {
+    set_error("edigpu_exchange_send_map: bad argument");
+    return 1;
+  }
+  const int64_t n = (int64_t)world * q * (pcol + 2 * halo);
+  for (int64_t e = 0; e < n; e++) src[e] = xch_send_source(e, dim_up, nrows, q, pcol, halo);
+  return 0;
+}
+
+int edigpu_exchange_back_map(int64_t dim_up, int64_t nrows, int64_t q, int32_t world, int64_t pcol, int32_t halo, int64_t* slot) {
+  if (!slot || dim_up < 1 || nrows < 0 || q < nrows || world < 1 || pcol < 1 || halo < 0 || pcol * world < dim_up) {
+    set_error("edigpu_exchange_back_map: bad argument");
+    return 1;
+  }
+  for (int64_t i = 0; i < nrows; i++)
+    for (int64_t col = 0; col < dim_up; col++) slot[i * dim_up + col] = xch_back_slot(i, col, q, pcol, halo);
   return 0;
 }
 

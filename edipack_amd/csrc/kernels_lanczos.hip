@@ -11,6 +11,7 @@
 //
 // Reductions are deterministic: a fixed grid writes one partial per workgroup
 // (wave shuffle + LDS), a single-workgroup kernel adds the partials in order.
+#include "exchange_index.hpp"
 #include "kernels.hpp"
 #include "lz_finalize.hpp"
 
@@ -452,7 +453,7 @@ __global__ void __launch_bounds__(kLzNT)
     b = sqrt(ab[1] - a * a);
     ib = 1.0 / b;
   }
-  const int64_t pw = pcol + 2 * halo, n = nrows * dim_up;
+  const int64_t n = nrows * dim_up;
   for (int64_t e = (int64_t)blockIdx.x * kLzNT + threadIdx.x; e < n; e += (int64_t)gridDim.x * kLzNT) {
     const int64_t i = e / dim_up, col = e - i * dim_up;
     double x = vin[e];
@@ -462,9 +463,9 @@ __global__ void __launch_bounds__(kLzNT)
       vin[e] = x;
       vout[e] = -b * t;
     }
-    int64_t clo = col >= halo ? (col - halo) / pcol : 0, chi = (col + halo) / pcol;
-    if (chi > world - 1) chi = world - 1;
-    for (int64_t c = clo; c <= chi; c++) send[(c * q + i) * pw + (col - c * pcol + halo)] = x;
+    int64_t clo, chi;
+    xch_blocks_of(col, pcol, halo, world, clo, chi);
+    for (int64_t c = clo; c <= chi; c++) send[xch_send_slot(c, i, col, q, pcol, halo)] = x;
   }
 }
 
@@ -473,12 +474,11 @@ __global__ void __launch_bounds__(kLzNT)
     kv_unpack_add_dot2(int64_t dim_up, int64_t nrows, int64_t q, int64_t pcol, int halo,
                        const double* __restrict__ vin, double* __restrict__ vout, const double* __restrict__ tmp,
                        const double* __restrict__ back, double* __restrict__ partial) {
-  const int64_t pw = pcol + 2 * halo, n = nrows * dim_up;
+  const int64_t n = nrows * dim_up;
   double s = 0.0, qq = 0.0;
   for (int64_t e = (int64_t)blockIdx.x * kLzNT + threadIdx.x; e < n; e += (int64_t)gridDim.x * kLzNT) {
     const int64_t i = e / dim_up, col = e - i * dim_up;
-    const int64_t c = col / pcol, j = col - c * pcol;
-    const double w = vout[e] + tmp[e] + back[(c * q + i) * pw + halo + j];
+    const double w = vout[e] + tmp[e] + back[xch_back_slot(i, col, q, pcol, halo)];
     vout[e] = w;
     s += vin[e] * w;
     qq += w * w;

@@ -9,6 +9,7 @@
 //     up  : dst[jdw][jup] = sgn(jup) * src[jdw][part(jup)]
 //     down: dst[jdw][jup] = sgn(jdw) * src[part(jdw)][jup]
 // part = index in the source sector | sign << 31, 0xFFFFFFFF = no preimage (host table, O(DimUp|DimDw)).
+#include "exchange_index.hpp"
 #include "kernels.hpp"
 
 namespace edigpu {
@@ -169,9 +170,8 @@ __global__ void __launch_bounds__(256)
   const int64_t pw = pcol + 2 * halo;
   const int64_t n = (int64_t)world * q * pw;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    const int64_t j = e % pw, i = (e / pw) % q, c = e / (pw * q);
-    const int64_t col = c * pcol - halo + j;
-    send[e] = (i < nrows && col >= 0 && col < dim_up) ? v[i * dim_up + col] : 0.0;
+    const int64_t src = xch_send_source(e, dim_up, nrows, q, pcol, halo);
+    send[e] = src >= 0 ? v[src] : 0.0;
   }
 }
 
@@ -179,12 +179,10 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     transpose_unpack_add_kernel(int64_t dim_up, int64_t nrows, int64_t q, int64_t pcol, int halo,
                                 const double* __restrict__ recv, double* __restrict__ hv) {
-  const int64_t pw = pcol + 2 * halo;
   const int64_t n = nrows * dim_up;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
     const int64_t i = e / dim_up, col = e - i * dim_up;
-    const int64_t c = col / pcol, j = col - c * pcol;
-    hv[e] += recv[(c * q + i) * pw + halo + j];
+    hv[e] += recv[xch_back_slot(i, col, q, pcol, halo)];
   }
 }
 

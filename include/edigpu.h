@@ -490,6 +490,17 @@ int edigpu_vec_add_dot2(int64_t n, const double *vin_dev, double *vout_dev, cons
 typedef struct edigpu_comm_s *edigpu_comm;
 #define EDIGPU_UNIQUE_ID_BYTES 128
 int edigpu_shard_plan(int64_t units, int32_t world, int32_t rank, int64_t *first, int64_t *count, int64_t *q);
+/* Host-only (no GPU needed): the index maps of the transposed exchange of normal mode exactly as the library's kernels
+ * compute them (reference: vector_transpose_MPI, ED_NORMAL/ED_HAMILTONIAN_NORMAL_COMMON.f90:66-167).
+ *   send_map: src[e], e < world*q*(pcol+2*halo) = element i*dim_up+col of the rank's row shard that send slot e
+ *             carries, or -1 for a zero (rows past nrows, columns outside the sector)
+ *   back_map: slot[i*dim_up+col] = where the column half of H*v for that element sits in the buffer the second
+ *             all-to-all delivers
+ * For hosts that stage the exchange themselves; the CPU test suite exchanges through them between gloo ranks. */
+int edigpu_exchange_send_map(int64_t dim_up, int64_t nrows, int64_t q, int32_t world, int64_t pcol, int32_t halo,
+                             int64_t *src);
+int edigpu_exchange_back_map(int64_t dim_up, int64_t nrows, int64_t q, int32_t world, int64_t pcol, int32_t halo,
+                             int64_t *slot);
 int edigpu_comm_unique_id(void *id128);
 /* id128 may be NULL when world == 1 (no RCCL communicator is made then) */
 int edigpu_comm_create(edigpu_comm *c, int32_t rank, int32_t world, const void *id128);

@@ -21,7 +21,8 @@ def main():
     import torch
     from edipack_amd import capi
     from edipack_amd.hamiltonian import SectorHamiltonian
-    from edipack_amd.sharding import ShardPlan, TransposedKernels, TransposedLanczos
+    from edipack_amd.sharding import ShardPlan
+    from tests.torch_sharded_loop import TransposedKernels, TransposedLanczos
     from edipack_amd.synthetic import WORKLOADS, synthetic_model
     capi.init(0)
     w = WORKLOADS[args.workload]

@@ -592,7 +592,7 @@ def test_golden_replica_general_energy_on_gpu(gpu, name):
 def test_sharded_lanczos_gpu_world1(gpu, mode, bath, norb, nbath, sec):
     import torch
     O = _oracle()
-    from edipack_amd.sharding import gpu_sharded_hamiltonian
+    from tests.torch_sharded_loop import gpu_sharded_hamiltonian
     om, pm = make_models(mode, bath, norb, nbath, seed=51)
     ho = O.HNormal(om, *sec) if mode == "normal" else O.HFlat(om, sec)
     plan, h, lz = gpu_sharded_hamiltonian(pm, sec, world=1, rank=0)
@@ -658,7 +658,7 @@ def test_direct_two_shards(gpu):
 def test_vec_kernels_match_torch(gpu, n):
     """edigpu_vec_* (sharded-loop vector kernels) against the torch formulation of the same updates."""
     import torch
-    from edipack_amd.sharding import NativeVecOps, TorchVecOps
+    from tests.torch_sharded_loop import NativeVecOps, TorchVecOps
     g = torch.Generator().manual_seed(n)
     vin0 = torch.randn(n, dtype=torch.float64, generator=g).cuda()
     vout0 = torch.randn(n, dtype=torch.float64, generator=g).cuda()
@@ -1322,7 +1322,7 @@ def _transposed_rank(rank, world, port, q, exact):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from edipack_amd import capi
-        from edipack_amd.sharding import gpu_transposed_hamiltonian
+        from tests.torch_sharded_loop import gpu_transposed_hamiltonian
         from oracle import oracle as O
         capi.init(0)
         torch.cuda.set_device(0)

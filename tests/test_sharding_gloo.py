@@ -1,10 +1,13 @@
-"""CPU tests of the multi-GPU host logic with world_size=2 over gloo: the shard plan, the
-all-gather exchange with padded equal chunks, the local/remote split of H*v and the sharded
-three-term recurrence (edipack_amd/sharding.py) reproduce the serial oracle.
+"""CPU tests of the multi-GPU host logic with world_size 2 and 3 over gloo: the shard plan (edigpu_shard_plan), the index
+maps of the transposed exchange AS THE LIBRARY'S KERNELS COMPUTE THEM (edigpu_exchange_send_map / _back_map: the same
+inline functions, csrc/exchange_index.hpp, that transpose_pack_kernel, ks_rotate3 and the unpack kernels call), the
+all-gather exchange with padded equal chunks, the local/remote split of H*v and the sharded three-term recurrence
+reproduce the serial oracle.
 
-The per-shard products are computed here with scipy on the ORACLE's matrices (test
-infrastructure standing in for the HIP kernels, which need a GPU); what is under test is the
-distributed data flow that replaces spMatVec_mpi_* / MPI_Allgatherv in the reference."""
+The per-shard products are computed here with scipy on the ORACLE's matrices (test infrastructure standing in for the
+HIP kernels, which need a GPU); what is under test is the distributed data flow that replaces spMatVec_mpi_* /
+vector_transpose_MPI / MPI_Allgatherv in the reference.  The loops that drive it (tests/torch_sharded_loop.py) are the
+torch-level second implementation; the buffers they exchange are packed and unpacked through the library's maps."""
 import os
 import socket
 
@@ -15,7 +18,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from edipack_amd.sharding import ShardedLanczos, ShardPlan, TransposedLanczos
+from edipack_amd.sharding import ShardPlan
+from tests.torch_sharded_loop import ShardedLanczos, TransposedLanczos
 from tests.common import make_models
 
 
@@ -25,9 +29,31 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _lib():
+    """libedigpu.so without a GPU: only its host-only entry points are called here."""
+    import ctypes as C
+    from edipack_amd import capi
+    return capi.lib(), C
+
+
+def _exchange_maps(dim_up, nrows, q, world, pcol, halo):
+    L, C = _lib()
+    send = np.empty(world * q * (pcol + 2 * halo), dtype=np.int64)
+    back = np.empty(nrows * dim_up, dtype=np.int64)
+    p64 = C.POINTER(C.c_int64)
+    assert L.edigpu_exchange_send_map(dim_up, nrows, q, world, pcol, halo, send.ctypes.data_as(p64)) == 0
+    assert L.edigpu_exchange_back_map(dim_up, nrows, q, world, pcol, halo, back.ctypes.data_as(p64)) == 0
+    return send, back
+
+
 def test_shard_plan_covers_everything():
+    L, C = _lib()
     for units, ulen, world in [(3432, 3432, 8), (20, 15, 2), (5, 7, 8), (924, 1, 3), (1, 1, 4)]:
         plans = [ShardPlan(units, ulen, world, r) for r in range(world)]
+        for r, p in enumerate(plans):      # the Python mirror == the library's plan
+            f, c, q = C.c_int64(), C.c_int64(), C.c_int64()
+            assert L.edigpu_shard_plan(units, world, r, C.byref(f), C.byref(c), C.byref(q)) == 0
+            assert (f.value, c.value, q.value) == (p.first, p.count, p.q)
         assert sum(p.count for p in plans) == units
         for r, p in enumerate(plans):
             assert p.first == min(r * p.q, units)
@@ -123,17 +149,17 @@ class _OracleTransposeKernels:
         # Hnd reaches a column at most `halo` away (impurity-level moves inside one bath configuration)
         self.halo = int(np.max(np.abs(nd.row % h.dimup - nd.col % h.dimup))) if nd.nnz else 0
 
+    def _maps(self, lz):
+        if getattr(self, "_m", None) is None:
+            self._m = _exchange_maps(self.dim_up, self.plan.count, self.plan.q, self.plan.world, lz.pcol, lz.halo)
+        return self._m
+
     def pack(self, lz, vin, send):
-        pl, du = self.plan, self.dim_up
-        v = np.zeros((pl.q, du))
-        v[:pl.count] = vin.numpy()[:pl.nloc].reshape(pl.count, du)
-        s = send.numpy().reshape(pl.world, pl.q, lz.pw)
-        s[:] = 0.0
-        for c in range(pl.world):
-            lo, hi = c * lz.pcol - lz.halo, (c + 1) * lz.pcol + lz.halo
-            a, b = max(lo, 0), min(hi, du)
-            if b > a:
-                s[c, :, a - lo:b - lo] = v[:, a:b]
+        # through the library's send map (what transpose_pack_kernel / ks_rotate3 compute on the device)
+        src, _ = self._maps(lz)
+        v = vin.numpy()[:self.plan.nloc]
+        s = send.numpy()
+        s[:src.size] = np.where(src >= 0, v[np.maximum(src, 0)], 0.0)
 
     def rows(self, lz, vin, out):
         pl, du = self.plan, self.dim_up
@@ -154,13 +180,9 @@ class _OracleTransposeKernels:
         np.add.at(o, (idw[m], iu[m] - cf + hl), self.nd_v[m] * w[jdw[m], ju[m] - cf + hl])
 
     def unpack_add(self, lz, back, out):
-        pl, du = self.plan, self.dim_up
-        b = back.numpy().reshape(pl.world, pl.q, lz.pw)
-        res = out.numpy()[:pl.nloc].reshape(pl.count, du)
-        for c in range(pl.world):
-            a, e = c * lz.pcol, min((c + 1) * lz.pcol, du)
-            if e > a:
-                res[:, a:e] += b[c, :pl.count, lz.halo:lz.halo + e - a]
+        # through the library's back map (transpose_unpack_add_kernel / kv_unpack_add_dot2 / ks_unpack...)
+        _, slot = self._maps(lz)
+        out.numpy()[:self.plan.nloc] += back.numpy()[slot]
 
 
 class _OracleTransposeKernelsFused(_OracleTransposeKernels):
@@ -221,3 +243,56 @@ def test_transposed_lanczos_gloo(world, fused):
     for rank, err, n, n_ref, halo, xb in res:
         assert n == n_ref == 40 and halo > 0 and xb > 0
         assert err < 1e-10, f"rank {rank}: alpha/beta deviate from the serial oracle by {err}"
+
+
+def _worker_maps(rank, world, port, q, dim_up, dim_dw, halo):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan = ShardPlan(dim_dw, dim_up, world, rank)
+        pcol = -(-dim_up // world)
+        pw = pcol + 2 * halo
+        v = np.random.default_rng(99).standard_normal((dim_dw, dim_up))            # the whole vector, on every rank
+        mine = v[plan.first:plan.first + plan.count].reshape(-1)
+        src, slot = _exchange_maps(dim_up, plan.count, plan.q, world, pcol, halo)
+        send = torch.from_numpy(np.where(src >= 0, mine[np.maximum(src, 0)] if mine.size else 0.0, 0.0).copy())
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send)                                         # equal splits of q * pw
+        # what vector_transpose_MPI delivers (ED_HAMILTONIAN_NORMAL_COMMON.f90:66-167): ALL rows of this rank's block of
+        # columns -- here with `halo` columns on both sides, zeros outside the sector and in the tail ranks' padding
+        got = recv.numpy().reshape(world * plan.q, pw)
+        want = np.zeros((world * plan.q, pw))
+        lo = rank * pcol - halo
+        for j in range(pw):
+            col = lo + j
+            if 0 <= col < dim_up:
+                for r in range(world):
+                    pr = ShardPlan(dim_dw, dim_up, world, r)
+                    want[r * plan.q:r * plan.q + pr.count, j] = v[pr.first:pr.first + pr.count, col]
+        err = float(np.max(np.abs(got - want)))
+        # the way back: every rank returns its block unchanged; the back map must pick exactly the own elements
+        back = torch.empty_like(recv)
+        dist.all_to_all_single(back, recv)
+        err2 = float(np.max(np.abs(back.numpy()[slot] - mine))) if mine.size else 0.0
+        q.put((rank, err, err2))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dim_up,dim_dw,halo", [(2, 20, 15, 2), (3, 35, 20, 3), (3, 7, 5, 0), (2, 9, 3, 1)])
+def test_library_exchange_maps_transpose_between_gloo_ranks(world, dim_up, dim_dw, halo):
+    """The library's own index maps (host-only entry points) move a row-sharded vector to column blocks and back between
+    real processes: the received buffer is the transposed shard vector_transpose_MPI produces."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_maps, args=(r, world, port, q, dim_up, dim_dw, halo)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, err2 in res:
+        assert err == 0.0 and err2 == 0.0, (rank, err, err2)
