@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace edigpu {
 
@@ -131,7 +132,12 @@ void build_sb(const HostNormal& hn, const HostIb& ib, int nb0, int max_chunk_row
   std::string e = build_side(hn, 0, hn.bup, hn.nup, nloc, out.up);
   if (e.empty()) e = build_side(hn, 1, hn.bdw, hn.ndw, nloc, out.dw);
   if (!e.empty()) return fail(e);
-  out.amode = (norb > 1 && out.up.single && out.dw.single) ? 1 : 0;
+  // The per-orbital walk (AMODE 1) issues only the multiply-adds of the orbital a level belongs to, but the lanes of a wave
+  // then walk unequal numbers of levels per orbital and wait for the longest: measured on config 2 (two orbitals, six levels
+  // each) 138 us per product against 126 with the all-orbital walk, whose extra multiply-adds (by amplitudes that are zero)
+  // are cheaper than the extra LDS round trips.  On request only: EDIGPU_SB_AMODE=1.
+  out.amode = 0;
+  if (const char* e = getenv("EDIGPU_SB_AMODE")) out.amode = (atoi(e) != 0 && norb > 1 && out.up.single && out.dw.single) ? 1 : 0;
   const int64_t du = hn.dim_up, dd = hn.dim_dw;
   const uint32_t lmask = (1u << nloc) - 1u, impmask = (1u << norb) - 1u;
   const size_t nw = (size_t)1 << nbw;

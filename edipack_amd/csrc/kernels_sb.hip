@@ -17,7 +17,7 @@ int sb_nb0(int norb) { return norb >= 1 && norb <= 3 ? 5 - norb : 0; }
 // columns kernel: blocks per wave-slot (8: two columns per lane, 256 threads; 4: one column per lane, 512 threads) and waves
 // per workgroup.  EDIGPU_SB_CW = 1 / 2 chooses (tuning)
 int sb_cols_gs() {
-  static const char* e = getenv("EDIGPU_SB_CW");
+  const char* e = getenv("EDIGPU_SB_CW");  // (read per sector set-up)
   return e && atoi(e) == 1 ? 4 : 8;
 }
 int sb_cols_waves() { return sb_cols_gs() == 4 ? 8 : 4; }
@@ -88,8 +88,6 @@ static void fill_sb_args(const IbDev* d, SbArgs& a) {
   a.scal = nullptr;
   a.partial = nullptr;
   a.lazy = 0;
-  static const char* e2 = getenv("EDIGPU_SB_DEPHASE");
-  a.dephase = e2 ? atoi(e2) : 0;
   a.dbg = nullptr;
 }
 

@@ -52,7 +52,6 @@ struct SbArgs {
   double* partial;
   int lazy;
   long long* dbg;  // EDIGPU_SB_STAMP: per-wave cycle sums of the rows kernel's phases (workgroup 0), else null
-  int dephase;  // columns kernel: units of 127 x 64 cycles the odd workgroups start late (EDIGPU_SB_DEPHASE)
 };
 
 // read-only tables through the constant address space: uniform loads become scalar loads (s_load) even in a kernel that
@@ -357,12 +356,6 @@ __global__ void __launch_bounds__((CW == 2 ? 256 : 512), (CW == 2 ? 2 : 4)) sb_c
   const int nch = a.nchunks;
   const int panels_x = (a.npanels - x + 7) >> 3;
   const int col = (lane & (LPB - 1)) * CW;
-  // The workgroups that share a CU start together and would stage and compute in step for the whole launch (measured: the
-  // memory skeleton alone 0.74 ms, the block updates 0.41 ms, the kernel their SUM).  Every second workgroup of an XCD (32
-  // CUs: the second resident one of its CU under the observed dispatch order; speed only) starts half a task late.
-  if (a.dephase > 0 && ((slot / 32) & 1)) {
-    for (int i = 0; i < a.dephase; i++) __builtin_amdgcn_s_sleep(127);
-  }
   int cur_panel = -1;
   // A panel's tasks are consecutive: the workgroups with equal blockIdx % 8 (one XCD under the observed round-robin
   // dispatch; speed only) sweep the chunks of one or two panels at a time, whose V segments the chunks gather their
@@ -445,17 +438,18 @@ __global__ void __launch_bounds__((CW == 2 ? 256 : 512), (CW == 2 ? 2 : 4)) sb_c
             constexpr int j = decltype(J)::value;
             const double* af = reinterpret_cast<const double*>(&acc[j]);
             const double* hf = reinterpret_cast<const double*>(&h0[j]);
-            const double* of = chunk + (own - row0 + j) * 16 + col;
-            T res;
+            T res, ov;
+            if constexpr (ALPHA) ov = *reinterpret_cast<const T*>(chunk + (own - row0 + j) * 16 + col);
             double* rf = reinterpret_cast<double*>(&res);
+            const double* of = reinterpret_cast<const double*>(&ov);
             sb::sfor<0, CW>([&](auto C) {
               constexpr int cc = decltype(C)::value;
               rf[cc] = af[cc] + hf[cc];
-              if (ALPHA) {
-                const double o = of[cc], dx = rf[cc] - sg * o;
-                asum += o * rf[cc];
-                qsum += dx * dx;
-                nsum += o * o;
+              if constexpr (ALPHA) {  // (fused multiply-adds: half the instructions of the separate form)
+                const double o = of[cc], dx = __builtin_fma(-sg, o, rf[cc]);
+                asum = __builtin_fma(o, rf[cc], asum);
+                qsum = __builtin_fma(dx, dx, qsum);
+                nsum = __builtin_fma(o, o, nsum);
               }
             });
             sb_nt_store<T>(orow + j * 16, res);

@@ -16,7 +16,7 @@
 
 // tuning variants of the columns kernel (scripts/ab_build.sh)
 #ifndef SB_V_HOPS
-#define SB_V_HOPS 1
+#define SB_V_HOPS 2
 #endif
 #ifndef SB_V_H0
 #define SB_V_H0 1

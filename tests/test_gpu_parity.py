@@ -2035,6 +2035,73 @@ def test_impurity_block_split_rows_match_oracle(gpu, monkeypatch, rows, bath, no
 
 
 # --------------------------------------------------------------------------------------------
+# local-block kernels (csrc/host_sb.hpp, sb_core.hpp, kernels_sb*.hip; round 4) on the impurity-block layout
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cw", [2, 1])
+@pytest.mark.parametrize("rows", [480, 24])
+@pytest.mark.parametrize("bath,norb,nbath,sec,extra", [
+    ("normal", 2, 3, (4, 4), {}),                      # one orbital per bath level (cw = 1 takes the per-orbital walk)
+    ("hybrid", 3, 5, (4, 3), {}),                      # three orbitals, Hnd terms, DimUp != DimDw
+    ("normal", 2, 4, (5, 5), dict(jxp=0.0)),           # no Hnd: unpadded columns
+    ("hybrid", 3, 6, (4, 5), {}),                      # 126 x 126: several chunks of rows at 24 rows per chunk
+    ("normal", 1, 8, (4, 5), {}),                      # one orbital: four bath levels folded into the blocks
+    ("hybrid", 3, 5, (1, 6), {}),                      # classes missing
+    ("hybrid", 2, 7, (5, 4), dict(exc_field=np.array([0.12, 0.5, 0.5, 0.07]))),   # impurity-impurity hops
+])
+def test_local_block_kernels_match_oracle(gpu, monkeypatch, cw, rows, bath, norb, nbath, sec, extra):
+    """sb_rows_kernel + sb_cols_kernel (blocks of 5 local levels; one or two columns per lane in the columns kernel):
+    the plain product, the fused Lanczos step on them (EDIGPU_SB_STEP=1) and the default pairing (their product, the
+    impurity-block kernels' fused step) against the oracle; EDIGPU_SB=0 on the same sector is the round-3 path."""
+    import os
+    if os.environ.get("EDIGPU_NORMAL_EXPLICIT") or os.environ.get("EDIGPU_LANCZOS_UNFUSED") or os.environ.get("EDIGPU_ROW_SPLIT") \
+            or os.environ.get("EDIGPU_IB_SPLIT") == "1" or os.environ.get("EDIGPU_SB") == "0":
+        pytest.skip("needs the whole-row impurity-block image and the local-block tables")
+    O = _oracle()
+    from edipack_amd.hamiltonian import SectorHamiltonian
+    om, pm = make_models("normal", bath, norb, nbath, seed=91, **extra)
+    ho = O.HNormal(om, *sec)
+    monkeypatch.setenv("EDIGPU_IB", "1")
+    monkeypatch.setenv("EDIGPU_IB_MIN", "0")
+    monkeypatch.setenv("EDIGPU_IB_ROWS", str(rows))
+    monkeypatch.setenv("EDIGPU_SB_CW", str(cw))
+    if cw == 1:
+        monkeypatch.setenv("EDIGPU_SB_AMODE", "1")     # bath_type normal: the per-orbital walk (default: all-orbital)
+    hb = SectorHamiltonian.normal_from_model(pm, *sec)
+    assert hb.image_info()[5] == 3 and hb.image_info()[4] == 16
+    monkeypatch.setenv("EDIGPU_SB", "0")
+    hi = SectorHamiltonian.normal_from_model(pm, *sec)
+    assert hi.image_info()[5] == 1
+    monkeypatch.delenv("EDIGPU_SB")
+    rng = np.random.default_rng(7)
+    for v in (rng.standard_normal(ho.dim), np.ones(ho.dim)):
+        ref = ho.matvec(v)
+        assert rel_err(hb.apply(v), ref) < TOL                 # the two local-block kernels (plain product)
+        assert rel_err(hi.apply(v), ref) < TOL
+    v = rng.standard_normal(ho.dim)
+    n = min(40, ho.dim)
+    k = min(15, n)
+    ao, bo, _ = ho.lanc_tridiag(v, n)
+    for step in ("1", "0"):                                      # fused step on the local-block kernels / default pairing
+        monkeypatch.setenv("EDIGPU_SB_STEP", step)
+        ab, bb, nb = hb.lanczos_tridiag(v, n)
+        assert nb == n
+        assert rel_err(ab[:k], ao[:k]) < 1e-10 and rel_err(bb[:k], bo[:k]) < 1e-10
+        for z in (40.0 + 0.1j, 25.0j):
+            assert abs(_cf(ab, bb, z) - _cf(ao, bo, z)) / abs(_cf(ao, bo, z)) < 1e-10
+    monkeypatch.setenv("EDIGPU_SB_STEP", "1")
+    monkeypatch.setenv("EDIGPU_LANCZOS_EXACTBETA", "1")          # the literal two-reduction recurrence, no lazy axpy
+    ae, be, _ = hb.lanczos_tridiag(v, n)
+    monkeypatch.delenv("EDIGPU_LANCZOS_EXACTBETA")
+    assert rel_err(ae[:k], ao[:k]) < 1e-10 and rel_err(be[:k], bo[:k]) < 1e-10
+    eb, xb, _ = hb.lanczos_eigh(nitermax=min(300, ho.dim), tol=1e-13, v0=v)
+    e0 = np.linalg.eigvalsh(ho.dense())[0] if ho.dim <= 5000 else hi.lanczos_eigh(nitermax=300, tol=1e-13, v0=v)[0]
+    assert abs(eb - e0) < 1e-9 * max(1.0, abs(e0))
+    assert rel_err(hb.apply(xb), eb * xb) < 1e-6
+    assert hb.lanczos_bench(2, 3)[1] > 0.0 and hb.time_apply(1, 2, lanczos=2) > 0.0
+    hb.destroy(), hi.destroy()
+
+
+# --------------------------------------------------------------------------------------------
 # nonsu2 sectors of JZ_BASIS=T (build_sector, ED_SECTOR.f90:289-350)
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("nbath,ntot,twojz", [(1, 6, 0), (1, 5, 1), (2, 9, 1), (2, 8, -4)])

@@ -64,7 +64,8 @@ CASES = [
 
 
 @pytest.mark.parametrize("bath,norb,nbath,sec,nb0,rows,extra", CASES)
-def test_local_block_product_matches_explicit_arrays(shim, bath, norb, nbath, sec, nb0, rows, extra):
+def test_local_block_product_matches_explicit_arrays(shim, monkeypatch, bath, norb, nbath, sec, nb0, rows, extra):
+    monkeypatch.setenv("EDIGPU_SB_AMODE", "1")      # the per-orbital walk where the bath allows it (the default is the other)
     _, pm = make_models("normal", bath, norb, nbath, seed=41, **extra)
     rc, info, diff, msg = _check(shim, pm, sec[0], sec[1], nb0, rows, gs=4 if nbath % 2 else 8)
     assert rc == 0, msg
@@ -75,6 +76,13 @@ def test_local_block_product_matches_explicit_arrays(shim, bath, norb, nbath, se
         assert info[5] == 0
     else:
         assert info[5] > 0
+
+
+def test_all_orbital_walk_on_a_one_orbital_per_level_bath(shim):
+    """bath_type normal with the default (all-orbital) walk: the amplitudes of the other orbitals are zeros in the tables."""
+    _, pm = make_models("normal", "normal", 2, 4, seed=47)
+    rc, info, diff, msg = _check(shim, pm, 5, 4, 3, 40)
+    assert rc == 0 and info[4] == 0 and diff < 1e-13, (msg, info, diff)
 
 
 def test_wave_slot_plan_is_a_permutation(shim):
