@@ -133,6 +133,7 @@ SIGNATURES = {
     "edigpu_dev_upload": (C.c_int, [_vp, _vp, _i64]),
     "edigpu_dev_download": (C.c_int, [_vp, _vp, _i64]),
     "edigpu_shard_plan": (C.c_int, [_i64, C.c_int32, C.c_int32, _pi64, _pi64, _pi64]),
+    "edigpu_shard_info": (C.c_int, [_vp, _vp, C.POINTER(C.c_int32)]),
     "edigpu_exchange_send_map": (C.c_int, [_i64, _i64, _i64, C.c_int32, _i64, C.c_int32, _pi64]),
     "edigpu_exchange_back_map": (C.c_int, [_i64, _i64, _i64, C.c_int32, _i64, C.c_int32, _pi64]),
     "edigpu_comm_unique_id": (C.c_int, [_vp]),

@@ -137,9 +137,10 @@ struct edigpu_comm_s {
   // sharded-recurrence workspace (grown on demand)
   // capacities in doubles: vin / vout / tmp, vfull (all-gather form only), the four exchange buffers.  Grow-only and
   // tracked one by one: a communicator serves sectors of different geometry (transposed and all-gather) in turn
-  int64_t ws_chunk = 0, ws_full = 0, ws_x = 0;
+  int64_t ws_chunk = 0, ws_full = 0, ws_x = 0, ws_bp = 0;
   double *vin = nullptr, *vout = nullptr, *tmp = nullptr, *vfull = nullptr;
   double *send = nullptr, *recv = nullptr, *hvc = nullptr, *back = nullptr;
+  double* bp[4] = {nullptr, nullptr, nullptr, nullptr};  // transposed exchange on padded panels (ShardGeom::block)
   double *hist = nullptr, *work = nullptr, *scr = nullptr;
   int64_t hist_cap = 0;
 };
@@ -431,6 +432,11 @@ struct ShardGeom {
   // transposed exchange
   int halo = 0;
   int64_t pcol = 0, col_first = 0, col_count = 0, pw = 0, xlen = 0;
+  // the same exchange on the padded panel layout of the local-block kernels (kernels_sb.hip, "row shards"): no packing,
+  // no halo -- the partner columns of an Hnd term sit in the same panel
+  bool block = false;
+  int npmax = 0;      // panels per rank
+  int64_t bplen = 0;  // doubles of a vector in the shard form: world * npmax * q * 16
 };
 
 static int shard_geometry(const edigpu_sector* s, const edigpu_comm_s* c, ShardGeom& g) {
@@ -458,6 +464,11 @@ static int shard_geometry(const edigpu_sector* s, const edigpu_comm_s* c, ShardG
     g.pw = g.pcol + 2 * g.halo;
     g.xlen = (int64_t)c->world * g.q * g.pw;
     if (g.pcol < 1 || g.halo > g.pcol) g.transposed = false;  // blocks narrower than the halo: all-gather form
+  }
+  if (g.transposed && g.nblk == 1 && sb_shardable(s) && g.q >= 1 && g.q <= 0xFFFF && !getenv("EDIGPU_SHARD_GENERIC")) {
+    g.block = true;
+    g.npmax = sb_shard_panels(s, c->world);
+    g.bplen = (int64_t)c->world * g.npmax * g.q * 16;
   }
   if (g.nblk > 1 && (s->sub_a || (s->kind == 0 && !g.transposed))) {
     // like spMatVec_mpi_normal_main (ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:841-904) and spMatVec_mpi_superc_main /
@@ -504,6 +515,11 @@ static int comm_workspace(edigpu_comm_s* c, const ShardGeom& g, int nlanc) {
     if (regrow(c->vfull, (size_t)chunk * c->world)) return 1;
     c->ws_full = chunk * c->world;
   }
+  if (g.block && g.bplen > c->ws_bp) {
+    for (double*& b : c->bp)
+      if (regrow(b, g.bplen)) return 1;
+    c->ws_bp = g.bplen;
+  }
   if (g.transposed && g.xlen > c->ws_x) {
     if (regrow(c->send, g.xlen) || regrow(c->recv, g.xlen) || regrow(c->hvc, g.xlen) || regrow(c->back, g.xlen)) return 1;
     c->ws_x = g.xlen;
@@ -521,6 +537,34 @@ static int comm_workspace(edigpu_comm_s* c, const ShardGeom& g, int nlanc) {
 // on the side stream beside the part of the product that needs no remote data.
 static int sharded_hv(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, bool pre_packed, hipStream_t st,
                       const double** back_out = nullptr) {
+  if (g.block) {
+    // Transposed exchange on padded panels (the local-block kernels' layout, shard form: kernels_sb.hip).  What a rank
+    // sends to rank d -- its rows of d's panels -- is one contiguous run of the converted vector, and what comes back lands
+    // in that layout again: the two all-to-alls move the buffers as they are.  bp[0] = v in the shard form, bp[1] = what
+    // the first exchange delivers, bp[2] = the column half on it, bp[3] = the row half; the exchange back reuses bp[1].
+    const bool alone = c->world == 1 && !force_collectives(c);
+    const size_t per = (size_t)g.npmax * g.q * 16;
+    if (sb_shard_to_panels(s, c->vin, c->bp[0], g.count, g.q, c->world, st)) return 1;
+    if (!alone) {
+      EDIGPU_HIP(hipEventRecord(c->ev_ready, st));
+      EDIGPU_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
+      if (comm_all_to_all(c, c->bp[0], c->bp[1], per, c->side)) return 1;
+      EDIGPU_HIP(hipEventRecord(c->ev_done, c->side));
+    }
+    if (launch_sb_rows_shard(s, g.first, g.count, g.q, c->bp[0], c->bp[3], st)) return 1;  // beside the exchange
+    if (!alone) EDIGPU_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
+    const int p0 = c->rank * g.npmax, np = std::max(0, std::min(g.npmax, s->ib->npanels - p0));
+    // (panels past the sector's last one are never computed: their slots must not hand stale numbers back)
+    if (np < g.npmax) EDIGPU_HIP(hipMemsetAsync(c->bp[2], 0, (size_t)g.bplen * sizeof(double), st));
+    if (launch_sb_cols_shard(s, p0, np, g.q, g.npmax, alone ? c->bp[0] : c->bp[1], c->bp[2], st)) return 1;
+    const double* colhalf = c->bp[2];
+    if (!alone) {
+      if (comm_all_to_all(c, c->bp[2], c->bp[1], per, st)) return 1;
+      colhalf = c->bp[1];
+    }
+    if (back_out) *back_out = nullptr;  // nothing left for the caller to add
+    return sb_shard_from_panels_add(s, c->bp[3], colhalf, c->tmp, g.count, g.q, st);
+  }
   if (g.transposed) {
     // a world of one exchanges nothing: the column half reads the packed buffer and the caller its result in place
     const bool alone = c->world == 1 && !force_collectives(c);
@@ -594,7 +638,7 @@ static int sharded_step(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, 
   const double* tpp = it > 1 ? c->hist + 3 * (size_t)(it - 2) : nullptr;
   if (n > 0)
     hipLaunchKernelGGL(ks_rotate3, sh_grid(n, 256 * 16), dim3(kShNT), 0, st, it == 0 ? 1 : 0, n, s->dim_up, g.q, c->world,
-                       g.pcol, g.halo, c->vin, c->vout, tp, tpp, g.transposed && g.nblk == 1 ? c->send : nullptr);
+                       g.pcol, g.halo, c->vin, c->vout, tp, tpp, g.transposed && g.nblk == 1 && !g.block ? c->send : nullptr);
   const double* back = nullptr;
   if (sharded_hv(s, c, g, true, st, &back)) return 1;
   const dim3 gr = sh_grid(std::max<int64_t>(n, 1), kRedBlocks);
@@ -918,7 +962,8 @@ int edigpu_comm_info(edigpu_comm c, int32_t* rank, int32_t* world, int32_t* kind
 int edigpu_comm_destroy(edigpu_comm c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
-  for (double** p : {&c->vin, &c->vout, &c->tmp, &c->vfull, &c->send, &c->recv, &c->hvc, &c->back, &c->hist, &c->work, &c->scr})
+  for (double** p : {&c->vin, &c->vout, &c->tmp, &c->vfull, &c->send, &c->recv, &c->hvc, &c->back, &c->hist, &c->work, &c->scr,
+                     &c->bp[0], &c->bp[1], &c->bp[2], &c->bp[3]})
     if (*p) (void)hipFree(*p);
   if (c->nccl && rccl()) (void)rccl()->CommDestroy(c->nccl);
   if (c->side) (void)hipStreamDestroy(c->side);
@@ -1179,8 +1224,24 @@ int edigpu_lanczos_bench_sharded(edigpu_handle s, edigpu_comm c, int warmup, int
   const auto t1 = std::chrono::steady_clock::now();
   *ms_per_step = std::chrono::duration<double, std::milli>(t1 - t0).count() / steps;
   if (exchange_bytes)
-    *exchange_bytes = g.transposed ? 2 * 8 * (int64_t)(c->world - 1) * g.q * g.pw * g.nblk
-                                   : 8 * g.chunk * g.w * (int64_t)(c->world - 1);
+    *exchange_bytes = g.block        ? 2 * 8 * (int64_t)(c->world - 1) * g.npmax * g.q * 16
+                      : g.transposed ? 2 * 8 * (int64_t)(c->world - 1) * g.q * g.pw * g.nblk
+                                     : 8 * g.chunk * g.w * (int64_t)(c->world - 1);
+  return 0;
+}
+
+int edigpu_shard_info(edigpu_handle s, edigpu_comm c, int32_t info[4]) {
+  if (!s || !c || !info) {
+    set_error("edigpu_shard_info: bad argument");
+    return 1;
+  }
+  if (s->kind == 4 && s->sub_d) s = s->sub_d;
+  ShardGeom g;
+  if (shard_geometry(s, c, g)) return 1;
+  info[0] = g.block ? 2 : g.transposed ? 1 : 0;
+  info[1] = (int32_t)g.q;
+  info[2] = g.block ? g.npmax : (int32_t)g.pcol;
+  info[3] = g.block ? 0 : g.halo;
   return 0;
 }
 

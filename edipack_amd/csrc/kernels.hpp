@@ -100,6 +100,13 @@ int launch_ib_lanczos(const edigpu_sector* s, const double* P, double* Q, double
 int launch_sb(const edigpu_sector* s, const double* v, double* hv, hipStream_t st);
 int launch_sb_lanczos(const edigpu_sector* s, const double* P, double* Q, double* X, const double* scal, double* partial,
                       int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial);
+// row shards on the padded panel layout (kernels_sb.hip): see there for the shard form of the layout
+bool sb_shardable(const edigpu_sector* s);
+int sb_shard_panels(const edigpu_sector* s, int world);
+int sb_shard_to_panels(const edigpu_sector* s, const double* rows, double* dst, int64_t count, int64_t q, int world, hipStream_t st);
+int sb_shard_from_panels_add(const edigpu_sector* s, const double* a, const double* b, double* rows, int64_t count, int64_t q, hipStream_t st);
+int launch_sb_rows_shard(const edigpu_sector* s, int64_t row0, int64_t count, int64_t q, const double* v, double* hv, hipStream_t st);
+int launch_sb_cols_shard(const edigpu_sector* s, int p0, int np, int64_t q, int npmax, const double* v, double* out, hipStream_t st);
 int sb_nb0(int norb);
 int sb_cols_waves();
 int sb_cols_gs();

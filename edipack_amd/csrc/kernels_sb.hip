@@ -7,9 +7,9 @@ namespace edigpu {
 int sb_rows_1(const IbDev* d, const SbArgs& a, int fuse, const double* P, double* Q, double* X, hipStream_t st);
 int sb_rows_2(const IbDev* d, const SbArgs& a, int fuse, const double* P, double* Q, double* X, hipStream_t st);
 int sb_rows_3(const IbDev* d, const SbArgs& a, int fuse, const double* P, double* Q, double* X, hipStream_t st);
-int sb_cols_1(const IbDev* d, const SbArgs& a, bool alpha, const double* v, double* hv, hipStream_t st, int* nblocks);
-int sb_cols_2(const IbDev* d, const SbArgs& a, bool alpha, const double* v, double* hv, hipStream_t st, int* nblocks);
-int sb_cols_3(const IbDev* d, const SbArgs& a, bool alpha, const double* v, double* hv, hipStream_t st, int* nblocks);
+int sb_cols_1(const IbDev* d, const SbArgs& a, int mode, const double* v, double* hv, hipStream_t st, int* nblocks);
+int sb_cols_2(const IbDev* d, const SbArgs& a, int mode, const double* v, double* hv, hipStream_t st, int* nblocks);
+int sb_cols_3(const IbDev* d, const SbArgs& a, int mode, const double* v, double* hv, hipStream_t st, int* nblocks);
 
 // low bath levels folded into the blocks, per orbital count: the kernels are built for 5 local levels
 int sb_nb0(int norb) { return norb >= 1 && norb <= 3 ? 5 - norb : 0; }
@@ -85,6 +85,11 @@ static void fill_sb_args(const IbDev* d, SbArgs& a) {
   a.dw_korb = s->dw_korb;
   a.nd_dw = s->nd_dw;
   a.nd_up = d->nd_up;
+  a.row0 = 0;
+  a.p0 = 0;
+  a.qmagic = 0;
+  a.kslot = 0;
+  a.q16 = d->ps;
   a.scal = nullptr;
   a.partial = nullptr;
   a.lazy = 0;
@@ -101,11 +106,11 @@ static int rows(const IbDev* d, const SbArgs& a, int fuse, const double* P, doub
   return 1;
 }
 
-static int cols(const IbDev* d, const SbArgs& a, bool alpha, const double* v, double* hv, hipStream_t st, int* nblocks) {
+static int cols(const IbDev* d, const SbArgs& a, int mode, const double* v, double* hv, hipStream_t st, int* nblocks) {
   switch (d->norb) {
-    case 1: return sb_cols_1(d, a, alpha, v, hv, st, nblocks);
-    case 2: return sb_cols_2(d, a, alpha, v, hv, st, nblocks);
-    case 3: return sb_cols_3(d, a, alpha, v, hv, st, nblocks);
+    case 1: return sb_cols_1(d, a, mode, v, hv, st, nblocks);
+    case 2: return sb_cols_2(d, a, mode, v, hv, st, nblocks);
+    case 3: return sb_cols_3(d, a, mode, v, hv, st, nblocks);
   }
   set_error("sb_cols_kernel: norb");
   return 1;
@@ -129,10 +134,10 @@ int launch_sb(const edigpu_sector* s, const double* v, double* hv, hipStream_t s
       fprintf(stderr, "sb_rows stamps wave %2d: compute %9lld bar1 %9lld writeback %9lld bar2 %9lld out+land %9lld bar3 %9lld\n", w, h[w * 8], h[w * 8 + 1],
               h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5]);
     a.dbg = nullptr;
-    return cols(s->ib, a, false, v, hv, st, nullptr);
+    return cols(s->ib, a, 0, v, hv, st, nullptr);
   }
   if (rows(s->ib, a, 0, v, hv, nullptr, st)) return 1;
-  return cols(s->ib, a, false, v, hv, st, nullptr);
+  return cols(s->ib, a, 0, v, hv, st, nullptr);
 }
 
 // One fused Lanczos step on THREE buffers (launch_ib_lanczos, kernels_ib.hip, has the protocol): here the rows kernel also
@@ -147,10 +152,89 @@ int launch_sb_lanczos(const edigpu_sector* s, const double* P, double* Q, double
   (void)partial_cap;  // >= kMaxPartials (ensure_workspace); sb_launch_cols_t checks its grid against that
   if (first) {
     if (rows(s->ib, a, 0, P, Q, nullptr, st)) return 1;
-    return cols(s->ib, a, true, P, Q, st, npartial);
+    return cols(s->ib, a, 1, P, Q, st, npartial);
   }
   if (rows(s->ib, a, 1, P, Q, X, st)) return 1;
-  return cols(s->ib, a, true, X, Q, st, npartial);
+  return cols(s->ib, a, 1, X, Q, st, npartial);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// row shards (edigpu_shard.hip): the two halves of the product on the rank's part of the padded panel layout
+// ---------------------------------------------------------------------------------------------------------
+// Shard form of the layout: P = world * npmax panels (npmax = ceil(npanels / world): rank d owns the panels [d npmax,
+// (d + 1) npmax) for the column half), every panel q = ceil(DimDw / world) rows of 16 doubles -- the rank's own rows;
+// rows past its count and panels past npanels hold zeros.  What rank d needs from rank r for the column half, r's q rows
+// of d's npmax panels, is ONE contiguous run of npmax * q * 16 doubles: the all-to-all needs no packing, and what it
+// delivers -- for every source rank its rows of my panels -- is what sb_cols_kernel<SH> reads through SbArgs::kslot.
+// The way back is the same exchange and lands in this layout again.
+__global__ void __launch_bounds__(256) k_shard_to_panels(const double* __restrict__ src, double* __restrict__ dst, const int32_t* __restrict__ colof,
+                                                         int64_t dim_up, int64_t count, int64_t q, int npanels, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int64_t p = e / (q * 16), rem = e - p * q * 16, i = rem >> 4;
+    const int c = p < npanels ? colof[p * 16 + (rem & 15)] : -1;
+    dst[e] = (c >= 0 && i < count) ? src[i * dim_up + c] : 0.0;
+  }
+}
+
+// dst (the rank's rows in the reference's layout) = a + b, both in the shard form
+__global__ void __launch_bounds__(256) k_shard_from_panels_add(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ dst,
+                                                               const int32_t* __restrict__ pos, int64_t dim_up, int64_t q, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int64_t i = e / dim_up, c = e - i * dim_up;
+    const int p = pos[c];
+    const int64_t at = ((int64_t)(p >> 4) * q + i) * 16 + (p & 15);
+    dst[e] = a[at] + b[at];
+  }
+}
+
+bool sb_shardable(const edigpu_sector* s) { return s->kind == 0 && s->ib && s->ib->sb && s->ib->nhalf == 1; }
+
+int sb_shard_panels(const edigpu_sector* s, int world) { return (s->ib->npanels + world - 1) / world; }
+
+int sb_shard_to_panels(const edigpu_sector* s, const double* rows, double* dst, int64_t count, int64_t q, int world, hipStream_t st) {
+  const int64_t n = (int64_t)world * sb_shard_panels(s, world) * q * 16;
+  const unsigned g = (unsigned)std::min<int64_t>((n + 255) / 256, 65536);
+  hipLaunchKernelGGL(k_shard_to_panels, dim3(std::max(g, 1u)), dim3(256), 0, st, rows, dst, s->ib->colof, s->ib->dim_up, count, q, s->ib->npanels, n);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+int sb_shard_from_panels_add(const edigpu_sector* s, const double* a, const double* b, double* rows, int64_t count, int64_t q, hipStream_t st) {
+  const int64_t n = count * s->ib->dim_up;
+  if (n == 0) return 0;
+  const unsigned g = (unsigned)std::min<int64_t>((n + 255) / 256, 65536);
+  hipLaunchKernelGGL(k_shard_from_panels_add, dim3(g), dim3(256), 0, st, a, b, rows, s->ib->pos, s->ib->dim_up, q, n);
+  EDIGPU_HIP(hipGetLastError());
+  return 0;
+}
+
+// hv = (Hd + 1 (x) Hup) v on the rank's rows [row0, row0 + count), both in the shard form
+int launch_sb_rows_shard(const edigpu_sector* s, int64_t row0, int64_t count, int64_t q, const double* v, double* hv, hipStream_t st) {
+  if (count == 0) return 0;
+  SbArgs a;
+  fill_sb_args(s->ib, a);
+  a.dim_dw = count;
+  a.ps = q * 16;
+  a.row0 = row0;
+  return rows(s->ib, a, 0, v, hv, nullptr, st);
+}
+
+// out = (Hdw (x) 1 + Hnd) v on the panels [p0, p0 + np) this rank owns, all rows; v, out: what the all-to-all delivers /
+// returns (every rank's rows in its slot of npmax * q * 16 doubles)
+int launch_sb_cols_shard(const edigpu_sector* s, int p0, int np, int64_t q, int npmax, const double* v, double* out, hipStream_t st) {
+  if (np <= 0) return 0;
+  if (q < 1 || q > 0xFFFF) {
+    set_error("launch_sb_cols_shard: rows per rank");
+    return 1;
+  }
+  SbArgs a;
+  fill_sb_args(s->ib, a);
+  a.npanels = np;
+  a.p0 = p0;
+  a.q16 = q * 16;
+  a.kslot = (int64_t)npmax * q * 16 - q * 16;
+  a.qmagic = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)q + 1);
+  return cols(s->ib, a, 2, v, out, st, nullptr);
 }
 
 }  // namespace edigpu

@@ -8,8 +8,8 @@ int sb_rows_1(const IbDev* d, const SbArgs& a, int fuse, const double* P, double
   return sb_launch_rows<1, 4, 0>(d, a, fuse, P, Q, X, st);
 }
 
-int sb_cols_1(const IbDev* d, const SbArgs& a, bool alpha, const double* v, double* hv, hipStream_t st, int* nblocks) {
-  return sb_launch_cols<1, 4, 0>(d, a, alpha, v, hv, st, nblocks);
+int sb_cols_1(const IbDev* d, const SbArgs& a, int mode, const double* v, double* hv, hipStream_t st, int* nblocks) {
+  return sb_launch_cols<1, 4, 0>(d, a, mode, v, hv, st, nblocks);
 }
 
 }  // namespace edigpu

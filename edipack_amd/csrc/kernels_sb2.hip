@@ -9,9 +9,9 @@ int sb_rows_2(const IbDev* d, const SbArgs& a, int fuse, const double* P, double
   return sb_launch_rows<2, 3, 0>(d, a, fuse, P, Q, X, st);
 }
 
-int sb_cols_2(const IbDev* d, const SbArgs& a, bool alpha, const double* v, double* hv, hipStream_t st, int* nblocks) {
-  if (d->sb->amode) return sb_launch_cols<2, 3, 1>(d, a, alpha, v, hv, st, nblocks);
-  return sb_launch_cols<2, 3, 0>(d, a, alpha, v, hv, st, nblocks);
+int sb_cols_2(const IbDev* d, const SbArgs& a, int mode, const double* v, double* hv, hipStream_t st, int* nblocks) {
+  if (d->sb->amode) return sb_launch_cols<2, 3, 1>(d, a, mode, v, hv, st, nblocks);
+  return sb_launch_cols<2, 3, 0>(d, a, mode, v, hv, st, nblocks);
 }
 
 }  // namespace edigpu

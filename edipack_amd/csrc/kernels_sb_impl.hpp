@@ -47,6 +47,13 @@ struct SbArgs {
   const uint32_t* dw_korb;
   const uint32_t* nd_dw;
   const uint8_t* nd_up;
+  // row shards (edigpu_shard.hip): the rows kernel works on the rank's rows [row0, row0 + dim_dw) of the sector; the columns
+  // kernel (SH) on its panels [p0, p0 + npanels) with every rank's q rows of a panel in that rank's slot of the buffer:
+  // row g of local panel pl at pl * q * 16 + g * 16 + (g / q) * kslot doubles (qmagic: g / q = (g * qmagic) >> 32)
+  int64_t row0;
+  int p0;
+  uint32_t qmagic;
+  int64_t kslot, q16;
   // fused Lanczos step
   const double* scal;
   double* partial;
@@ -191,8 +198,9 @@ __global__ void __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) sb_rows_kernel
     asm volatile("v_mov_b32 %0, 0" : "=v"(zr));
     asm volatile("s_mov_b32 %0, 0" : "=s"(zs));
     pstride = pstride0 + zs;
-    const double edr = sb_const(a.ed)[r];
-    const int ic = (int)((sb_const(reinterpret_cast<const uint32_t*>(a.impd))[r >> 2] >> (8 * (int)(r & 3))) & 0xFFu);
+    const int64_t rg = r + a.row0;  // the row's number in the sector (a.row0 = 0 unless the vector is a row shard)
+    const double edr = sb_const(a.ed)[rg];
+    const int ic = (int)((sb_const(reinterpret_cast<const uint32_t*>(a.impd))[rg >> 2] >> (8 * (int)(rg & 3))) & 0xFFu);
     const auto xuc = sb_const(a.xu) + ic * (1 << NIMP);
     double acc[NBT][MAXM];
     sb::sfor<0, NBT>([&](auto S) {
@@ -323,8 +331,12 @@ __host__ __device__ inline SbColsLds sb_cols_layout(int nbw, int nloc, int mcr, 
 // ALPHA: the fused Lanczos step -- the three sums <v|w>, sum (w - sigma v)^2, <v|v> are accumulated from the staged rows
 // CW: columns per lane.  2: a group of 8 lanes x 16 bytes per block, 8 blocks per wave-slot, 256 threads (two waves per
 // SIMD with up to 256 registers); 1: 16 lanes x 8 bytes, 4 blocks per wave-slot, 512 threads (four waves with 128)
-template <int NIMP, int NB0, int AMODE, int CW, bool DO_ND, bool ALPHA>
+// SH (row shards, edigpu_shard.hip): v = what the all-to-all delivered -- for each of this rank's panels every rank's rows in
+// that rank's slot (SbArgs::kslot) -- and hv receives (Hdw (x) 1 + Hnd) v in the same form; nothing is read from hv (the
+// rows kernel's part is added after the exchange back).
+template <int NIMP, int NB0, int AMODE, int CW, bool DO_ND, bool ALPHA, bool SH = false>
 __global__ void __launch_bounds__((CW == 2 ? 256 : 512), (CW == 2 ? 2 : 4)) sb_cols_kernel(SbArgs a, const double* __restrict__ v, double* __restrict__ hv) {
+  static_assert(!(SH && ALPHA), "row shards: plain product only");
   constexpr int NT = CW == 2 ? 256 : 512;
   constexpr int GS = 4 * CW;                 // blocks per wave-slot
   constexpr int LPB = 64 / GS;               // lanes per block
@@ -361,12 +373,17 @@ __global__ void __launch_bounds__((CW == 2 ? 256 : 512), (CW == 2 ? 2 : 4)) sb_c
   // dispatch; speed only) sweep the chunks of one or two panels at a time, whose V segments the chunks gather their
   // partners over the high levels from.
   for (int tt = slot; tt < panels_x * nch; tt += nslots) {
-    const int pi = tt / nch, panel = pi * 8 + x;
+    const int pi = tt / nch, panel = pi * 8 + x + (SH ? a.p0 : 0);
     const int c = (tt - pi * nch + pi) % nch;  // rotated: a slot meets chunks of every size
     const int row0 = a.chunk_row[c], nrows = a.chunk_row[c + 1] - row0;
     const int slot0 = a.chunk_slot[c], nsl = a.chunk_slot[c + 1] - slot0;
-    const double* __restrict__ vp = v + (int64_t)panel * a.ps;
-    double* __restrict__ hp = hv + (int64_t)panel * a.ps;
+    // doubles from the panel's base to row g (SH: + the slot of the rank that owns the row)
+    auto roff = [&](int g) -> int64_t {
+      if constexpr (SH) return (int64_t)g * 16 + (int64_t)__umulhi((uint32_t)g, a.qmagic) * a.kslot;
+      else return (int64_t)g * 16;
+    };
+    const double* __restrict__ vp = v + (SH ? (int64_t)(panel - a.p0) * a.q16 : (int64_t)panel * a.ps);
+    double* __restrict__ hp = hv + (SH ? (int64_t)(panel - a.p0) * a.q16 : (int64_t)panel * a.ps);
     // Staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land in 1 KiB of consecutive LDS bytes; no
     // registers, every piece of the task in flight at once): the chunk's rows (one contiguous run of the panel) and the
     // chunk's packed descriptors.  Staged through registers four pieces at a time, the 60 KB of a chunk took four
@@ -378,7 +395,8 @@ __global__ void __launch_bounds__((CW == 2 ? 256 : 512), (CW == 2 ? 2 : 4)) sb_c
       const int n16 = nrows * 8;  // 16-byte units
       for (int u0 = wave * 64; u0 < n16; u0 += NW * 64) {
         const int u = u0 + lane < n16 ? u0 + lane : n16 - 1;  // the tail lanes re-read the last unit (their bytes are never used)
-        __builtin_amdgcn_global_load_lds((glb_void*)(src + (size_t)u * 16), (lds_void*)(base + L.chunk + (size_t)u0 * 16), 16, 0, 0);
+        const char* from = SH ? reinterpret_cast<const char*>(vp + roff(row0 + (u >> 3))) + (size_t)(u & 7) * 16 : src + (size_t)u * 16;
+        __builtin_amdgcn_global_load_lds((glb_void*)from, (lds_void*)(base + L.chunk + (size_t)u0 * 16), 16, 0, 0);
       }
       // one word of every result row of the chunk: the line comes into the L2 beside the chunk, so that the block updates
       // below find the rows kernel's part of the result there instead of paying an HBM round trip per wave-slot
@@ -420,8 +438,12 @@ __global__ void __launch_bounds__((CW == 2 ? 256 : 512), (CW == 2 ? 2 : 4)) sb_c
         T acc[M], h0[M];
         sb::sfor<0, M>([&](auto J) { acc[decltype(J)::value] = T{}; });
         auto get_h0 = [&]() {
-          const double* hrow = hp + (int64_t)own * 16 + col;
-          sb::sfor<0, M>([&](auto J) { h0[decltype(J)::value] = sb_nt_load<T>(hrow + decltype(J)::value * 16); });
+          if constexpr (SH) {
+            sb::sfor<0, M>([&](auto J) { h0[decltype(J)::value] = T{}; });
+          } else {
+            const double* hrow = hp + (int64_t)own * 16 + col;
+            sb::sfor<0, M>([&](auto J) { h0[decltype(J)::value] = sb_nt_load<T>(hrow + decltype(J)::value * 16); });
+          }
         };
 #if SB_V_H0 == 1
         get_h0();
@@ -429,8 +451,8 @@ __global__ void __launch_bounds__((CW == 2 ? 256 : 512), (CW == 2 ? 2 : 4)) sb_c
 #else
         auto mid = [&]() { get_h0(); };
 #endif
-        auto gload = [&](int grow) -> const double* { return vp + (int64_t)grow * 16 + col; };
-        sb::cols_block<NIMP, NB0, AMODE, nn, T>(chunk, row0, w, whigh, own, meta, nbw, a.lowbits, vtab, kSbVs, sb_const(a.dw_korb), sb_const(a.dw_tloc), col, gload, acc, mid);
+        auto gload = [&](int grow) -> const double* { return vp + roff(grow) + col; };
+        sb::cols_block<NIMP, NB0, AMODE, nn, T, !SH>(chunk, row0, w, whigh, own, meta, nbw, a.lowbits, vtab, kSbVs, sb_const(a.dw_korb), sb_const(a.dw_tloc), col, gload, acc, mid);
         if (DO_ND) sb::cols_block_nd<NIMP, NB0, nn, T>(chunk, own - row0, col, a.nterms, sb_const(a.ndcoef), sb_const(a.nd_dw), ndu, 16, acc);
         if (!(e & 0x8000u)) {
           double* orow = hp + (int64_t)own * 16 + col;
@@ -452,7 +474,8 @@ __global__ void __launch_bounds__((CW == 2 ? 256 : 512), (CW == 2 ? 2 : 4)) sb_c
                 nsum = __builtin_fma(o, o, nsum);
               }
             });
-            sb_nt_store<T>(orow + j * 16, res);
+            if constexpr (SH) sb_nt_store<T>(hp + roff(own + j) + col, res);
+            else sb_nt_store<T>(orow + j * 16, res);
           });
         }
       });
@@ -505,7 +528,7 @@ int sb_launch_rows_t(const IbDev* d, const SbArgs& a, int fuse, const double* P,
     set_error("sb_rows_kernel: does not fit a CU");
     return 1;
   }
-  const int64_t grid = std::min<int64_t>(d->dim_dw, (int64_t)per_cu * device_cu_count());
+  const int64_t grid = std::min<int64_t>(std::max<int64_t>(a.dim_dw, 1), (int64_t)per_cu * device_cu_count());
   if (fuse)
     hipLaunchKernelGGL((sb_rows_kernel<NIMP, NB0, AMODE, NT, NBT, CS, 1>), dim3((unsigned)grid), dim3(NT), lds, st, a, P, Q, X);
   else
@@ -529,11 +552,11 @@ int sb_launch_rows(const IbDev* d, const SbArgs& a, int fuse, const double* P, d
   return 1;
 }
 
-template <int NIMP, int NB0, int AMODE, int CW, bool DO_ND, bool ALPHA>
+template <int NIMP, int NB0, int AMODE, int CW, bool DO_ND, bool ALPHA, bool SH>
 int sb_launch_cols_t(const IbDev* d, const SbArgs& a, const double* v, double* hv, hipStream_t st, int* nblocks) {
   constexpr int NT = CW == 2 ? 256 : 512;
   const size_t lds = d->sb->cols_lds;
-  const void* k = (const void*)sb_cols_kernel<NIMP, NB0, AMODE, CW, DO_ND, ALPHA>;
+  const void* k = (const void*)sb_cols_kernel<NIMP, NB0, AMODE, CW, DO_ND, ALPHA, SH>;
   if (ensure_dynamic_lds(k, lds)) return 1;
   const int per_cu = resident_blocks(k, NT, lds);
   if (per_cu < 1) {
@@ -541,32 +564,36 @@ int sb_launch_cols_t(const IbDev* d, const SbArgs& a, const double* v, double* h
     return 1;
   }
   int64_t grid = (int64_t)per_cu * device_cu_count();
-  const int64_t tasks = (int64_t)d->npanels * d->sb->nchunks;
+  const int64_t tasks = (int64_t)a.npanels * d->sb->nchunks;
   grid = std::min<int64_t>(grid, (tasks + 7) / 8 * 8);
   grid = std::max<int64_t>(8, grid / 8 * 8);
   if (ALPHA && 3 * grid > kMaxPartials) {
     set_error("sb_cols_kernel: partial buffer too small");
     return 1;
   }
-  hipLaunchKernelGGL((sb_cols_kernel<NIMP, NB0, AMODE, CW, DO_ND, ALPHA>), dim3((unsigned)grid), dim3(NT), lds, st, a, v, hv);
+  hipLaunchKernelGGL((sb_cols_kernel<NIMP, NB0, AMODE, CW, DO_ND, ALPHA, SH>), dim3((unsigned)grid), dim3(NT), lds, st, a, v, hv);
   EDIGPU_HIP(hipGetLastError());
   if (nblocks) *nblocks = (int)grid;
   return 0;
 }
 
+// mode: 0 plain product, 1 fused Lanczos step (the three sums), 2 row shards (write-only, rank slots)
 template <int NIMP, int NB0, int AMODE, int CW>
-int sb_launch_cols_w(const IbDev* d, const SbArgs& a, bool alpha, const double* v, double* hv, hipStream_t st, int* nblocks) {
-  if (d->nterms > 0)
-    return alpha ? sb_launch_cols_t<NIMP, NB0, AMODE, CW, true, true>(d, a, v, hv, st, nblocks)
-                 : sb_launch_cols_t<NIMP, NB0, AMODE, CW, true, false>(d, a, v, hv, st, nblocks);
-  return alpha ? sb_launch_cols_t<NIMP, NB0, AMODE, CW, false, true>(d, a, v, hv, st, nblocks)
-               : sb_launch_cols_t<NIMP, NB0, AMODE, CW, false, false>(d, a, v, hv, st, nblocks);
+int sb_launch_cols_w(const IbDev* d, const SbArgs& a, int mode, const double* v, double* hv, hipStream_t st, int* nblocks) {
+  if (d->nterms > 0) {
+    if (mode == 2) return sb_launch_cols_t<NIMP, NB0, AMODE, CW, true, false, true>(d, a, v, hv, st, nblocks);
+    return mode ? sb_launch_cols_t<NIMP, NB0, AMODE, CW, true, true, false>(d, a, v, hv, st, nblocks)
+                : sb_launch_cols_t<NIMP, NB0, AMODE, CW, true, false, false>(d, a, v, hv, st, nblocks);
+  }
+  if (mode == 2) return sb_launch_cols_t<NIMP, NB0, AMODE, CW, false, false, true>(d, a, v, hv, st, nblocks);
+  return mode ? sb_launch_cols_t<NIMP, NB0, AMODE, CW, false, true, false>(d, a, v, hv, st, nblocks)
+              : sb_launch_cols_t<NIMP, NB0, AMODE, CW, false, false, false>(d, a, v, hv, st, nblocks);
 }
 
 template <int NIMP, int NB0, int AMODE>
-int sb_launch_cols(const IbDev* d, const SbArgs& a, bool alpha, const double* v, double* hv, hipStream_t st, int* nblocks) {
-  if (d->sb->cols_gs == 4) return sb_launch_cols_w<NIMP, NB0, AMODE, 1>(d, a, alpha, v, hv, st, nblocks);
-  return sb_launch_cols_w<NIMP, NB0, AMODE, 2>(d, a, alpha, v, hv, st, nblocks);
+int sb_launch_cols(const IbDev* d, const SbArgs& a, int mode, const double* v, double* hv, hipStream_t st, int* nblocks) {
+  if (d->sb->cols_gs == 4) return sb_launch_cols_w<NIMP, NB0, AMODE, 1>(d, a, mode, v, hv, st, nblocks);
+  return sb_launch_cols_w<NIMP, NB0, AMODE, 2>(d, a, mode, v, hv, st, nblocks);
 }
 
 }  // namespace edigpu

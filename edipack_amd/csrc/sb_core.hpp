@@ -211,7 +211,7 @@ template <> struct FmaOf<Pair> { using type = FmaP; };
 // whigh = w >> low, the SAME for the eight blocks of a wave-slot (host_sb.cpp deals the slots per (class, high word)): the
 // direction of a hop over a level >= low, and with it the number of partner rows and the coupling code, is uniform.
 // mid(): called between the LDS work and the hops over the levels >= low
-template <int NIMP, int NB0, int AMODE, int N, class T, class GLoad, class TP, class KP, class Mid>
+template <int NIMP, int NB0, int AMODE, int N, class T, bool LINEAR = true, class GLoad, class TP, class KP, class Mid>
 IB_HD void cols_block(const double* chunk, int chunk_row0, uint32_t w, uint32_t whigh, int own_row, const uint16_t* meta, int nbw, int low,
                       const double* vtab, int vs, KP korb, TP tloc, int col, GLoad&& gload, T* acc, Mid&& mid) {
   using Fma = typename FmaOf<T>::type;
@@ -253,11 +253,17 @@ IB_HD void cols_block(const double* chunk, int chunk_row0, uint32_t w, uint32_t 
   const int nhigh = nbw - low;
   // partner rows of the block over level low + h (uniform direction: see whigh)
   auto load_hop = [&](int h, T* xg) {
-    const auto g0 = gload((int)meta[low + h]);  // the partner block's first row; its rows follow 16 doubles apart
+    // LINEAR: the partner block's rows follow its first row 16 doubles apart (one address + immediate offsets); else every
+    // row has its own address (row shards: a block may straddle the rows of two ranks)
+    const int r2 = (int)meta[low + h];
+    const auto g0 = gload(r2);
     const int n2 = ((whigh >> h) & 1u) ? MPU : MPD;
     sfor<0, MPX>([&](auto J) {
       constexpr int j2 = decltype(J)::value;
-      if (j2 < n2) xg[j2] = *reinterpret_cast<const T*>(g0 + j2 * 16);  // uniform
+      if (j2 < n2) {  // uniform
+        if constexpr (LINEAR) xg[j2] = *reinterpret_cast<const T*>(g0 + j2 * 16);
+        else xg[j2] = *reinterpret_cast<const T*>(gload(r2 + j2));
+      }
     });
   };
   auto use_hop = [&](int h, const T* xg) {

@@ -99,6 +99,14 @@ class LibraryComm:
                                                             C.byref(q)), "edigpu_shard_plan")
         return f.value, n.value, q.value
 
+    def shard_info(self, h):
+        """(exchange kind: 0 all-gather, 1 transposed on column blocks, 2 transposed on padded panels; q; columns or
+        panels per rank; halo)."""
+        import ctypes as C
+        a = (C.c_int32 * 4)()
+        self._capi.check(self._capi.lib().edigpu_shard_info(h._h, self._c, a), "edigpu_shard_info")
+        return tuple(a)
+
     def apply(self, h, v_shard):
         """spMatVec_mpi_*: (Nloc, v, Hv) on this rank's shard, host arrays."""
         import numpy as np

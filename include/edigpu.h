@@ -490,6 +490,12 @@ int edigpu_vec_add_dot2(int64_t n, const double *vin_dev, double *vout_dev, cons
 typedef struct edigpu_comm_s *edigpu_comm;
 #define EDIGPU_UNIQUE_ID_BYTES 128
 int edigpu_shard_plan(int64_t units, int32_t world, int32_t rank, int64_t *first, int64_t *count, int64_t *q);
+/* Which exchange a sharded call on (h, c) takes: info[0] = 0 all-gather (the handle is the rank's shard), 1 transposed
+ * exchange on column blocks with halo columns (spMatVec_mpi_normal_main's vector_transpose_MPI,
+ * ED_NORMAL/ED_HAMILTONIAN_NORMAL_STORED_HxV.f90:834-866), 2 the same exchange on the padded 16-column panels of the
+ * local-block kernels (no packing, no halo; whole normal-mode sectors with that image, EDIGPU_SHARD_GENERIC=1 switches
+ * it off); info[1] = q (units per rank), info[2] = columns (1) / panels (2) per rank, info[3] = halo columns. */
+int edigpu_shard_info(edigpu_handle h, edigpu_comm c, int32_t info[4]);
 /* Host-only (no GPU needed): the index maps of the transposed exchange of normal mode exactly as the library's kernels
  * compute them (reference: vector_transpose_MPI, ED_NORMAL/ED_HAMILTONIAN_NORMAL_COMMON.f90:66-167).
  *   send_map: src[e], e < world*q*(pcol+2*halo) = element i*dim_up+col of the rank's row shard that send slot e

@@ -27,6 +27,10 @@ CASES = [
     ("normal", "normal", 2, 2, (3, 2), False, "phonon"),     # (Nph + 1) blocks, one exchange per block, local phonon pass
     ("superc", "hybrid", 2, 2, 0, False, "phonon"),          # stored rows: one all-gather per phonon block
     ("nonsu2", "normal", 2, 2, 4, True, "phonon"),           # on the fly
+    # transposed exchange on the padded panels of the local-block kernels (round 4): no packing, no halo
+    ("normal", "normal", 2, 3, (4, 4), False, "block"),      # Hnd terms inside the panels, 5 panels over 1-3 ranks
+    ("normal", "hybrid", 3, 5, (4, 3), False, "block"),      # three orbitals; DimDw = 56 rows: ragged tails, blocks cut by ranks
+    ("normal", "hybrid", 3, 6, (4, 5), False, "block"),      # 126 x 126
 ]
 NPH = 3
 
@@ -69,8 +73,14 @@ def _rank_main(rank, world, name, case, q):
         mode, bath, norb, nbath, sector, direct, exchange = case
         ho, pm, v = _reference(mode, bath, norb, nbath, sector, cmplx=exchange == "cmplx", phonon=exchange == "phonon")
         comm = LibraryComm(rank, world, shm_name=name, slot_bytes=1 << 22)
-        h, first, count = library_sharded_sector(pm, sector, comm, direct=direct, exchange=exchange,
+        if exchange == "block":      # small sectors get the impurity-block image + local-block tables on request only
+            os.environ.update(EDIGPU_IB="1", EDIGPU_IB_MIN="0", EDIGPU_IB_ROWS="24")
+        h, first, count = library_sharded_sector(pm, sector, comm, direct=direct, exchange="auto" if exchange == "block" else exchange,
                                                  cmplx=exchange == "cmplx")
+        if exchange == "block":
+            assert comm.shard_info(h)[0] == 2, comm.shard_info(h)
+        elif exchange == "auto" and mode == "normal":
+            assert comm.shard_info(h)[0] == 1, comm.shard_info(h)
         ix = _shard_index(ho, mode, first, count, exchange == "phonon")
         hv = comm.apply(h, v[ix])
         a, b, nd, n2 = comm.tridiag(h, v[ix], 20)
@@ -112,7 +122,7 @@ def test_library_shards_share_one_gpu(gpu, world, case):
 # eigenpairs with the vector sharded (sp_eigh / sp_lanc_eigh with MpiComm,
 # ED_NORMAL/ED_DIAG_NORMAL.f90:179-214)
 # ---------------------------------------------------------------------------------------------------------
-EIG_CASES = [CASES[0], CASES[1], CASES[2], CASES[3], CASES[4], CASES[5], CASES[6]]
+EIG_CASES = [CASES[0], CASES[1], CASES[2], CASES[3], CASES[4], CASES[5], CASES[6], CASES[10]]
 
 
 def _eig_rank_main(rank, world, name, case, q):
@@ -124,8 +134,11 @@ def _eig_rank_main(rank, world, name, case, q):
         mode, bath, norb, nbath, sector, direct, exchange = case
         ho, pm, v = _reference(mode, bath, norb, nbath, sector, cmplx=exchange == "cmplx", phonon=exchange == "phonon")
         comm = LibraryComm(rank, world, shm_name=name, slot_bytes=1 << 22)
-        h, first, count = library_sharded_sector(pm, sector, comm, direct=direct, exchange=exchange,
+        if exchange == "block":
+            os.environ.update(EDIGPU_IB="1", EDIGPU_IB_MIN="0", EDIGPU_IB_ROWS="24")
+        h, first, count = library_sharded_sector(pm, sector, comm, direct=direct, exchange="auto" if exchange == "block" else exchange,
                                                  cmplx=exchange == "cmplx")
+        assert exchange != "block" or comm.shard_info(h)[0] == 2
         ix = _shard_index(ho, mode, first, count, exchange == "phonon")
         ev, x, nconv, nmv = comm.eigh_multi(h, 3, len(ix), v0_shard=v[ix], tol=1e-11)
         e1, x1, nm1 = comm.eigh(h, len(ix), v0_shard=v[ix], tol=1e-11)
