@@ -24,7 +24,7 @@ def main():
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
             # (the two launches of a row staged in halves are two kernels of one product: ib_rows_kernel<..., 1> / <..., 2>)
-            key = ("ib_rowsB" if ("ib_rows" in kn and ", 0, 2>" in kn) else "ib_rows" if "ib_rows" in kn else "ib_cols" if "ib_cols" in kn else "tile" if "dw_tile" in kn else "panel2" if "panel2" in kn else "panel" if "panel" in kn else "rows" if "normal_rows" in kn else
+            key = ("sb_rows" if "sb_rows" in kn else "sb_cols" if "sb_cols" in kn else "ib_rowsB" if ("ib_rows" in kn and ", 0, 2>" in kn) else "ib_rows" if "ib_rows" in kn else "ib_cols" if "ib_cols" in kn else "tile" if "dw_tile" in kn else "panel2" if "panel2" in kn else "panel" if "panel" in kn else "rows" if "normal_rows" in kn else
                    "csr" if ("csr_rows" in kn or "sell_rows" in kn) else "direct" if "direct_rows" in kn else None)
             if key:
                 agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
