@@ -1018,13 +1018,11 @@ int launch_ib(const edigpu_sector* s, const double* v, double* hv, hipStream_t s
 // the caller then takes X as the new P and the old P as the next X).
 int launch_ib_lanczos(const edigpu_sector* s, const double* P, double* Q, double* X, const double* scal, double* partial,
                       int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial) {
-  // The fused step of the local-block kernels: taken where their fused rows kernel (three more streams of pieces) fits its
-  // registers -- the 256- and 512-thread geometries (Ns = 15: 0.73 against 0.84 ms per step).  In the 768-thread geometry of
-  // the longest rows it spills (Ns = 16: 2.4 ms per launch against 0.83 plain), so there the step stays on the kernels below
-  // while the plain product runs on the local blocks (1.87 against 2.35 ms).  EDIGPU_SB_STEP=0 / 1 overrides.
+  // The Lanczos step of the local-block kernels (launch_sb_lanczos chooses between its fused and its semi-fused form);
+  // EDIGPU_SB_STEP=0 keeps the step on the kernels below while the plain product runs on the local blocks.
   if (s->ib->sb) {
     const char* es = getenv("EDIGPU_SB_STEP");
-    const bool sb_step = es ? atoi(es) != 0 : s->ib->sb->rows_nt != 768;
+    const bool sb_step = es ? atoi(es) != 0 : true;
     if (sb_step) return launch_sb_lanczos(s, P, Q, X, scal, partial, partial_cap, first, lazy_axpy, st, npartial);
   }
   IbArgs a;

@@ -93,6 +93,7 @@ static void fill_sb_args(const IbDev* d, SbArgs& a) {
   a.scal = nullptr;
   a.partial = nullptr;
   a.lazy = 0;
+  a.pold = nullptr;
   a.dbg = nullptr;
 }
 
@@ -153,6 +154,16 @@ int launch_sb_lanczos(const edigpu_sector* s, const double* P, double* Q, double
   if (first) {
     if (rows(s->ib, a, 0, P, Q, nullptr, st)) return 1;
     return cols(s->ib, a, 1, P, Q, st, npartial);
+  }
+  // The fused rows kernel (x formed while the row is staged, - beta P_old subtracted when the result leaves: three more
+  // streams of pieces) fits its registers in the 256- and 512-thread geometries.  In the 768-thread geometry of the longest
+  // rows it spills (2.4 ms per launch at Ns = 16 against 0.83 plain): there the new vector is its own pass, the plain rows
+  // kernel follows, and the columns kernel joins - beta P_old to the rows kernel's part.  EDIGPU_SB_STEP=2 forces that form.
+  const char* es = getenv("EDIGPU_SB_STEP");
+  if (s->ib->sb->rows_nt == 768 || (es && atoi(es) == 2)) {
+    if (lz_next_vector(P, Q, X, s->ib->len, scal, lazy_axpy, st) || rows(s->ib, a, 0, X, Q, nullptr, st)) return 1;
+    a.pold = P;
+    return cols(s->ib, a, 1, X, Q, st, npartial);
   }
   if (rows(s->ib, a, 1, P, Q, X, st)) return 1;
   return cols(s->ib, a, 1, X, Q, st, npartial);

@@ -58,6 +58,7 @@ struct SbArgs {
   const double* scal;
   double* partial;
   int lazy;
+  const double* pold;  // columns kernel (ALPHA): the previous Lanczos vector, whose - beta multiple joins the rows kernel's part; or null
   long long* dbg;  // EDIGPU_SB_STAMP: per-wave cycle sums of the rows kernel's phases (workgroup 0), else null
 };
 
@@ -362,6 +363,7 @@ __global__ void __launch_bounds__((CW == 2 ? 256 : 512), (CW == 2 ? 2 : 4)) sb_c
     return;
   }
   const double sg = ALPHA ? sb_const(a.scal)[SC_ALPHA] : 0.0;  // <Q|Q> is accumulated about the previous alpha (k_finalize_ab)
+  const double nbeta = (ALPHA && a.pold) ? -sb_const(a.scal)[SC_BETA] : 0.0;
   double asum = 0.0, qsum = 0.0, nsum = 0.0;
   for (int i = tid; i < nbw * 4; i += NT) vtab[(i >> 2) * kSbVs + (i & 3)] = a.dw_vtab[i];
   const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
@@ -384,6 +386,7 @@ __global__ void __launch_bounds__((CW == 2 ? 256 : 512), (CW == 2 ? 2 : 4)) sb_c
     };
     const double* __restrict__ vp = v + (SH ? (int64_t)(panel - a.p0) * a.q16 : (int64_t)panel * a.ps);
     double* __restrict__ hp = hv + (SH ? (int64_t)(panel - a.p0) * a.q16 : (int64_t)panel * a.ps);
+    const double* __restrict__ pp = (ALPHA && a.pold) ? a.pold + (int64_t)panel * a.ps : nullptr;
     // Staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land in 1 KiB of consecutive LDS bytes; no
     // registers, every piece of the task in flight at once): the chunk's rows (one contiguous run of the panel) and the
     // chunk's packed descriptors.  Staged through registers four pieces at a time, the 60 KB of a chunk took four
@@ -447,7 +450,24 @@ __global__ void __launch_bounds__((CW == 2 ? 256 : 512), (CW == 2 ? 2 : 4)) sb_c
         };
 #if SB_V_H0 == 1
         get_h0();
-        auto mid = [] {};
+        // (ALPHA with P_old: its rows are requested beside the rows kernel's part and joined to it after the LDS work, before
+        // the hops over the high levels take the registers)
+        T pq[ALPHA ? M : 1];
+        if constexpr (ALPHA)
+          if (pp) {  // uniform
+            const double* prow = pp + (int64_t)own * 16 + col;
+            sb::sfor<0, M>([&](auto J) { pq[decltype(J)::value] = sb_nt_load<T>(prow + decltype(J)::value * 16); });
+          }
+        auto mid = [&]() {
+          if constexpr (ALPHA)
+            if (pp)
+              sb::sfor<0, M>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                double* hf = reinterpret_cast<double*>(&h0[j]);
+                const double* pf = reinterpret_cast<const double*>(&pq[j]);
+                sb::sfor<0, CW>([&](auto C) { hf[decltype(C)::value] = __builtin_fma(nbeta, pf[decltype(C)::value], hf[decltype(C)::value]); });
+              });
+        };
 #else
         auto mid = [&]() { get_h0(); };
 #endif
