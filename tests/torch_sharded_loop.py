@@ -68,7 +68,7 @@ class NativeVecOps:
     launch per update instead of 3-4 torch ops, no temporaries, no host synchronisation."""
 
     def __init__(self, device="cuda"):
-        from . import capi
+        from edipack_amd import capi
         self.L, self.check = capi.lib(), capi.check
         self.work = torch.zeros(self.L.edigpu_vec_work_doubles(), dtype=torch.float64, device=device)
         self.zero = None
@@ -257,7 +257,7 @@ class TransposedKernels:
     """The four device steps of the transposed exchange through libedigpu.so (include/edigpu.h)."""
 
     def __init__(self, h, plan: ShardPlan):
-        from . import capi
+        from edipack_amd import capi
         self.h, self.L, self.check, self.plan = h, capi.lib(), capi.check, plan
         self.halo = h.transpose_halo()
         self.dim_up, self.dim_dw = h.dim_up, h.dim_dw
@@ -306,7 +306,7 @@ def _bind_fused_kernels(k: "TransposedKernels", lz, ab: torch.Tensor):
     pointers, the stream): the per-step host cost of the N > 1 loop is launch-bound at 8 ranks, and argument
     marshalling was half of it.  Returns (rotate_pack(it), rows(), cols(), unpack_dot2(it))."""
     import ctypes as C
-    from . import capi
+    from edipack_amd import capi
     L, pl, h = k.L, k.plan, k.h
     if k.work is None:
         k.work = torch.zeros(L.edigpu_vec_work_doubles(), dtype=torch.float64, device=lz.vin.device)
@@ -452,7 +452,7 @@ def gpu_transposed_hamiltonian(model, sector, world: int, rank: int, group=None,
     """Normal mode, transposed exchange: every rank builds the whole sector (factored tables only) and runs
     TransposedLanczos on its row shard.  Raises RuntimeError when the sector cannot be served this way
     (explicit spH0nd, phonons): fall back to gpu_sharded_hamiltonian (all-gather form)."""
-    from .hamiltonian import SectorHamiltonian
+    from edipack_amd.hamiltonian import SectorHamiltonian
     nup, ndw = sector
     h = SectorHamiltonian.normal_from_model(model, nup, ndw)
     try:
@@ -467,8 +467,8 @@ def gpu_transposed_hamiltonian(model, sector, world: int, rank: int, group=None,
 
 def gpu_sharded_hamiltonian(model, workload_sector, world: int, rank: int, direct: bool = False):
     """Build this rank's shard on its GPU and return (plan, SectorHamiltonian, ShardedLanczos)."""
-    from . import capi
-    from .hamiltonian import SectorHamiltonian
+    from edipack_amd import capi
+    from edipack_amd.hamiltonian import SectorHamiltonian
 
     L = capi.lib()
     import ctypes as C
