@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Write the measurement table of DESIGN.md section 6 (between the BENCH TABLE markers) from the bench lines in
-profiles/r03_bench_*.json, so that the text always quotes the committed evidence (round-2 figures in brackets from
-profiles/r02_bench_*.json).   python scripts/sync_design_numbers.py   [--check: exit 1 when the table is stale]"""
+profiles/r04_bench_*.json, so that the text always quotes the committed evidence (round-3 figures in brackets from
+profiles/r03_bench_*.json).   python scripts/sync_design_numbers.py   [--check: exit 1 when the table is stale]"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
-TAG, PREV = "r03", "r02"
+TAG, PREV = "r04", "r03"
 ROWS = [("cfg1", "cfg1 normal 1orb Nbath4 (2,3)"), ("cfg2", "cfg2 normal 2orb Nbath6 (7,7)"),
         ("cfg2_handover", "cfg2 through `edigpu_normal_create`"), ("cfg3", "cfg3 normal 3orb hybrid 8 (5,6)"),
         ("cfg3_ns15", "cfg3 ladder Ns=15"), ("cfg3_ns16", "cfg3 ladder Ns=16"), ("cfg3_ns17", "cfg3 ladder Ns=17"),
@@ -32,7 +32,7 @@ def fmt(x, f):
 
 
 def table():
-    out = ["| workload | Dim | it/s (r2) | H·v ms (r2) | GB/s alg. | frac | counter traffic per H·v | CPU H·v/s (cores) | CPU 1 thread |",
+    out = ["| workload | Dim | it/s (r3) | H·v ms (r3) | GB/s alg. | frac | counter traffic per H·v | CPU H·v/s (cores) | CPU 1 thread |",
            "|---|---|---|---|---|---|---|---|---|"]
     for wl, name in ROWS:
         d, p = load(TAG, wl), load(PREV, wl)
