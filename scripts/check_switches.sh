@@ -10,7 +10,9 @@ for sw in EDIGPU_LANCZOS_UNFUSED EDIGPU_NORMAL_EXPLICIT EDIGPU_FLAT_HOSTBUILD ED
           EDIGPU_TILE_PERSIST "EDIGPU_HANDOVER_FACTOR=0" EDIGPU_ND_NO_MERGE EDIGPU_CMPLX_FOURPRODUCTS EDIGPU_DIRECT_NOSORT EDIGPU_LANCZOS_GRAPH EDIGPU_LANCZOS_INKERNEL_FINALIZE EDIGPU_EIGH_TWOPASS "EDIGPU_BLOCKED=1 EDIGPU_BLOCKED_MIN=0" \
           "EDIGPU_BLOCKED=1 EDIGPU_BLOCKED_MIN=0 EDIGPU_BLOCKED_W=16 EDIGPU_BLOCKED_LDS_KB=4" \
           "EDIGPU_IB=1 EDIGPU_IB_MIN=0" "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_IB_SPLIT=1" \
-          "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_IB_COLS2=1" "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_IB_ROWS=16" EDIGPU_TRL_FULL; do
+          "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_IB_COLS2=1" "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_IB_ROWS=16" EDIGPU_TRL_FULL \
+          "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_SB=0" "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_SB_STEP=0" "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_SB_STEP=2" \
+          "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_SB_CW=1" "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_SB_AMODE=1"; do
   N=$((N+1)); [ $N -le $SKIP ] && continue
   [ $N -gt $((SKIP+COUNT)) ] && break
   case $sw in *=*) kv=$sw;; *) kv=$sw=1;; esac
