@@ -148,6 +148,45 @@ def cpu_baseline(h, workload, budget_s: float = 15.0):
                       f"({dtm * 1e3:.1f} ms each); serial loop order, 1 thread: {n1} products, {dt1 * 1e3:.1f} ms each"}
 
 
+def cpu_baseline_direct(w, budget_s: float = 15.0):
+    """On-the-fly workload (nonsu2): the oracle's restatement of directMatVec_nonsu2_main
+    (ED_NONSU2/ED_HAMILTONIAN_NONSU2_DIRECT_HxV.f90:22-126) -- elements regenerated row by row, one binary search of the
+    sector map per element -- on the SAME sector and model as the GPU run.  A whole product of config 5 is ~10 M rows x
+    ~60 searched elements; the bounded sample is a leading range of rows, timed on one thread and on all host cores
+    (row ranges, as the reference's MPI ranks take them), scaled to the sector's rows."""
+    import numpy as np
+    from oracle import oracle as O
+    from edipack_amd.synthetic import synthetic_model
+    pm = synthetic_model(w)
+    om = O.Model(ed_mode=pm.ed_mode, bath_type=pm.bath_type, norb=pm.norb, nbath=pm.nbath, nspin=pm.nspin, hfmode=pm.hfmode,
+                 xmu=pm.xmu, uloc=tuple(float(u) for u in pm.uloc), ust=pm.ust, jh=pm.jh, jx=pm.jx, jp=pm.jp,
+                 hloc=pm.hloc, be=pm.be, bv=pm.bv, bd=pm.bd, bu=pm.bu)
+    d = O.DirectNonsu2(om, w.sector)
+    rng = np.random.default_rng(12345)
+    v = (rng.standard_normal(d.dim) + 1j * rng.standard_normal(d.dim)).astype(np.complex128)
+    v /= np.linalg.norm(v)
+    hv = np.zeros_like(v)
+    cores = _host_cores()
+
+    def timed(rows, threads):
+        t0 = time.perf_counter()
+        d.matvec(v, hv, threads=threads, rows=rows)
+        return time.perf_counter() - t0
+
+    probe = min(d.dim, 20000)
+    t1 = timed(probe, 1)
+    rows1 = int(min(d.dim, max(probe, probe * 0.4 * budget_s / max(t1, 1e-6))))
+    dt1 = timed(rows1, 1) * d.dim / rows1
+    tm = timed(min(d.dim, probe * cores), cores)
+    rowsm = int(min(d.dim, max(probe * cores, probe * cores * 0.6 * budget_s / max(tm, 1e-6))))
+    dtm = timed(rowsm, cores) * d.dim / rowsm
+    return {"value": 1.0 / dtm, "unit": "H*v/s", "cores": cores, "kind": "port", "single_thread_value": 1.0 / dt1,
+            "sample": f"rows 1..{rowsm} of the {d.dim} of workload {w.name} (same sector and model as the GPU run) through the "
+                      f"oracle's C restatement of directMatVec_nonsu2_main (elements regenerated on the fly, a binary search "
+                      f"per element) on {cores} threads over row ranges, scaled by rows: {dtm * 1e3:.0f} ms per product; "
+                      f"1 thread, rows 1..{rows1}: {dt1 * 1e3:.0f} ms per product"}
+
+
 def run_single(args):
     import torch  # noqa: F401  (first: one HIP runtime per process, see edipack_amd/capi.py)
     from edipack_amd import capi
@@ -215,21 +254,7 @@ def run_single(args):
     dim_gpu = h.dim
     h.destroy()
     if not args.no_cpu and out.get("cpu_baseline") is None:
-        # On-the-fly workload: nothing is stored on the GPU, and the stored matrix of this sector (666 M entries for
-        # config 5) is beyond a bounded CPU sample.  The sample is the SAME operator structure one size down (Ns = 11,
-        # stored by the library, multiplied by the oracle's restatement of spMatVec_mpi_nonsu2_main), scaled by rows.
-        small = {"cfg5": "cfg5_stored_ns11", "cfg5_ns11": "cfg5_stored_ns11"}.get(w.name)
-        if small:
-            hs = build_workload(WORKLOADS[small])
-            cb = cpu_baseline(hs, small, args.cpu_seconds)
-            scale = hs.dim / dim_gpu
-            cb["value"] *= scale
-            cb["single_thread_value"] *= scale
-            cb["sample"] = (f"scaled by rows ({hs.dim} -> {dim_gpu}) from: " + cb["sample"] +
-                            "; the reference's CPU path for this workload regenerates the elements on the fly "
-                            "(directMatVec_MPI_nonsu2_main), which is slower than the stored product timed here")
-            out["cpu_baseline"] = cb
-            hs.destroy()
+        out["cpu_baseline"] = cpu_baseline_direct(w, args.cpu_seconds)
     if args.workload == "cfg2" and not args.no_resident:
         out["config"]["hbm_resident"] = _hbm_resident(args.steps)
     print(json.dumps(out), flush=True)

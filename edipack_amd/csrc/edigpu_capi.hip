@@ -417,6 +417,7 @@ static void free_ib(IbDev* p) {
   dev_free(p->xu); dev_free(p->ed); dev_free(p->impd); dev_free(p->pos); dev_free(p->colof); dev_free(p->chunk_row);
   dev_free(p->chunk_blk); dev_free(p->dcls); dev_free(p->dblist); dev_free(p->dmeta); dev_free(p->dw_vtab);
   dev_free(p->dw_timp); dev_free(p->ndcoef); dev_free(p->nd_dw); dev_free(p->nd_up);
+  dev_free(p->up_pmask); dev_free(p->dw_pmask); dev_free(p->up_pt); dev_free(p->dw_pt);
   dev_free(p->urank_low);
   for (IbDevHalf& h : p->half) {
     dev_free(h.ublist); dev_free(h.utop); dev_free(h.rmap2);
@@ -562,6 +563,13 @@ static int setup_ib(edigpu_sector* s, const HostNormal& hn, int chunk_rows) {
       dev_upload(&p->dblist, h.dblist.data(), h.dblist.size()) || dev_upload(&p->dmeta, h.dmeta.data(), h.dmeta.size()) ||
       dev_upload(&p->dw_vtab, h.dw.vtab.data(), h.dw.vtab.size()) || dev_upload(&p->dw_timp, h.dw.timp.data(), h.dw.timp.size()) ||
       dev_upload(&p->nd_dw, h.nd_dw.data(), h.nd_dw.size()) || dev_upload(&p->nd_up, h.nd_up.data(), h.nd_up.size())) {
+    free_ib(p);
+    return 1;
+  }
+  p->up_np = (int)h.up.pmask.size();
+  p->dw_np = (int)h.dw.pmask.size();
+  if ((p->up_np > 0 && (dev_upload(&p->up_pmask, h.up.pmask.data(), h.up.pmask.size()) || dev_upload(&p->up_pt, h.up.pt.data(), h.up.pt.size()))) ||
+      (p->dw_np > 0 && (dev_upload(&p->dw_pmask, h.dw.pmask.data(), h.dw.pmask.size()) || dev_upload(&p->dw_pt, h.dw.pt.data(), h.dw.pt.size())))) {
     free_ib(p);
     return 1;
   }
@@ -807,7 +815,25 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
     int chunk_rows = (e = getenv("EDIGPU_IB_ROWS")) ? atoi(e) : 480;
     chunk_rows = std::max(4, std::min(chunk_rows, 480));
     const int64_t min_row_bytes = (e = getenv("EDIGPU_IB_MINROW")) ? atoll(e) : (min_rows == 0 ? 0 : 40 * 1024);
-    if (on && s->nloc >= min_rows && dim_up * 8 >= min_row_bytes && !env_flag("EDIGPU_LANCZOS_UNFUSED") &&
+    // Replica / general baths (hops between the bath levels of a replica, host_ib.hpp IbSide::pmask): the image and its
+    // kernels hold them as pair hops of whole blocks -- tested, golden-pinned -- but every lane runs through every pair
+    // (half of them idle), which costs as much as the walk over the levels: measured on the 3-orbital x 4-replica sector
+    // of Ns = 15 the product takes 1.16 ms on the blocks against 0.81 ms on the generic kernels.  So the default keeps
+    // such sectors on the generic kernels; EDIGPU_IB_PAIRS=1 (or EDIGPU_IB_MIN=0, the tests) takes the image.
+    bool pairs = false;
+    for (int sp = 0; sp < 2 && !pairs; sp++) {
+      const std::vector<double>& a = built->ob_a[sp];
+      const int ns = built->ns;
+      if ((int)a.size() == ns * ns)
+        for (int p = built->norb; p < ns && !pairs; p++)
+          for (int q = p + 1; q < ns; q++)
+            if (a[(size_t)p * ns + q] != 0.0) {
+              pairs = true;
+              break;
+            }
+    }
+    const bool pairs_ok = !pairs || min_rows == 0 || env_flag("EDIGPU_IB_PAIRS");
+    if (on && pairs_ok && s->nloc >= min_rows && dim_up * 8 >= min_row_bytes && !env_flag("EDIGPU_LANCZOS_UNFUSED") &&
         setup_ib(s, *built, chunk_rows))
       return 1;
   }

@@ -131,6 +131,10 @@ struct IbDev {
   uint16_t *dblist = nullptr, *dmeta = nullptr;
   double *dw_vtab = nullptr, *dw_timp = nullptr, *ndcoef = nullptr;
   uint8_t *nd_dw = nullptr, *nd_up = nullptr;
+  // bath-bath hops (host_ib.hpp IbSide::pmask, pt): replica / general baths
+  int up_np = 0, dw_np = 0;
+  uint32_t *up_pmask = nullptr, *dw_pmask = nullptr;
+  double *up_pt = nullptr, *dw_pt = nullptr;
 };
 
 }  // namespace edigpu

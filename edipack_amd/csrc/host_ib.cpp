@@ -26,8 +26,18 @@ std::string build_side(const HostNormal& hn, int sp, const CombBasis& bs, int np
     for (int q = 0; q < ns; q++) {
       if (p == q) continue;
       if (a[p * ns + q] != a[q * ns + p]) return "hop matrix not symmetric";
-      if (p >= norb && q >= norb && a[p * ns + q] != 0.0) return "bath-bath hops";
     }
+  s.pmask.clear();
+  s.pt.clear();
+  for (int p = norb; p < ns; p++)
+    for (int q = p + 1; q < ns; q++)
+      if (a[p * ns + q] != 0.0) {
+        const int k1 = p - norb, k2 = q - norb;
+        const uint32_t btw = ((1u << k2) - 1u) & ~((1u << (k1 + 1)) - 1u);
+        s.pmask.push_back((1u << k1) | (1u << k2) | (btw << 16));
+        s.pt.push_back(a[p * ns + q]);
+      }
+  if ((int)s.pmask.size() > kIbMaxPairs) return "more than 64 bath-bath hops";
   s.vtab.assign((size_t)nb * 4, 0.0);
   for (int k = 0; k < nb; k++)
     for (int ia = 0; ia < norb; ia++) s.vtab[(size_t)k * 4 + ia] = a[(norb + k) * ns + ia];
@@ -206,6 +216,7 @@ void build_ib(const HostNormal& hn, int max_chunk_rows, HostIb& out, int lds_bud
   auto rows_lds = [](int img_words, int nbits) { return (int64_t)img_words * 8 + (int64_t)(nbits + 2) * 32 + ((int64_t)2 << nbits); };
   if (lds_budget < 0 || (lds_budget > 0 && rows_lds(out.rimg_len, nb) > lds_budget)) {  // (< 0: always, tests)
     if (nb < 2) return fail("row image longer than the LDS");
+    if (!out.up.pmask.empty()) return fail("bath-bath hops in a row staged in halves");
     e = build_up(true);
     if (!e.empty()) return fail(e);
     if (lds_budget > 0 && rows_lds(std::max(out.half[0].rimg_len, out.half[1].rimg_len), nb - 1) > lds_budget)

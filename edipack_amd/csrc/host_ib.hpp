@@ -7,7 +7,8 @@
 // impurity hops; H_non_local.f90 for the two-body terms) moves one electron between an impurity level and ONE bath
 // level k, or between two impurity levels: it couples block b to block b ^ (1 << k) (or to itself) through a small
 // matrix on the impurity patterns whose entries are +/- V(a,k) with a sign that factorises into (impurity bits above
-// a) x (bath bits below k).  The kernels of kernels_ib.hip work on whole blocks:
+// a) x (bath bits below k).  A hop between TWO bath levels (replica / general baths, H_up.f90:26-50) couples block b to
+// b ^ (1 << k1 | 1 << k2) element by element (IbSide::pmask).  The kernels of kernels_ib.hip work on whole blocks:
 //   rows kernel   a lane owns a block of COLUMNS of one staged row; per bath level one table look-up gives the
 //                 partner block, its <= C(Norb, n+-1) adjacent words come from the LDS
 //   columns kernel a lane group owns a block of ROWS x 16 columns; the row blocks of a chunk (rows that share their
@@ -27,6 +28,7 @@ constexpr int kIbPanel = 16;     // columns per panel of the vector layout (one 
 constexpr int kIbMaxNorb = 3;    // impurity levels per block the kernels are instantiated for
 constexpr int kIbMaxBath = 14;   // bath levels per species (block tables have 2^nb entries of 16 bits)
 constexpr int kIbMaxTerms = 16;  // factored Hnd terms
+constexpr int kIbMaxPairs = 64;  // bath-bath hops per species (replica / general baths)
 
 struct IbSide {                  // one spin species
   int ns = 0, npart = 0, norb = 0, nb = 0;
@@ -37,6 +39,12 @@ struct IbSide {                  // one spin species
   std::vector<double> timp;      // [norb][norb], symmetric, zero diagonal: impurity-impurity hops
   std::vector<double> ebath;     // [2^nb]: one-body energy of the bath part of a block
   std::vector<double> eimp;      // [2^norb]: one-body + same-spin density-density energy of an impurity pattern
+  // bath-bath hops (bath_type replica / general, stored/H_up.f90:26-50: the off-diagonal elements of a replica's matrix
+  // between the levels of two orbitals): t (c+_k1 c_k2 + h.c.) couples block b to block b ^ mask -- same class, same
+  // impurity patterns -- with the sign of the occupied bath levels strictly between the two.
+  // pmask[q] = (1 << k1 | 1 << k2) | (levels strictly between) << 16, pt[q] = t
+  std::vector<uint32_t> pmask;
+  std::vector<double> pt;
 };
 
 // Rows longer than the LDS: the row image is built for ONE value of the top bath bit at a time ("half").  The hops over

@@ -166,9 +166,11 @@ struct RowImage {
 // timp  : [NORB][NORB] (uniform: scalar loads on the device)
 // dconst: ed[idw];  xu: [2^NORB] diagonal part that depends on this block's impurity pattern (+ that of the down word)
 // acc[M] receives (Hd + 1 (x) Hup) v for the block's columns
+// np, pmask, pt: the bath-bath hops (host_ib.hpp IbSide::pmask; np = 0 for normal / hybrid baths), uniform
 template <int NORB, int N>
 IB_HD void rows_block(const RowImage& im, uint32_t b, uint32_t i, int nb, const double* vtab, const double* timp,
-                      double dconst, const double* xu, double* acc) {
+                      double dconst, const double* xu, double* acc, int np = 0, const uint32_t* pmask = nullptr,
+                      const double* pt = nullptr) {
   constexpr int M = binom(NORB, N);
   const double* row = im.row;
   const double* own = row + im.cb[N + 1] + i;
@@ -222,6 +224,18 @@ IB_HD void rows_block(const RowImage& im, uint32_t b, uint32_t i, int nb, const 
       }
     }
   }
+  // bath-bath hops: the partner block has the same class and the same impurity patterns, word j pairs with word j
+  for (int q = 0; q < np; q++) {  // uniform
+    const uint32_t pm = pmask[q], mk = pm & 0xFFFFu, occ = b & mk;
+    if (occ != 0u && occ != mk) {  // exactly one of the two levels is occupied
+      const double* pp = row + im.cb[N + 1] + im.rank[b ^ mk];
+      const double ts = flip(pt[q], (uint32_t)popc32(b & (pm >> 16)) & 1u);
+      sfor<0, M>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        acc[j] = __builtin_fma(ts, pp[j * so], acc[j]);
+      });
+    }
+  }
   sfor<0, M>([&](auto J) {
     constexpr int j = decltype(J)::value;
     acc[j] = __builtin_fma(ebath + dconst + xu[pat(NORB, N, j)], x[j], acc[j]);
@@ -253,9 +267,11 @@ constexpr int rows_top_words() {
 // acc[M] is added to: + (Hdw (x) 1) v
 constexpr int kHB = 3;  // high bath levels whose partner rows are in flight together
 
+// np, pmask, pt: the bath-bath hops; dmeta = the whole table (the first row of the partner block b ^ mask is its entry 14)
 template <int NORB, int N, class GLoad>
 IB_HD void cols_block(const double* chunk, int chunk_row0, uint32_t b, int own_row, const uint16_t* meta, int nb, int low,
-                      const double* vtab, const double* timp, int col, GLoad&& gload, Pair* acc) {
+                      const double* vtab, const double* timp, int col, GLoad&& gload, Pair* acc, int np = 0,
+                      const uint32_t* pmask = nullptr, const double* pt = nullptr, const uint16_t* dmeta = nullptr) {
   constexpr int M = binom(NORB, N);
   constexpr int MPD = binom(NORB, N - 1), MPU = binom(NORB, N + 1);
   constexpr int MPX = MPD > MPU ? MPD : MPU;
@@ -332,6 +348,20 @@ IB_HD void cols_block(const double* chunk, int chunk_row0, uint32_t b, int own_r
   }
   low_walk(std::false_type{}, b & lowmask);
   consume(nbatch == 2 ? kHB : 0);
+  // bath-bath hops: rows of the partner block, in the chunk when both levels are low ones
+  for (int q = 0; q < np; q++) {  // uniform
+    const uint32_t pm = pmask[q], mk = pm & 0xFFFFu, occ = b & mk;
+    if (occ != 0u && occ != mk) {
+      const int r2 = dmeta[(size_t)(b ^ mk) * 16 + 14];
+      const double ts = flip(pt[q], (uint32_t)popc32(b & (pm >> 16)) & 1u);
+      const bool inside = (mk >> low) == 0u;  // uniform
+      sfor<0, M>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        const Pair xp = inside ? lds_pair(r2 - chunk_row0 + j) : gload(r2 + j);
+        FmaP{}(acc[j], ts, xp);
+      });
+    }
+  }
 }
 
 // ---- columns kernel: the factored Hnd terms of one block of rows x two columns -------------------------------------

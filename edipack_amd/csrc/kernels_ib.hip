@@ -45,6 +45,10 @@ struct IbArgs {
   const uint16_t *dblist, *dmeta;
   const double *dw_vtab, *dw_timp, *ndcoef;
   const uint8_t *nd_dw, *nd_up;
+  // bath-bath hops (replica / general baths; 0 otherwise)
+  int up_np, dw_np;
+  const uint32_t *up_pmask, *dw_pmask;
+  const double *up_pt, *dw_pt;
   // split rows (host_ib.hpp IbUpHalf): the rows kernel sees ONE half -- nb_up, nlist, plen, ucls, rcb, rcs, rimg_len,
   // ublist, rmap2 and urank are that half's; panel0 = its first panel; utop = per list entry the position of the partner
   // block over the top bath level; top_eps = that level's energy when it is occupied in this half (else 0).  up_vtab
@@ -210,7 +214,7 @@ __global__ void __launch_bounds__(NT, (NT == 768 ? 3 : (NT == 512 && NBT >= 12) 
           constexpr int nn = decltype(N)::value;
           constexpr int MPT = TOP ? ib::rows_top_words<NORB, nn, TOP == 2>() : 0;
           ib::rows_block<NORB, nn>(im, (entry(S) + (uint32_t)zr) & 0x7FFFu, (uint32_t)(s * NT + tid - a.ucls[nn] + zr), nb, vtab, a.up_timp, edr, xuc,
-                                   acc[s]);
+                                   acc[s], TOP ? 0 : a.up_np, a.up_pmask, a.up_pt);
           double xg[MPT > 0 ? MPT : 1];
           if constexpr (MPT > 0) {
             // the partner block over the top level, word by word (without Hnd terms the columns are not padded and a
@@ -404,7 +408,7 @@ __global__ void __launch_bounds__(kColsNT, 4) ib_cols_kernel(IbArgs a, const dou
             if (IB_ABL & 2) return *reinterpret_cast<const ib::Pair*>(chunk + (grow & 63) * 16 + col);
             return *reinterpret_cast<const ib::Pair*>(vp + (int64_t)grow * 16 + col);
           };
-        ib::cols_block<NORB, nn>(chunk, row0, b, own, meta, nb, a.lowbits, vtab, timp, col, gload, acc);
+        ib::cols_block<NORB, nn>(chunk, row0, b, own, meta, nb, a.lowbits, vtab, timp, col, gload, acc, a.dw_np, a.dw_pmask, a.dw_pt, a.dmeta);
         if (DO_ND) ib::cols_block_nd<NORB, nn>(chunk, own - row0, col, a.nterms, ndc, nddw, ndu, 16, acc);
         if constexpr (!ALPHA)
           ib::sfor<0, M>([&](auto J) {
@@ -627,7 +631,7 @@ __global__ void __launch_bounds__(kCols2NT) ib_cols2_kernel(IbArgs a, const doub
             if (IB_ABL & 2) return *reinterpret_cast<const ib::Pair*>(chunk + (grow & 63) * 16 + col);
             return *reinterpret_cast<const ib::Pair*>(vp + (int64_t)grow * 16 + col);
           };
-          ib::cols_block<NORB, nn>(chunk, row0, b, own, meta, nb, a.lowbits, vtab, timp, col, gload, acc);
+          ib::cols_block<NORB, nn>(chunk, row0, b, own, meta, nb, a.lowbits, vtab, timp, col, gload, acc, a.dw_np, a.dw_pmask, a.dw_pt, a.dmeta);
           if (DO_ND) ib::cols_block_nd<NORB, nn>(chunk, own - row0, col, a.nterms, ndc, nddw, ndu, 16, acc);
           if constexpr (!ALPHA)
             ib::sfor<0, M>([&](auto J) {
@@ -765,6 +769,12 @@ static void fill_ib_args(const IbDev* d, IbArgs& a, int half = -1) {
   a.ndcoef = d->ndcoef;
   a.nd_dw = d->nd_dw;
   a.nd_up = d->nd_up;
+  a.up_np = d->up_np;
+  a.dw_np = d->dw_np;
+  a.up_pmask = d->up_pmask;
+  a.dw_pmask = d->dw_pmask;
+  a.up_pt = d->up_pt;
+  a.dw_pt = d->dw_pt;
   a.scal = nullptr;
   a.partial = nullptr;
   a.lazy = 0;

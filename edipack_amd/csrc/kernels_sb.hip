@@ -20,7 +20,7 @@ int sb_cols_gs() {
   const char* e = getenv("EDIGPU_SB_CW");  // (read per sector set-up)
   return e && atoi(e) == 1 ? 4 : 8;
 }
-int sb_cols_waves() { return sb_cols_gs() == 4 ? 8 : 4; }
+int sb_cols_waves() { return sb_cols_gs() == 4 ? 8 : SB_COLS_NT2 / 64; }
 
 size_t sb_rows_lds(int nbw, int rimg_len) { return sb_rows_lds_bytes(nbw, rimg_len); }
 

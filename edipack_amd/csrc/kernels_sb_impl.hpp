@@ -306,6 +306,11 @@ __device__ inline void sb_nt_store<double>(double* p, const double& v) {
   __builtin_nontemporal_store(v, p);
 }
 
+// threads of the columns kernel with two columns per lane (tuning: 128 with chunks of <= 256 rows puts four workgroups on a CU)
+#ifndef SB_COLS_NT2
+#define SB_COLS_NT2 256
+#endif
+
 struct SbColsLds {  // byte offsets inside the dynamic LDS
   uint32_t chunk, desc, vtab, ndu, total;
 };
@@ -336,9 +341,9 @@ __host__ __device__ inline SbColsLds sb_cols_layout(int nbw, int nloc, int mcr, 
 // that rank's slot (SbArgs::kslot) -- and hv receives (Hdw (x) 1 + Hnd) v in the same form; nothing is read from hv (the
 // rows kernel's part is added after the exchange back).
 template <int NIMP, int NB0, int AMODE, int CW, bool DO_ND, bool ALPHA, bool SH = false>
-__global__ void __launch_bounds__((CW == 2 ? 256 : 512), (CW == 2 ? 2 : 4)) sb_cols_kernel(SbArgs a, const double* __restrict__ v, double* __restrict__ hv) {
+__global__ void __launch_bounds__((CW == 2 ? SB_COLS_NT2 : 512), (CW == 2 ? 2 : 4)) sb_cols_kernel(SbArgs a, const double* __restrict__ v, double* __restrict__ hv) {
   static_assert(!(SH && ALPHA), "row shards: plain product only");
-  constexpr int NT = CW == 2 ? 256 : 512;
+  constexpr int NT = CW == 2 ? SB_COLS_NT2 : 512;
   constexpr int GS = 4 * CW;                 // blocks per wave-slot
   constexpr int LPB = 64 / GS;               // lanes per block
   using T = std::conditional_t<CW == 2, sb::Pair, double>;
@@ -574,7 +579,7 @@ int sb_launch_rows(const IbDev* d, const SbArgs& a, int fuse, const double* P, d
 
 template <int NIMP, int NB0, int AMODE, int CW, bool DO_ND, bool ALPHA, bool SH>
 int sb_launch_cols_t(const IbDev* d, const SbArgs& a, const double* v, double* hv, hipStream_t st, int* nblocks) {
-  constexpr int NT = CW == 2 ? 256 : 512;
+  constexpr int NT = CW == 2 ? SB_COLS_NT2 : 512;
   const size_t lds = d->sb->cols_lds;
   const void* k = (const void*)sb_cols_kernel<NIMP, NB0, AMODE, CW, DO_ND, ALPHA, SH>;
   if (ensure_dynamic_lds(k, lds)) return 1;

@@ -37,6 +37,8 @@ WORKLOADS = {
     "cfg3_ns15": Workload("cfg3_ns15", 3, "normal", "hybrid", 3, 12, (7, 8), "Ns=15, Dim=41 409 225"),
     "cfg3_ns16": Workload("cfg3_ns16", 3, "normal", "hybrid", 3, 13, (8, 8), "Ns=16, Dim=165 636 900"),
     "cfg3_ns17": Workload("cfg3_ns17", 3, "normal", "hybrid", 3, 14, (8, 9), "Ns=17, Dim=590 976 100"),
+    # the same size with a replica bath (3 orbitals x 4 replicas: hops between the bath levels of a replica)
+    "cfg3_replica_ns15": Workload("cfg3_replica_ns15", 3, "normal", "replica", 3, 4, (7, 8), "Ns=15, replica bath, Dim=41 409 225"),
     # scale-up of the flat-CSR modes
     "cfg4_ns12": Workload("cfg4_ns12", 4, "superc", "hybrid", 2, 10, 0, "Ns=12, Sz=0, Dim=2 704 156"),
     # BASELINE.json configs[4]: 3 orbitals, Nbath=10 (hybrid), nonsu2, on-the-fly kernel
@@ -84,6 +86,21 @@ def synthetic_model(w: Workload) -> ImpurityModel:
             for t in range(2):
                 hl[s, t] = a[s * w.norb:(s + 1) * w.norb, t * w.norb:(t + 1) * w.norb]
     multi = w.norb > 1
+    if w.bath_type in ("replica", "general"):
+        # per replica a symmetric Norb x Norb matrix (levels e~U(-2,2) on the diagonal, inter-orbital hops ~U(-0.2,0.2)),
+        # one hybridisation per replica (item(k)%v) -- the structure build_Hreplica gives with a symmetric basis
+        n1 = nspin
+        hb = np.zeros((n1, n1, w.norb, w.norb, w.nbath), complex)
+        for k in range(w.nbath):
+            a = rng.uniform(-0.4, 0.4, (w.norb, w.norb))
+            a = 0.5 * (a + a.T) + np.diag(rng.uniform(-2.0, 2.0, w.norb))
+            for sp in range(n1):
+                hb[sp, sp, :, :, k] = a
+        bvr = np.broadcast_to(rng.uniform(0.1, 0.6, w.nbath), (nspin, w.norb, w.nbath)).copy()
+        return ImpurityModel(ed_mode=w.ed_mode, bath_type=w.bath_type, norb=w.norb, nbath=w.nbath, nspin=nspin,
+                             hfmode=True, xmu=0.0, uloc=np.full(w.norb, 2.0), ust=1.5 if multi else 0.0,
+                             jh=0.25 if multi else 0.0, jx=0.25 if multi else 0.0, jp=0.25 if multi else 0.0,
+                             hloc=hl, bv=bvr, hb=hb)
     return ImpurityModel(ed_mode=w.ed_mode, bath_type=w.bath_type, norb=w.norb, nbath=w.nbath, nspin=nspin,
                          hfmode=True, xmu=0.0, uloc=np.full(w.norb, 2.0), ust=1.5 if multi else 0.0,
                          jh=0.25 if multi else 0.0, jx=0.25 if multi else 0.0, jp=0.25 if multi else 0.0,

@@ -151,6 +151,11 @@ orc_hflat *orc_buildh_superc_main(const orc_model *m, int sz);
 orc_hflat *orc_buildh_nonsu2_main(const orc_model *m, int ntot);
 /* the same builder on a Jz_basis=T sector (Ntot, twoJz): build_sector's map is the only difference */
 orc_hflat *orc_buildh_nonsu2_jz(const orc_model *m, int ntot, int twojz);
+/* on-the-fly product of the nonsu2 mode (directMatVec_nonsu2_main, ED_NONSU2/ED_HAMILTONIAN_NONSU2_DIRECT_HxV.f90:22-126);
+ * v, hv: complex, re/im interleaved.  _rows: rows [row0, row1) with the sector map handed in (one call per thread) */
+int orc_directmatvec_nonsu2_main(const orc_model *m, int ntot, const double *v, double *hv);
+void orc_directmatvec_nonsu2_rows(const orc_model *m, const int32_t *map, int64_t dim, int64_t row0, int64_t row1,
+                                  const double *v, double *hv);
 void orc_hflat_free(orc_hflat *h);
 /* ED_SUPERC/..._STORED_HxV.f90:312-362, ED_NONSU2/..._STORED_HxV.f90:194-209 */
 void orc_spmatvec_flat_z(const orc_hflat *h, const double *v, double *hv);

@@ -278,6 +278,9 @@ def lib() -> C.CDLL:
     L.orc_buildh_nonsu2_jz.argtypes = [C.POINTER(OrcModel), C.c_int, C.c_int]
     L.orc_build_sector_nonsu2_jz.restype = C.c_int64
     L.orc_build_sector_nonsu2_jz.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, i32p]
+    L.orc_directmatvec_nonsu2_main.restype = C.c_int
+    L.orc_directmatvec_nonsu2_main.argtypes = [C.POINTER(OrcModel), C.c_int, dp, dp]
+    L.orc_directmatvec_nonsu2_rows.argtypes = [C.POINTER(OrcModel), i32p, C.c_int64, C.c_int64, C.c_int64, dp, dp]
     L.orc_hflat_free.argtypes = [vp]
     L.orc_hflat_sizes.argtypes = [vp, i64p]
     L.orc_spmatvec_flat_z.argtypes = [vp, dp, dp]
@@ -528,6 +531,49 @@ class HNormalCmplx:
             if it < nitermax:
                 b[it] = b_
         return a, b, done
+
+
+def direct_matvec_nonsu2(model: Model, ntot: int, v: np.ndarray) -> np.ndarray:
+    """directMatVec_nonsu2_main (ED_NONSU2/ED_HAMILTONIAN_NONSU2_DIRECT_HxV.f90:22-126): the elements regenerated row by
+    row and applied to v; nothing stored."""
+    L = lib()
+    s = to_struct(model)
+    v = np.ascontiguousarray(v, dtype=np.complex128)
+    hv = np.empty_like(v)
+    if L.orc_directmatvec_nonsu2_main(C.byref(s), ntot, _dp(v.view(np.float64)), _dp(hv.view(np.float64))):
+        raise RuntimeError("oracle: direct nonsu2 product: unsupported terms")
+    return hv
+
+
+class DirectNonsu2:
+    """The on-the-fly nonsu2 product on a fixed sector, threaded over row ranges (bench.py's cpu_baseline for the on-the-fly
+    workload: the reference's MPI ranks each take a range of rows, directMatVec_MPI_nonsu2_main)."""
+
+    def __init__(self, model: Model, ntot: int):
+        self._L = lib()
+        self._s = to_struct(model)
+        ns = self._L.orc_ns(C.byref(self._s))
+        self._L.orc_build_sector_nonsu2.restype = C.c_int64
+        self.dim = int(self._L.orc_build_sector_nonsu2(ns, ntot, None))
+        self.map = np.zeros(max(self.dim, 1), dtype=np.int32)
+        self._L.orc_build_sector_nonsu2(ns, ntot, self.map.ctypes.data_as(C.POINTER(C.c_int32)))
+
+    def matvec(self, v: np.ndarray, hv: np.ndarray, threads: int = 1, rows: int | None = None) -> None:
+        """hv[:rows] = (H v)[:rows] (rows=None: all); ctypes releases the GIL, so Python threads run the ranges in parallel"""
+        import threading
+        n = self.dim if rows is None else min(rows, self.dim)
+        mp = self.map.ctypes.data_as(C.POINTER(C.c_int32))
+        vp_, hp_ = _dp(v.view(np.float64)), _dp(hv.view(np.float64))
+        bounds = [n * t // threads for t in range(threads + 1)]
+        if threads == 1:
+            self._L.orc_directmatvec_nonsu2_rows(C.byref(self._s), mp, self.dim, 0, n, vp_, hp_)
+            return
+        ts = [threading.Thread(target=self._L.orc_directmatvec_nonsu2_rows,
+                               args=(C.byref(self._s), mp, self.dim, bounds[t], bounds[t + 1], vp_, hp_)) for t in range(threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
 
 
 class HFlat:

@@ -45,7 +45,7 @@ void emulate_rows(const HostIb& ib, const std::vector<double>& v, std::vector<do
           constexpr int nn = decltype(N)::value;
           double acc[ib::binom(NORB, nn)];
           ib::rows_block<NORB, nn>(im, b, i, ib.up.nb, ib.up.vtab.data(), ib.up.timp.data(), ib.ed[r],
-                                   &ib.xu[(size_t)ib.impd[r] * nimp], acc);
+                                   &ib.xu[(size_t)ib.impd[r] * nimp], acc, (int)ib.up.pmask.size(), ib.up.pmask.data(), ib.up.pt.data());
           if (!(e & kIbSkip))
             for (int j = 0; j < ib::binom(NORB, nn); j++) res[(size_t)ib.rcb[nn + 1] + (size_t)j * ib.rcs[nn + 1] + i] = acc[j];
         });
@@ -128,7 +128,8 @@ void emulate_cols(const HostIb& ib, const std::vector<double>& v, std::vector<do
                 return ib::Pair{g[0], g[1]};
               };
               ib::cols_block<NORB, nn>(chunk, row0, b, own, &ib.dmeta[(size_t)b * 16], ib.dw.nb, ib.lowbits,
-                                       ib.dw.vtab.data(), ib.dw.timp.data(), col, gload, acc);
+                                       ib.dw.vtab.data(), ib.dw.timp.data(), col, gload, acc, (int)ib.dw.pmask.size(),
+                                       ib.dw.pmask.data(), ib.dw.pt.data(), ib.dmeta.data());
               if (ib.nterms > 0)
                 ib::cols_block_nd<NORB, nn>(chunk, own - row0, col, ib.nterms, ib.ndcoef.data(), ib.nd_dw.data(),
                                             &ib.nd_up[(size_t)pn * kIbPanel], ib.npanels * kIbPanel, acc);

@@ -517,6 +517,40 @@ def test_golden_replica_sigma_momenta_through_gpu_tridiag(gpu, name):
     cache.destroy()
 
 
+@pytest.mark.parametrize("name", ["REPLICA_NORMAL", "GENERAL_NORMAL"])
+def test_golden_replica_through_block_kernels(gpu, monkeypatch, name):
+    """REPLICA_NORMAL / GENERAL_NORMAL once more with the impurity-block image forced on every sector (EDIGPU_IB_MIN=0):
+    the hops between the bath levels of one replica (ED_NORMAL/stored/H_up.f90:26-50) run as block-to-block pair hops
+    of ib_rows_kernel / ib_cols_kernel (host_ib.hpp IbSide::pmask).  Golden ground-state energy and Sigma momenta."""
+    import os
+    if os.environ.get("EDIGPU_NORMAL_EXPLICIT") or os.environ.get("EDIGPU_LANCZOS_UNFUSED") or os.environ.get("EDIGPU_ROW_SPLIT") \
+            or os.environ.get("EDIGPU_IB_SPLIT") == "1" or os.environ.get("EDIGPU_IB") == "0":
+        pytest.skip("needs the impurity-block image with whole rows")
+    from edipack_amd.hamiltonian import SectorCache
+    from tests.common import replica_golden_models
+    from tests.gf_normal import sigma_momenta_normal
+    from tests.test_oracle_golden import GOLD
+    monkeypatch.setenv("EDIGPU_IB", "1")
+    monkeypatch.setenv("EDIGPU_IB_MIN", "0")
+    g = GOLD[name]
+    om, pm = replica_golden_models(g["input"])
+    assert abs(_gpu_ground_state_energy(om, pm, "normal") - g["evals"][0]) < 1e-9
+    cache = SectorCache(1 << 30)
+    kinds = []
+
+    def tridiag(sec, v, nl):
+        h = cache.get(pm, "normal", *sec)
+        kinds.append(h.image_info()[5])
+        a, b, _ = h.lanczos_tridiag(v, nl)
+        return a, b
+
+    m = sigma_momenta_normal(om, tridiag, beta=g["input"]["BETA"], ngfiter=int(g["input"]["LANC_NGFITER"]))
+    gold = np.array(g["Sigma_momenta"]).reshape(m.shape)
+    assert np.max(np.abs(m - gold) / np.abs(gold)) < 1e-10
+    assert kinds.count(1) > len(kinds) // 2, kinds      # the impurity-block kernels, not the generic ones
+    cache.destroy()
+
+
 def test_apply_op_and_device_seeded_tridiag(gpu):
     """edigpu_apply_op_normal (c / c^+ device to device, both spins) against the test-side restatement of
     apply_op_C/CDG, and edigpu_lanczos_tridiag_dev (seed and norm2 on the device side) against the
@@ -1928,6 +1962,10 @@ def test_panel_major_lanczos_matches_oracle(gpu, monkeypatch, w, bath, norb, nba
     ("normal", 1, 8, (4, 5), {}),                      # one orbital: one state per block
     ("hybrid", 3, 5, (1, 6), {}),                      # classes missing
     ("hybrid", 2, 7, (5, 4), dict(exc_field=np.array([0.12, 0.5, 0.5, 0.07]))),   # impurity-impurity hops
+    ("replica", 2, 3, (4, 4), {}),                     # hops between the bath levels of a replica: pair hops of the blocks
+    ("replica", 3, 2, (4, 5), {}),
+    ("general", 3, 2, (5, 4), {}),
+    ("general", 2, 4, (5, 4), dict(jxp=0.0)),
 ])
 def test_impurity_block_image_matches_oracle(gpu, monkeypatch, rows, bath, norb, nbath, sec, extra):
     """The device-resident loops on the impurity-block image (ib_rows_kernel + ib_cols_kernel on the padded panel
@@ -1937,6 +1975,8 @@ def test_impurity_block_image_matches_oracle(gpu, monkeypatch, rows, bath, norb,
     import os
     if os.environ.get("EDIGPU_NORMAL_EXPLICIT") or os.environ.get("EDIGPU_LANCZOS_UNFUSED") or os.environ.get("EDIGPU_ROW_SPLIT"):
         pytest.skip("the impurity-block image needs the factored image and the fused step")
+    if bath in ("replica", "general") and os.environ.get("EDIGPU_IB_SPLIT") == "1":
+        pytest.skip("bath-bath hops: rows staged in halves are refused (generic kernels)")
     O = _oracle()
     from edipack_amd.hamiltonian import SectorHamiltonian
     om, pm = make_models("normal", bath, norb, nbath, seed=71, **extra)

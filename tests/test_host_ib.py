@@ -89,6 +89,33 @@ def test_split_row_image_matches_explicit_arrays(shim, bath, norb, nbath, sec, r
     assert info[0] == 1 and info[7] == 2 and diff.value < 1e-13, (list(info), diff.value)
 
 
+PAIR_CASES = [
+    # replica / general baths: hops between the levels of one replica (stored/H_up.f90:26-50)
+    ("replica", 2, 2, (3, 3), 480),
+    ("replica", 2, 3, (4, 3), 12),          # chunks of 12 rows: bath-bath hops that leave the chunk
+    ("replica", 3, 2, (4, 5), 24),
+    ("replica", 3, 3, (6, 5), 40),
+    ("general", 2, 3, (3, 5), 16),
+    ("general", 3, 2, (5, 4), 480),
+    ("replica", 1, 4, (2, 3), 8),           # one orbital: a replica is one level, no bath-bath hop
+]
+
+
+@pytest.mark.parametrize("bath,norb,nbath,sec,rows", PAIR_CASES)
+def test_bath_bath_hops_of_replica_baths(shim, bath, norb, nbath, sec, rows):
+    _, pm = make_models("normal", bath, norb, nbath, seed=33)
+    rc, info, diff, msg = _check(shim, pm, sec[0], sec[1], rows)
+    assert rc == 0, msg
+    assert info[0] == 1 and diff < 1e-13, (info, diff)
+    # rows staged in halves: refused with bath-bath hops (the generic kernels take the sector)
+    info2 = (C.c_int32 * 8)()
+    d2 = C.c_double(-1.0)
+    m = pm.to_c()
+    rc = shim.host_ib_check2(C.byref(m), sec[0], sec[1], rows, -1, info2, C.byref(d2))
+    if norb > 1:
+        assert rc == 1 and "bath-bath hops in a row staged in halves" in shim.host_ib_error().decode()
+
+
 def test_chunks_follow_the_row_budget(shim):
     _, pm = make_models("normal", "hybrid", 3, 6, seed=5)
     few = _check(shim, pm, 4, 4, 480)[1]
@@ -97,10 +124,6 @@ def test_chunks_follow_the_row_budget(shim):
 
 
 def test_refusals(shim):
-    # replica baths hop between bath levels: not of the block form
-    _, pm = make_models("normal", "replica", 2, 2, seed=3)
-    rc, _, _, msg = _check(shim, pm, 3, 3, 480)
-    assert rc == 1 and "bath-bath" in msg
     # more than three orbitals
     _, pm = make_models("normal", "normal", 4, 1, seed=3)
     rc, _, _, msg = _check(shim, pm, 4, 4, 480)
