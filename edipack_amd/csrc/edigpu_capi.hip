@@ -406,6 +406,9 @@ static void free_sb(DevSb* q) {
   dev_free(q->urank); dev_free(q->ublist); dev_free(q->uslot); dev_free(q->rmap2); dev_free(q->up_vtab); dev_free(q->up_tloc);
   dev_free(q->e0); dev_free(q->ebw); dev_free(q->up_korb); dev_free(q->chunk_row); dev_free(q->chunk_slot); dev_free(q->cdesc_off);
   dev_free(q->cdesc); dev_free(q->dw_vtab); dev_free(q->dw_tloc); dev_free(q->dw_korb); dev_free(q->nd_dw);
+  for (DevSb::Half& h : q->half) {
+    dev_free(h.ublist32); dev_free(h.ugap); dev_free(h.uslot); dev_free(h.rmap2); dev_free(h.ebw);
+  }
   delete q;
 }
 
@@ -435,18 +438,28 @@ static int setup_sb(IbDev* d, const HostNormal& hn, const HostIb& h, int chunk_r
     if (verbose) fprintf(stderr, "edigpu: no local-block tables: %s\n", why.c_str());
     return 0;
   };
-  if (h.nhalf != 1) return skip("rows staged in halves");
+  const bool split = h.nhalf == 2;  // rows staged in halves: the local-block ROWS kernel per half, the impurity-block columns kernel
+  if (split) {
+    // Opt-in (EDIGPU_SB_SPLIT=1): measured at Ns = 17 the local-block rows kernel on half rows takes 3.30 + 3.15 ms against
+    // 2.77 + 2.58 ms for the round-3 kernel (kernels_sb_impl.hpp, TOP) -- the gathers of the hop over the top level cost it
+    // more than the cheaper walk gains.  Kept, tested (CPU shim and GPU), off.
+    const char* e = getenv("EDIGPU_SB_SPLIT");
+    if (!e || atoi(e) == 0) return skip("rows staged in halves (EDIGPU_SB_SPLIT=1 takes the local-block rows kernel)");
+  }
   const int nb0 = sb_nb0(h.norb);
   if (nb0 < 1 || hn.ns - h.norb - nb0 < 2) return skip("too few bath levels");
-  const int slots = sb_rows_slots(hn, nb0);
+  const int slots = sb_rows_slots(hn, nb0, split);
   if (slots < 1) return skip("not of the local-block form");
+  const int plen_rows = split ? std::max(h.half[0].npanels, h.half[1].npanels) * kIbPanel : h.npanels * kIbPanel;
   HostSb t;
   build_sb(hn, h, nb0, chunk_rows, 64 * slots, 1, sb_cols_waves(), t, sb_cols_gs());  // (the class stride of the row image: needed to choose the geometry)
   if (!t.valid) return skip(t.why);
   int nt = 0, nbt = 0;
-  if (!sb_rows_config(h.norb, slots, h.npanels * kIbPanel, t.rcs, &nt, &nbt)) return skip("no geometry of the rows kernel fits");
+  if (!sb_rows_config(h.norb, slots, plen_rows, t.rcs, &nt, &nbt)) return skip("no geometry of the rows kernel fits");
+  if (split && nbt > 4) return skip("rows staged in halves: more than 4 blocks per thread");
   build_sb(hn, h, nb0, chunk_rows, nt, nbt, sb_cols_waves(), t, sb_cols_gs());
   if (!t.valid) return skip(t.why);
+  if (split && t.amode != 0) return skip("rows staged in halves: all-orbital walk only");
   std::unique_ptr<DevSb, void (*)(DevSb*)> q(new DevSb(), free_sb);
   q->nb0 = t.nb0;
   q->nloc = t.nloc;
@@ -457,7 +470,8 @@ static int setup_sb(IbDev* d, const HostNormal& hn, const HostIb& h, int chunk_r
   q->rows_nbt = nbt;
   q->rimg_len = t.rimg_len;
   q->rcs = t.rcs;
-  q->rows_lds = sb_rows_lds(t.up.nbw, t.rimg_len);
+  q->rows_lds = split ? sb_rows_lds(t.up.nbw - 1, t.rimg_len, true) : sb_rows_lds(t.up.nbw, t.rimg_len);
+  q->nhalf = t.nhalf;
   q->lowbits = t.lowbits;
   q->nchunks = (int)t.chunk_row.size() - 1;
   q->max_chunk_rows = t.max_chunk_rows;
@@ -467,8 +481,24 @@ static int setup_sb(IbDev* d, const HostNormal& hn, const HostIb& h, int chunk_r
   if (q->rows_lds > 158 * 1024 || q->cols_lds > 158 * 1024) return skip("tables larger than the LDS");
   std::vector<uint32_t> rmap2(t.rmap.size() / 2);
   for (size_t i = 0; i < rmap2.size(); i++) rmap2[i] = (uint32_t)t.rmap[2 * i] | ((uint32_t)t.rmap[2 * i + 1] << 16);
-  if (dev_upload(&q->urank, t.urank.data(), t.urank.size()) || dev_upload(&q->ublist, t.ublist.data(), t.ublist.size()) ||
-      dev_upload(&q->uslot, t.uslot.data(), t.uslot.size()) || dev_upload(&q->rmap2, rmap2.data(), rmap2.size()) ||
+  if (split) {
+    for (int hh = 0; hh < 2; hh++) {
+      const SbUpHalf& hf = t.half[hh];
+      DevSb::Half& dh = q->half[hh];
+      dh.panel0 = hf.panel0;
+      dh.npanels = hf.npanels;
+      std::vector<uint32_t> ub(hf.ublist.size()), rm(hf.rmap.size() / 2);
+      for (size_t i = 0; i < ub.size(); i++) ub[i] = (uint32_t)hf.ublist[i] | ((uint32_t)hf.utop[i] << 16);
+      for (size_t i = 0; i < rm.size(); i++) rm[i] = (uint32_t)hf.rmap[2 * i] | ((uint32_t)hf.rmap[2 * i + 1] << 16);
+      if (dev_upload(&dh.ublist32, ub.data(), ub.size()) || dev_upload(&dh.ugap, hf.ugap.data(), hf.ugap.size()) ||
+          dev_upload(&dh.uslot, hf.uslot.data(), hf.uslot.size()) || dev_upload(&dh.rmap2, rm.data(), rm.size()) ||
+          dev_upload(&dh.ebw, hf.ebw.data(), hf.ebw.size()))
+        return 1;
+    }
+  }
+  if (dev_upload(&q->urank, t.urank.data(), t.urank.size()) ||
+      (!split && (dev_upload(&q->ublist, t.ublist.data(), t.ublist.size()) ||
+                  dev_upload(&q->uslot, t.uslot.data(), t.uslot.size()) || dev_upload(&q->rmap2, rmap2.data(), rmap2.size()))) ||
       dev_upload(&q->up_vtab, t.up.vtab.data(), t.up.vtab.size()) || dev_upload(&q->up_tloc, t.up.tloc.data(), t.up.tloc.size()) ||
       dev_upload(&q->e0, t.e0.data(), t.e0.size()) || dev_upload(&q->ebw, t.ebw.data(), t.ebw.size()) || dev_upload(&q->up_korb, t.up.korb.data(), t.up.korb.size()) ||
       dev_upload(&q->chunk_row, t.chunk_row.data(), t.chunk_row.size()) ||
@@ -2171,7 +2201,7 @@ int edigpu_image_info(edigpu_handle s, int32_t image[6]) {
   image[2] = s->factored ? s->fac_nimp : 0;
   image[3] = s->panel_mode;
   image[4] = s->ib ? kIbPanel : (s->blk_shift ? (1 << s->blk_shift) : 0);
-  image[5] = s->ib ? (s->ib->sb ? 3 : s->ib->nhalf) : 0;  // 1: impurity-block image, 2: with rows staged in halves, 3: local-block tables
+  image[5] = s->ib ? (s->ib->sb ? (s->ib->sb->nhalf == 2 ? 4 : 3) : s->ib->nhalf) : 0;  // 1: impurity-block image, 2: with rows staged in halves, 3: local-block tables, 4: local-block rows kernel on half rows
   return 0;
 }
 

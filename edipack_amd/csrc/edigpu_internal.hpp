@@ -107,6 +107,18 @@ struct DevSb {
   double *dw_vtab = nullptr, *dw_tloc = nullptr;
   uint32_t* dw_korb = nullptr;
   uint32_t* nd_dw = nullptr;
+  // rows staged in halves (host_sb.hpp SbUpHalf): nhalf = 2; urank then ranks the LOW words, ublist / uslot / rmap2 / ebw of the
+  // whole row are absent and rows_lds, rimg_len, rows_nt / rows_nbt serve both halves; the columns kernel of such a sector is
+  // the impurity-block one
+  int nhalf = 1;
+  struct Half {
+    int panel0 = 0, npanels = 0;
+    uint32_t* ublist32 = nullptr;  // low word | skip | partner position over the top level << 16
+    uint8_t* ugap = nullptr;
+    int32_t* uslot = nullptr;
+    uint32_t* rmap2 = nullptr;
+    double* ebw = nullptr;
+  } half[2];
 };
 
 struct IbDev {

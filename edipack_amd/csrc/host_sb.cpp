@@ -99,17 +99,23 @@ long slot_cost(int nloc, int nbw, int npart, int n) {
 
 }  // namespace
 
-int sb_rows_slots(const HostNormal& hn, int nb0) {
+int sb_rows_slots(const HostNormal& hn, int nb0, bool split) {
   const int nloc = hn.norb + nb0, nbw = hn.ns - nloc;
   if (nb0 < 1 || nloc > kSbMaxLoc || nbw < 1 || nbw > 14) return -1;
-  std::vector<int> count((size_t)nloc + 1, 0);
-  for (uint32_t w = 0; w < (1u << nbw); w++) {
-    const int n = hn.nup - popc(w);
-    if (n >= 0 && n <= nloc) count[n]++;
+  if (split && nbw < 2) return -1;
+  int most = 0;
+  for (int h = 0; h < (split ? 2 : 1); h++) {
+    std::vector<int> count((size_t)nloc + 1, 0);
+    for (uint32_t w = 0; w < (1u << nbw); w++) {
+      if (split && (int)(w >> (nbw - 1)) != h) continue;
+      const int n = hn.nup - popc(w);
+      if (n >= 0 && n <= nloc) count[n]++;
+    }
+    int slots = 0;
+    for (int n = 0; n <= nloc; n++) slots += (count[n] + 63) / 64;
+    most = std::max(most, slots);
   }
-  int slots = 0;
-  for (int n = 0; n <= nloc; n++) slots += (count[n] + 63) / 64;
-  return slots;
+  return most;
 }
 
 void build_sb(const HostNormal& hn, const HostIb& ib, int nb0, int max_chunk_rows, int rows_nt, int rows_nbt, int cols_nw,
@@ -120,7 +126,8 @@ void build_sb(const HostNormal& hn, const HostIb& ib, int nb0, int max_chunk_row
     out.valid = false;
     out.why = w;
   };
-  if (!ib.valid || ib.nhalf != 1) return fail("no whole-row impurity-block image to derive the tables from");
+  if (!ib.valid) return fail("no impurity-block image to derive the tables from");
+  const bool split = ib.nhalf == 2;
   const int norb = hn.norb, ns = hn.ns, nloc = norb + nb0, nbw = ns - nloc;
   if (nb0 < 1 || nloc > kSbMaxLoc) return fail("local levels per block not in norb+1 .. 6");
   if (nbw < 1 || nbw > 14) return fail("walked bath levels per species not in 1..14");
@@ -145,7 +152,7 @@ void build_sb(const HostNormal& hn, const HostIb& ib, int nb0, int max_chunk_row
   auto rows_of = [&](const SbSide& s, uint32_t w) { return (int)binomial(nloc, cls_of(s, w)); };
 
   // ---- up side: row image, wave-slots ----
-  {
+  if (!split) {
     std::vector<std::vector<uint16_t>> bycls((size_t)nloc + 1);
     for (uint32_t w = 0; w < nw; w++)
       if (out.up.first[w] != kIbNone) bycls[(size_t)cls_of(out.up, w)].push_back((uint16_t)w);
@@ -190,6 +197,104 @@ void build_sb(const HostNormal& hn, const HostIb& ib, int nb0, int max_chunk_row
           out.ublist[((size_t)s * nwv + v) * 64 + l] = i < (int)lst.size() ? lst[(size_t)i] : (uint16_t)(lst[0] | kIbSkip);
         }
       }
+  }
+  if (split) {
+    // rows staged in halves (SbUpHalf): one image per value of the top walked bit
+    if (nbw < 2) return fail("one walked level: nothing to split");
+    const int top = nbw - 1;
+    const uint32_t lowm = (1u << top) - 1u;
+    out.nhalf = 2;
+    out.urank.assign((size_t)1 << top, 0);
+    {
+      std::vector<int> cnt((size_t)nbw + 1, 0);
+      for (uint32_t wl = 0; wl <= lowm; wl++) out.urank[wl] = (uint16_t)cnt[(size_t)popc(wl)]++;
+    }
+    std::vector<std::vector<uint16_t>> bycls[2];
+    int maxcnt = 1;
+    for (int h = 0; h < 2; h++) {
+      bycls[h].assign((size_t)nloc + 1, {});
+      for (uint32_t w = 0; w < nw; w++)
+        if ((int)(w >> top) == h && out.up.first[w] != kIbNone) {
+          std::vector<uint16_t>& lst = bycls[h][(size_t)cls_of(out.up, w)];
+          // a class's list must be in rank order: a partner block is found through urank
+          if (out.urank[w & lowm] != (int)lst.size()) return fail("a half does not hold every low word of an occupation");
+          lst.push_back((uint16_t)(w & lowm));
+        }
+      for (int n = 0; n <= nloc; n++) maxcnt = std::max(maxcnt, (int)bycls[h][n].size());
+    }
+    int cs = 64;
+    while (cs < maxcnt) cs *= 2;
+    cs += 1;
+    out.rcs = cs;
+    std::vector<int> wb((size_t)nloc + 2, 0);
+    for (int n = 0; n <= nloc; n++) wb[n + 1] = wb[n] + (int)binomial(nloc, n);
+    out.rimg_len = (wb[nloc + 1] * cs + 8 + 1) & ~1;
+    if (out.rimg_len >= 0xFFF0) return fail("row image longer than 65519 words");
+    const int nwv = rows_nt / 64;
+    out.rows_nt = rows_nt;
+    out.rows_nbt = rows_nbt;
+    const double eps_top = out.up.vtab[(size_t)top * 4 + 3];
+    for (int h = 0; h < 2; h++) {
+      SbUpHalf& hf = out.half[h];
+      hf = SbUpHalf();
+      hf.panel0 = ib.half[h].panel0;
+      hf.npanels = ib.half[h].npanels;
+      hf.rmap.assign((size_t)hf.npanels * kIbPanel, (uint16_t)(out.rimg_len - 1));
+      for (int64_t i = 0; i < du; i++) {
+        const uint32_t st = (uint32_t)hn.bup.states[i], w = st >> nloc;
+        if ((int)(w >> top) != h) continue;
+        const int64_t rel = (int64_t)ib.pos[(size_t)i] - (int64_t)hf.panel0 * kIbPanel;
+        if (rel < 0 || rel >= (int64_t)hf.rmap.size()) return fail("a column of a half lies outside its panels");
+        hf.rmap[(size_t)rel] = (uint16_t)((wb[cls_of(out.up, w)] + pat_rank(st & lmask)) * cs + out.urank[w & lowm]);
+      }
+      std::vector<Slot> slots;
+      for (int n = 0; n <= nloc; n++)
+        for (int i0 = 0; i0 < (int)bycls[h][n].size(); i0 += 64) slots.push_back(Slot{n, i0, slot_cost(nloc, top, out.up.npart - h, n)});
+      std::vector<std::vector<Slot>> order;
+      if (!deal(slots, nwv, rows_nbt, order)) return fail("more wave-slots than the rows kernel holds");
+      hf.uslot.assign((size_t)rows_nbt * nwv, -1);
+      hf.ublist.assign((size_t)rows_nbt * nwv * 64, 0);
+      hf.utop.assign(hf.ublist.size(), kIbNone);
+      hf.ugap.assign(hf.ublist.size(), 0x0F);
+      for (int v = 0; v < nwv; v++)
+        for (int sidx = 0; sidx < (int)order[v].size(); sidx++) {
+          const Slot& sl = order[v][sidx];
+          hf.uslot[(size_t)sidx * nwv + v] = sl.cls | (sl.i0 << 8);
+          const std::vector<uint16_t>& lst = bycls[h][(size_t)sl.cls];
+          for (int l = 0; l < 64; l++) {
+            const int i = sl.i0 + l;
+            const size_t at = ((size_t)sidx * nwv + v) * 64 + l;
+            const uint16_t wl = i < (int)lst.size() ? lst[(size_t)i] : lst[0];
+            hf.ublist[at] = i < (int)lst.size() ? wl : (uint16_t)(wl | kIbSkip);
+            const uint32_t wp = (uint32_t)wl | ((uint32_t)(1 - h) << top);  // the block with the top bit toggled
+            if (out.up.first[wp] == kIbNone) continue;
+            const int64_t f = out.up.first[wp];
+            const int m = rows_of(out.up, wp);
+            const int p0 = ib.pos[(size_t)f];
+            hf.utop[at] = (uint16_t)p0;
+            int jg = -1, g = 0;
+            for (int j = 1; j < m; j++) {
+              const int d = ib.pos[(size_t)(f + j)] - (p0 + j);
+              if (jg < 0 && d != 0) {
+                jg = j;
+                g = d;
+              }
+              if (d != (jg >= 0 && j >= jg ? g : 0)) return fail("a block's columns have more than one gap");
+            }
+            if (jg >= 0) {
+              if (jg > 14 || g < 1 || g > 15) return fail("gap of a block's columns out of range");
+              hf.ugap[at] = (uint8_t)(jg | (g << 4));
+            }
+          }
+        }
+      hf.ebw.assign((size_t)1 << top, 0.0);
+      for (uint32_t wl = 0; wl <= lowm; wl++) {
+        double e2 = h ? eps_top : 0.0;
+        for (int k = 0; k < top; k++)
+          if ((wl >> k) & 1u) e2 += out.up.vtab[(size_t)k * 4 + 3];
+        hf.ebw[wl] = e2;
+      }
+    }
   }
   out.ebw.assign(nw, 0.0);
   for (uint32_t w = 0; w < nw; w++)

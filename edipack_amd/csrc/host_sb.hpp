@@ -31,6 +31,23 @@ struct SbSide {  // one spin species
   bool single = false;          // every walked level couples to at most one impurity level
 };
 
+// Rows longer than the LDS (the impurity-block image has nhalf = 2: the first block with the top bath bit set starts a
+// panel): the rows kernel stages ONE value of the top walked bit at a time.  Inside a half the walk runs over the nbw - 1
+// lower levels and the LOW word; the hop over the top level reads the partner block's words (same low word, other half)
+// from the vector itself.
+struct SbUpHalf {
+  int panel0 = 0, npanels = 0;   // this half's panels of the padded row
+  std::vector<uint16_t> ublist;  // as HostSb::ublist, with the low word (top bit cleared)
+  std::vector<int32_t> uslot;
+  // per ublist entry: position (whole padded row) of the first column of the block with the top bit toggled, kIbNone
+  // when the sector has no such block; and where that block's columns are NOT consecutive (a panel edge between two of
+  // its impurity blocks): ugap = (first column after the gap) | (positions skipped << 4), 0x0F = none
+  std::vector<uint16_t> utop;
+  std::vector<uint8_t> ugap;
+  std::vector<uint16_t> rmap;    // [npanels * 16]: image word of a position counted from panel0 * 16
+  std::vector<double> ebw;       // [2^(nbw-1)] one-body energy of the low word (+ the top level's when this half has it)
+};
+
 struct HostSb {
   bool valid = false;
   std::string why;
@@ -53,6 +70,10 @@ struct HostSb {
   int rimg_len = 0;
   std::vector<double> e0;   // [2^nb0] one-body energy of the low bath bits of the up species
   std::vector<double> ebw;  // [2^nbw] one-body energy of the walked levels of the up species a word occupies
+  // split rows (SbUpHalf): nhalf = 2, the tables above that describe a whole row (ublist, uslot, rmap, ebw) are empty, urank
+  // holds the rank of a LOW word among the low words of equal occupation (2^(nbw-1) entries), rcs / rimg_len serve both halves
+  int nhalf = 1;
+  SbUpHalf half[2];
   // ---- columns kernel ----
   // chunk = rows that share the walked levels >= lowbits.  A wave-slot = cols_gs blocks of one class AND one high word w >>
   // lowbits (padded to multiples of cols_gs per such group: the hops over the levels >= lowbits are then uniform in a slot); wave v of a workgroup takes the slots v, v + cols_nw, ... of a chunk: dslot[chunk_slot[c] + q] =
@@ -83,7 +104,7 @@ inline uint32_t sb_desc_bytes(int nsl, int gs) {
 }
 
 // wave-slots of the rows kernel a sector needs with nb0 low levels folded in (to choose rows_nt / rows_nbt); -1: not of
-// the form
-int sb_rows_slots(const HostNormal& hn, int nb0);
+// the form.  split: rows staged in halves -- the larger of the two halves' counts
+int sb_rows_slots(const HostNormal& hn, int nb0, bool split = false);
 
 }  // namespace edigpu

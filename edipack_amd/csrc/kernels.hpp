@@ -110,7 +110,10 @@ int launch_sb_cols_shard(const edigpu_sector* s, int p0, int np, int64_t q, int 
 int sb_nb0(int norb);
 int sb_cols_waves();
 int sb_cols_gs();
-size_t sb_rows_lds(int nbw, int rimg_len);
+size_t sb_rows_lds(int nbw, int rimg_len, bool top = false);
+// one half of the rows kernel's product on a sector whose rows are staged in halves (h = 0 / 1: top walked level empty /
+// occupied); scal: the recurrence's scalars (stop flag) or null
+int launch_sb_rows_half(const edigpu_sector* s, int h, const double* v, double* hv, const double* scal, hipStream_t st);
 size_t sb_cols_lds(int nbw, int nloc, int max_chunk_rows, int max_chunk_slots, int gs);
 bool sb_rows_config(int norb, int slots, int plen, int cs, int* nt_out, int* nbt_out);
 size_t ib_rows_lds_bytes(int nb, int rimg_len);

@@ -1007,11 +1007,16 @@ static int launch_ib_cols(const IbDev* d, const IbArgs& a, bool alpha, const dou
 
 // plain product on vectors in the padded panel layout
 int launch_ib(const edigpu_sector* s, const double* v, double* hv, hipStream_t st) {
-  if (s->ib->sb) return launch_sb(s, v, hv, st);
+  if (s->ib->sb && s->ib->sb->nhalf == 1) return launch_sb(s, v, hv, st);
   IbArgs a;
   if (s->ib->nhalf == 2) {
-    // rows longer than the LDS: one launch per half of the row (each reads the other half's words for the top level)
+    // rows longer than the LDS: one launch per half of the row (each reads the other half's words for the top level); the
+    // local-block rows kernel where its tables exist, the columns kernel below either way
     for (int h = 0; h < 2; h++) {
+      if (s->ib->sb) {
+        if (launch_sb_rows_half(s, h, v, hv, nullptr, st)) return 1;
+        continue;
+      }
       fill_ib_args(s->ib, a, h);
       if (launch_ib_rows_top(s->ib, a, h + 1, v, hv, st)) return 1;
     }
@@ -1030,7 +1035,7 @@ int launch_ib_lanczos(const edigpu_sector* s, const double* P, double* Q, double
                       int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial) {
   // The Lanczos step of the local-block kernels (launch_sb_lanczos chooses between its fused and its semi-fused form);
   // EDIGPU_SB_STEP=0 keeps the step on the kernels below while the plain product runs on the local blocks.
-  if (s->ib->sb) {
+  if (s->ib->sb && s->ib->sb->nhalf == 1) {
     const char* es = getenv("EDIGPU_SB_STEP");
     const bool sb_step = es ? atoi(es) != 0 : true;
     if (sb_step) return launch_sb_lanczos(s, P, Q, X, scal, partial, partial_cap, first, lazy_axpy, st, npartial);
@@ -1046,6 +1051,10 @@ int launch_ib_lanczos(const edigpu_sector* s, const double* P, double* Q, double
     // columns kernel with the - beta P_old term and the three sums is the one of the fused step
     auto rows2 = [&](const double* in, double* out) -> int {
       for (int h = 0; h < 2; h++) {
+        if (s->ib->sb) {
+          if (launch_sb_rows_half(s, h, in, out, scal, st)) return 1;
+          continue;
+        }
         IbArgs ah;
         fill_ib_args(s->ib, ah, h);
         ah.scal = scal;

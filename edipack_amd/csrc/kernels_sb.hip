@@ -22,7 +22,7 @@ int sb_cols_gs() {
 }
 int sb_cols_waves() { return sb_cols_gs() == 4 ? 8 : SB_COLS_NT2 / 64; }
 
-size_t sb_rows_lds(int nbw, int rimg_len) { return sb_rows_lds_bytes(nbw, rimg_len); }
+size_t sb_rows_lds(int nbw, int rimg_len, bool top) { return sb_rows_lds_bytes(nbw, rimg_len, top); }
 
 size_t sb_cols_lds(int nbw, int nloc, int max_chunk_rows, int max_chunk_slots, int gs) {
   return sb_cols_layout(nbw, nloc, max_chunk_rows, max_chunk_slots, gs).total;
@@ -85,6 +85,9 @@ static void fill_sb_args(const IbDev* d, SbArgs& a) {
   a.dw_korb = s->dw_korb;
   a.nd_dw = s->nd_dw;
   a.nd_up = d->nd_up;
+  a.ublist32 = nullptr;
+  a.ugap = nullptr;
+  a.pfull = nullptr;
   a.row0 = 0;
   a.p0 = 0;
   a.qmagic = 0;
@@ -115,6 +118,25 @@ static int cols(const IbDev* d, const SbArgs& a, int mode, const double* v, doub
   }
   set_error("sb_cols_kernel: norb");
   return 1;
+}
+
+// rows staged in halves: (Hd + 1 (x) Hup) v for the columns of half h (the other half's part of the result is untouched)
+int launch_sb_rows_half(const edigpu_sector* s, int h, const double* v, double* hv, const double* scal, hipStream_t st) {
+  const IbDev* d = s->ib;
+  const DevSb::Half& hf = d->sb->half[h];
+  SbArgs a;
+  fill_sb_args(d, a);
+  a.nbw_up = d->sb->nbw_up - 1;
+  a.plen = hf.npanels * kIbPanel;
+  a.uslot = hf.uslot;
+  a.rmap2 = hf.rmap2;
+  a.ebw = hf.ebw;
+  a.ublist32 = hf.ublist32;
+  a.ugap = hf.ugap;
+  a.pfull = v;
+  a.scal = scal;
+  const int64_t off = (int64_t)hf.panel0 * d->ps;
+  return rows(d, a, 2 + h, v + off, hv + off, nullptr, st);
 }
 
 // plain product on vectors in the padded panel layout

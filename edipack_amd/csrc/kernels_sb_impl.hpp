@@ -39,6 +39,13 @@ struct SbArgs {
   const double *up_vtab, *up_tloc, *e0, *xu, *ed;
   const uint32_t* up_korb;
   const uint8_t* impd;
+  // rows staged in halves (host_sb.hpp SbUpHalf; TOP != 0): nbw_up, rimg_len, plen, uslot, rmap2, ebw are the half's, P / Q
+  // point at its first panel; ublist32 = low word | skip flag | position of the partner block over the top level << 16,
+  // ugap = where that block's columns skip positions, pfull = the whole vector the partner words are read from.  up_vtab
+  // keeps all nbw_up + 1 rows.
+  const uint32_t* ublist32;
+  const uint8_t* ugap;
+  const double* pfull;
   // columns kernel
   int nbw_dw, lowbits, nchunks, max_chunk_rows, max_chunk_slots;
   const int32_t *chunk_row, *chunk_slot, *cdesc_off;
@@ -86,8 +93,11 @@ constexpr int kSbVs = 10;  // doubles per level of the LDS copy of the amplitude
 //         Lanczos vector goes to a THIRD buffer.  P's pieces are read a second time when the result leaves (the term
 //         - beta P_old of the recurrence; the round-3 kernels left it to the columns kernel, which has no registers to
 //         spare for it here).
-template <int NIMP, int NB0, int AMODE, int NT, int NBT, int CS, int FUSE>
+// TOP (rows staged in halves, FUSE 0 only): 0 = the whole row is staged; 1 / 2 = the half with the top walked level empty /
+//         occupied: the walk runs over the lower levels, the hop over the top one reads the partner block from a.pfull.
+template <int NIMP, int NB0, int AMODE, int NT, int NBT, int CS, int FUSE, int TOP = 0>
 __global__ void __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) sb_rows_kernel(SbArgs a, const double* __restrict__ P, double* __restrict__ Q, double* __restrict__ X) {
+  static_assert(TOP == 0 || FUSE == 0, "rows staged in halves: plain product only");
   extern __shared__ double lds[];
   constexpr int NLOC = NIMP + NB0;
   constexpr int MAXM = sb::binom(NLOC, NLOC / 2);
@@ -95,13 +105,14 @@ __global__ void __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) sb_rows_kernel
   constexpr int NLD = sb_rows_nld(NBT, MAXM);
   const int nbw = a.nbw_up, plen2 = a.plen >> 1;
   double* row = lds;
-  double* vtab = row + a.rimg_len;                                  // [nbw][kSbVs]
-  double* ebath = vtab + nbw * kSbVs;                               // [2^nbw]
+  double* vtab = row + a.rimg_len;                                  // [nbw (+ 1: TOP)][kSbVs]
+  double* ebath = vtab + (nbw + (TOP ? 1 : 0)) * kSbVs;             // [2^nbw]
   uint16_t* rank = reinterpret_cast<uint16_t*>(ebath + (1 << nbw)); // [2^nbw]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t dd = a.dim_dw, ps = a.ps;
   double ibeta = 1.0, alpha = 0.0, beta = 0.0;
+  if (TOP != 0 && a.scal && sb_const(a.scal)[SC_STOP] != 0.0) return;  // (inside a recurrence that has terminated: uniform)
   if (FUSE) {
     const auto sc = sb_const(a.scal);  // (scalar loads: the three numbers stay in scalar registers)
     if (sc[SC_STOP] != 0.0) return;  // recurrence already terminated (uniform)
@@ -113,7 +124,7 @@ __global__ void __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) sb_rows_kernel
     rank[i] = a.urank[i];
     ebath[i] = a.ebw[i];
   }
-  for (int i = tid; i < nbw * 4; i += NT) vtab[(i >> 2) * kSbVs + (i & 3)] = a.up_vtab[i];
+  for (int i = tid; i < (nbw + (TOP ? 1 : 0)) * 4; i += NT) vtab[(i >> 2) * kSbVs + (i & 3)] = a.up_vtab[i];
   for (int i = tid; i < a.rimg_len; i += NT) row[i] = 0.0;  // slack and the zero word stay zero
   sb::RowImage im;
   im.row = row;
@@ -126,8 +137,17 @@ __global__ void __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) sb_rows_kernel
   sb::sfor<0, NBT>([&](auto S) {
     constexpr int s = decltype(S)::value;
     sd[s] = __builtin_amdgcn_readfirstlane(a.uslot[s * NW + wave]);
-    bw[s] = a.ublist[(size_t)(s * NW + wave) * 64 + (tid & 63)];
+    if constexpr (TOP != 0) bw[s] = a.ublist32[(size_t)(s * NW + wave) * 64 + (tid & 63)];
+    else bw[s] = a.ublist[(size_t)(s * NW + wave) * 64 + (tid & 63)];
   });
+  uint32_t ug = 0;  // TOP: the gap bytes of this thread's (at most four) partner blocks
+  if constexpr (TOP != 0) {
+    static_assert(NBT <= 4 || TOP == 0, "gap bytes: four blocks per thread");
+    sb::sfor<0, (NBT < 4 ? NBT : 4)>([&](auto S) {
+      constexpr int s = decltype(S)::value;
+      ug |= (uint32_t)a.ugap[(size_t)(s * NW + wave) * 64 + (tid & 63)] << (8 * s);
+    });
+  }
   // A thread moves the 16-byte pieces tid, tid + NT, ... of a row: piece q2 is the column pair (q2 & 7) of panel q2 >> 3.
   const int64_t pstride0 = (int64_t)(NT / 8) * ps;
   int64_t pstride = pstride0;  // (+ an opaque zero inside the row loop: the per-piece addresses are not hoisted)
@@ -211,6 +231,24 @@ __global__ void __launch_bounds__(NT, (NT <= 512 ? 2 : NT / 256)) sb_rows_kernel
           constexpr int nn = decltype(N)::value;
           sb::rows_block<NIMP, NB0, AMODE, nn, CS>(im, (bw[s] + (uint32_t)zr) & 0x7FFFu, (uint32_t)((sd[s] >> 8) + lane + zr), nbw, vtab, kSbVs, sb_const(a.up_korb), sb_const(a.up_tloc), edr,
                                                xuc, sb_const(a.e0), acc[s]);
+          if constexpr (TOP != 0) {
+            // The partner block over the top level, word by word from the vector, requested after the walk.  Measured at
+            // Ns = 17 (3.30 + 3.15 ms for the two halves; the round-3 kernel 2.77 + 2.58): the 8-byte gathers of 64 lanes land
+            // in ~40 different lines per instruction and wait, on the in-order memory counter, behind the next row's pieces.
+            // Requested BEFORE those pieces -- all blocks at once, or two at a time -- the kernel spills and takes 4.7-5.1 ms.
+            constexpr int MPT = sb::rows_top_words<NLOC, nn, TOP == 2>();
+            if constexpr (MPT > 0) {
+              const uint32_t tp = (bw[s] >> 16) + (uint32_t)zr;
+              const uint32_t gi = (ug >> (8 * (s & 3))) & 0xFFu, jg = gi & 15u, gg = gi >> 4;
+              double xg[MPT];
+              sb::sfor<0, MPT>([&](auto J) {
+                constexpr uint32_t j = (uint32_t)decltype(J)::value;
+                const uint32_t pj = tp + j + (j >= jg ? gg : 0u);
+                xg[j] = tp != 0xFFFFu ? a.pfull[(int64_t)(pj >> 4) * ps + r * 16 + (pj & 15u)] : 0.0;
+              });
+              sb::rows_top<NIMP, NB0, nn, TOP == 2>(bw[s] & 0x7FFFu, vtab + nbw * kSbVs, xg, acc[s]);
+            }
+          }
         });
       }
     });
@@ -539,13 +577,35 @@ __global__ void __launch_bounds__((CW == 2 ? SB_COLS_NT2 : 512), (CW == 2 ? 2 : 
 // launchers of one (NIMP, NB0, AMODE)
 // ---------------------------------------------------------------------------------------------------------
 
-inline size_t sb_rows_lds_bytes(int nbw, int rimg_len) {
-  return ((size_t)rimg_len + (size_t)nbw * kSbVs + ((size_t)1 << nbw)) * sizeof(double) + ((size_t)1 << nbw) * sizeof(uint16_t);
+// (top: rows staged in halves -- nbw counts the walked levels below the top one, whose amplitudes take one more table row)
+inline size_t sb_rows_lds_bytes(int nbw, int rimg_len, bool top = false) {
+  return ((size_t)rimg_len + (size_t)(nbw + (top ? 1 : 0)) * kSbVs + ((size_t)1 << nbw)) * sizeof(double) + ((size_t)1 << nbw) * sizeof(uint16_t);
 }
 
 template <int NIMP, int NB0, int AMODE, int NT, int NBT, int CS>
 int sb_launch_rows_t(const IbDev* d, const SbArgs& a, int fuse, const double* P, double* Q, double* X, hipStream_t st) {
   const size_t lds = d->sb->rows_lds;
+  if (fuse >= 2) {  // rows staged in halves: fuse = 2 / 3 = the half with the top walked level empty / occupied
+    if constexpr (AMODE == 0 && NBT <= 4) {
+      const void* kt = fuse == 2 ? (const void*)sb_rows_kernel<NIMP, NB0, 0, NT, NBT, CS, 0, 1> : (const void*)sb_rows_kernel<NIMP, NB0, 0, NT, NBT, CS, 0, 2>;
+      if (ensure_dynamic_lds(kt, lds)) return 1;
+      const int pc = resident_blocks(kt, NT, lds);
+      if (pc < 1) {
+        set_error("sb_rows_kernel: does not fit a CU");
+        return 1;
+      }
+      const int64_t g = std::min<int64_t>(std::max<int64_t>(a.dim_dw, 1), (int64_t)pc * device_cu_count());
+      if (fuse == 2)
+        hipLaunchKernelGGL((sb_rows_kernel<NIMP, NB0, 0, NT, NBT, CS, 0, 1>), dim3((unsigned)g), dim3(NT), lds, st, a, P, Q, X);
+      else
+        hipLaunchKernelGGL((sb_rows_kernel<NIMP, NB0, 0, NT, NBT, CS, 0, 2>), dim3((unsigned)g), dim3(NT), lds, st, a, P, Q, X);
+      EDIGPU_HIP(hipGetLastError());
+      return 0;
+    } else {
+      set_error("sb_rows_kernel: rows staged in halves are built for the all-orbital walk and at most 4 blocks per thread");
+      return 1;
+    }
+  }
   const void* k = fuse ? (const void*)sb_rows_kernel<NIMP, NB0, AMODE, NT, NBT, CS, 1> : (const void*)sb_rows_kernel<NIMP, NB0, AMODE, NT, NBT, CS, 0>;
   if (ensure_dynamic_lds(k, lds)) return 1;
   const int per_cu = resident_blocks(k, NT, lds);

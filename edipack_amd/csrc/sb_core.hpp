@@ -196,6 +196,26 @@ IB_HD void rows_block(const RowImage& im, uint32_t w, uint32_t i, int nbw, const
   }
 }
 
+// ---- rows kernel, rows staged in halves (host_sb.hpp SbUpHalf): the hop over the TOP walked level ----------------------
+// The image holds the blocks with one value of the top walked bit; rows_block walks the other levels with nbw - 1 and the
+// LOW word.  xp: the words of the partner block (same low word, top bit toggled), read from the vector itself.  TOPSET = the
+// top level is occupied in our block: partner class N + 1, else N - 1.  Every walked level below the top one is in wlow, so
+// the sign is its parity.
+template <int NIMP, int NB0, int N, bool TOPSET>
+IB_HD void rows_top(uint32_t wlow, const double* vtop /* [NIMP]: V(a, top) */, const double* xp, double* acc) {
+  constexpr int NLOC = NIMP + NB0;
+  constexpr int ALL = (1 << NIMP) - 1;
+  const uint32_t neg = (uint32_t)popc32(wlow) & 1u;
+  double v[NIMP];
+  sfor<0, NIMP>([&](auto A) { v[decltype(A)::value] = flip(vtop[decltype(A)::value], neg); });
+  couple<NLOC, NIMP, ALL, N, !TOPSET, double>(v, xp, acc, FmaD{});
+}
+// words of the partner block of a class-N block over the top level (0: no such class)
+template <int NLOC, int N, bool TOPSET>
+constexpr int rows_top_words() {
+  return TOPSET ? (N < NLOC ? binom(NLOC, N + 1) : 0) : (N >= 1 ? binom(NLOC, N - 1) : 0);
+}
+
 // ---- columns kernel: one block of rows x CW adjacent columns (T = Pair: two, T = double: one) ----------------------------
 template <class T> struct FmaOf;
 template <> struct FmaOf<double> { using type = FmaD; };

@@ -58,6 +58,59 @@ void emulate_rows(const HostIb& ib, const HostSb& sbt, const std::vector<double>
   }
 }
 
+// rows staged in halves: one image per value of the top walked bit, the hop over the top level from the vector itself
+template <int NIMP, int NB0, int AMODE>
+void emulate_rows_split(const HostIb& ib, const HostSb& sbt, const std::vector<double>& v, std::vector<double>& hv) {
+  constexpr int NLOC = NIMP + NB0;
+  const int nimp = 1 << NIMP, nwv = sbt.rows_nt / 64, top = sbt.up.nbw - 1;
+  for (int h = 0; h < 2; h++) {
+    const SbUpHalf& hf = sbt.half[h];
+    const int plen = hf.npanels * kIbPanel, p00 = hf.panel0 * kIbPanel;
+    std::vector<double> img((size_t)sbt.rimg_len, 0.0), res((size_t)sbt.rimg_len, 0.0);
+    sb::RowImage im;
+    im.row = img.data();
+    im.rank = sbt.urank.data();
+    im.ebath = hf.ebw.data();
+    im.cs = sbt.rcs;
+    for (int64_t r = 0; r < ib.dw.dim; r++) {
+      for (int p = 0; p < plen; p++) img[hf.rmap[p]] = v[vec_at(ib, r, p00 + p)];
+      res = img;
+      for (int s = 0; s < sbt.rows_nbt; s++)
+        for (int wv = 0; wv < nwv; wv++) {
+          const int32_t sd = hf.uslot[(size_t)s * nwv + wv];
+          if (sd < 0) continue;
+          const int n = sd & 0xFF, i0 = sd >> 8;
+          for (int l = 0; l < 64; l++) {
+            const size_t at = ((size_t)s * nwv + wv) * 64 + l;
+            const uint16_t e = hf.ublist[at];
+            const uint32_t wl = e & 0x7FFFu, i = (uint32_t)(i0 + l);
+            sb::for_class<NLOC>(n, [&](auto N) {
+              constexpr int nn = decltype(N)::value;
+              double acc[sb::binom(NLOC, nn)];
+              sb::rows_block<NIMP, NB0, AMODE, nn, 0>(im, wl, i, top, sbt.up.vtab.data(), 4, sbt.up.korb.data(), sbt.up.tloc.data(),
+                                                   ib.ed[r], &ib.xu[(size_t)ib.impd[r] * nimp], sbt.e0.data(), acc);
+              auto top_hop = [&](auto TS) {
+                constexpr bool ts = decltype(TS)::value;
+                constexpr int MP = sb::rows_top_words<NLOC, nn, ts>();
+                if constexpr (MP > 0) {
+                  double xp[MP];
+                  const int jg = hf.ugap[at] & 0x0F, g = hf.ugap[at] >> 4;
+                  for (int j = 0; j < MP; j++)
+                    xp[j] = hf.utop[at] == kIbNone ? 0.0 : v[vec_at(ib, r, hf.utop[at] + j + (j >= jg ? g : 0))];
+                  sb::rows_top<NIMP, NB0, nn, ts>(wl, &sbt.up.vtab[(size_t)top * 4], xp, acc);
+                }
+              };
+              if (h) top_hop(std::true_type{}); else top_hop(std::false_type{});
+              if (!(e & kIbSkip))
+                for (int j = 0; j < sb::binom(NLOC, nn); j++) res[(size_t)(sb::wbase(NLOC, nn) + j) * sbt.rcs + i] = acc[j];
+            });
+          }
+        }
+      for (int p = 0; p < plen; p++) hv[vec_at(ib, r, p00 + p)] = res[hf.rmap[p]];
+    }
+  }
+}
+
 template <int NIMP, int NB0, int AMODE, class T>
 void emulate_cols(const HostIb& ib, const HostSb& sbt, const std::vector<double>& v, std::vector<double>& hv) {
   constexpr int NLOC = NIMP + NB0;
@@ -103,11 +156,11 @@ template <int NIMP, int NB0>
 void emulate(const HostIb& ib, const HostSb& sbt, const std::vector<double>& v, std::vector<double>& hv) {
   if (sbt.amode == 1) {
     if constexpr (NIMP > 1) {
-      emulate_rows<NIMP, NB0, 1>(ib, sbt, v, hv);
+      if (sbt.nhalf == 2) emulate_rows_split<NIMP, NB0, 1>(ib, sbt, v, hv); else emulate_rows<NIMP, NB0, 1>(ib, sbt, v, hv);
       if (sbt.cols_gs == 8) emulate_cols<NIMP, NB0, 1, sb::Pair>(ib, sbt, v, hv); else emulate_cols<NIMP, NB0, 1, double>(ib, sbt, v, hv);
     }
   } else {
-    emulate_rows<NIMP, NB0, 0>(ib, sbt, v, hv);
+    if (sbt.nhalf == 2) emulate_rows_split<NIMP, NB0, 0>(ib, sbt, v, hv); else emulate_rows<NIMP, NB0, 0>(ib, sbt, v, hv);
     if (sbt.cols_gs == 8) emulate_cols<NIMP, NB0, 0, sb::Pair>(ib, sbt, v, hv); else emulate_cols<NIMP, NB0, 0, double>(ib, sbt, v, hv);
   }
 }
@@ -119,13 +172,24 @@ void emulate(const HostIb& ib, const HostSb& sbt, const std::vector<double>& v, 
 // [5] Hnd terms, [6] wave-slots of the rows kernel in use, [7] local levels.
 // Returns 0 and *maxdiff = max |difference| / max |reference|; 1 when the tables are refused (message in
 // host_sb_error()); 2 on a builder error.
+static int sb_check(const edigpu_model* m, int nup, int ndw, int nb0, int max_chunk_rows, int rows_nt, int rows_nbt,
+                    int cols_nw, int cols_gs, int lds_budget, int32_t* info, double* maxdiff);
 extern "C" int host_sb_check(const edigpu_model* m, int nup, int ndw, int nb0, int max_chunk_rows, int rows_nt, int rows_nbt,
                              int cols_nw, int cols_gs, int32_t* info, double* maxdiff) {
+  return sb_check(m, nup, ndw, nb0, max_chunk_rows, rows_nt, rows_nbt, cols_nw, cols_gs, 0, info, maxdiff);
+}
+// the same with the rows staged in halves (impurity-block image built with lds_budget < 0: always split)
+extern "C" int host_sb_check_split(const edigpu_model* m, int nup, int ndw, int nb0, int max_chunk_rows, int rows_nt, int rows_nbt,
+                                   int cols_nw, int cols_gs, int32_t* info, double* maxdiff) {
+  return sb_check(m, nup, ndw, nb0, max_chunk_rows, rows_nt, rows_nbt, cols_nw, cols_gs, -1, info, maxdiff);
+}
+static int sb_check(const edigpu_model* m, int nup, int ndw, int nb0, int max_chunk_rows, int rows_nt, int rows_nbt,
+                    int cols_nw, int cols_gs, int lds_budget, int32_t* info, double* maxdiff) {
   HostNormal hn;
   g_err = build_normal(*m, nup, ndw, 0, -1, hn, true);
   if (!g_err.empty()) return 2;
   HostIb ib;
-  build_ib(hn, max_chunk_rows, ib, 0);
+  build_ib(hn, max_chunk_rows, ib, lds_budget);
   std::memset(info, 0, 8 * sizeof(int32_t));
   if (!ib.valid) {
     g_err = ib.why;
@@ -144,6 +208,7 @@ extern "C" int host_sb_check(const edigpu_model* m, int nup, int ndw, int nb0, i
   info[4] = sbt.amode;
   info[5] = ib.nterms;
   for (int32_t sd : sbt.uslot) info[6] += sd >= 0;
+  if (sbt.nhalf == 2) info[6] = 200 + (int)sbt.half[0].uslot.size();
   info[7] = sbt.nloc;
   const int64_t du = hn.dim_up, dd = hn.dim_dw, dim = du * dd;
   std::vector<double> v((size_t)dim), ref((size_t)dim, 0.0);

@@ -375,7 +375,7 @@ def test_ns17_rows_staged_in_halves_vs_generic_kernels(gpu, monkeypatch):
     w = WORKLOADS["cfg3_ns17"]
     pm = synthetic_model(w)
     hb = SectorHamiltonian.normal_from_model(pm, *w.sector)
-    assert hb.image_info()[4] == 16 and hb.image_info()[5] == 2
+    assert hb.image_info()[4] == 16 and hb.image_info()[5] in (2, 4)   # 4: the local-block rows kernel on the halves
     rng = np.random.default_rng(17)
     v = rng.standard_normal(hb.dim)
     v /= np.linalg.norm(v)

@@ -1986,7 +1986,7 @@ def test_impurity_block_image_matches_oracle(gpu, monkeypatch, rows, bath, norb,
     monkeypatch.setenv("EDIGPU_IB_ROWS", str(rows))
     hb = SectorHamiltonian.normal_from_model(pm, *sec)
     # (scripts/check_switches.sh runs the suite with EDIGPU_IB_SPLIT=1: rows staged in halves, unfused recurrence)
-    assert hb.image_info()[5] in ((2,) if os.environ.get("EDIGPU_IB_SPLIT") == "1" else (1, 3)) and hb.image_info()[4] == 16
+    assert hb.image_info()[5] in ((2, 4) if os.environ.get("EDIGPU_IB_SPLIT") == "1" else (1, 3)) and hb.image_info()[4] == 16
     monkeypatch.setenv("EDIGPU_IB", "0")
     hn = SectorHamiltonian.normal_from_model(pm, *sec)
     assert hn.image_info()[5] == 0
@@ -2029,11 +2029,13 @@ def test_impurity_block_image_matches_oracle(gpu, monkeypatch, rows, bath, norb,
     ("normal", 1, 8, (4, 5), {}),
     ("hybrid", 2, 7, (5, 4), dict(exc_field=np.array([0.12, 0.5, 0.5, 0.07]))),
 ])
-def test_impurity_block_split_rows_match_oracle(gpu, monkeypatch, rows, bath, norb, nbath, sec, extra):
+@pytest.mark.parametrize("local_blocks", [0, 1])
+def test_impurity_block_split_rows_match_oracle(gpu, monkeypatch, local_blocks, rows, bath, norb, nbath, sec, extra):
     """Rows longer than the LDS (Ns = 17: 194 KB) are staged one half at a time -- the blocks with the top bath level
     empty, then those with it occupied -- and the hop over that level reads the partner block from the vector
-    (ib_rows_kernel TOP).  Forced here on small sectors: the plain product, the (unfused) recurrence on the padded
-    layout and the ground state against the oracle and the generic kernels."""
+    (ib_rows_kernel TOP; local_blocks = 1: sb_rows_kernel TOP on the halves, image kind 4).  Forced here on small
+    sectors: the plain product, the (unfused) recurrence on the padded layout and the ground state against the oracle and
+    the generic kernels."""
     import os
     if os.environ.get("EDIGPU_NORMAL_EXPLICIT") or os.environ.get("EDIGPU_LANCZOS_UNFUSED") or os.environ.get("EDIGPU_ROW_SPLIT"):
         pytest.skip("the impurity-block image needs the factored image")
@@ -2045,8 +2047,12 @@ def test_impurity_block_split_rows_match_oracle(gpu, monkeypatch, rows, bath, no
     monkeypatch.setenv("EDIGPU_IB_MIN", "0")
     monkeypatch.setenv("EDIGPU_IB_ROWS", str(rows))
     monkeypatch.setenv("EDIGPU_IB_SPLIT", "1")
+    monkeypatch.setenv("EDIGPU_SB_SPLIT", str(local_blocks))
     hb = SectorHamiltonian.normal_from_model(pm, *sec)
-    assert hb.image_info()[5] == 2 and hb.image_info()[4] == 16
+    kind = hb.image_info()[5]
+    assert kind in ((2, 4) if local_blocks else (2,)) and hb.image_info()[4] == 16
+    if local_blocks and os.environ.get("EDIGPU_SB", "1") != "0" and os.environ.get("EDIGPU_SB_AMODE") != "1" and nbath >= 5:
+        assert kind == 4                 # (enough walked levels for two halves: the local-block rows kernel is taken)
     v = np.random.default_rng(5).standard_normal(ho.dim)
     assert rel_err(hb.apply(v), ho.matvec(v)) < TOL
     assert rel_err(hb.apply(np.ones(ho.dim)), ho.matvec(np.ones(ho.dim))) < TOL

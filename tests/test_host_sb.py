@@ -78,6 +78,24 @@ def test_local_block_product_matches_explicit_arrays(shim, monkeypatch, bath, no
         assert info[5] > 0
 
 
+@pytest.mark.parametrize("bath,norb,nbath,sec,nb0,rows,extra", CASES)
+def test_split_rows_match_explicit_arrays(shim, bath, norb, nbath, sec, nb0, rows, extra):
+    """Rows staged in halves (one value of the top walked bit at a time, the hop over the top level from the vector
+    itself): the form the rows kernel takes when a row image does not fit the LDS (Ns = 17).  Forced here."""
+    _, pm = make_models("normal", bath, norb, nbath, seed=43, **extra)
+    info = (C.c_int32 * 8)()
+    diff = C.c_double(-1.0)
+    m = pm.to_c()
+    rc = shim.host_sb_check_split(C.byref(m), sec[0], sec[1], nb0, rows, 128, 8, 2, 4 if nbath % 2 else 8, info, C.byref(diff))
+    msg = shim.host_sb_error().decode()
+    if rc == 1:
+        # every block has the same top bit, or a single walked level: refused (the whole-row kernels or the round-3 ones)
+        assert "half of the split row is empty" in msg or "nothing to split" in msg or "every low word" in msg, msg
+        return
+    assert rc == 0, msg
+    assert info[0] == 1 and info[6] >= 200 and diff.value < 1e-13, (list(info), diff.value)
+
+
 def test_all_orbital_walk_on_a_one_orbital_per_level_bath(shim):
     """bath_type normal with the default (all-orbital) walk: the amplitudes of the other orbitals are zeros in the tables."""
     _, pm = make_models("normal", "normal", 2, 4, seed=47)
