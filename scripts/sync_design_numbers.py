@@ -12,6 +12,7 @@ TAG, PREV = "r04", "r03"
 ROWS = [("cfg1", "cfg1 normal 1orb Nbath4 (2,3)"), ("cfg2", "cfg2 normal 2orb Nbath6 (7,7)"),
         ("cfg2_handover", "cfg2 through `edigpu_normal_create`"), ("cfg3", "cfg3 normal 3orb hybrid 8 (5,6)"),
         ("cfg3_ns15", "cfg3 ladder Ns=15"), ("cfg3_ns16", "cfg3 ladder Ns=16"), ("cfg3_ns17", "cfg3 ladder Ns=17"),
+        ("cfg3_replica_ns15", "Ns=15 with a replica bath (3 orb x 4 replicas)"),
         ("cfg4", "cfg4 superc 2orb hybrid 8 Sz=0"), ("cfg4_ns12", "cfg4 ladder Ns=12"),
         ("cfg5", "cfg5 nonsu2 3orb hybrid 10 N=13, on the fly"), ("cfg5_stored", "cfg5 the same, stored"),
         ("cfg5_stored_ns11", "cfg5 structure, stored, Ns=11")]
