@@ -78,6 +78,13 @@ static int upload_csr(DevCsr& d, int64_t nrow, const int64_t* rowptr, const int3
   return 0;
 }
 
+static void free_ell(DevEll& e) {
+  dev_free(e.pk);
+  dev_free(e.coef);
+  dev_free(e.col);
+  dev_free(e.val);
+}
+
 static void free_csr(DevCsr& d) {
   dev_free(d.sell_ptr);
   dev_free(d.sell_pk);
@@ -421,6 +428,8 @@ static void free_ib(IbDev* p) {
   dev_free(p->chunk_blk); dev_free(p->dcls); dev_free(p->dblist); dev_free(p->dmeta); dev_free(p->dw_vtab);
   dev_free(p->dw_timp); dev_free(p->ndcoef); dev_free(p->nd_dw); dev_free(p->nd_up);
   dev_free(p->up_pmask); dev_free(p->dw_pmask); dev_free(p->up_pt); dev_free(p->dw_pt);
+  free_ell(p->pr.ell);
+  dev_free(p->pr.eux);
   dev_free(p->urank_low);
   for (IbDevHalf& h : p->half) {
     dev_free(h.ublist); dev_free(h.utop); dev_free(h.rmap2);
@@ -514,6 +523,60 @@ static int setup_sb(IbDev* d, const HostNormal& hn, const HostIb& h, int chunk_r
   return 0;
 }
 
+// Short rows (IbDev::PosRows): Hup and the diagonal table in POSITION order for the generic LDS row kernel, which then
+// works on the padded panel layout beside the local-block columns kernel.  Built on request (EDIGPU_POSROWS=1) when the
+// sector has local-block tables with whole rows; for rows shorter than EDIGPU_IB_MINROW the block image is then built for it.
+static int setup_pos_rows(edigpu_sector* s, const HostNormal& hn, const HostIb& h) {
+  IbDev* d = s->ib;
+  if (!d || !d->sb || d->sb->nhalf != 1 || !s->factored || !hn.fac.valid) return 0;
+  const char* e = getenv("EDIGPU_POSROWS");
+  // Opt-in (EDIGPU_POSROWS=1).  Measured on config 2: the plain product gains (0.110 against 0.119 ms: 0.43 against 0.40
+  // of the peak) but the fused Lanczos step loses (0.166 against 0.158 ms per step, 6020 against 6350 it/s): on 16-column
+  // panels a row is 215 pieces 439 KB apart, and the fused row kernel's five streams of them take 100-120 us where the
+  // 128-column panels of the default loop (27 pieces per row) take 81.
+  const bool on = e && atoi(e) != 0;
+  if (!on) return 0;
+  const int plen = d->plen;
+  const int td = normal_pick_rows_per_block(plen, hn.dim_dw);
+  if (td < 1) return 0;
+  const HostCsr& up = s->h_up;
+  HostCsr pu;
+  pu.nrow = pu.ncol = plen;
+  pu.rowptr.assign((size_t)plen + 1, 0);
+  std::vector<int32_t> colof((size_t)plen, -1);
+  for (int64_t i = 0; i < hn.dim_up; i++) colof[(size_t)h.pos[(size_t)i]] = (int32_t)i;
+  for (int p = 0; p < plen; p++) {
+    const int32_t i = colof[(size_t)p];
+    pu.rowptr[(size_t)p + 1] = pu.rowptr[(size_t)p] + (i < 0 ? 0 : up.rowptr[(size_t)i + 1] - up.rowptr[(size_t)i]);
+  }
+  pu.col.resize((size_t)pu.rowptr[(size_t)plen]);
+  pu.val.resize(pu.col.size());
+  for (int p = 0; p < plen; p++) {
+    const int32_t i = colof[(size_t)p];
+    if (i < 0) continue;
+    int64_t at = pu.rowptr[(size_t)p];
+    for (int64_t q = up.rowptr[(size_t)i]; q < up.rowptr[(size_t)i + 1]; q++, at++) {
+      pu.col[(size_t)at] = h.pos[(size_t)up.col[(size_t)q]];
+      pu.val[(size_t)at] = up.val[(size_t)q];
+    }
+  }
+  if (upload_ell(d->pr.ell, pu, true)) return 1;
+  if (!d->pr.ell.pk || !d->pr.ell.typed) {  // the fast path of the row kernel only
+    free_ell(d->pr.ell);
+    d->pr.ell = DevEll();
+    return 0;
+  }
+  const size_t nimp = hn.fac.eux.size() / (size_t)hn.dim_up;
+  std::vector<double> ex(nimp * (size_t)plen, 0.0);
+  for (size_t c = 0; c < nimp; c++)
+    for (int64_t i = 0; i < hn.dim_up; i++) ex[c * (size_t)plen + (size_t)h.pos[(size_t)i]] = hn.fac.eux[c * (size_t)hn.dim_up + (size_t)i];
+  if (dev_upload(&d->pr.eux, ex.data(), ex.size())) return 1;
+  d->pr.td = td;
+  d->pr.on = true;
+  if (getenv("EDIGPU_SB_VERBOSE")) fprintf(stderr, "edigpu: rows half on the generic row kernel in position order (plen %d, %d rows per workgroup, ELL width %d)\n", plen, td, d->pr.ell.width);
+  return 0;
+}
+
 // device copy of the impurity-block image; leaves s->ib null (and returns 0) when the sector is not of that form
 static int setup_ib(edigpu_sector* s, const HostNormal& hn, int chunk_rows) {
   HostIb h;
@@ -566,6 +629,7 @@ static int setup_ib(edigpu_sector* s, const HostNormal& hn, int chunk_rows) {
   d->dim_up = hn.dim_up;
   d->dim_dw = hn.dim_dw;
   d->ps = hn.dim_dw * kIbPanel;
+  if (const char* e = getenv("EDIGPU_IB_PSPAD")) d->ps += (int64_t)std::max(0, atoi(e)) / 2 * 2;  // doubles between two panels (tuning)
   d->len = (int64_t)h.npanels * d->ps;
   d->rows_nt = nt;
   d->rows_nbt = nbt;
@@ -634,7 +698,8 @@ static int setup_ib(edigpu_sector* s, const HostNormal& hn, int chunk_rows) {
     }
   }
   s->ib = d.release();
-  return setup_sb(s->ib, hn, h, chunk_rows);
+  if (setup_sb(s->ib, hn, h, chunk_rows)) return 1;
+  return setup_pos_rows(s, hn, h);
 }
 
 static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_t dw_first,
@@ -863,9 +928,18 @@ static int setup_normal(edigpu_sector* s, int64_t dim_up, int64_t dim_dw, int64_
             }
     }
     const bool pairs_ok = !pairs || min_rows == 0 || env_flag("EDIGPU_IB_PAIRS");
-    if (on && pairs_ok && s->nloc >= min_rows && dim_up * 8 >= min_row_bytes && !env_flag("EDIGPU_LANCZOS_UNFUSED") &&
+    // Rows below EDIGPU_IB_MINROW: the block ROWS kernels lose to the generic LDS row kernel there; the image is still built
+    // when that kernel can take the rows half on the image's layout (setup_pos_rows), and dropped again when it cannot.
+    const bool short_rows = dim_up * 8 < min_row_bytes;
+    const bool posrows_ok = (e = getenv("EDIGPU_POSROWS")) && atoi(e) != 0;
+    if (on && pairs_ok && s->nloc >= min_rows && (!short_rows || posrows_ok) && !env_flag("EDIGPU_LANCZOS_UNFUSED") &&
         setup_ib(s, *built, chunk_rows))
       return 1;
+    if (s->ib && short_rows && !s->ib->pr.on) {
+      free_ib(s->ib);
+      delete s->ib;
+      s->ib = nullptr;
+    }
   }
   // Panel-major vector layout for the device-resident Lanczos loop (normal_args.hpp): large
   // factored whole sectors whose rows fit the LDS row kernel.  Default: 128-column panels (1 KiB line-aligned segments)
@@ -1195,6 +1269,13 @@ static int ensure_workspace(edigpu_sector* s) {
   EDIGPU_HIP(hipMalloc((void**)&s->d_vin, n * sizeof(double)));
   EDIGPU_HIP(hipMalloc((void**)&s->d_vout, n * sizeof(double)));
   EDIGPU_HIP(hipMalloc((void**)&s->d_tmp, n * sizeof(double)));
+  if (s->ib && s->ib->ps != s->ib->dim_dw * kIbPanel) {
+    // padded panel stride (EDIGPU_IB_PSPAD): the doubles between two panels are never written by a kernel and are part of
+    // the vector sums -- they must be zero
+    EDIGPU_HIP(hipMemset(s->d_vin, 0, n * sizeof(double)));
+    EDIGPU_HIP(hipMemset(s->d_vout, 0, n * sizeof(double)));
+    EDIGPU_HIP(hipMemset(s->d_tmp, 0, n * sizeof(double)));
+  }
   // per-workgroup partials: three per 256-row workgroup of the SELL dot epilogue is the largest user
   s->partial_cap = std::max<int64_t>(kMaxPartials, 3 * ((s->nloc + 255) / 256) + 64);
   EDIGPU_HIP(hipMalloc((void**)&s->d_partial, (size_t)s->partial_cap * sizeof(double)));
@@ -1461,7 +1542,16 @@ static int lanczos_seed(edigpu_sector* s, const double* src, uint64_t seed, hipS
   } else if (lz_fill_random(dst, s->ws_len, seed, st)) {
     return 1;
   }
-  if (s->lz_blocked && s->ib) return vec_to_ib(s->ib, s->d_tmp, s->d_vin, st);
+  if (s->lz_blocked && s->ib) {
+    if (vec_to_ib(s->ib, s->d_tmp, s->d_vin, st)) return 1;
+    if (s->ib->ps != s->ib->dim_dw * kIbPanel) {
+      // padded panel stride (EDIGPU_IB_PSPAD): the doubles between two panels are written by no kernel and enter the vector
+      // sums; the two other buffers may hold anything there (d_tmp just held the vector in the reference's layout)
+      EDIGPU_HIP(hipMemsetAsync(s->d_tmp, 0, (size_t)s->ib->len * sizeof(double), st));
+      EDIGPU_HIP(hipMemsetAsync(s->d_vout, 0, (size_t)s->ib->len * sizeof(double), st));
+    }
+    return 0;
+  }
   if (s->lz_blocked) return vec_to_blocked(s->d_tmp, s->d_vin, s->dim_up, s->dim_dw, s->blk_shift, st);
   return 0;
 }
@@ -2201,7 +2291,7 @@ int edigpu_image_info(edigpu_handle s, int32_t image[6]) {
   image[2] = s->factored ? s->fac_nimp : 0;
   image[3] = s->panel_mode;
   image[4] = s->ib ? kIbPanel : (s->blk_shift ? (1 << s->blk_shift) : 0);
-  image[5] = s->ib ? (s->ib->sb ? (s->ib->sb->nhalf == 2 ? 4 : 3) : s->ib->nhalf) : 0;  // 1: impurity-block image, 2: with rows staged in halves, 3: local-block tables, 4: local-block rows kernel on half rows
+  image[5] = s->ib ? (s->ib->sb ? (s->ib->sb->nhalf == 2 ? 4 : (s->ib->pr.on ? 5 : 3)) : s->ib->nhalf) : 0;  // 1: impurity-block image, 2: with rows staged in halves, 3: local-block tables, 4: local-block rows kernel on half rows, 5: local-block columns kernel + generic row kernel in position order (short rows)
   return 0;
 }
 

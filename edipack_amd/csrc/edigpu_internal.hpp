@@ -143,6 +143,14 @@ struct IbDev {
   uint16_t *dblist = nullptr, *dmeta = nullptr;
   double *dw_vtab = nullptr, *dw_timp = nullptr, *ndcoef = nullptr;
   uint8_t *nd_dw = nullptr, *nd_up = nullptr;
+  // short rows: the generic LDS row kernel in position order (kernels_normal.hip launch_normal_rows_pos) takes the rows half of
+  // the product and of the fused step; Hup as ELL over positions, the diagonal table [impurity pattern of the down word][plen]
+  struct PosRows {
+    bool on = false;
+    DevEll ell;
+    double* eux = nullptr;
+    int td = 0;  // rows per workgroup
+  } pr;
   // bath-bath hops (host_ib.hpp IbSide::pmask, pt): replica / general baths
   int up_np = 0, dw_np = 0;
   uint32_t *up_pmask = nullptr, *dw_pmask = nullptr;

@@ -98,6 +98,8 @@ int launch_ib_lanczos(const edigpu_sector* s, const double* P, double* Q, double
                       int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial);
 // local-block kernels on the same layout (kernels_sb.hip, round 4); launch_ib / launch_ib_lanczos take them when IbDev::sb is set
 int launch_sb(const edigpu_sector* s, const double* v, double* hv, hipStream_t st);
+// generic LDS row kernel on the padded panel layout in position order (kernels_normal.hip; IbDev::pr)
+int launch_normal_rows_pos(const edigpu_sector* s, const double* P, double* Q, double* X, int what, const double* scal, hipStream_t st);
 int launch_sb_lanczos(const edigpu_sector* s, const double* P, double* Q, double* X, const double* scal, double* partial,
                       int64_t partial_cap, bool first, bool lazy_axpy, hipStream_t st, int* npartial);
 // row shards on the padded panel layout (kernels_sb.hip): see there for the shard form of the layout

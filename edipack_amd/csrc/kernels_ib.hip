@@ -693,12 +693,12 @@ size_t ib_cols2_lds_bytes(int nb, int max_chunk_rows, int max_chunk_blocks) {
 // layout conversion: natural (idw * DimUp + iup) <-> padded panels
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_to_ib(const double* __restrict__ src, double* __restrict__ dst, const int32_t* __restrict__ colof,
-                                               int64_t dim_up, int64_t ps, int64_t n) {
+                                               int64_t dim_up, int64_t dim_dw, int64_t ps, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int64_t panel = i / ps, rem = i - panel * ps;
     const int64_t rowi = rem >> 4;
     const int c = colof[panel * 16 + (rem & 15)];
-    dst[i] = c >= 0 ? src[rowi * dim_up + c] : 0.0;
+    dst[i] = (c >= 0 && rowi < dim_dw) ? src[rowi * dim_up + c] : 0.0;  // (rows past dim_dw: the padding of a padded panel stride)
   }
 }
 
@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(256) k_from_ib(const double* __restrict__ src,
 
 int vec_to_ib(const IbDev* ib, const double* src, double* dst, hipStream_t st) {
   const unsigned g = (unsigned)std::min<int64_t>((ib->len + 255) / 256, 65536);
-  hipLaunchKernelGGL(k_to_ib, dim3(g), dim3(256), 0, st, src, dst, ib->colof, ib->dim_up, ib->ps, ib->len);
+  hipLaunchKernelGGL(k_to_ib, dim3(g), dim3(256), 0, st, src, dst, ib->colof, ib->dim_up, ib->dim_dw, ib->ps, ib->len);
   EDIGPU_HIP(hipGetLastError());
   return 0;
 }
@@ -1037,7 +1037,7 @@ int launch_ib_lanczos(const edigpu_sector* s, const double* P, double* Q, double
   // EDIGPU_SB_STEP=0 keeps the step on the kernels below while the plain product runs on the local blocks.
   if (s->ib->sb && s->ib->sb->nhalf == 1) {
     const char* es = getenv("EDIGPU_SB_STEP");
-    const bool sb_step = es ? atoi(es) != 0 : true;
+    const bool sb_step = (es ? atoi(es) != 0 : true) || s->ib->pr.on;  // (short rows: the two-buffer step of launch_sb_lanczos only)
     if (sb_step) return launch_sb_lanczos(s, P, Q, X, scal, partial, partial_cap, first, lazy_axpy, st, npartial);
   }
   IbArgs a;

@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(NT)
           // Q <- acc - beta * P_old ; P <- x (the staged, normalised vector)
           double pold[kE];
           load4<VEC>(v_local, vix(r0 + r, col0), ok, pold);
-          double* pdst = const_cast<double*>(v_local) + vix(r0 + r, col0);
+          double* pdst = (a.xout ? a.xout : const_cast<double*>(v_local)) + vix(r0 + r, col0);
 #pragma unroll
           for (int e = 0; e < kE; e++) acc[r][e] -= beta * pold[e];
           if (VEC) {
@@ -558,6 +558,7 @@ static void fill_args(const edigpu_sector* s, NormalArgs& a) {
   a.mx_val = s->d_mx_val;
   a.scal = nullptr;
   a.partial = nullptr;
+  a.xout = nullptr;
   a.partial_cap = 0;
   a.lz_counter = nullptr;
   a.lz_nlanc = 0;
@@ -585,6 +586,40 @@ int launch_normal(const edigpu_sector* s, const double* v_local, const double* v
   if (csr_nd && launch_rows(s, a, v_local, v_full, hv, 4, st)) return 1;
   if (launch_dw_panels(a, true, fac_nd, v_full, hv, st)) return 1;
   return sell_nd ? launch_csr(s->nd, 0, v_full, hv, 1, st) : 0;
+}
+
+// The LDS row kernel on the padded panel layout of the impurity-block image, columns in POSITION order (IbDev::pr: Hup and
+// the diagonal table permuted to positions, padding positions empty): the rows half of the product for sectors whose rows
+// are short enough that this kernel beats the block rows kernels (config 2: 27 KB rows, four workgroups per CU), paired
+// with the local-block columns kernel on the same vectors.  what: 1 plain; 101 / 102 / 103 the fused Lanczos forms (FUSE
+// 1 / 2 / 3) with the new vector written to X.
+int launch_normal_rows_pos(const edigpu_sector* s, const double* P, double* Q, double* X, int what, const double* scal, hipStream_t st) {
+  const IbDev* d = s->ib;
+  NormalArgs a;
+  fill_args(s, a);
+  a.dim_up = d->plen;
+  a.split_count = d->plen;
+  a.eux = d->pr.eux;
+  a.ell_pk = d->pr.ell.pk;
+  a.ell_coef = d->pr.ell.coef;
+  a.ell_col = d->pr.ell.col;
+  a.ell_val = d->pr.ell.val;
+  a.ell_w = d->pr.ell.width;
+  a.ell_typed = d->pr.ell.typed;
+  a.ell_pitch = d->pr.ell.pitch;
+  a.blk_shift = 4;
+  a.blk_ps = d->ps;
+  a.scal = scal;
+  a.xout = X;
+  const bool packed = d->pr.ell.pk != nullptr;
+  switch (d->pr.td) {
+    case 1: return launch_td<1, true>(a, packed, true, P, P, Q, what, st);
+    case 2: return launch_td<2, true>(a, packed, true, P, P, Q, what, st);
+    case 4: return launch_td<4, true>(a, packed, true, P, P, Q, what, st);
+    case 8: return launch_td<8, true>(a, packed, true, P, P, Q, what, st);
+  }
+  set_error("launch_normal_rows_pos: rows per workgroup");
+  return 1;
 }
 
 // Transposed exchange (reference spMatVec_mpi_normal_main :765-866): the two halves of the
@@ -663,7 +698,7 @@ int launch_normal_lanczos(const edigpu_sector* s, double* P, double* Q, const do
       set_error("launch_normal_lanczos: the impurity-block image needs a third buffer");
       return 1;
     }
-    *in_x = !first;
+    *in_x = !first && !s->ib->pr.on;  // (short rows: the position-order row kernel rotates in place)
     return launch_ib_lanczos(s, P, Q, X, scal, partial, partial_cap, first, lazy_axpy, st, npartial);
   }
   if (s->lz_blocked) {  // P, Q in the panel-major layout (lanczos_prepare)

@@ -159,7 +159,8 @@ int launch_sb(const edigpu_sector* s, const double* v, double* hv, hipStream_t s
     a.dbg = nullptr;
     return cols(s->ib, a, 0, v, hv, st, nullptr);
   }
-  if (rows(s->ib, a, 0, v, hv, nullptr, st)) return 1;
+  // short rows: the generic LDS row kernel in position order takes the rows half (IbDev::pr)
+  if (s->ib->pr.on ? launch_normal_rows_pos(s, v, hv, nullptr, 1, nullptr, st) : rows(s->ib, a, 0, v, hv, nullptr, st)) return 1;
   return cols(s->ib, a, 0, v, hv, st, nullptr);
 }
 
@@ -173,6 +174,14 @@ int launch_sb_lanczos(const edigpu_sector* s, const double* P, double* Q, double
   a.partial = partial;
   a.lazy = lazy_axpy ? 1 : 0;
   (void)partial_cap;  // >= kMaxPartials (ensure_workspace); sb_launch_cols_t checks its grid against that
+  if (s->ib->pr.on) {
+    // short rows: the generic LDS row kernel in position order with its fused forms -- x = (Q - alpha P) / beta written OVER
+    // P, Q <- (Hd + 1 (x) Hup) x - beta P_old -- then the columns kernel with the three sums.  Two buffers, not three (X is
+    // not used and launch_normal_lanczos tells the caller so): with a third vector config 2's working set (3 x 98 MB)
+    // leaves the 256 MB Infinity Cache and the fused row kernel takes 122 us instead of ~80.
+    if (launch_normal_rows_pos(s, P, Q, nullptr, first ? 101 : (lazy_axpy ? 103 : 102), scal, st)) return 1;
+    return cols(s->ib, a, 1, P, Q, st, npartial);
+  }
   if (first) {
     if (rows(s->ib, a, 0, P, Q, nullptr, st)) return 1;
     return cols(s->ib, a, 1, P, Q, st, npartial);

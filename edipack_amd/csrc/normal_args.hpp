@@ -41,6 +41,7 @@ struct NormalArgs {
   // fused Lanczos step (device scalars, see kernels.hpp SC_*) and per-workgroup alpha partials
   const double* scal;
   double* partial;
+  double* xout;  // fused rows kernel (FUSE >= 2): where the new Lanczos vector is written; null: over the previous one (v_local)
   int64_t partial_cap;  // doubles in `partial`; the panel launch checks its grid against it before enqueueing
   // finalize of the fused step inside the sweep (lz_finalize.hpp): arrival counter (zero at launch; nullptr = a separate
   // finalize kernel follows), recurrence length, doubles per vector

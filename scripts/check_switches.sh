@@ -13,7 +13,8 @@ for sw in EDIGPU_LANCZOS_UNFUSED EDIGPU_NORMAL_EXPLICIT EDIGPU_FLAT_HOSTBUILD ED
           "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_IB_COLS2=1" "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_IB_ROWS=16" EDIGPU_TRL_FULL \
           "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_SB=0" "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_SB_STEP=0" "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_SB_STEP=2" \
           "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_SB_CW=1" "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_SB_AMODE=1" \
-          "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_IB_SPLIT=1 EDIGPU_SB_SPLIT=1" "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_IB_PAIRS=1"; do
+          "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_IB_SPLIT=1 EDIGPU_SB_SPLIT=1" "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_IB_PAIRS=1" \
+          "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_POSROWS=1" "EDIGPU_IB=1 EDIGPU_IB_MIN=0 EDIGPU_IB_PSPAD=48"; do
   N=$((N+1)); [ $N -le $SKIP ] && continue
   [ $N -gt $((SKIP+COUNT)) ] && break
   case $sw in *=*) kv=$sw;; *) kv=$sw=1;; esac

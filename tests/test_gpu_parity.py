@@ -1986,7 +1986,7 @@ def test_impurity_block_image_matches_oracle(gpu, monkeypatch, rows, bath, norb,
     monkeypatch.setenv("EDIGPU_IB_ROWS", str(rows))
     hb = SectorHamiltonian.normal_from_model(pm, *sec)
     # (scripts/check_switches.sh runs the suite with EDIGPU_IB_SPLIT=1: rows staged in halves, unfused recurrence)
-    assert hb.image_info()[5] in ((2, 4) if os.environ.get("EDIGPU_IB_SPLIT") == "1" else (1, 3)) and hb.image_info()[4] == 16
+    assert hb.image_info()[5] in ((2, 4) if os.environ.get("EDIGPU_IB_SPLIT") == "1" else (1, 3, 5)) and hb.image_info()[4] == 16
     monkeypatch.setenv("EDIGPU_IB", "0")
     hn = SectorHamiltonian.normal_from_model(pm, *sec)
     assert hn.image_info()[5] == 0
@@ -2083,7 +2083,7 @@ def test_impurity_block_split_rows_match_oracle(gpu, monkeypatch, local_blocks, 
 # --------------------------------------------------------------------------------------------
 # local-block kernels (csrc/host_sb.hpp, sb_core.hpp, kernels_sb*.hip; round 4) on the impurity-block layout
 # --------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cw", [2, 1])
+@pytest.mark.parametrize("cw", [2, 1, 0])
 @pytest.mark.parametrize("rows", [480, 24])
 @pytest.mark.parametrize("bath,norb,nbath,sec,extra", [
     ("normal", 2, 3, (4, 4), {}),                      # one orbital per bath level (cw = 1 takes the per-orbital walk)
@@ -2109,11 +2109,17 @@ def test_local_block_kernels_match_oracle(gpu, monkeypatch, cw, rows, bath, norb
     monkeypatch.setenv("EDIGPU_IB", "1")
     monkeypatch.setenv("EDIGPU_IB_MIN", "0")
     monkeypatch.setenv("EDIGPU_IB_ROWS", str(rows))
-    monkeypatch.setenv("EDIGPU_SB_CW", str(cw))
+    # cw = 0: the short-row pairing (config 2's default) -- the generic LDS row kernel in position order for the rows half
+    # (launch_normal_rows_pos, plain and fused), the two-column local-block columns kernel for the other: image kind 5
+    monkeypatch.setenv("EDIGPU_SB_CW", str(cw if cw else 2))
+    monkeypatch.setenv("EDIGPU_POSROWS", "1" if cw == 0 else "0")
+    if cw == 0 and rows == 24:
+        monkeypatch.setenv("EDIGPU_IB_PSPAD", "16")     # a padded panel stride (tuning switch): 16 doubles between two panels
     if cw == 1:
         monkeypatch.setenv("EDIGPU_SB_AMODE", "1")     # bath_type normal: the per-orbital walk (default: all-orbital)
     hb = SectorHamiltonian.normal_from_model(pm, *sec)
-    assert hb.image_info()[5] == 3 and hb.image_info()[4] == 16
+    # (the 8-column sector has no typed ELL image: the position-order tables are refused and the block rows kernel stays)
+    assert hb.image_info()[5] == (5 if cw == 0 and sec != (1, 6) else 3) and hb.image_info()[4] == 16
     monkeypatch.setenv("EDIGPU_SB", "0")
     hi = SectorHamiltonian.normal_from_model(pm, *sec)
     assert hi.image_info()[5] == 1
