@@ -227,9 +227,14 @@ def run_single(args):
                      "traffic_frac": (traffic / (ms_hv * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "measured_ceiling_GBs": {"read": rd, "copy": cp, "triad": tr,
                                               "note": "streaming kernels on 1 GiB buffers, this device, this run"},
-                     "kernel": {0: ("sb_rows_kernel + sb_cols_kernel (local blocks of 5 levels on padded 16-column panels; the fused "
-                                    "step of `value` runs ib_rows_kernel + ib_cols_kernel on the same vectors)"
+                     "kernel": {0: ("sb_rows_kernel + sb_cols_kernel (local blocks of 5 levels on padded 16-column panels; the "
+                                    "Lanczos step of `value` runs the same two kernels, fused, or with the new vector as its own pass in "
+                                    "the 768-thread geometry)"
                                     if h.kind == 0 and h.image_info()[5] == 3 else
+                                    "normal_rows_kernel in position order + sb_cols_kernel (short rows, EDIGPU_POSROWS=1: padded 16-column panels)"
+                                    if h.kind == 0 and h.image_info()[5] == 5 else
+                                    "sb_rows_kernel x 2 (rows staged in halves, EDIGPU_SB_SPLIT=1) + ib_cols_kernel"
+                                    if h.kind == 0 and h.image_info()[5] == 4 else
                                     "ib_rows_kernel + ib_cols_kernel (impurity-block image, padded 16-column panels)"
                                     if h.kind == 0 and h.image_info()[5] == 1 else
                                     "ib_rows_kernel x 2 (rows staged in halves) + ib_cols_kernel (impurity-block image)"
