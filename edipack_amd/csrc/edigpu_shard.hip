@@ -140,7 +140,8 @@ struct edigpu_comm_s {
   int64_t ws_chunk = 0, ws_full = 0, ws_x = 0, ws_bp = 0;
   double *vin = nullptr, *vout = nullptr, *tmp = nullptr, *vfull = nullptr;
   double *send = nullptr, *recv = nullptr, *hvc = nullptr, *back = nullptr;
-  double* bp[4] = {nullptr, nullptr, nullptr, nullptr};  // transposed exchange on padded panels (ShardGeom::block)
+  // transposed exchange on padded panels (ShardGeom::block); bp[4]: the work vector of the recurrence kept in that layout
+  double* bp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   double *hist = nullptr, *work = nullptr, *scr = nullptr;
   int64_t hist_cap = 0;
 };
@@ -368,6 +369,27 @@ __global__ void __launch_bounds__(kShNT)
   block_sum3(s0, s1, s2, partial, kRedBlocks);
 }
 
+// the same on vectors that share one layout element by element (the recurrence kept in the padded panel layout: the
+// padding holds zeros in all four, so the three sums are those of the shard): w += t1 + t2
+__global__ void __launch_bounds__(kShNT)
+    ks_add2_dot3(int64_t n, const double* __restrict__ vin, double* __restrict__ vout, const double* __restrict__ t1,
+                 const double* __restrict__ t2, const double* __restrict__ tprev, double* __restrict__ partial) {
+  const double sg = tprev ? tprev[0] : 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const int64_t n2 = n >> 1;  // (n is a multiple of 16)
+  for (int64_t e = (int64_t)blockIdx.x * kShNT + threadIdx.x; e < n2; e += (int64_t)gridDim.x * kShNT) {
+    const double2 o = reinterpret_cast<const double2*>(vout)[e], a = reinterpret_cast<const double2*>(t1)[e],
+                  b = reinterpret_cast<const double2*>(t2)[e], v = reinterpret_cast<const double2*>(vin)[e];
+    const double2 w = make_double2(o.x + a.x + b.x, o.y + a.y + b.y);
+    reinterpret_cast<double2*>(vout)[e] = w;
+    const double dx = w.x - sg * v.x, dy = w.y - sg * v.y;
+    s0 += v.x * w.x + v.y * w.y;
+    s1 += dx * dx + dy * dy;
+    s2 += v.x * v.x + v.y * v.y;
+  }
+  block_sum3(s0, s1, s2, partial, kRedBlocks);
+}
+
 __global__ void __launch_bounds__(1024) ks_sum3(const double* __restrict__ partial, int np, double* __restrict__ out) {
   __shared__ double sh[3][1024];
   double s[3] = {0.0, 0.0, 0.0};
@@ -533,37 +555,46 @@ static int comm_workspace(edigpu_comm_s* c, const ShardGeom& g, int nlanc) {
   return 0;
 }
 
+// Transposed exchange on padded panels (the local-block kernels' layout, shard form: kernels_sb.hip).  What a rank
+// sends to rank d -- its rows of d's panels -- is one contiguous run of the vector in that form, and what comes back lands
+// in that layout again: the two all-to-alls move the buffers as they are.  bp[0] = v in the shard form, bp[1] = what
+// the first exchange delivers, bp[2] = the column half on it, bp[3] = the row half; the exchange back reuses bp[1].
+// H v = *rowhalf + *colhalf, element by element in the shard form.
+static int sharded_hv_panels(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, hipStream_t st, const double** rowhalf,
+                             const double** colhalf) {
+  const bool alone = c->world == 1 && !force_collectives(c);
+  const size_t per = (size_t)g.npmax * g.q * 16;
+  if (!alone) {
+    EDIGPU_HIP(hipEventRecord(c->ev_ready, st));
+    EDIGPU_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
+    if (comm_all_to_all(c, c->bp[0], c->bp[1], per, c->side)) return 1;
+    EDIGPU_HIP(hipEventRecord(c->ev_done, c->side));
+  }
+  if (launch_sb_rows_shard(s, g.first, g.count, g.q, c->bp[0], c->bp[3], st)) return 1;  // beside the exchange
+  if (!alone) EDIGPU_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
+  const int p0 = c->rank * g.npmax, np = std::max(0, std::min(g.npmax, s->ib->npanels - p0));
+  // (panels past the sector's last one are never computed: their slots must not hand stale numbers back)
+  if (np < g.npmax) EDIGPU_HIP(hipMemsetAsync(c->bp[2], 0, (size_t)g.bplen * sizeof(double), st));
+  if (launch_sb_cols_shard(s, p0, np, g.q, g.npmax, alone ? c->bp[0] : c->bp[1], c->bp[2], st)) return 1;
+  *rowhalf = c->bp[3];
+  *colhalf = c->bp[2];
+  if (!alone) {
+    if (comm_all_to_all(c, c->bp[2], c->bp[1], per, st)) return 1;
+    *colhalf = c->bp[1];
+  }
+  return 0;
+}
+
 // tmp <- (H vin) on the local rows.  pre_packed: the send buffer already holds vin (fused rotate).  The exchange runs
 // on the side stream beside the part of the product that needs no remote data.
 static int sharded_hv(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, bool pre_packed, hipStream_t st,
                       const double** back_out = nullptr) {
   if (g.block) {
-    // Transposed exchange on padded panels (the local-block kernels' layout, shard form: kernels_sb.hip).  What a rank
-    // sends to rank d -- its rows of d's panels -- is one contiguous run of the converted vector, and what comes back lands
-    // in that layout again: the two all-to-alls move the buffers as they are.  bp[0] = v in the shard form, bp[1] = what
-    // the first exchange delivers, bp[2] = the column half on it, bp[3] = the row half; the exchange back reuses bp[1].
-    const bool alone = c->world == 1 && !force_collectives(c);
-    const size_t per = (size_t)g.npmax * g.q * 16;
+    const double *rowhalf = nullptr, *colhalf = nullptr;
     if (sb_shard_to_panels(s, c->vin, c->bp[0], g.count, g.q, c->world, st)) return 1;
-    if (!alone) {
-      EDIGPU_HIP(hipEventRecord(c->ev_ready, st));
-      EDIGPU_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
-      if (comm_all_to_all(c, c->bp[0], c->bp[1], per, c->side)) return 1;
-      EDIGPU_HIP(hipEventRecord(c->ev_done, c->side));
-    }
-    if (launch_sb_rows_shard(s, g.first, g.count, g.q, c->bp[0], c->bp[3], st)) return 1;  // beside the exchange
-    if (!alone) EDIGPU_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
-    const int p0 = c->rank * g.npmax, np = std::max(0, std::min(g.npmax, s->ib->npanels - p0));
-    // (panels past the sector's last one are never computed: their slots must not hand stale numbers back)
-    if (np < g.npmax) EDIGPU_HIP(hipMemsetAsync(c->bp[2], 0, (size_t)g.bplen * sizeof(double), st));
-    if (launch_sb_cols_shard(s, p0, np, g.q, g.npmax, alone ? c->bp[0] : c->bp[1], c->bp[2], st)) return 1;
-    const double* colhalf = c->bp[2];
-    if (!alone) {
-      if (comm_all_to_all(c, c->bp[2], c->bp[1], per, st)) return 1;
-      colhalf = c->bp[1];
-    }
+    if (sharded_hv_panels(s, c, g, st, &rowhalf, &colhalf)) return 1;
     if (back_out) *back_out = nullptr;  // nothing left for the caller to add
-    return sb_shard_from_panels_add(s, c->bp[3], colhalf, c->tmp, g.count, g.q, st);
+    return sb_shard_from_panels_add(s, rowhalf, colhalf, c->tmp, g.count, g.q, st);
   }
   if (g.transposed) {
     // a world of one exchanges nothing: the column half reads the packed buffer and the caller its result in place
@@ -649,6 +680,38 @@ static int sharded_step(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, 
   return comm_all_reduce(c, t, 3, st);
 }
 
+// The recurrence with its two vectors KEPT in the padded panel layout (ShardGeom::block; EDIGPU_SHARD_PANEL_LOOP=0 falls back
+// to the rows of the reference's layout with a conversion on either side of every product): v = bp[0] is what the first
+// all-to-all sends as it is, w = bp[4]; the padding of the layout holds zeros in every buffer and stays zero under the
+// element-wise updates, so the three sums are those of the shard.
+static bool panel_loop(const ShardGeom& g) {
+  const char* e = getenv("EDIGPU_SHARD_PANEL_LOOP");
+  return g.block && !(e && atoi(e) == 0);
+}
+
+// after load_seed: the normalised seed goes into the panel layout, every other buffer of the loop starts from zeros
+// (the buffers serve sectors of different geometry in turn: what one leaves behind is not zero in another's padding)
+static int panel_loop_begin(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, hipStream_t st) {
+  for (int k = 1; k < 5; k++) EDIGPU_HIP(hipMemsetAsync(c->bp[k], 0, (size_t)g.bplen * sizeof(double), st));
+  return sb_shard_to_panels(s, c->vin, c->bp[0], g.count, g.q, c->world, st);
+}
+
+static int sharded_step_panels(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, int it, hipStream_t st) {
+  const int64_t n = g.bplen;
+  double* t = c->hist + 3 * (size_t)it;
+  const double* tp = it > 0 ? c->hist + 3 * (size_t)(it - 1) : nullptr;
+  const double* tpp = it > 1 ? c->hist + 3 * (size_t)(it - 2) : nullptr;
+  hipLaunchKernelGGL(ks_rotate3, sh_grid(n, 256 * 16), dim3(kShNT), 0, st, it == 0 ? 1 : 0, n, (int64_t)1, g.q, c->world,
+                     (int64_t)1, 0, c->bp[0], c->bp[4], tp, tpp, (double*)nullptr);
+  const double *rowhalf = nullptr, *colhalf = nullptr;
+  if (sharded_hv_panels(s, c, g, st, &rowhalf, &colhalf)) return 1;
+  const dim3 gr = sh_grid(std::max<int64_t>(n / 2, 1), kRedBlocks);
+  hipLaunchKernelGGL(ks_add2_dot3, gr, dim3(kShNT), 0, st, n, c->bp[0], c->bp[4], rowhalf, colhalf, tp, c->work);
+  hipLaunchKernelGGL(ks_sum3, dim3(1), dim3(1024), 0, st, c->work, (int)gr.x, t);
+  EDIGPU_HIP(hipGetLastError());
+  return comm_all_reduce(c, t, 3, st);
+}
+
 // literal two-reduction step (beta = |w - alpha v|): alpha_it -> hist[it], beta_it^2 -> hist[nlanc + it]
 static int sharded_step_exact(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, int it, int nlanc, hipStream_t st) {
   const int64_t n = g.nloc * g.w;
@@ -692,8 +755,12 @@ static int sharded_tridiag(edigpu_sector* s, edigpu_comm_s* c, const double* vin
   for (int pass = force_exact ? 1 : 0; pass < 2; pass++) {
     EDIGPU_HIP(hipMemsetAsync(c->hist, 0, (size_t)c->hist_cap * sizeof(double), st));
     if (load_seed(c, g, vin_shard, st)) return 1;
+    const bool panels = pass == 0 && panel_loop(g);
+    if (panels && panel_loop_begin(s, c, g, st)) return 1;
     for (int it = 0; it < nlanc; it++)
-      if (pass == 0 ? sharded_step(s, c, g, it, st) : sharded_step_exact(s, c, g, it, nlanc, st)) return 1;
+      if (pass == 0 ? (panels ? sharded_step_panels(s, c, g, it, st) : sharded_step(s, c, g, it, st))
+                    : sharded_step_exact(s, c, g, it, nlanc, st))
+        return 1;
     EDIGPU_HIP(hipMemcpyAsync(h.data(), c->hist, (3 * (size_t)nlanc) * sizeof(double), hipMemcpyDeviceToHost, st));
     double n2 = 0.0;
     EDIGPU_HIP(hipMemcpyAsync(&n2, c->scr, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -963,7 +1030,7 @@ int edigpu_comm_destroy(edigpu_comm c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   for (double** p : {&c->vin, &c->vout, &c->tmp, &c->vfull, &c->send, &c->recv, &c->hvc, &c->back, &c->hist, &c->work, &c->scr,
-                     &c->bp[0], &c->bp[1], &c->bp[2], &c->bp[3]})
+                     &c->bp[0], &c->bp[1], &c->bp[2], &c->bp[3], &c->bp[4]})
     if (*p) (void)hipFree(*p);
   if (c->nccl && rccl()) (void)rccl()->CommDestroy(c->nccl);
   if (c->side) (void)hipStreamDestroy(c->side);
@@ -1211,13 +1278,16 @@ int edigpu_lanczos_bench_sharded(edigpu_handle s, edigpu_comm c, int warmup, int
   EDIGPU_HIP(hipMemsetAsync(c->tmp, 0, (size_t)std::max<int64_t>(chunk, 1) * sizeof(double), st));
   if (n > 0 && lz_fill_random(c->tmp, n, 12345ull + (uint64_t)c->rank, st)) return 1;
   if (load_seed(c, g, c->tmp, st)) return 1;
+  const bool panels = panel_loop(g);
+  if (panels && panel_loop_begin(s, c, g, st)) return 1;
+  auto step = [&](int it) -> int { return panels ? sharded_step_panels(s, c, g, it, st) : sharded_step(s, c, g, it, st); };
   for (int it = 0; it < warmup; it++)
-    if (sharded_step(s, c, g, it, st)) return 1;
+    if (step(it)) return 1;
   if (comm_all_reduce(c, c->scr + 2, 1, st)) return 1;  // barrier
   EDIGPU_HIP(hipStreamSynchronize(st));
   const auto t0 = std::chrono::steady_clock::now();
   for (int it = warmup; it < total; it++)
-    if (sharded_step(s, c, g, it, st)) return 1;
+    if (step(it)) return 1;
   EDIGPU_HIP(hipStreamSynchronize(st));
   if (comm_all_reduce(c, c->scr + 2, 1, st)) return 1;
   EDIGPU_HIP(hipStreamSynchronize(st));

@@ -31,6 +31,9 @@ CASES = [
     ("normal", "normal", 2, 3, (4, 4), False, "block"),      # Hnd terms inside the panels, 5 panels over 1-3 ranks
     ("normal", "hybrid", 3, 5, (4, 3), False, "block"),      # three orbitals; DimDw = 56 rows: ragged tails, blocks cut by ranks
     ("normal", "hybrid", 3, 6, (4, 5), False, "block"),      # 126 x 126
+    # the same exchange with the recurrence's vectors in the reference's row layout (EDIGPU_SHARD_PANEL_LOOP=0: a conversion
+    # on either side of every product) -- the default keeps them in the panel layout from the seed on
+    ("normal", "hybrid", 3, 5, (4, 3), False, "block-rowloop"),
 ]
 NPH = 3
 
@@ -73,11 +76,14 @@ def _rank_main(rank, world, name, case, q):
         mode, bath, norb, nbath, sector, direct, exchange = case
         ho, pm, v = _reference(mode, bath, norb, nbath, sector, cmplx=exchange == "cmplx", phonon=exchange == "phonon")
         comm = LibraryComm(rank, world, shm_name=name, slot_bytes=1 << 22)
-        if exchange == "block":      # small sectors get the impurity-block image + local-block tables on request only
+        block = exchange.startswith("block")
+        if block:      # small sectors get the impurity-block image + local-block tables on request only
             os.environ.update(EDIGPU_IB="1", EDIGPU_IB_MIN="0", EDIGPU_IB_ROWS="24")
-        h, first, count = library_sharded_sector(pm, sector, comm, direct=direct, exchange="auto" if exchange == "block" else exchange,
+            if exchange == "block-rowloop":
+                os.environ["EDIGPU_SHARD_PANEL_LOOP"] = "0"
+        h, first, count = library_sharded_sector(pm, sector, comm, direct=direct, exchange="auto" if block else exchange,
                                                  cmplx=exchange == "cmplx")
-        if exchange == "block":
+        if block:
             assert comm.shard_info(h)[0] == 2, comm.shard_info(h)
         elif exchange == "auto" and mode == "normal":
             assert comm.shard_info(h)[0] == 1, comm.shard_info(h)
