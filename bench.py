@@ -323,6 +323,11 @@ def run_multi(args):
     if comm is None:
         comm = LibraryComm(rank, world, shm_name=f"edigpu_bench_{os.environ['MASTER_PORT']}", slot_bytes=1 << 30)
     exchange = os.environ.get("EDIGPU_EXCHANGE", "auto")
+    # Short rows (config 2: 27 KB): a single GPU keeps such sectors on the generic kernels (the block ROWS kernel loses to
+    # the generic one there), but on shards the block image wins -- its exchange moves the padded panels as they are and
+    # the recurrence stays in that layout (0.49 against 0.58 ms per step in the one-rank rehearsal;
+    # INTEGRATION.md recommends the same switch for -D_MPI hosts).  Set before the sector is built; a user's value wins.
+    os.environ.setdefault("EDIGPU_IB_MINROW", "0")
     h, first, count = library_sharded_sector(model, w.sector, comm, direct=w.direct, exchange=exchange)
     transposed = False
     if h.kind == 0 and h.nloc == h.dim and exchange != "allgather":
@@ -365,6 +370,10 @@ def run_multi(args):
                                        if transposed else
                                        f"row-sharded over {world} GPUs, in-library loop, RCCL all-gather of v beside the "
                                        f"shard-local part of H*v"),
+                       "exchange": {0: "all-gather", 1: "transposed, column blocks with halo columns",
+                                    2: "transposed, padded panels (no packing; recurrence kept in the panel layout"
+                                       + (")" if os.environ.get("EDIGPU_SHARD_PANEL_LOOP", "1") != "0" else
+                                          " SWITCHED OFF: row loop)")}.get(comm.shard_info(h)[0], "?"),
                        "transport": {"nccl": "rccl", "shm-fallback": "shared memory, host-staged (RCCL NOT AVAILABLE: "
                                      "not an xGMI measurement)"}.get(backend, "shared memory (one-GPU rehearsal)"),
                        "exchange_bytes_per_rank_per_hv": int(sent),
