@@ -1135,6 +1135,12 @@ int edigpu_lanczos_eigh_multi_sharded(edigpu_handle h, edigpu_comm c, int neigen
   EDIGPU_HIP(hipMemsetAsync(c->tmp, 0, (size_t)std::max<int64_t>(chunk, 1) * sizeof(double), st));
   TrlOps ops;
   ops.apply = [&](const double* in, double* out, hipStream_t s2) -> int {
+    if (g.block) {  // padded panels: the conversions read and write the solver's vectors themselves (no staging copies)
+      const double *rowhalf = nullptr, *colhalf = nullptr;
+      if (sb_shard_to_panels(h, in, c->bp[0], g.count, g.q, c->world, s2)) return 1;
+      if (sharded_hv_panels(h, c, g, s2, &rowhalf, &colhalf)) return 1;
+      return sb_shard_from_panels_add(h, rowhalf, colhalf, out, g.count, g.q, s2);
+    }
     if (len > 0) EDIGPU_HIP(hipMemcpyAsync(c->vin, in, (size_t)len * sizeof(double), hipMemcpyDeviceToDevice, s2));
     const double* back = nullptr;
     if (sharded_hv(h, c, g, false, s2, &back)) return 1;

@@ -314,10 +314,22 @@ def test_one_communicator_serves_sectors_of_changing_geometry(gpu, monkeypatch):
            ("nonsu2", "hybrid", 2, 3, 5, False, "auto"),        # all-gather again, larger than the first
            ("normal", "hybrid", 3, 3, (3, 2), False, "allgather"),
            ("superc", "hybrid", 2, 3, 0, False, "auto"),
-           ("normal", "normal", 2, 3, (4, 4), False, "allgather")]
+           ("normal", "normal", 2, 3, (4, 4), False, "allgather"),
+           # padded panels, the recurrence kept in that layout: a larger sector, then a smaller one whose padding lies
+           # where the larger one left numbers (the loop clears its buffers when it starts)
+           ("normal", "hybrid", 3, 5, (4, 3), False, "block"),
+           ("normal", "normal", 2, 3, (4, 4), False, "block"),
+           ("normal", "hybrid", 3, 5, (4, 3), False, "auto")]
     for mode, bath, norb, nbath, sector, direct, exchange in seq:
         ho, pm, v = _reference(mode, bath, norb, nbath, sector)
-        h, first, count = library_sharded_sector(pm, sector, comm, direct=direct, exchange=exchange)
+        for k, val in (("EDIGPU_IB", "1"), ("EDIGPU_IB_MIN", "0"), ("EDIGPU_IB_ROWS", "24")):
+            if exchange == "block":
+                monkeypatch.setenv(k, val)
+            else:
+                monkeypatch.delenv(k, raising=False)
+        h, first, count = library_sharded_sector(pm, sector, comm, direct=direct,
+                                                 exchange="auto" if exchange == "block" else exchange)
+        assert (comm.shard_info(h)[0] == 2) == (exchange == "block")
         assert rel_err(comm.apply(h, v), ho.matvec(v)) < 1e-12
         a, b, nd, _ = comm.tridiag(h, v, 12)
         a_ref, b_ref, _ = ho.lanc_tridiag(v, 12)
@@ -325,6 +337,54 @@ def test_one_communicator_serves_sectors_of_changing_geometry(gpu, monkeypatch):
         assert comm.exchange_bench(h, 3)[0] in (-1, 1)          # RCCL (world of one: no communicator object, reported as 1)
         h.destroy()
     comm.destroy()
+
+
+def _full_rank_main(rank, world, name, wl, nlanc, q):
+    try:
+        import torch  # noqa: F401
+        from edipack_amd import capi
+        from edipack_amd.sharding import LibraryComm, library_sharded_sector
+        from edipack_amd.synthetic import WORKLOADS, synthetic_model
+        capi.init(0)
+        os.environ["EDIGPU_IB_MINROW"] = "0"     # what bench.py --gpus N sets: shards of short rows on the padded panels
+        w = WORKLOADS[wl]
+        comm = LibraryComm(rank, world, shm_name=name, slot_bytes=1 << 30)
+        h, first, count = library_sharded_sector(synthetic_model(w), w.sector, comm)
+        kind = comm.shard_info(h)[0]
+        v = np.random.default_rng(5).standard_normal(h.dim)
+        a, b, nd, _ = comm.tridiag(h, v[first * h.dim_up:(first + count) * h.dim_up], nlanc)
+        ref = h.lanczos_tridiag(v, nlanc)[:2] if rank == 0 else None   # the single-GPU loop of the same handle
+        h.destroy()
+        comm.destroy()
+        q.put((rank, kind, a, b, nd, ref, None))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, -1, None, None, 0, None, traceback.format_exc() + str(e)))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_recurrence_at_full_size(gpu, world):
+    """BASELINE config 2 (Dim = 11 778 624) tridiagonalised by 2 and 3 ranks that share the GPU (shared-memory transport):
+    transposed exchange on padded panels with the recurrence kept in that layout, ragged last rank (3432 rows and 215
+    panels over 3 ranks).  Every rank's coefficients equal those of the single-GPU loop of the same sector, which the
+    parity suite pins on the oracle at the sizes the oracle reaches (size-independent property: the sharding is not
+    observable)."""
+    nlanc = 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"edigpu_full_{os.getpid()}_{world}"
+    procs = [ctx.Process(target=_full_rank_main, args=(r, world, name, "cfg2", nlanc, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[6] is None, r[6]
+    ra, rb = [r[5] for r in res if r[5] is not None][0]
+    for _, kind, a, b, nd, _, _ in res:
+        assert kind == 2 and nd == nlanc
+        assert rel_err(a, ra) < 1e-11 and rel_err(b, rb) < 1e-11
 
 
 def test_library_shard_error_paths(gpu):
