@@ -325,7 +325,7 @@ def run_multi(args):
     exchange = os.environ.get("EDIGPU_EXCHANGE", "auto")
     # Short rows (config 2: 27 KB): a single GPU keeps such sectors on the generic kernels (the block ROWS kernel loses to
     # the generic one there), but on shards the block image wins -- its exchange moves the padded panels as they are and
-    # the recurrence stays in that layout (0.49 against 0.58 ms per step in the one-rank rehearsal;
+    # the recurrence stays in that layout (0.465 against 0.58 ms per step in the one-rank rehearsal;
     # INTEGRATION.md recommends the same switch for -D_MPI hosts).  Set before the sector is built; a user's value wins.
     os.environ.setdefault("EDIGPU_IB_MINROW", "0")
     h, first, count = library_sharded_sector(model, w.sector, comm, direct=w.direct, exchange=exchange)

@@ -369,19 +369,40 @@ __global__ void __launch_bounds__(kShNT)
   block_sum3(s0, s1, s2, partial, kRedBlocks);
 }
 
-// the same on vectors that share one layout element by element (the recurrence kept in the padded panel layout: the
-// padding holds zeros in all four, so the three sums are those of the shard): w += t1 + t2
+// The recurrence on vectors that share one layout element by element (kept in the padded panel layout: the padding holds
+// zeros in every buffer, so the three sums are those of the shard).  Two buffers that swap roles every step, eight vector
+// passes per step:
+//   ks_panel_rotate : x <- (x - alpha v) / beta   in place on the buffer that held w (v = the previous Lanczos vector)
+//   ks_panel_add_dot: w = rowhalf + colhalf - beta v, written OVER v (no longer needed), and the three sums with x
 __global__ void __launch_bounds__(kShNT)
-    ks_add2_dot3(int64_t n, const double* __restrict__ vin, double* __restrict__ vout, const double* __restrict__ t1,
-                 const double* __restrict__ t2, const double* __restrict__ tprev, double* __restrict__ partial) {
-  const double sg = tprev ? tprev[0] : 0.0;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  const int64_t n2 = n >> 1;  // (n is a multiple of 16)
+    ks_panel_rotate(int64_t n2, double2* __restrict__ x, const double2* __restrict__ v, const double* __restrict__ t,
+                    const double* __restrict__ tprev) {
+  double a, b;
+  ab_from_sums(t, tprev, a, b);
+  const double ib = 1.0 / b;
   for (int64_t e = (int64_t)blockIdx.x * kShNT + threadIdx.x; e < n2; e += (int64_t)gridDim.x * kShNT) {
-    const double2 o = reinterpret_cast<const double2*>(vout)[e], a = reinterpret_cast<const double2*>(t1)[e],
-                  b = reinterpret_cast<const double2*>(t2)[e], v = reinterpret_cast<const double2*>(vin)[e];
-    const double2 w = make_double2(o.x + a.x + b.x, o.y + a.y + b.y);
-    reinterpret_cast<double2*>(vout)[e] = w;
+    const double2 w = x[e], p = v[e];
+    x[e] = make_double2((w.x - a * p.x) * ib, (w.y - a * p.y) * ib);
+  }
+}
+
+// t / tprev: the reduced sums of the two previous steps (null on the first step, where there is no v: dst = the other buffer)
+__global__ void __launch_bounds__(kShNT)
+    ks_panel_add_dot(int64_t n2, const double2* __restrict__ x, double2* vdst, const double2* __restrict__ t1,
+                     const double2* __restrict__ t2, const double* __restrict__ t, const double* __restrict__ tprev,
+                     double* __restrict__ partial) {
+  double sg = 0.0, b = 0.0;
+  if (t) ab_from_sums(t, tprev, sg, b);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * kShNT + threadIdx.x; e < n2; e += (int64_t)gridDim.x * kShNT) {
+    const double2 r = t1[e], c = t2[e], v = x[e];
+    double2 w = make_double2(r.x + c.x, r.y + c.y);
+    if (t) {
+      const double2 p = vdst[e];
+      w.x -= b * p.x;
+      w.y -= b * p.y;
+    }
+    vdst[e] = w;
     const double dx = w.x - sg * v.x, dy = w.y - sg * v.y;
     s0 += v.x * w.x + v.y * w.y;
     s1 += dx * dx + dy * dy;
@@ -560,22 +581,22 @@ static int comm_workspace(edigpu_comm_s* c, const ShardGeom& g, int nlanc) {
 // in that layout again: the two all-to-alls move the buffers as they are.  bp[0] = v in the shard form, bp[1] = what
 // the first exchange delivers, bp[2] = the column half on it, bp[3] = the row half; the exchange back reuses bp[1].
 // H v = *rowhalf + *colhalf, element by element in the shard form.
-static int sharded_hv_panels(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, hipStream_t st, const double** rowhalf,
-                             const double** colhalf) {
+static int sharded_hv_panels(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, hipStream_t st, const double* v,
+                             const double** rowhalf, const double** colhalf) {
   const bool alone = c->world == 1 && !force_collectives(c);
   const size_t per = (size_t)g.npmax * g.q * 16;
   if (!alone) {
     EDIGPU_HIP(hipEventRecord(c->ev_ready, st));
     EDIGPU_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
-    if (comm_all_to_all(c, c->bp[0], c->bp[1], per, c->side)) return 1;
+    if (comm_all_to_all(c, v, c->bp[1], per, c->side)) return 1;
     EDIGPU_HIP(hipEventRecord(c->ev_done, c->side));
   }
-  if (launch_sb_rows_shard(s, g.first, g.count, g.q, c->bp[0], c->bp[3], st)) return 1;  // beside the exchange
+  if (launch_sb_rows_shard(s, g.first, g.count, g.q, v, c->bp[3], st)) return 1;  // beside the exchange
   if (!alone) EDIGPU_HIP(hipStreamWaitEvent(st, c->ev_done, 0));
   const int p0 = c->rank * g.npmax, np = std::max(0, std::min(g.npmax, s->ib->npanels - p0));
   // (panels past the sector's last one are never computed: their slots must not hand stale numbers back)
   if (np < g.npmax) EDIGPU_HIP(hipMemsetAsync(c->bp[2], 0, (size_t)g.bplen * sizeof(double), st));
-  if (launch_sb_cols_shard(s, p0, np, g.q, g.npmax, alone ? c->bp[0] : c->bp[1], c->bp[2], st)) return 1;
+  if (launch_sb_cols_shard(s, p0, np, g.q, g.npmax, alone ? v : c->bp[1], c->bp[2], st)) return 1;
   *rowhalf = c->bp[3];
   *colhalf = c->bp[2];
   if (!alone) {
@@ -592,7 +613,7 @@ static int sharded_hv(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, bo
   if (g.block) {
     const double *rowhalf = nullptr, *colhalf = nullptr;
     if (sb_shard_to_panels(s, c->vin, c->bp[0], g.count, g.q, c->world, st)) return 1;
-    if (sharded_hv_panels(s, c, g, st, &rowhalf, &colhalf)) return 1;
+    if (sharded_hv_panels(s, c, g, st, c->bp[0], &rowhalf, &colhalf)) return 1;
     if (back_out) *back_out = nullptr;  // nothing left for the caller to add
     return sb_shard_from_panels_add(s, rowhalf, colhalf, c->tmp, g.count, g.q, st);
   }
@@ -681,9 +702,10 @@ static int sharded_step(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, 
 }
 
 // The recurrence with its two vectors KEPT in the padded panel layout (ShardGeom::block; EDIGPU_SHARD_PANEL_LOOP=0 falls back
-// to the rows of the reference's layout with a conversion on either side of every product): v = bp[0] is what the first
-// all-to-all sends as it is, w = bp[4]; the padding of the layout holds zeros in every buffer and stays zero under the
-// element-wise updates, so the three sums are those of the shard.
+// to the rows of the reference's layout with a conversion on either side of every product): the Lanczos vector is what the
+// first all-to-all sends as it is; it and the work vector live in bp[0] and bp[4] and swap roles every step
+// (sharded_step_panels); the padding of the layout holds zeros in every buffer and stays zero under the element-wise
+// updates, so the three sums are those of the shard.
 static bool panel_loop(const ShardGeom& g) {
   const char* e = getenv("EDIGPU_SHARD_PANEL_LOOP");
   return g.block && !(e && atoi(e) == 0);
@@ -697,16 +719,23 @@ static int panel_loop_begin(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom&
 }
 
 static int sharded_step_panels(edigpu_sector* s, edigpu_comm_s* c, const ShardGeom& g, int it, hipStream_t st) {
-  const int64_t n = g.bplen;
+  const int64_t n2 = g.bplen / 2;  // (a multiple of 8)
   double* t = c->hist + 3 * (size_t)it;
   const double* tp = it > 0 ? c->hist + 3 * (size_t)(it - 1) : nullptr;
   const double* tpp = it > 1 ? c->hist + 3 * (size_t)(it - 2) : nullptr;
-  hipLaunchKernelGGL(ks_rotate3, sh_grid(n, 256 * 16), dim3(kShNT), 0, st, it == 0 ? 1 : 0, n, (int64_t)1, g.q, c->world,
-                     (int64_t)1, 0, c->bp[0], c->bp[4], tp, tpp, (double*)nullptr);
+  // the two buffers swap roles every step: x = the vector of this step (the seed in bp[0] on step 0), o = the other one,
+  // which holds the previous vector and receives the new work vector
+  double* x = (it & 1) ? c->bp[4] : c->bp[0];
+  double* o = (it & 1) ? c->bp[0] : c->bp[4];
+  if (it > 0)
+    hipLaunchKernelGGL(ks_panel_rotate, sh_grid(n2, 256 * 16), dim3(kShNT), 0, st, n2, reinterpret_cast<double2*>(x),
+                       reinterpret_cast<const double2*>(o), tp, tpp);
   const double *rowhalf = nullptr, *colhalf = nullptr;
-  if (sharded_hv_panels(s, c, g, st, &rowhalf, &colhalf)) return 1;
-  const dim3 gr = sh_grid(std::max<int64_t>(n / 2, 1), kRedBlocks);
-  hipLaunchKernelGGL(ks_add2_dot3, gr, dim3(kShNT), 0, st, n, c->bp[0], c->bp[4], rowhalf, colhalf, tp, c->work);
+  if (sharded_hv_panels(s, c, g, st, x, &rowhalf, &colhalf)) return 1;
+  const dim3 gr = sh_grid(std::max<int64_t>(n2, 1), kRedBlocks);
+  hipLaunchKernelGGL(ks_panel_add_dot, gr, dim3(kShNT), 0, st, n2, reinterpret_cast<const double2*>(x),
+                     reinterpret_cast<double2*>(o), reinterpret_cast<const double2*>(rowhalf),
+                     reinterpret_cast<const double2*>(colhalf), tp, tpp, c->work);
   hipLaunchKernelGGL(ks_sum3, dim3(1), dim3(1024), 0, st, c->work, (int)gr.x, t);
   EDIGPU_HIP(hipGetLastError());
   return comm_all_reduce(c, t, 3, st);
@@ -1138,7 +1167,7 @@ int edigpu_lanczos_eigh_multi_sharded(edigpu_handle h, edigpu_comm c, int neigen
     if (g.block) {  // padded panels: the conversions read and write the solver's vectors themselves (no staging copies)
       const double *rowhalf = nullptr, *colhalf = nullptr;
       if (sb_shard_to_panels(h, in, c->bp[0], g.count, g.q, c->world, s2)) return 1;
-      if (sharded_hv_panels(h, c, g, s2, &rowhalf, &colhalf)) return 1;
+      if (sharded_hv_panels(h, c, g, s2, c->bp[0], &rowhalf, &colhalf)) return 1;
       return sb_shard_from_panels_add(h, rowhalf, colhalf, out, g.count, g.q, s2);
     }
     if (len > 0) EDIGPU_HIP(hipMemcpyAsync(c->vin, in, (size_t)len * sizeof(double), hipMemcpyDeviceToDevice, s2));

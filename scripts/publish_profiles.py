@@ -23,7 +23,14 @@ for d in sorted(glob.glob(f"gpurun_out/prof_{tag}_*")):
     if ks:
         shutil.copy(ks[0], f"profiles/{tag}_{wl}_kernel_stats.csv")
 if merged:
-    json.dump(merged, open("profiles/pmc_traffic.json", "w"), indent=1)
+    # workloads that were not re-collected in this call keep their entry (and its source-hash stamp: bench.py drops a
+    # figure whose stamp is not the hash of the current sources)
+    try:
+        old = json.load(open("profiles/pmc_traffic.json"))
+    except Exception:
+        old = {}
+    old.update(merged)
+    json.dump(old, open("profiles/pmc_traffic.json", "w"), indent=1)
 for f in glob.glob(f"gpurun_out/bench/{tag}_bench_*.json"):
     if os.path.getsize(f) > 0:
         shutil.copy(f, "profiles/" + os.path.basename(f))
